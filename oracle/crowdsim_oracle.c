@@ -1,0 +1,715 @@
+/*
+ * crowdsim_oracle.c -- see crowdsim_oracle.h.  TEST INFRASTRUCTURE ONLY (parity oracle + CPU baseline).
+ * Scalar, one env at a time, written for clarity: each function cites the reference lines it restates.
+ */
+#include "crowdsim_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * numpy legacy RandomState == MT19937 (np.random.seed(int) -> init_genrand; random_sample -> 53-bit double)
+ * reference use: crowd_sim_var_num.py:338, :98, :122-126; agent.py:22,49-50
+ * ---------------------------------------------------------------------------------------------- */
+void orc_mt_seed(OrcMT *mt, uint32_t seed)
+{
+    for (int pos = 0; pos < 624; ++pos) {
+        mt->key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+    mt->pos = 624;
+}
+
+static void mt_twist(OrcMT *mt)
+{
+    uint32_t *k = mt->key;
+    uint32_t y;
+    int i;
+    for (i = 0; i < 624 - 397; ++i) {
+        y = (k[i] & 0x80000000u) | (k[i + 1] & 0x7fffffffu);
+        k[i] = k[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; i < 623; ++i) {
+        y = (k[i] & 0x80000000u) | (k[i + 1] & 0x7fffffffu);
+        k[i] = k[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    y = (k[623] & 0x80000000u) | (k[0] & 0x7fffffffu);
+    k[623] = k[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    mt->pos = 0;
+}
+
+uint32_t orc_mt_next(OrcMT *mt)
+{
+    if (mt->pos == 624) mt_twist(mt);
+    uint32_t y = mt->key[mt->pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+double orc_mt_double(OrcMT *mt)
+{
+    uint32_t a = orc_mt_next(mt) >> 5, b = orc_mt_next(mt) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+static double env_random(OrcEnv *e)
+{
+    e->rng_draws += 2;
+    return orc_mt_double(&e->rng);
+}
+static double env_uniform(OrcEnv *e, double lo, double hi) { return lo + (hi - lo) * env_random(e); }
+
+/* ------------------------------------------------------------------------------------------------
+ * deterministic sin/cos for x in [0, 2*pi]: Cody-Waite reduction by pi/2 + the classic minimax
+ * kernels.  Plain +,-,* only (no FMA) so the HIP twin is bit-identical.  <= ~1 ulp.
+ * Stands in for np.cos/np.sin at crowd_sim_var_num.py:127-128 and crowd_sim.py:427-428.
+ * ---------------------------------------------------------------------------------------------- */
+static double k_sin(double x)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x, w = z * z;
+    double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    double v = z * x;
+    return x + v * (S1 + z * r);
+}
+static double k_cos(double x)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x, w = z * z;
+    double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + z * r);
+}
+void orc_sincos(double x, double *s, double *c)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+    const double PIO2_1T = 6.07710050650619224932e-11; /* pi/2 - PIO2_1 */
+    int k = (int)(x * INV_PIO2 + 0.5);
+    double fk = (double)k;
+    double r = (x - fk * PIO2_1) - fk * PIO2_1T;
+    double sr = k_sin(r), cr = k_cos(r);
+    switch (k & 3) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ORCA -- restatement of RVO2 Library v2.0.2 (Agent.cpp), fp32, RVO_EPSILON = 1e-5.
+ * Reference call site: crowd_nav/policy/orca.py:80-114 (only agent 0's velocity is read, :114).
+ * ---------------------------------------------------------------------------------------------- */
+#define RVO_EPSILON 0.00001f
+typedef struct { float x, y; } V2;
+typedef struct { V2 point, direction; } Line;
+
+static inline V2 v2(float x, float y) { V2 r = {x, y}; return r; }
+static inline V2 vadd(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+static inline V2 vsub(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+static inline V2 vscale(float s, V2 a) { return v2(s * a.x, s * a.y); }
+static inline float vdot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+static inline float vdet(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+static inline float vabssq(V2 a) { return vdot(a, a); }
+static inline float vabs(V2 a) { return sqrtf(vdot(a, a)); }
+static inline V2 vdiv(V2 a, float s) { const float inv = 1.0f / s; return v2(a.x * inv, a.y * inv); } /* Vector2::operator/ */
+static inline V2 vnormalize(V2 a) { return vdiv(a, vabs(a)); }
+static inline float sqrf(float a) { return a * a; }
+
+static int lp1(const Line *lines, int lineNo, float radius, V2 optVelocity, int directionOpt, V2 *result)
+{
+    const float dotProduct = vdot(lines[lineNo].point, lines[lineNo].direction);
+    const float discriminant = sqrf(dotProduct) + sqrf(radius) - vabssq(lines[lineNo].point);
+    if (discriminant < 0.0f) return 0;
+    const float sqrtDiscriminant = sqrtf(discriminant);
+    float tLeft = -dotProduct - sqrtDiscriminant;
+    float tRight = -dotProduct + sqrtDiscriminant;
+    for (int i = 0; i < lineNo; ++i) {
+        const float denominator = vdet(lines[lineNo].direction, lines[i].direction);
+        const float numerator = vdet(lines[i].direction, vsub(lines[lineNo].point, lines[i].point));
+        if (fabsf(denominator) <= RVO_EPSILON) {
+            if (numerator < 0.0f) return 0;
+            continue;
+        }
+        const float t = numerator / denominator;
+        if (denominator >= 0.0f) tRight = fminf(tRight, t);
+        else tLeft = fmaxf(tLeft, t);
+        if (tLeft > tRight) return 0;
+    }
+    if (directionOpt) {
+        if (vdot(optVelocity, lines[lineNo].direction) > 0.0f)
+            *result = vadd(lines[lineNo].point, vscale(tRight, lines[lineNo].direction));
+        else
+            *result = vadd(lines[lineNo].point, vscale(tLeft, lines[lineNo].direction));
+    } else {
+        const float t = vdot(lines[lineNo].direction, vsub(optVelocity, lines[lineNo].point));
+        if (t < tLeft) *result = vadd(lines[lineNo].point, vscale(tLeft, lines[lineNo].direction));
+        else if (t > tRight) *result = vadd(lines[lineNo].point, vscale(tRight, lines[lineNo].direction));
+        else *result = vadd(lines[lineNo].point, vscale(t, lines[lineNo].direction));
+    }
+    return 1;
+}
+
+static int lp2(const Line *lines, int n, float radius, V2 optVelocity, int directionOpt, V2 *result)
+{
+    if (directionOpt) *result = vscale(radius, optVelocity);
+    else if (vabssq(optVelocity) > sqrf(radius)) *result = vscale(radius, vnormalize(optVelocity));
+    else *result = optVelocity;
+    for (int i = 0; i < n; ++i) {
+        if (vdet(lines[i].direction, vsub(lines[i].point, *result)) > 0.0f) {
+            const V2 tempResult = *result;
+            if (!lp1(lines, i, radius, optVelocity, directionOpt, result)) {
+                *result = tempResult;
+                return i;
+            }
+        }
+    }
+    return n;
+}
+
+static void lp3(const Line *lines, int n, int beginLine, float radius, V2 *result)
+{
+    float distance = 0.0f;
+    Line proj[ORC_MAX_HUMANS];
+    for (int i = beginLine; i < n; ++i) {
+        if (vdet(lines[i].direction, vsub(lines[i].point, *result)) > distance) {
+            int np = 0;
+            for (int j = 0; j < i; ++j) {
+                Line line;
+                const float determinant = vdet(lines[i].direction, lines[j].direction);
+                if (fabsf(determinant) <= RVO_EPSILON) {
+                    if (vdot(lines[i].direction, lines[j].direction) > 0.0f) continue;
+                    line.point = vscale(0.5f, vadd(lines[i].point, lines[j].point));
+                } else {
+                    line.point = vadd(lines[i].point,
+                                      vscale(vdet(lines[j].direction, vsub(lines[i].point, lines[j].point)) / determinant,
+                                             lines[i].direction));
+                }
+                line.direction = vnormalize(vsub(lines[j].direction, lines[i].direction));
+                proj[np++] = line;
+            }
+            const V2 tempResult = *result;
+            if (lp2(proj, np, radius, v2(-lines[i].direction.y, lines[i].direction.x), 1, result) < np)
+                *result = tempResult;
+            distance = vdet(lines[i].direction, vsub(lines[i].point, *result));
+        }
+    }
+}
+
+int orc_orca_velocity(float self_px, float self_py, float self_vx, float self_vy, float self_radius,
+                      float max_speed, float pref_vx, float pref_vy, float neighbor_dist,
+                      int max_neighbors, float time_horizon, float time_step, int n_other,
+                      const float *opx, const float *opy, const float *ovx, const float *ovy,
+                      const float *oradius, float *out_vx, float *out_vy, float *lines_out, int *line_fail_out)
+{
+    /* Agent::computeNeighbors + insertAgentNeighbor: others with distSq < neighborDist^2, ascending distSq,
+     * at most maxNeighbors.  Ties keep index order (RVO2's kd-tree visit order is the only other candidate;
+     * exact fp32 ties between distinct agents do not occur in generated scenes). */
+    int idx[ORC_MAX_HUMANS];
+    float dsq[ORC_MAX_HUMANS];
+    int nn = 0;
+    float rangeSq = sqrf(neighbor_dist);
+    const V2 pos = v2(self_px, self_py), vel = v2(self_vx, self_vy);
+    if (max_neighbors > 0) {
+        for (int j = 0; j < n_other; ++j) {
+            const float d = vabssq(vsub(pos, v2(opx[j], opy[j])));
+            if (d < rangeSq) {
+                if (nn < max_neighbors) { idx[nn] = j; dsq[nn] = d; ++nn; }
+                int i = nn - 1;
+                /* when the list was already full the last element is overwritten (RVO2 behaviour) */
+                while (i != 0 && d < dsq[i - 1]) { dsq[i] = dsq[i - 1]; idx[i] = idx[i - 1]; --i; }
+                dsq[i] = d; idx[i] = j;
+                if (nn == max_neighbors) rangeSq = dsq[nn - 1];
+            }
+        }
+    }
+    Line lines[ORC_MAX_HUMANS];
+    const float invTimeHorizon = 1.0f / time_horizon;
+    for (int k = 0; k < nn; ++k) {
+        const int j = idx[k];
+        const V2 relativePosition = vsub(v2(opx[j], opy[j]), pos);
+        const V2 relativeVelocity = vsub(vel, v2(ovx[j], ovy[j]));
+        const float distSq = vabssq(relativePosition);
+        const float combinedRadius = self_radius + oradius[j];
+        const float combinedRadiusSq = sqrf(combinedRadius);
+        Line line;
+        V2 u;
+        if (distSq > combinedRadiusSq) {
+            const V2 w = vsub(relativeVelocity, vscale(invTimeHorizon, relativePosition));
+            const float wLengthSq = vabssq(w);
+            const float dotProduct1 = vdot(w, relativePosition);
+            if (dotProduct1 < 0.0f && sqrf(dotProduct1) > combinedRadiusSq * wLengthSq) {
+                const float wLength = sqrtf(wLengthSq);
+                const V2 unitW = vdiv(w, wLength);
+                line.direction = v2(unitW.y, -unitW.x);
+                u = vscale(combinedRadius * invTimeHorizon - wLength, unitW);
+            } else {
+                const float leg = sqrtf(distSq - combinedRadiusSq);
+                if (vdet(relativePosition, w) > 0.0f) {
+                    line.direction = vdiv(v2(relativePosition.x * leg - relativePosition.y * combinedRadius,
+                                             relativePosition.x * combinedRadius + relativePosition.y * leg), distSq);
+                } else {
+                    const V2 t = vdiv(v2(relativePosition.x * leg + relativePosition.y * combinedRadius,
+                                         -relativePosition.x * combinedRadius + relativePosition.y * leg), distSq);
+                    line.direction = v2(-t.x, -t.y);
+                }
+                const float dotProduct2 = vdot(relativeVelocity, line.direction);
+                u = vsub(vscale(dotProduct2, line.direction), relativeVelocity);
+            }
+        } else {
+            const float invTimeStep = 1.0f / time_step;
+            const V2 w = vsub(relativeVelocity, vscale(invTimeStep, relativePosition));
+            const float wLength = vabs(w);
+            const V2 unitW = vdiv(w, wLength);
+            line.direction = v2(unitW.y, -unitW.x);
+            u = vscale(combinedRadius * invTimeStep - wLength, unitW);
+        }
+        line.point = vadd(vel, vscale(0.5f, u));
+        lines[k] = line;
+        if (lines_out) {
+            lines_out[4 * k + 0] = line.point.x; lines_out[4 * k + 1] = line.point.y;
+            lines_out[4 * k + 2] = line.direction.x; lines_out[4 * k + 3] = line.direction.y;
+        }
+    }
+    V2 result;
+    const int lineFail = lp2(lines, nn, max_speed, v2(pref_vx, pref_vy), 0, &result);
+    if (lineFail < nn) lp3(lines, nn, lineFail, max_speed, &result);
+    if (line_fail_out) *line_fail_out = lineFail;
+    *out_vx = result.x;
+    *out_vy = result.y;
+    return nn;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Environment
+ * ---------------------------------------------------------------------------------------------- */
+void orc_config_default(OrcConfig *c)
+{
+    /* crowd_nav/configs/config.py:16-120 with the non-randomised training preset of
+     * trained_models/GST_predictor_non_rand/configs/config.py (BASELINE configs[1]) */
+    memset(c, 0, sizeof(*c));
+    c->human_num = 20; c->predict_steps = 5; c->env_kind = ORC_ENV_VARNUM;
+    c->randomize_attributes = 0; c->random_goal_changing = 0; c->end_goal_changing = 1;
+    c->sort_humans = 1; c->phase = ORC_PHASE_TRAIN; c->nenv = 1;
+    c->val_size = 100; c->test_size = 500;
+    c->time_step = 0.25; c->time_limit = 50.0;
+    c->success_reward = 10.0; c->collision_penalty = -20.0; c->discomfort_dist = 0.25;
+    c->discomfort_penalty_factor = 10.0;
+    c->circle_radius = 6.0 * sqrt(2.0); c->arena_size = 6.0;
+    c->human_radius = 0.3; c->human_v_pref = 1.0; c->robot_radius = 0.3; c->robot_v_pref = 1.0;
+    c->sensor_range = 5.0; c->goal_change_chance = 0.5; c->end_goal_change_chance = 1.0;
+    c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0;
+    c->orca_time_horizon_obst = 5.0;
+}
+
+int orc_obs_width(const OrcConfig *cfg) { return cfg->env_kind == ORC_ENV_VARNUM ? 2 : 2 * (cfg->predict_steps + 1); }
+
+void orc_env_init(OrcEnv *e, const OrcConfig *cfg, int64_t this_seed)
+{
+    memset(e, 0, sizeof(*e));
+    e->cfg = *cfg;
+    e->this_seed = this_seed;
+    e->shared_neighbor_dist = cfg->orca_neighbor_dist;
+    orc_mt_seed(&e->rng, 0);
+}
+
+static double norm2(double x, double y) { return sqrt(x * x + y * y); }
+
+/* crowd_sim_var_num.py:116-146 generate_circle_crossing_human; `slot` is the index the new human will occupy,
+ * `n_existing` how many entries of e->humans are currently in self.humans (on respawn that includes the
+ * human being replaced: the list still holds it while the right-hand side is evaluated, :455). */
+static void gen_circle_crossing_human(OrcEnv *e, int slot, int n_existing)
+{
+    const OrcConfig *c = &e->cfg;
+    OrcHuman h;
+    h.radius = c->human_radius;
+    h.v_pref = c->human_v_pref;
+    if (c->randomize_attributes) {
+        e->shared_neighbor_dist = env_uniform(e, 5.0, 10.0); /* Agent.__init__, agent.py:21-22 */
+        h.v_pref = env_uniform(e, 0.5, 1.5);                  /* agent.py:49 */
+        h.radius = env_uniform(e, 0.3, 0.5);                  /* agent.py:50 */
+    }
+    double px, py;
+    for (;;) {
+        const double angle = env_random(e) * M_PI * 2.0;
+        const double px_noise = env_uniform(e, 0.0, 1.0) * 2.0;
+        const double py_noise = env_uniform(e, 0.0, 1.0) * 2.0;
+        double s, co;
+        orc_sincos(angle, &s, &co);
+        px = c->circle_radius * co + px_noise;
+        py = c->circle_radius * s + py_noise;
+        int collide = 0;
+        /* [self.robot] + self.humans */
+        {
+            const double min_dist = h.radius + c->robot_radius + c->discomfort_dist;
+            if (norm2(px - e->rpx, py - e->rpy) < min_dist || norm2(px - e->rgx, py - e->rgy) < min_dist) collide = 1;
+        }
+        for (int j = 0; j < n_existing && !collide; ++j) {
+            const OrcHuman *a = &e->humans[j];
+            const double min_dist = h.radius + a->radius + c->discomfort_dist;
+            if (norm2(px - a->px, py - a->py) < min_dist || norm2(px - a->gx, py - a->gy) < min_dist) collide = 1;
+        }
+        if (!collide) break;
+    }
+    h.px = px; h.py = py; h.gx = -px; h.gy = -py; h.vx = 0.0; h.vy = 0.0;
+    e->humans[slot] = h;
+    e->sim_valid[slot] = 0; /* new Human -> new ORCA policy object with sim None */
+}
+
+/* crowd_sim.py:513-552 detect_visible(robot, human, robot1=True) with robot FOV = 2*pi:
+ * the arccos test is always true unless the two agents coincide (0/0 -> NaN -> False). */
+static int robot_sees(const OrcEnv *e, const OrcHuman *h)
+{
+    const double dx = e->rpx - h->px, dy = e->rpy - h->py;
+    if (dx == 0.0 && dy == 0.0) return 0;
+    const double dist = norm2(dx, dy) - e->cfg.robot_radius - h->radius;
+    return dist <= e->cfg.sensor_range;
+}
+
+static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = c->human_num, D = orc_obs_width(c), P = c->predict_steps;
+    /* get_num_human_in_fov, crowd_sim.py:558-572 */
+    int num_visible = 0;
+    for (int i = 0; i < H; ++i) {
+        e->human_visibility[i] = robot_sees(e, &e->humans[i]);
+        num_visible += e->human_visibility[i];
+    }
+    /* robot_node = get_full_state_list_noV (agent.py:105): px, py, r, gx, gy, v_pref, theta */
+    obs->robot_node[0] = (float)e->rpx; obs->robot_node[1] = (float)e->rpy; obs->robot_node[2] = (float)c->robot_radius;
+    obs->robot_node[3] = (float)e->rgx; obs->robot_node[4] = (float)e->rgy; obs->robot_node[5] = (float)c->robot_v_pref;
+    obs->robot_node[6] = (float)e->rtheta;
+    double prev_vel[ORC_MAX_HUMANS][2];
+    for (int i = 0; i < H; ++i) { prev_vel[i][0] = e->last_human_states[i][2]; prev_vel[i][1] = e->last_human_states[i][3]; }
+    /* update_last_human_states, crowd_sim.py:243-273 */
+    for (int i = 0; i < H; ++i) {
+        double *s = e->last_human_states[i];
+        if (e->human_visibility[i]) {
+            const OrcHuman *h = &e->humans[i];
+            s[0] = h->px; s[1] = h->py; s[2] = h->vx; s[3] = h->vy; s[4] = h->radius;
+        } else if (reset) {
+            s[0] = 15.0; s[1] = 15.0; s[2] = 0.0; s[3] = 0.0; s[4] = 0.3;
+        } else {
+            s[0] = s[0] + s[2] * c->time_step;
+            s[1] = s[1] + s[3] * c->time_step;
+        }
+    }
+    obs->temporal_edges[0] = (float)e->rvx; obs->temporal_edges[1] = (float)e->rvy;
+
+    double edges[ORC_MAX_HUMANS][2 * (ORC_MAX_PRED + 1)];
+    for (int i = 0; i < H; ++i)
+        for (int d = 0; d < D; ++d) edges[i][d] = INFINITY;
+    if (c->env_kind == ORC_ENV_VARNUM) {
+        /* crowd_sim_var_num.py:249-256 */
+        for (int i = 0; i < H; ++i)
+            if (e->human_visibility[i]) {
+                edges[i][0] = e->last_human_states[i][0] - e->rpx;
+                edges[i][1] = e->last_human_states[i][1] - e->rpy;
+            }
+    } else {
+        /* calc_human_future_traj('const_vel'), crowd_sim_var_num.py:166-226 + crowd_sim_pred.py:80-86.
+         * PredRealGST (crowd_sim_pred_real_gst.py:78-93) fills the future slots with the current
+         * relative position (np.tile), the wrapper overwrites them later. */
+        for (int k = 0; k <= P; ++k)
+            for (int i = 0; i < H; ++i) {
+                if (e->human_visibility[i]) {
+                    const double t = (double)k * c->time_step * 1.0;
+                    e->future_traj[k][i][0] = e->humans[i].px + t * prev_vel[i][0];
+                    e->future_traj[k][i][1] = e->humans[i].py + t * prev_vel[i][1];
+                } else {
+                    e->future_traj[k][i][0] = 15.0; e->future_traj[k][i][1] = 15.0;
+                }
+            }
+        for (int i = 0; i < H; ++i)
+            if (e->human_visibility[i])
+                for (int k = 0; k <= P; ++k) {
+                    if (c->env_kind == ORC_ENV_PRED) {
+                        edges[i][2 * k] = e->future_traj[k][i][0] - e->rpx;
+                        edges[i][2 * k + 1] = e->future_traj[k][i][1] - e->rpy;
+                    } else {
+                        edges[i][2 * k] = e->last_human_states[i][0] - e->rpx;
+                        edges[i][2 * k + 1] = e->last_human_states[i][1] - e->rpy;
+                    }
+                }
+    }
+    /* sorted(..., key=norm of first two) is stable; all-inf rows keep index order and end last */
+    int order[ORC_MAX_HUMANS];
+    for (int i = 0; i < H; ++i) order[i] = i;
+    /* PredRealGST never sorts in the env (crowd_sim_pred_real_gst.py:80: sort=False; the wrapper sorts later) */
+    const int do_sort = c->sort_humans && c->env_kind != ORC_ENV_PRED_GST;
+    if (do_sort) {
+        double key[ORC_MAX_HUMANS];
+        for (int i = 0; i < H; ++i) key[i] = sqrt(edges[i][0] * edges[i][0] + edges[i][1] * edges[i][1]);
+        for (int i = 1; i < H; ++i) { /* stable insertion sort */
+            int oi = order[i]; double ki = key[oi]; int j = i - 1;
+            while (j >= 0 && key[order[j]] > ki) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = oi;
+        }
+    }
+    for (int r = 0; r < H; ++r)
+        for (int d = 0; d < D; ++d) {
+            double v = edges[order[r]][d];
+            if (isinf(v)) v = 15.0;
+            obs->spatial_edges[r * D + d] = (float)v;
+        }
+    memset(obs->visible_masks, 0, sizeof(obs->visible_masks));
+    if (do_sort) {
+        for (int i = 0; i < num_visible; ++i) obs->visible_masks[i] = 1;
+    } else {
+        for (int i = 0; i < H; ++i) obs->visible_masks[i] = (uint8_t)e->human_visibility[i];
+    }
+    obs->detected_human_num = (float)(num_visible == 0 ? 1 : num_visible);
+}
+
+void orc_env_reset(OrcEnv *e, OrcObs *obs)
+{
+    const OrcConfig *c = &e->cfg;
+    /* crowd_sim_var_num.py:333-338; configure(): case_capacity val/test = 1000 */
+    const uint64_t offset[3] = {2000u, 0u, 1000u};
+    const int ph = c->phase;
+    const uint64_t seed = offset[ph] + e->case_counter[ph] + (uint64_t)e->this_seed;
+    orc_mt_seed(&e->rng, (uint32_t)seed);
+    e->rng_draws = 0;
+    e->step_counter = 0;
+    /* generate_robot_humans, holonomic branch :97-104 */
+    double px, py, gx, gy;
+    for (;;) {
+        px = env_uniform(e, -c->arena_size, c->arena_size);
+        py = env_uniform(e, -c->arena_size, c->arena_size);
+        gx = env_uniform(e, -c->arena_size, c->arena_size);
+        gy = env_uniform(e, -c->arena_size, c->arena_size);
+        if (norm2(px - gx, py - gy) >= 8.0) break;
+    }
+    e->rpx = px; e->rpy = py; e->rgx = gx; e->rgy = gy; e->rvx = 0.0; e->rvy = 0.0; e->rtheta = M_PI / 2.0;
+    /* randint(H, H+1) consumes no draw (human_num_range == 0) */
+    for (int i = 0; i < c->human_num; ++i) gen_circle_crossing_human(e, i, i);
+    memset(e->last_human_states, 0, sizeof(e->last_human_states)); /* :108 */
+    const uint64_t case_size[3] = {4294967295ull - 2000ull, c->val_size, c->test_size};
+    e->case_counter[ph] = (e->case_counter[ph] + (uint64_t)c->nenv) % case_size[ph];
+    e->potential = -fabs(norm2(e->rgx - e->rpx, e->rgy - e->rpy));
+    e->ep_return = 0.0; e->ep_len = 0;
+    write_obs(e, obs, 1);
+}
+
+/* ORCA.predict for human i, orca.py:64-117 */
+static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = c->human_num;
+    const OrcHuman *me = &e->humans[i];
+    if (!e->sim_valid[i]) { /* :83-89 */
+        e->sim_nd[i] = (float)e->shared_neighbor_dist;
+        e->sim_self_radius[i] = (float)(me->radius + 0.01 + c->orca_safety_space);
+        e->sim_self_maxspeed[i] = (float)me->v_pref;
+        for (int j = 0; j < H; ++j)
+            if (j != i) e->sim_seen_radius[i][j] = (float)(e->humans[j].radius + 0.01 + c->orca_safety_space);
+        e->sim_valid[i] = 1;
+    }
+    float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
+    int n = 0;
+    for (int j = 0; j < H; ++j) {
+        if (j == i) continue;
+        const OrcHuman *o = &e->humans[j];
+        /* get_human_actions, crowd_sim.py:686-693: human FOV = 2*pi -> visible unless coincident, else dummy (7,7,0,0) */
+        if (o->px == me->px && o->py == me->py) {
+            opx[n] = 7.0f; opy[n] = 7.0f; ovx[n] = 0.0f; ovy[n] = 0.0f;
+        } else {
+            opx[n] = (float)o->px; opy[n] = (float)o->py; ovx[n] = (float)o->vx; ovy[n] = (float)o->vy;
+        }
+        orad[n] = e->sim_seen_radius[i][j];
+        ++n;
+    }
+    /* :97-100 pref velocity: goal vector, normalised only when longer than 1 */
+    double vx = me->gx - me->px, vy = me->gy - me->py;
+    const double speed = norm2(vx, vy);
+    if (speed > 1.0) { vx = vx / speed; vy = vy / speed; }
+    orc_orca_velocity((float)me->px, (float)me->py, (float)me->vx, (float)me->vy, e->sim_self_radius[i],
+                      e->sim_self_maxspeed[i], (float)vx, (float)vy, e->sim_nd[i], H - 1,
+                      (float)c->orca_time_horizon, (float)c->time_step, n, opx, opy, ovx, ovy, orad, avx, avy, 0, 0);
+}
+
+/* crowd_sim.py:415-450 */
+static void update_human_goals_randomly(OrcEnv *e)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = c->human_num;
+    for (int i = 0; i < H; ++i) {
+        OrcHuman *h = &e->humans[i];
+        if (h->v_pref == 0.0) continue;
+        if (env_random(e) <= c->goal_change_chance) {
+            double gx, gy;
+            for (;;) {
+                const double angle = env_random(e) * M_PI * 2.0;
+                const double v_pref = h->v_pref == 0.0 ? 1.0 : h->v_pref;
+                const double gx_noise = (env_random(e) - 0.5) * v_pref;
+                const double gy_noise = (env_random(e) - 0.5) * v_pref;
+                double s, co;
+                orc_sincos(angle, &s, &co);
+                gx = c->circle_radius * co + gx_noise;
+                gy = c->circle_radius * s + gy_noise;
+                int collide = 0;
+                {
+                    const double md = h->radius + c->robot_radius + c->discomfort_dist;
+                    if (norm2(gx - e->rpx, gy - e->rpy) < md || norm2(gx - e->rgx, gy - e->rgy) < md) collide = 1;
+                }
+                for (int j = 0; j < H && !collide; ++j) {
+                    if (j == i) continue;
+                    const OrcHuman *a = &e->humans[j];
+                    const double md = h->radius + a->radius + c->discomfort_dist;
+                    if (norm2(gx - a->px, gy - a->py) < md || norm2(gx - a->gx, gy - a->gy) < md) collide = 1;
+                }
+                if (!collide) break;
+            }
+            h->gx = gx; h->gy = gy;
+        }
+    }
+}
+
+int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *reward_out, int *info_out, double *danger_min_dist)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = c->human_num;
+    /* srnn.clip_action (srnn.py:17-34): float32 arithmetic on the raw action */
+    float ax = action_in[0], ay = action_in[1];
+    {
+        const float act_norm = sqrtf(ax * ax + ay * ay);
+        const float vp = (float)c->robot_v_pref;
+        if (act_norm > vp) { ax = ax / act_norm * vp; ay = ay / act_norm * vp; }
+    }
+    /* get_human_actions, crowd_sim.py:680-703 */
+    float hax[ORC_MAX_HUMANS], hay[ORC_MAX_HUMANS];
+    for (int i = 0; i < H; ++i) {
+        human_orca_action(e, i, &hax[i], &hay[i]);
+        e->last_human_actions[i][0] = hax[i]; e->last_human_actions[i][1] = hay[i];
+    }
+    /* calc_reward, crowd_sim_var_num.py:465-561 (train phase: danger zone = circle) */
+    double dmin = INFINITY;
+    int collision = 0;
+    for (int i = 0; i < H; ++i) {
+        const double dx = e->humans[i].px - e->rpx, dy = e->humans[i].py - e->rpy;
+        const double closest = sqrt(dx * dx + dy * dy) - e->humans[i].radius - c->robot_radius;
+        if (closest < 0.0) { collision = 1; break; }
+        else if (closest < dmin) dmin = closest;
+    }
+    const int reaching_goal = norm2(e->rpx - e->rgx, e->rpy - e->rgy) < c->robot_radius;
+    const double global_time = (double)e->step_counter * c->time_step;
+    double reward; int done, info; double mind = 0.0;
+    if (global_time >= c->time_limit - 1.0) { reward = 0.0; done = 1; info = ORC_INFO_TIMEOUT; }
+    else if (collision) { reward = c->collision_penalty; done = 1; info = ORC_INFO_COLLISION; }
+    else if (reaching_goal) { reward = c->success_reward; done = 1; info = ORC_INFO_REACHGOAL; }
+    else if (dmin < c->discomfort_dist) {
+        reward = (dmin - c->discomfort_dist) * c->discomfort_penalty_factor * c->time_step;
+        done = 0; info = ORC_INFO_DANGER;
+    } else {
+        const double potential_cur = norm2(e->rpx - e->rgx, e->rpy - e->rgy);
+        reward = 2.0 * (-fabs(potential_cur) - e->potential);
+        e->potential = -fabs(potential_cur);
+        done = 0; info = ORC_INFO_NOTHING;
+    }
+    if (c->env_kind == ORC_ENV_PRED) {
+        /* social reward, crowd_sim_pred.py:216-233; future_traj is the one stored by the previous generate_ob */
+        double rf = 0.0; /* np.min over products collision_idx * penalty (0 where no collision) */
+        for (int k = 1; k <= c->predict_steps; ++k) {
+            const double pen = c->collision_penalty / ldexp(1.0, k + 1);
+            for (int i = 0; i < H; ++i) {
+                const double dx = e->future_traj[k][i][0] - e->rpx, dy = e->future_traj[k][i][1] - e->rpy;
+                if (sqrt(dx * dx + dy * dy) < c->robot_radius + c->human_radius) { if (pen < rf) rf = pen; }
+            }
+        }
+        reward = reward + rf;
+    }
+    /* apply actions, agent.py:170-183 (holonomic) */
+    e->rpx = e->rpx + (double)(ax * (float)c->time_step); /* float32 * python float stays float32 (NEP 50), exact for 0.25 */
+    e->rpy = e->rpy + (double)(ay * (float)c->time_step);
+    e->rvx = (double)ax; e->rvy = (double)ay;
+    for (int i = 0; i < H; ++i) {
+        OrcHuman *h = &e->humans[i];
+        h->px = h->px + (double)hax[i] * c->time_step;
+        h->py = h->py + (double)hay[i] * c->time_step;
+        h->vx = (double)hax[i]; h->vy = (double)hay[i];
+    }
+    e->step_counter += 1;
+    write_obs(e, obs, 0);
+    /* :446-448 random goal changing every 5 s of sim time */
+    if (c->random_goal_changing && (e->step_counter % (int)llround(5.0 / c->time_step)) == 0) update_human_goals_randomly(e);
+    /* :451-456 respawn humans that reached their goal */
+    if (c->end_goal_changing) {
+        for (int i = 0; i < H; ++i) {
+            const OrcHuman *h = &e->humans[i];
+            if (norm2(h->gx - h->px, h->gy - h->py) < h->radius) gen_circle_crossing_human(e, i, H);
+        }
+    }
+    e->ep_return += reward; e->ep_len += 1;
+    *reward_out = reward; *info_out = info;
+    if (danger_min_dist) *danger_min_dist = mind;
+    return done;
+}
+
+int orc_env_step_autoreset(OrcEnv *e, const float action[2], OrcObs *obs, double *reward, int *info,
+                           double *ep_return, int *ep_len)
+{
+    const int done = orc_env_step(e, action, obs, reward, info, 0);
+    if (done) {
+        /* bench.Monitor: info['episode'] = {'r': round(sum, 6), 'l': steps}; shmem_vec_env.py:139-142 auto-reset */
+        if (ep_return) *ep_return = e->ep_return;
+        if (ep_len) *ep_len = e->ep_len;
+        orc_env_reset(e, obs);
+    }
+    return done;
+}
+
+OrcEnv *orc_env_new(const OrcConfig *cfg, int64_t this_seed)
+{
+    OrcEnv *e = (OrcEnv *)malloc(sizeof(OrcEnv));
+    if (e) orc_env_init(e, cfg, this_seed);
+    return e;
+}
+void orc_env_free(OrcEnv *e) { free(e); }
+int orc_sizeof_env(void) { return (int)sizeof(OrcEnv); }
+int orc_sizeof_obs(void) { return (int)sizeof(OrcObs); }
+int orc_sizeof_config(void) { return (int)sizeof(OrcConfig); }
+
+void orc_env_batch_step(OrcEnv **envs, int n, const float *actions, float *robot_node, float *temporal_edges,
+                        float *spatial_edges, float *detected, uint8_t *visible, float *rewards, uint8_t *dones,
+                        uint8_t *infos)
+{
+    for (int i = 0; i < n; ++i) {
+        OrcObs obs;
+        double r; int info;
+        const int H = envs[i]->cfg.human_num, D = orc_obs_width(&envs[i]->cfg);
+        const int done = orc_env_step_autoreset(envs[i], actions + 2 * i, &obs, &r, &info, 0, 0);
+        memcpy(robot_node + 7 * i, obs.robot_node, 7 * sizeof(float));
+        memcpy(temporal_edges + 2 * i, obs.temporal_edges, 2 * sizeof(float));
+        memcpy(spatial_edges + (size_t)i * H * D, obs.spatial_edges, (size_t)H * D * sizeof(float));
+        detected[i] = obs.detected_human_num;
+        memcpy(visible + (size_t)i * H, obs.visible_masks, (size_t)H);
+        rewards[i] = (float)r; dones[i] = (uint8_t)done; infos[i] = (uint8_t)info;
+    }
+}
+
+/* storage.py:123-132 (use_gae=True, use_proper_time_limits=False), torch fp32 op order:
+ * delta = r + gamma * V[t+1] * m[t+1] - V[t];  gae = delta + gamma * lam * m[t+1] * gae;  R = gae + V[t] */
+void orc_gae(int T, int N, const float *rewards, const float *values, const float *masks, double gamma_d, double lam_d, float *returns)
+{
+    /* python scalars: gamma -> float32 when multiplied into a tensor; gamma*gae_lambda is a python (double) product first */
+    const float gamma = (float)gamma_d, gl = (float)(gamma_d * lam_d);
+    for (int n = 0; n < N; ++n) {
+        float gae = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            const float delta = rewards[t * N + n] + gamma * values[(t + 1) * N + n] * masks[(t + 1) * N + n] - values[t * N + n];
+            gae = delta + gl * masks[(t + 1) * N + n] * gae;
+            returns[t * N + n] = gae + values[t * N + n];
+        }
+    }
+}

@@ -1,0 +1,169 @@
+/*
+ * crowdsim_oracle.h -- CPU restatement (plain C, scalar, one env at a time) of the CrowdNav++
+ * simulator hot path.  THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The shipped HIP path
+ * (crowdnav_prediction_attngraph_amd/csrc) never links, imports or calls anything in oracle/.
+ *
+ * What it restates (reference file:line, all under /root/reference):
+ *   - numpy legacy RandomState stream (MT19937 init_genrand / random_sample / uniform)
+ *       used by crowd_sim/envs/crowd_sim_var_num.py:338 (np.random.seed) and the draws at
+ *       :98, :122-126, crowd_sim/envs/utils/agent.py:21-22,49-50, crowd_sim/envs/crowd_sim.py:418-431
+ *   - scenario generation: crowd_sim_var_num.py:64-146 (generate_robot_humans,
+ *       generate_circle_crossing_human), reset :303-363
+ *   - per-step logic: crowd_sim_var_num.py:366-460 (step), :465-561 (calc_reward),
+ *       :233-279 (generate_ob); crowd_sim.py:513-572 (detect_visible/get_num_human_in_fov),
+ *       :243-273 (update_last_human_states), :415-450 (update_human_goals_randomly),
+ *       :680-703 (get_human_actions); crowd_nav/policy/srnn.py:17-34 (clip_action);
+ *       crowd_sim/envs/utils/agent.py:143-183 (holonomic kinematics)
+ *   - CrowdSimPred-v0 (const_vel predictor): crowd_sim_pred.py:62-97 (generate_ob),
+ *       :216-233 (social reward); crowd_sim_var_num.py:152-228 (calc_human_future_traj)
+ *   - ORCA human policy: crowd_nav/policy/orca.py:64-117, which calls the THIRD-PARTY library
+ *       rvo2 (sybrenstuvel/Python-RVO2 wrapping RVO2 Library v2.0.2 -- NOT vendored in
+ *       /root/reference, no version pinned in requirements.txt).  The ORCA arithmetic below is a
+ *       restatement of the published RVO2 v2.0.2 algorithm (Agent::computeNeighbors /
+ *       computeNewVelocity / linearProgram1-3, fp32, RVO_EPSILON=1e-5).  PARITY UNPINNED for this
+ *       one function: the reference holds no test or golden vector for rvo2 output; it is anchored
+ *       on the reference's call sites (orca.py:80-114) and defended by property tests.
+ *   - vec-env wrapper semantics: rl/networks/shmem_vec_env.py:136-142 (auto-reset on done),
+ *       rl/networks/envs.py:49-58 (thisSeed = seed + rank, nenv, phase)
+ *   - rollout math: rl/networks/storage.py:123-132 (GAE), rl/ppo/ppo.py:37-39 (advantage norm)
+ *
+ * Everything outside ORCA is pinned against golden vectors captured by importing the Python
+ * reference in the build container (tests/golden/make_golden.py -> tests/golden/ npz files).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  -ffp-contract=off is
+ * part of the semantics: rvo2 wheels are built for baseline x86-64 (no FMA).
+ */
+#ifndef CROWDSIM_ORACLE_H
+#define CROWDSIM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_HUMANS 64
+#define ORC_MAX_PRED 8
+
+enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
+enum { ORC_PHASE_TRAIN = 0, ORC_PHASE_VAL = 1, ORC_PHASE_TEST = 2 };
+/* episode info codes, crowd_sim/envs/utils/info.py */
+enum { ORC_INFO_NOTHING = 0, ORC_INFO_TIMEOUT = 1, ORC_INFO_COLLISION = 2, ORC_INFO_REACHGOAL = 3, ORC_INFO_DANGER = 4 };
+
+typedef struct {
+    int32_t human_num;            /* config.sim.human_num (human_num_range must be 0) */
+    int32_t predict_steps;        /* config.sim.predict_steps */
+    int32_t env_kind;             /* ORC_ENV_* */
+    int32_t randomize_attributes; /* config.env.randomize_attributes */
+    int32_t random_goal_changing; /* config.humans.random_goal_changing */
+    int32_t end_goal_changing;    /* config.humans.end_goal_changing */
+    int32_t sort_humans;          /* config.args.sort_humans */
+    int32_t phase;                /* ORC_PHASE_* */
+    int32_t nenv;                 /* env.nenv (case_counter stride), envs.py:54 */
+    uint32_t val_size, test_size; /* config.env.val_size/test_size */
+    double time_step, time_limit;
+    double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
+    double circle_radius, arena_size;
+    double human_radius, human_v_pref;
+    double robot_radius, robot_v_pref, sensor_range;
+    double goal_change_chance, end_goal_change_chance;
+    double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
+} OrcConfig;
+
+typedef struct {
+    uint32_t key[624];
+    int32_t pos;
+} OrcMT;
+
+typedef struct {
+    double px, py, vx, vy, gx, gy, radius, v_pref;
+} OrcHuman;
+
+typedef struct OrcEnv {
+    OrcConfig cfg;
+    int64_t this_seed;
+    uint64_t case_counter[3];
+    OrcMT rng;
+    uint64_t rng_draws;            /* number of 32-bit words consumed since the last seed */
+    /* robot */
+    double rpx, rpy, rvx, rvy, rgx, rgy, rtheta;
+    OrcHuman humans[ORC_MAX_HUMANS];
+    /* per-observer ORCA simulator state (orca.py:80-89: sim built lazily, radii frozen at addAgent) */
+    int32_t sim_valid[ORC_MAX_HUMANS];
+    float sim_nd[ORC_MAX_HUMANS];       /* neighborDist of human i's private simulator */
+    float sim_self_radius[ORC_MAX_HUMANS];
+    float sim_self_maxspeed[ORC_MAX_HUMANS];
+    float sim_seen_radius[ORC_MAX_HUMANS][ORC_MAX_HUMANS]; /* [observer][other] */
+    double shared_neighbor_dist;   /* config.orca.neighbor_dist (class attribute, agent.py:21-22) */
+    /* robot belief */
+    double last_human_states[ORC_MAX_HUMANS][5];
+    int32_t human_visibility[ORC_MAX_HUMANS];
+    double future_traj[ORC_MAX_PRED + 1][ORC_MAX_HUMANS][2]; /* const_vel predictions (positions) */
+    double potential;
+    int32_t step_counter;          /* global_time == step_counter * time_step */
+    /* bench.Monitor stand-in (envs.py:70-73) */
+    double ep_return;
+    int32_t ep_len;
+    /* last human actions (diagnostics for tests) */
+    float last_human_actions[ORC_MAX_HUMANS][2];
+} OrcEnv;
+
+/* observation of one env, float32 as produced after the vec-env cast (shmem_vec_env.py:124-129) */
+typedef struct {
+    float robot_node[7];
+    float temporal_edges[2];
+    float spatial_edges[ORC_MAX_HUMANS * 2 * (ORC_MAX_PRED + 1)]; /* [H][D] packed */
+    float detected_human_num;
+    uint8_t visible_masks[ORC_MAX_HUMANS];
+} OrcObs;
+
+/* ---- RNG ---- */
+void orc_mt_seed(OrcMT *mt, uint32_t seed);
+uint32_t orc_mt_next(OrcMT *mt);
+double orc_mt_double(OrcMT *mt);
+
+/* ---- deterministic sin/cos on [0, 2*pi) (shared algorithm with the HIP path) ---- */
+void orc_sincos(double x, double *s, double *c);
+
+/* ---- ORCA (RVO2 v2.0.2 semantics, fp32) ----
+ * Computes agent 0's new velocity given n_other other agents (already in the observer's order).
+ * pos/vel/radius arrays are for the others.  Returns number of ORCA lines built. */
+int orc_orca_velocity(float self_px, float self_py, float self_vx, float self_vy, float self_radius,
+                      float max_speed, float pref_vx, float pref_vy, float neighbor_dist,
+                      int max_neighbors, float time_horizon, float time_step, int n_other,
+                      const float *opx, const float *opy, const float *ovx, const float *ovy,
+                      const float *oradius, float *out_vx, float *out_vy, float *lines_out /* optional [n][4] */,
+                      int *line_fail_out /* optional */);
+
+/* ---- environment ---- */
+void orc_config_default(OrcConfig *cfg);
+void orc_env_init(OrcEnv *env, const OrcConfig *cfg, int64_t this_seed);
+void orc_env_reset(OrcEnv *env, OrcObs *obs);
+/* raw single-env step (no auto-reset): returns done */
+int orc_env_step(OrcEnv *env, const float action[2], OrcObs *obs, double *reward, int *info, double *danger_min_dist);
+/* vec-env style step: auto-reset on done, obs replaced by reset obs; ep_* receive Monitor output */
+int orc_env_step_autoreset(OrcEnv *env, const float action[2], OrcObs *obs, double *reward, int *info,
+                           double *ep_return, int *ep_len);
+int orc_obs_width(const OrcConfig *cfg);
+
+/* flat helpers for ctypes */
+OrcEnv *orc_env_new(const OrcConfig *cfg, int64_t this_seed);
+void orc_env_free(OrcEnv *env);
+int orc_sizeof_env(void);
+int orc_sizeof_obs(void);
+int orc_sizeof_config(void);
+
+/* batched convenience used by the CPU baseline: steps envs [0,n) sequentially (one thread) */
+void orc_env_batch_step(OrcEnv **envs, int n, const float *actions /*[n][2]*/, float *robot_node, float *temporal_edges,
+                        float *spatial_edges, float *detected, uint8_t *visible, float *rewards, uint8_t *dones,
+                        uint8_t *infos);
+
+/* ---- rollout math (storage.py:123-132, ppo.py:37-39), fp32 like torch ---- */
+void orc_gae(int T, int N, const float *rewards /*[T][N]*/, const float *values /*[T+1][N]*/, const float *masks /*[T+1][N]*/,
+             double gamma, double lam, float *returns /*[T+1][N], last row untouched*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the *Python reference* (build container only).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures are data only (inputs + the reference's outputs).  The reference itself never ships.
+See _ref_import.py for the import recipe and the rvo2 caveat (ORCA arithmetic comes from the oracle's
+RVO2 restatement because rvo2 is not available; everything around it is the reference's own Python).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import as R  # noqa: E402
+
+_ARGV = sys.argv[1:]
+R.install()
+
+INFO_CODE = {"Nothing": 0, "Timeout": 1, "Collision": 2, "ReachGoal": 3, "Danger": 4}
+
+
+def info_code(obj):
+    return INFO_CODE[type(obj).__name__]
+
+
+def make_env(env_name, cfg, seed, rank, nenv):
+    import crowd_sim.envs as E
+
+    cls = {"CrowdSimVarNum-v0": E.CrowdSimVarNum, "CrowdSimPred-v0": E.CrowdSimPred,
+           "CrowdSimPredRealGST-v0": E.CrowdSimPredRealGST}[env_name]
+    env = cls()
+    env.configure(cfg)
+    # rl/networks/envs.py:49-58
+    env.thisSeed = seed + rank
+    env.nenv = nenv
+    env.phase = "train" if nenv > 1 else "test"
+    return env
+
+
+def cast_obs(ob, H):
+    """What the vec-env does: copy into float32 / bool shared buffers (shmem_vec_env.py:124-129)."""
+    out = {
+        "robot_node": np.asarray(ob["robot_node"], dtype=np.float32).reshape(1, 7),
+        "temporal_edges": np.asarray(ob["temporal_edges"], dtype=np.float32).reshape(1, 2),
+        "spatial_edges": np.asarray(ob["spatial_edges"], dtype=np.float32),
+        "detected_human_num": np.asarray([ob["detected_human_num"]], dtype=np.float32),
+    }
+    if "visible_masks" in ob:
+        out["visible_masks"] = np.asarray(ob["visible_masks"], dtype=bool)
+    else:
+        out["visible_masks"] = np.zeros(H, dtype=bool)
+    return out
+
+
+def action_for(env, t, ep, rank):
+    """Deterministic action script (never touches the global numpy RNG the env uses)."""
+    gx, gy = env.robot.gx - env.robot.px, env.robot.gy - env.robot.py
+    n = max(np.hypot(gx, gy), 1e-9)
+    mode = (ep + rank) % 4
+    if mode == 0:    # goal seeking, over-speed (exercises clip_action)
+        a = np.array([1.7 * gx / n, 1.7 * gy / n])
+    elif mode == 1:  # goal seeking with a wobble
+        a = np.array([0.9 * gx / n + 0.5 * np.sin(0.37 * t), 0.9 * gy / n + 0.5 * np.cos(0.23 * t)])
+    elif mode == 2:  # slow drift -> timeouts / danger
+        a = np.array([0.12 * np.sin(0.11 * t + rank), 0.12 * np.cos(0.07 * t)])
+    else:            # head for the centre then the goal
+        a = np.array([-0.8 * env.robot.px / 6.0 + 0.5 * gx / n, -0.8 * env.robot.py / 6.0 + 0.5 * gy / n])
+    return a.astype(np.float32)
+
+
+def trace(env_name, over, seed, rank, nenv, steps, tag):
+    cfg = R.make_config(**over)
+    cfg.args.env_name = env_name
+    env = make_env(env_name, cfg, seed, rank, nenv)
+    H = cfg.sim.human_num
+    rec = {k: [] for k in ("actions", "reward", "done", "info", "ep_return", "ep_len", "robot_state", "human_state",
+                           "robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks",
+                           "human_action")}
+    ob0 = cast_obs(env.reset(), H)
+    init_humans = np.array([[h.px, h.py, h.vx, h.vy, h.gx, h.gy, h.radius, h.v_pref] for h in env.humans])
+    init_robot = np.array(env.robot.get_full_state_list(), dtype=np.float64)
+    ep, ep_ret, ep_len = 0, 0.0, 0
+    rets = []
+    for t in range(steps):
+        a = action_for(env, t, ep, rank)
+        rec["actions"].append(a.copy())
+        pre = np.array([[h.px, h.py] for h in env.humans])
+        ob, reward, done, info = env.step(a.copy())
+        # human actions = displacement / dt is lossy; read velocities of humans that were not respawned instead
+        rec["human_action"].append(np.array([[h.vx, h.vy] for h in env.humans], dtype=np.float64))
+        rets.append(reward)
+        ep_len += 1
+        code = info_code(info["info"])
+        if done:
+            ep_ret = round(sum(rets), 6)
+            rec["ep_return"].append(ep_ret)
+            rec["ep_len"].append(ep_len)
+            ob = env.reset()
+            rets, ep_len = [], 0
+            ep += 1
+        else:
+            rec["ep_return"].append(np.nan)
+            rec["ep_len"].append(0)
+        ob = cast_obs(ob, H)
+        for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks"):
+            rec[k].append(ob[k])
+        rec["reward"].append(np.float32(reward))
+        rec["done"].append(bool(done))
+        rec["info"].append(code)
+        rec["robot_state"].append(np.array(env.robot.get_full_state_list(), dtype=np.float64))
+        rec["human_state"].append(np.array([[h.px, h.py, h.gx, h.gy, h.radius, h.v_pref] for h in env.humans]))
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["reward64"] = np.array([float(x) for x in rec["reward"]])
+    for k, v in ob0.items():
+        out["reset_" + k] = v
+    out["init_humans"] = init_humans
+    out["init_robot"] = init_robot
+    out["meta"] = np.array(json.dumps(dict(env_name=env_name, over=over, seed=seed, rank=rank, nenv=nenv, steps=steps,
+                                           sort_humans=bool(cfg.args.sort_humans))))
+    path = os.path.join(HERE, "env_%s.npz" % tag)
+    np.savez_compressed(path, **out)
+    dn = int(np.sum(out["done"]))
+    print("%-28s steps=%d episodes=%d infos=%s  -> %s (%.0f KB)" % (
+        tag, steps, dn, np.bincount(out["info"], minlength=5).tolist(), os.path.basename(path), os.path.getsize(path) / 1024))
+
+
+NON_RAND = {"env.randomize_attributes": False, "humans.random_goal_changing": False, "humans.end_goal_changing": True,
+            "sim.predict_method": "none", "env.use_wrapper": False}
+RAND = {"env.randomize_attributes": True, "humans.random_goal_changing": True, "humans.end_goal_changing": True,
+        "sim.predict_method": "none", "env.use_wrapper": False}
+
+
+def env_goldens():
+    for rank in (0, 1):
+        trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20}), 425, rank, 4, 320, "varnum_h20_nonrand_r%d" % rank)
+    for rank in (0, 3):
+        trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 5}), 425, rank, 4, 420, "varnum_h5_rand_r%d" % rank)
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 50}), 425, 2, 8, 130, "varnum_h50_rand_r2")
+    for rank in (0, 1):
+        trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 20, "sim.predict_method": "const_vel"}), 425, rank, 4,
+              260, "pred_h20_constvel_r%d" % rank)
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 10, "sim.predict_method": "const_vel"}), 77, 1, 2, 200,
+          "pred_h10_rand_r1")
+    trace("CrowdSimPredRealGST-v0", dict(NON_RAND, **{"sim.human_num": 20, "sim.predict_method": "inferred"}), 425, 0, 4,
+          140, "predgst_h20_r0")
+
+
+if __name__ == "__main__":
+    what = _ARGV or ["env"]
+    if "env" in what:
+        env_goldens()
+    if "policy" in what:
+        import make_golden_policy
+        make_golden_policy.main()

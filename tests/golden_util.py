@@ -1,0 +1,34 @@
+"""Shared helpers for the golden-vector tests (fixtures were produced by tests/golden/make_golden.py)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ENV_KIND = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
+
+
+def env_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return z, meta
+
+
+def sim_kwargs(meta):
+    """Reference config overrides -> the flat keyword set both the oracle and the HIP env understand."""
+    over = meta["over"]
+    return dict(
+        human_num=int(over.get("sim.human_num", 20)),
+        env_kind=ENV_KIND[meta["env_name"]],
+        randomize_attributes=int(bool(over.get("env.randomize_attributes", True))),
+        random_goal_changing=int(bool(over.get("humans.random_goal_changing", True))),
+        end_goal_changing=int(bool(over.get("humans.end_goal_changing", True))),
+        sort_humans=int(bool(meta.get("sort_humans", True))),
+        nenv=int(meta["nenv"]),
+        phase=0 if meta["nenv"] > 1 else 2,
+    )

@@ -1,0 +1,56 @@
+"""Pin the CPU oracle against golden vectors captured from the Python reference.
+
+Bar: flags / indices / sort order exact; float32 observations equal to <= 1e-6 (the oracle's sin/cos is its own
+deterministic <=1ulp(fp64) implementation, numpy's is libm -- see DESIGN.md); fp64 state <= 1e-9.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import golden_util as G
+
+
+def test_mt19937_matches_numpy_legacy_stream():
+    for seed in (0, 425, 2425, 2 ** 32 - 1):
+        np.random.seed(seed)
+        ref = [np.random.random() for _ in range(1500)]  # crosses two twist boundaries
+        m = O.MT(seed)
+        assert ref == [m.random() for _ in range(1500)]
+
+
+def test_sincos_accuracy():
+    xs = np.linspace(0.0, 2 * np.pi, 20001)
+    got = np.array([O.sincos(x) for x in xs])
+    assert np.max(np.abs(got[:, 0] - np.sin(xs))) <= 2.3e-16
+    assert np.max(np.abs(got[:, 1] - np.cos(xs))) <= 2.3e-16
+
+
+@pytest.mark.parametrize("path", G.env_fixtures(), ids=lambda p: p.split("env_")[-1][:-4])
+def test_env_trace_matches_reference(path):
+    z, meta = G.load(path)
+    cfg = O.default_config(**G.sim_kwargs(meta))
+    env = O.OracleEnv(cfg, meta["seed"] + meta["rank"])
+    ob = env.reset()
+    for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num"):
+        np.testing.assert_allclose(ob[k], z["reset_" + k], rtol=0, atol=1e-6, err_msg="reset " + k)
+    has_masks = meta["env_name"] != "CrowdSimPred-v0"  # CrowdSimPred's obs dict has no visible_masks key
+    if has_masks:
+        np.testing.assert_array_equal(ob["visible_masks"], z["reset_visible_masks"])
+    T = len(z["done"])
+    n_bit_equal = n_vals = 0
+    for t in range(T):
+        ob, r, done, info = env.step(z["actions"][t], autoreset=True)
+        assert done == bool(z["done"][t]), "done @%d" % t
+        assert info["info"] == int(z["info"][t]), "info @%d" % t
+        assert np.float32(r) == pytest.approx(z["reward"][t], abs=1e-6), "reward @%d" % t
+        if done:
+            assert info["episode"]["l"] == int(z["ep_len"][t])
+            assert info["episode"]["r"] == pytest.approx(float(z["ep_return"][t]), abs=2e-6)
+        for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num"):
+            np.testing.assert_allclose(ob[k], z[k][t], rtol=0, atol=1e-6, err_msg="%s @%d" % (k, t))
+            n_bit_equal += int(np.sum(ob[k] == z[k][t]))
+            n_vals += ob[k].size
+        if has_masks:
+            np.testing.assert_array_equal(ob["visible_masks"], z["visible_masks"][t], err_msg="visible_masks @%d" % t)
+    # float32 observations are bit-identical except where a 1ulp(fp64) sin/cos difference crosses a rounding boundary
+    assert n_bit_equal / n_vals > 0.999
