@@ -1,0 +1,163 @@
+"""ctypes binding of libcrowdnav_hip.so -- the C ABI declared in include/crowdnav_hip.h.
+
+PyTorch is plumbing here (device memory, streams): tensors cross the boundary as raw device pointers
+(`tensor.data_ptr()`) plus the current HIP stream.  There is no CPU fallback: if the extension is missing,
+or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcrowdnav_hip.so")
+
+CN_MAX_HUMANS = 64
+ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
+INFO_NOTHING, INFO_TIMEOUT, INFO_COLLISION, INFO_REACHGOAL, INFO_DANGER = range(5)
+
+
+class CnError(RuntimeError):
+    pass
+
+
+class EnvConfig(C.Structure):
+    """cn_env_config (mirrors the crowd_nav/configs/config.py fields the path reads)."""
+    _fields_ = [
+        ("human_num", C.c_int32), ("predict_steps", C.c_int32), ("env_kind", C.c_int32),
+        ("randomize_attributes", C.c_int32), ("random_goal_changing", C.c_int32),
+        ("end_goal_changing", C.c_int32), ("sort_humans", C.c_int32), ("phase", C.c_int32),
+        ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32),
+        ("time_step", C.c_double), ("time_limit", C.c_double),
+        ("success_reward", C.c_double), ("collision_penalty", C.c_double),
+        ("discomfort_dist", C.c_double), ("discomfort_penalty_factor", C.c_double),
+        ("circle_radius", C.c_double), ("arena_size", C.c_double),
+        ("human_radius", C.c_double), ("human_v_pref", C.c_double),
+        ("robot_radius", C.c_double), ("robot_v_pref", C.c_double), ("sensor_range", C.c_double),
+        ("goal_change_chance", C.c_double), ("end_goal_change_chance", C.c_double),
+        ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
+        ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
+    ]
+
+
+class Obs(C.Structure):
+    _fields_ = [("robot_node", C.c_void_p), ("temporal_edges", C.c_void_p), ("spatial_edges", C.c_void_p),
+                ("detected_human_num", C.c_void_p), ("visible_masks", C.c_void_p)]
+
+
+# order == field order of cn_policy_weights; values == reference state_dict keys
+POLICY_WEIGHT_KEYS = [
+    ("robot_linear_w", "base.robot_linear.0.weight"), ("robot_linear_b", "base.robot_linear.0.bias"),
+    ("emb0_w", "base.spatial_attn.embedding_layer.0.weight"), ("emb0_b", "base.spatial_attn.embedding_layer.0.bias"),
+    ("emb2_w", "base.spatial_attn.embedding_layer.2.weight"), ("emb2_b", "base.spatial_attn.embedding_layer.2.bias"),
+    ("q_w", "base.spatial_attn.q_linear.weight"), ("q_b", "base.spatial_attn.q_linear.bias"),
+    ("k_w", "base.spatial_attn.k_linear.weight"), ("k_b", "base.spatial_attn.k_linear.bias"),
+    ("v_w", "base.spatial_attn.v_linear.weight"), ("v_b", "base.spatial_attn.v_linear.bias"),
+    ("in_proj_w", "base.spatial_attn.multihead_attn.in_proj_weight"), ("in_proj_b", "base.spatial_attn.multihead_attn.in_proj_bias"),
+    ("out_proj_w", "base.spatial_attn.multihead_attn.out_proj.weight"), ("out_proj_b", "base.spatial_attn.multihead_attn.out_proj.bias"),
+    ("spatial_linear_w", "base.spatial_linear.0.weight"), ("spatial_linear_b", "base.spatial_linear.0.bias"),
+    ("attn_temporal_w", "base.attn.temporal_edge_layer.0.weight"), ("attn_temporal_b", "base.attn.temporal_edge_layer.0.bias"),
+    ("attn_spatial_w", "base.attn.spatial_edge_layer.0.weight"), ("attn_spatial_b", "base.attn.spatial_edge_layer.0.bias"),
+    ("enc_w", "base.humanNodeRNN.encoder_linear.weight"), ("enc_b", "base.humanNodeRNN.encoder_linear.bias"),
+    ("edge_embed_w", "base.humanNodeRNN.edge_attention_embed.weight"), ("edge_embed_b", "base.humanNodeRNN.edge_attention_embed.bias"),
+    ("gru_w_ih", "base.humanNodeRNN.gru.weight_ih_l0"), ("gru_w_hh", "base.humanNodeRNN.gru.weight_hh_l0"),
+    ("gru_b_ih", "base.humanNodeRNN.gru.bias_ih_l0"), ("gru_b_hh", "base.humanNodeRNN.gru.bias_hh_l0"),
+    ("out_w", "base.humanNodeRNN.output_linear.weight"), ("out_b", "base.humanNodeRNN.output_linear.bias"),
+    ("actor0_w", "base.actor.0.weight"), ("actor0_b", "base.actor.0.bias"),
+    ("actor2_w", "base.actor.2.weight"), ("actor2_b", "base.actor.2.bias"),
+    ("critic0_w", "base.critic.0.weight"), ("critic0_b", "base.critic.0.bias"),
+    ("critic2_w", "base.critic.2.weight"), ("critic2_b", "base.critic.2.bias"),
+    ("critic_linear_w", "base.critic_linear.weight"), ("critic_linear_b", "base.critic_linear.bias"),
+    ("fc_mean_w", "dist.fc_mean.weight"), ("fc_mean_b", "dist.fc_mean.bias"),
+    ("logstd", "dist.logstd._bias"),
+]
+
+
+class PolicyWeights(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in POLICY_WEIGHT_KEYS]
+
+
+# every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
+ABI_SYMBOLS = [
+    "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
+    "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_orca_solve",
+    "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
+    "cn_policy_get_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension (fails loudly if it was not built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CnError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C crowdnav_prediction_attngraph_amd/csrc)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+        L.cn_last_error.restype = C.c_char_p
+        L.cn_env_config_default.argtypes = [C.POINTER(EnvConfig)]
+        L.cn_env_config_default.restype = None
+        L.cn_env_create.argtypes = [C.POINTER(EnvConfig), i32, i64, i64, C.POINTER(vp)]
+        L.cn_env_destroy.argtypes = [vp]
+        L.cn_env_obs_width.argtypes = [C.POINTER(EnvConfig)]
+        L.cn_env_reset.argtypes = [vp, C.POINTER(Obs), vp]
+        L.cn_env_step.argtypes = [vp, vp, C.POINTER(Obs), vp, vp, vp, vp, vp, vp]
+        L.cn_env_get_state.argtypes = [vp, vp, vp, vp]
+        L.cn_env_get_human_actions.argtypes = [vp, vp, vp]
+        L.cn_orca_solve.argtypes = [i32, i32, vp, vp, f32, i32, f32, f32, vp, vp]
+        L.cn_policy_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+        L.cn_policy_destroy.argtypes = [vp]
+        L.cn_policy_set_weights.argtypes = [vp, C.POINTER(PolicyWeights), vp]
+        L.cn_policy_act.argtypes = [vp, i32, C.POINTER(Obs), vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cn_policy_get_value.argtypes = [vp, i32, C.POINTER(Obs), vp, vp, vp, vp]
+        L.cn_policy_get_taps.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        L.cn_policy_set_profiling.argtypes = [vp, i32]
+        L.cn_policy_get_profile.argtypes = [vp, C.POINTER(f64), C.POINTER(i64)]
+        L.cn_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp]
+        L.cn_adv_stats.argtypes = [i64, vp, vp, vp, vp]
+        L.cn_adv_normalize.argtypes = [i64, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cn_last_error()
+        raise CnError("%s failed (status %d): %s" % (what or "libcrowdnav_hip call", rc, msg.decode() if msg else ""))
+
+
+def default_env_config(**over):
+    cfg = EnvConfig()
+    lib().cn_env_config_default(C.byref(cfg))
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise AttributeError("cn_env_config has no field %r" % k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise CnError("tensor must live on the GPU (no CPU fallback)")
+    if not t.is_contiguous():
+        raise CnError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def obs_struct(obs):
+    o = Obs()
+    o.robot_node = ptr(obs["robot_node"])
+    o.temporal_edges = ptr(obs["temporal_edges"])
+    o.spatial_edges = ptr(obs["spatial_edges"])
+    o.detected_human_num = ptr(obs["detected_human_num"])
+    o.visible_masks = ptr(obs.get("visible_masks"))
+    return o

@@ -1,0 +1,70 @@
+// Shared host/device helpers for libcrowdnav_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "crowdnav_hip.h"
+
+void cn_set_error(const char *fmt, ...);
+
+#define CN_HIP(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t cn_e_ = (expr);                                                                           \
+        if (cn_e_ != hipSuccess) {                                                                           \
+            cn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(cn_e_), __FILE__, __LINE__);      \
+            return CN_ERR_HIP;                                                                               \
+        }                                                                                                    \
+    } while (0)
+
+#define CN_CHECK_LAUNCH() CN_HIP(hipGetLastError())
+
+#define CN_REQUIRE(cond, ...)               \
+    do {                                    \
+        if (!(cond)) {                      \
+            cn_set_error(__VA_ARGS__);      \
+            return CN_ERR_INVALID;          \
+        }                                   \
+    } while (0)
+
+int cn_require_device();
+
+#define CN_WAVE 64
+
+// ---- wave-level primitives (64 lanes) ----
+__device__ __forceinline__ float wv_readlane(float x, int lane_uniform)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane_uniform));
+}
+__device__ __forceinline__ float wv_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wv_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wv_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wv_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wv_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

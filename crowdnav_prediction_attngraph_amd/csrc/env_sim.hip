@@ -1,0 +1,919 @@
+// env_sim.hip -- batched CrowdNav++ simulator on gfx950: ORCA humans, reward / termination, observation assembly,
+// numpy-compatible scenario generation and auto-reset, all device resident.
+//
+// Compile with -ffp-contract=off: ORCA follows RVO2's fp32 operation order (no FMA), positions are fp64 like the
+// Python reference, so results are reproducible bit for bit against the scalar CPU restatement used by the tests.
+//
+// Mapping (one wavefront = 64 lanes everywhere in this file; a lane is a human):
+//   orca_kernel      one wavefront per (env, human i): lanes = the other humans.  Lanes build their ORCA half-plane
+//                    in parallel, a rank sort orders them by distance, and the linear programs run wave-cooperatively
+//                    (outer loop over lines is the serial dependence of RVO2's LP; the inner clip of a line against all
+//                    earlier lines is one lane-parallel min/max reduction).
+//   env_step_kernel  one wavefront per env: robot clip + reward/collision (lane-parallel distances, ballot/any),
+//                    kinematics, visibility, belief update, distance rank sort + observation scatter, goal changes,
+//                    respawns and the in-launch auto-reset.  The MT19937 stream of the env lives in HBM ([E][624]) and
+//                    is staged into LDS only by the (rare) wavefronts that draw from it; the 624-word twist is
+//                    lane-parallel.
+// Reference semantics (file:line under the reference repo) are cited at each block.
+#include "common.h"
+
+#include <cmath>
+#include <new>
+
+namespace {
+
+constexpr int MT_N = 624;
+constexpr float RVO_EPS = 0.00001f;
+
+struct EnvDev {
+    cn_env_config cfg;
+    int E, H, D, P;
+    int64_t seed_base; // thisSeed of env 0 of this batch
+    // humans [E][8][H] double: px,py,vx,vy,gx,gy,radius,v_pref
+    double *hum;
+    // robot [E][8] double: px,py,vx,vy,gx,gy,theta,potential
+    double *rob;
+    double *lhs;   // last_human_states [E][5][H]
+    double *ftraj; // [E][P][2][H] predicted positions k=1..P (const_vel), only for CN_ENV_PRED
+    int32_t *step_counter; // [E]
+    uint64_t *case_counter; // [E]
+    double *ep_ret;         // [E] running episode return
+    int32_t *ep_cnt;        // [E] running episode length
+    double *shared_nd;      // [E] config.orca.neighbor_dist
+    uint8_t *sim_valid;     // [E][H]
+    float *sim_nd, *sim_self_radius, *sim_self_maxspeed; // [E][H]
+    float *sim_seen; // [E][H][H] or nullptr (non-randomised: radii never change)
+    uint32_t *mt;    // [E][624]
+    int32_t *mt_pos; // [E]
+    float *hact;     // [E][2][H] ORCA velocities of this step
+};
+
+enum { F_PX = 0, F_PY, F_VX, F_VY, F_GX, F_GY, F_RAD, F_VPREF };
+enum { R_PX = 0, R_PY, R_VX, R_VY, R_GX, R_GY, R_THETA, R_POT };
+
+// ------------------------------------------------------------------------------------------------------------------
+// deterministic sin/cos on [0, 2*pi]: Cody-Waite reduction by pi/2 + minimax kernels, +,-,* only.  Stands in for
+// np.cos/np.sin (crowd_sim_var_num.py:127-128); documented in DESIGN.md (<= 1 ulp from libm).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double poly_sin(double x)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, w = z * z;
+    const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double v = z * x;
+    return x + v * (S1 + z * r);
+}
+__device__ __forceinline__ double poly_cos(double x)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    double w = z * z;
+    const double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z;
+    w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + z * r);
+}
+__device__ __forceinline__ void det_sincos(double x, double &s, double &c)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
+                 PIO2_1T = 6.07710050650619224932e-11;
+    const int k = (int)(x * INV_PIO2 + 0.5);
+    const double fk = (double)k;
+    const double r = (x - fk * PIO2_1) - fk * PIO2_1T;
+    const double sr = poly_sin(r), cr = poly_cos(r);
+    switch (k & 3) {
+    case 0: s = sr; c = cr; break;
+    case 1: s = cr; c = -sr; break;
+    case 2: s = -sr; c = -cr; break;
+    default: s = -cr; c = sr; break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-cooperative RVO2 linear programs.  Lane k holds line k = (point, direction); `valid` marks live lines
+// (bit k).  All scalars (result, t bounds, ...) are wave-uniform: every lane computes them identically.
+// RVO2 v2.0.2 Agent.cpp linearProgram1/2/3; call site crowd_nav/policy/orca.py:113 (doStep).
+// ------------------------------------------------------------------------------------------------------------------
+struct LpLine { float px, py, dx, dy; };
+
+__device__ __forceinline__ bool wv_any(bool p) { return __ballot(p) != 0ull; }
+
+// Optimise along line i subject to the disc and to every earlier valid line (lane-parallel clip).  Returns success.
+__device__ __forceinline__ bool lp1_wave(const LpLine &L, uint64_t valid, int i, float ipx, float ipy, float idx, float idy,
+                                         float radius, float optx, float opty, bool dirOpt, int lane, float &rx, float &ry)
+{
+    const float dotProduct = ipx * idx + ipy * idy;
+    const float discriminant = dotProduct * dotProduct + radius * radius - (ipx * ipx + ipy * ipy);
+    if (discriminant < 0.0f) return false;
+    const float sq = sqrtf(discriminant);
+    float tLeft = -dotProduct - sq;
+    float tRight = -dotProduct + sq;
+    const bool mine = lane < i && ((valid >> lane) & 1ull);
+    const float denominator = idx * L.dy - idy * L.dx;
+    const float numerator = L.dx * (ipy - L.py) - L.dy * (ipx - L.px);
+    const bool parallel = fabsf(denominator) <= RVO_EPS;
+    const bool pfail = mine && parallel && numerator < 0.0f;
+    const float t = numerator / denominator;
+    const float candR = (mine && !parallel && denominator >= 0.0f) ? t : INFINITY;
+    const float candL = (mine && !parallel && denominator < 0.0f) ? t : -INFINITY;
+    tRight = fminf(tRight, wv_min(candR));
+    tLeft = fmaxf(tLeft, wv_max(candL));
+    // sequential RVO2 fails at the first prefix with tLeft > tRight or a parallel infeasible line; bounds are monotone,
+    // so "any prefix fails" == "final bounds cross or any parallel line fails".
+    if (wv_any(pfail) || tLeft > tRight) return false;
+    float t_opt;
+    if (dirOpt) {
+        t_opt = (optx * idx + opty * idy > 0.0f) ? tRight : tLeft;
+    } else {
+        const float tt = idx * (optx - ipx) + idy * (opty - ipy);
+        t_opt = tt < tLeft ? tLeft : (tt > tRight ? tRight : tt);
+    }
+    rx = ipx + t_opt * idx;
+    ry = ipy + t_opt * idy;
+    return true;
+}
+
+// Returns n on success, else the index of the line that failed.
+__device__ __forceinline__ int lp2_wave(const LpLine &L, uint64_t valid, int n, float radius, float optx, float opty,
+                                        bool dirOpt, int lane, float &rx, float &ry)
+{
+    if (dirOpt) {
+        rx = radius * optx; ry = radius * opty;
+    } else if (optx * optx + opty * opty > radius * radius) {
+        const float inv = 1.0f / sqrtf(optx * optx + opty * opty);
+        rx = radius * (optx * inv); ry = radius * (opty * inv);
+    } else {
+        rx = optx; ry = opty;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!((valid >> i) & 1ull)) continue;
+        const float ipx = wv_readlane(L.px, i), ipy = wv_readlane(L.py, i);
+        const float idx = wv_readlane(L.dx, i), idy = wv_readlane(L.dy, i);
+        if (idx * (ipy - ry) - idy * (ipx - rx) > 0.0f) {
+            const float tx = rx, ty = ry;
+            if (!lp1_wave(L, valid, i, ipx, ipy, idx, idy, radius, optx, opty, dirOpt, lane, rx, ry)) {
+                rx = tx; ry = ty;
+                return i;
+            }
+        }
+    }
+    return n;
+}
+
+__device__ __forceinline__ void lp3_wave(const LpLine &L, int n, int beginLine, float radius, int lane, float &rx, float &ry)
+{
+    float distance = 0.0f;
+    for (int i = beginLine; i < n; ++i) {
+        const float ipx = wv_readlane(L.px, i), ipy = wv_readlane(L.py, i);
+        const float idx = wv_readlane(L.dx, i), idy = wv_readlane(L.dy, i);
+        if (idx * (ipy - ry) - idy * (ipx - rx) > distance) {
+            // every lane j < i projects its line onto line i (RVO2 builds projLines sequentially; same set, same order)
+            LpLine Pj;
+            const float determinant = idx * L.dy - idy * L.dx;
+            const bool par = fabsf(determinant) <= RVO_EPS;
+            const bool skip = par && (idx * L.dx + idy * L.dy > 0.0f);
+            if (par) {
+                Pj.px = 0.5f * (ipx + L.px); Pj.py = 0.5f * (ipy + L.py);
+            } else {
+                const float s = (L.dx * (ipy - L.py) - L.dy * (ipx - L.px)) / determinant;
+                Pj.px = ipx + s * idx; Pj.py = ipy + s * idy;
+            }
+            const float ddx = L.dx - idx, ddy = L.dy - idy;
+            const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+            Pj.dx = ddx * inv; Pj.dy = ddy * inv;
+            const uint64_t pvalid = __ballot(lane < i && !skip);
+            const float tx = rx, ty = ry;
+            if (lp2_wave(Pj, pvalid, i, radius, -idy, idx, true, lane, rx, ry) < i) { rx = tx; ry = ty; }
+            distance = idx * (ipy - ry) - idy * (ipx - rx);
+        }
+    }
+}
+
+// One agent's new velocity.  Lane j < nl holds candidate neighbour j (cand == true) in index order.
+// RVO2 Agent::computeNeighbors (range filter, ascending distSq, at most maxNeighbors) + computeNewVelocity.
+__device__ __forceinline__ void orca_wave(int lane, int nl, bool cand, float opx, float opy, float ovx, float ovy, float orad,
+                                          float spx, float spy, float svx, float svy, float srad, float maxspeed, float prefx,
+                                          float prefy, float nd, int max_nb, float th, float dt, float &outx, float &outy)
+{
+    // neighbour selection: key = distSq if within range else +inf; rank by (key, index) -> stable ascending order
+    const float ddx0 = spx - opx, ddy0 = spy - opy;
+    const float dq = ddx0 * ddx0 + ddy0 * ddy0;
+    const bool inrange = cand && dq < nd * nd;
+    const float key = inrange ? dq : INFINITY;
+    int rank = 0;
+    for (int m = 0; m < nl; ++m) {
+        const float km = wv_readlane(key, m);
+        rank += (km < key || (km == key && m < lane)) ? 1 : 0;
+    }
+    if (lane >= nl) rank = lane;
+    int nn = __popcll(__ballot(inrange));
+    if (nn > max_nb) nn = max_nb;
+    // ORCA half-plane of this lane's neighbour
+    const float rpx = opx - spx, rpy = opy - spy;   // relativePosition
+    const float rvx = svx - ovx, rvy = svy - ovy;   // relativeVelocity
+    const float distSq = rpx * rpx + rpy * rpy;
+    const float cr = srad + orad;
+    const float crSq = cr * cr;
+    float ldx, ldy, ux, uy;
+    if (distSq > crSq) {
+        const float invTH = 1.0f / th;
+        const float wx = rvx - invTH * rpx, wy = rvy - invTH * rpy;
+        const float wLenSq = wx * wx + wy * wy;
+        const float dot1 = wx * rpx + wy * rpy;
+        if (dot1 < 0.0f && dot1 * dot1 > crSq * wLenSq) {
+            const float wLen = sqrtf(wLenSq);
+            const float inv = 1.0f / wLen;
+            const float uwx = wx * inv, uwy = wy * inv;
+            ldx = uwy; ldy = -uwx;
+            const float s = cr * invTH - wLen;
+            ux = s * uwx; uy = s * uwy;
+        } else {
+            const float leg = sqrtf(distSq - crSq);
+            const float invD = 1.0f / distSq;
+            if (rpx * wy - rpy * wx > 0.0f) {
+                ldx = (rpx * leg - rpy * cr) * invD;
+                ldy = (rpx * cr + rpy * leg) * invD;
+            } else {
+                ldx = -((rpx * leg + rpy * cr) * invD);
+                ldy = -((-rpx * cr + rpy * leg) * invD);
+            }
+            const float dot2 = rvx * ldx + rvy * ldy;
+            ux = dot2 * ldx - rvx; uy = dot2 * ldy - rvy;
+        }
+    } else {
+        const float invDT = 1.0f / dt;
+        const float wx = rvx - invDT * rpx, wy = rvy - invDT * rpy;
+        const float wLen = sqrtf(wx * wx + wy * wy);
+        const float inv = 1.0f / wLen;
+        const float uwx = wx * inv, uwy = wy * inv;
+        ldx = uwy; ldy = -uwx;
+        const float s = cr * invDT - wLen;
+        ux = s * uwx; uy = s * uwy;
+    }
+    const float lpx = svx + 0.5f * ux, lpy = svy + 0.5f * uy;
+    // scatter lines into sorted order: lane `rank` receives this lane's line
+    LpLine L;
+    L.px = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(lpx)));
+    L.py = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(lpy)));
+    L.dx = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(ldx)));
+    L.dy = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(ldy)));
+    const uint64_t valid = nn >= 64 ? ~0ull : ((1ull << nn) - 1ull);
+    float rx, ry;
+    const int lineFail = lp2_wave(L, valid, nn, maxspeed, prefx, prefy, false, lane, rx, ry);
+    if (lineFail < nn) lp3_wave(L, nn, lineFail, maxspeed, lane, rx, ry);
+    outx = rx; outy = ry;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ORCA for every human of every env.  crowd_sim.py:680-703 get_human_actions + crowd_nav/policy/orca.py:64-117.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
+{
+    const int lane = threadIdx.x & 63;
+    const int agent = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (agent >= s.E * s.H) return;
+    const int H = s.H;
+    const int e = agent / H, i = agent - e * H;
+    const double *hum = s.hum + (size_t)e * 8 * H;
+    const bool isH = lane < H;
+    const int lj = isH ? lane : 0;
+    const double px = hum[F_PX * H + lj], py = hum[F_PY * H + lj], vx = hum[F_VX * H + lj], vy = hum[F_VY * H + lj];
+    const double rad = hum[F_RAD * H + lj];
+    // self (lane i) values, wave-uniform
+    const double spx = __shfl(px, i, 64), spy = __shfl(py, i, 64), svx = __shfl(vx, i, 64), svy = __shfl(vy, i, 64);
+    const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i], srad = hum[F_RAD * H + i], svpref = hum[F_VPREF * H + i];
+    const double safety = s.cfg.orca_safety_space;
+    // lazily (re)build human i's private simulator: orca.py:83-89
+    const size_t ei = (size_t)e * H + i;
+    float nd, self_r, self_ms, seen_r;
+    if (!s.sim_valid[ei]) {
+        nd = (float)s.shared_nd[e];
+        self_r = (float)(srad + 0.01 + safety);
+        self_ms = (float)svpref;
+        seen_r = (float)(rad + 0.01 + safety);
+        if (s.sim_seen && isH) s.sim_seen[ei * H + lane] = seen_r;
+        if (lane == 0) {
+            s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1;
+        }
+    } else {
+        nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
+        seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + safety);
+    }
+    // other humans as seen by i (human FOV = 2*pi: always the true state unless coincident -> dummy (7,7,0,0))
+    const bool cand = isH && lane != i;
+    const bool coincident = (px == spx) && (py == spy);
+    const float opx = coincident ? 7.0f : (float)px, opy = coincident ? 7.0f : (float)py;
+    const float ovx = coincident ? 0.0f : (float)vx, ovy = coincident ? 0.0f : (float)vy;
+    // preferred velocity: orca.py:97-100
+    double gvx = sgx - spx, gvy = sgy - spy;
+    const double speed = sqrt(gvx * gvx + gvy * gvy);
+    if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
+    float ox, oy;
+    orca_wave(lane, H, cand, opx, opy, ovx, ovy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
+              (float)gvx, (float)gvy, nd, H - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
+    if (lane == 0) {
+        s.hact[(size_t)e * 2 * H + i] = ox;
+        s.hact[(size_t)e * 2 * H + H + i] = oy;
+    }
+}
+
+// stand-alone batched solve (cn_orca_solve)
+__global__ __launch_bounds__(256) void orca_solve_kernel(int B, int n_other, const float *self, const float *others, float nd,
+                                                         int max_nb, float th, float dt, float *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (b >= B) return;
+    const float *sp = self + (size_t)b * 8;
+    const bool cand = lane < n_other;
+    const float *o = others + ((size_t)b * n_other + (cand ? lane : 0)) * 5;
+    float ox, oy;
+    orca_wave(lane, n_other, cand, o[0], o[1], o[2], o[3], o[4], sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], sp[6], sp[7], nd,
+              max_nb, th, dt, ox, oy);
+    if (lane == 0) { out[2 * b] = ox; out[2 * b + 1] = oy; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MT19937 (numpy legacy RandomState) staged in LDS, wave-uniform draws.  The block is exactly one wavefront, so
+// __syncthreads() is a wave barrier.
+// ------------------------------------------------------------------------------------------------------------------
+__shared__ uint32_t g_mt_lds[MT_N]; // the block's (= the wavefront's) staged MT19937 state
+struct Rng {
+    int pos;
+    bool loaded;
+};
+
+__device__ __forceinline__ void rng_load(Rng &R, const EnvDev &s, int e, int lane)
+{
+    if (R.loaded) return;
+    for (int k = lane; k < MT_N; k += 64) g_mt_lds[k] = s.mt[(size_t)e * MT_N + k];
+    R.pos = s.mt_pos[e];
+    R.loaded = true;
+    __syncthreads();
+}
+__device__ __forceinline__ void rng_store(Rng &R, const EnvDev &s, int e, int lane)
+{
+    if (!R.loaded) return;
+    __syncthreads();
+    for (int k = lane; k < MT_N; k += 64) s.mt[(size_t)e * MT_N + k] = g_mt_lds[k];
+    if (lane == 0) s.mt_pos[e] = R.pos;
+}
+// np.random.seed(int) == init_genrand: serial recurrence, computed redundantly by all lanes (wave-uniform)
+__device__ __forceinline__ void rng_seed(Rng &R, uint32_t seed, int lane)
+{
+    __syncthreads();
+    uint32_t sd = seed;
+    for (int base = 0; base < MT_N; base += 64) {
+        uint32_t mine = 0;
+        for (int t = 0; t < 64; ++t) {
+            const int pos = base + t;
+            if (pos < MT_N) {
+                if (t == lane) mine = sd;
+                sd = 1812433253u * (sd ^ (sd >> 30)) + (uint32_t)pos + 1u;
+            }
+        }
+        if (base + lane < MT_N) g_mt_lds[base + lane] = mine;
+    }
+    R.pos = MT_N;
+    R.loaded = true;
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+// lane-parallel regeneration of the 624-word block; dependencies are at distance 227 (>= 64), so 64-wide chunks
+// processed in order reproduce the sequential recurrence exactly.
+__device__ __forceinline__ void rng_twist(Rng &R, int lane)
+{
+    uint32_t *k = g_mt_lds;
+    __syncthreads();
+    for (int base = 0; base < 227; base += 64) {
+        const int i = base + lane;
+        const bool act = i < 227;
+        uint32_t a = 0, b = 0, c = 0;
+        if (act) { a = k[i]; b = k[i + 1]; c = k[i + 397]; }
+        __syncthreads();
+        if (act) k[i] = mt_mix(a, b, c);
+        __syncthreads();
+    }
+    for (int base = 227; base < 623; base += 64) {
+        const int i = base + lane;
+        const bool act = i < 623;
+        uint32_t a = 0, b = 0, c = 0;
+        if (act) { a = k[i]; b = k[i + 1]; c = k[i - 227]; }
+        __syncthreads();
+        if (act) k[i] = mt_mix(a, b, c);
+        __syncthreads();
+    }
+    if (lane == 0) k[623] = mt_mix(k[623], k[0], k[396]);
+    __syncthreads();
+    R.pos = 0;
+}
+__device__ __forceinline__ uint32_t rng_u32(Rng &R, int lane)
+{
+    if (R.pos == MT_N) rng_twist(R, lane);
+    uint32_t y = g_mt_lds[R.pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+// random_sample(): 53-bit double from two words
+__device__ __forceinline__ double rng_double(Rng &R, int lane)
+{
+    const uint32_t a = rng_u32(R, lane) >> 5, b = rng_u32(R, lane) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+__device__ __forceinline__ double rng_uniform(Rng &R, int lane, double lo, double hi) { return lo + (hi - lo) * rng_double(R, lane); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-env wavefront state: lane j owns human j.
+// ------------------------------------------------------------------------------------------------------------------
+struct Lane {
+    double px, py, vx, vy, gx, gy, rad, vpref; // human j
+    double l0, l1, l2, l3, l4;                  // last_human_states[j]
+    uint8_t simv;
+};
+struct Robot { double px, py, vx, vy, gx, gy, theta, pot; };
+
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
+
+// crowd_sim_var_num.py:116-146 generate_circle_crossing_human (+ Agent.__init__/sample_random_attributes draws).
+// All lanes compute the candidate position identically; the min-distance test against the existing agents is
+// lane-parallel.  n_existing = number of humans currently in self.humans (slot itself included on respawn, :455).
+__device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int slot, int n_existing, const Robot &rb, Lane &h, double &shared_nd)
+{
+    const cn_env_config &c = s.cfg;
+    double radius = c.human_radius, vpref = c.human_v_pref;
+    if (c.randomize_attributes) {
+        shared_nd = rng_uniform(R, lane, 5.0, 10.0); // agent.py:21-22
+        vpref = rng_uniform(R, lane, 0.5, 1.5);      // agent.py:49
+        radius = rng_uniform(R, lane, 0.3, 0.5);     // agent.py:50
+    }
+    double px, py;
+    for (;;) {
+        const double angle = rng_double(R, lane) * M_PI * 2.0;
+        const double px_noise = rng_uniform(R, lane, 0.0, 1.0) * 2.0;
+        const double py_noise = rng_uniform(R, lane, 0.0, 1.0) * 2.0;
+        double sn, cs;
+        det_sincos(angle, sn, cs);
+        px = c.circle_radius * cs + px_noise;
+        py = c.circle_radius * sn + py_noise;
+        const double md_r = radius + c.robot_radius + c.discomfort_dist;
+        const bool coll_r = norm2(px - rb.px, py - rb.py) < md_r || norm2(px - rb.gx, py - rb.gy) < md_r;
+        const double md = radius + h.rad + c.discomfort_dist;
+        const bool coll_h = lane < n_existing && (norm2(px - h.px, py - h.py) < md || norm2(px - h.gx, py - h.gy) < md);
+        if (!(coll_r || wv_any(coll_h))) break;
+    }
+    if (lane == slot) {
+        h.px = px; h.py = py; h.gx = -px; h.gy = -py; h.vx = 0.0; h.vy = 0.0; h.rad = radius; h.vpref = vpref;
+        h.simv = 0; // new Human -> new ORCA object, sim rebuilt on next use
+    }
+}
+
+// crowd_sim.py:415-450 update_human_goals_randomly
+__device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, const Robot &rb, Lane &h)
+{
+    const cn_env_config &c = s.cfg;
+    const int H = s.H;
+    for (int i = 0; i < H; ++i) {
+        const double vp_i = __shfl(h.vpref, i, 64), rad_i = __shfl(h.rad, i, 64);
+        if (vp_i == 0.0) continue;
+        if (rng_double(R, lane) <= c.goal_change_chance) {
+            double gx, gy;
+            for (;;) {
+                const double angle = rng_double(R, lane) * M_PI * 2.0;
+                const double gx_noise = (rng_double(R, lane) - 0.5) * vp_i;
+                const double gy_noise = (rng_double(R, lane) - 0.5) * vp_i;
+                double sn, cs;
+                det_sincos(angle, sn, cs);
+                gx = c.circle_radius * cs + gx_noise;
+                gy = c.circle_radius * sn + gy_noise;
+                const double md_r = rad_i + c.robot_radius + c.discomfort_dist;
+                const bool coll_r = norm2(gx - rb.px, gy - rb.py) < md_r || norm2(gx - rb.gx, gy - rb.gy) < md_r;
+                const double md = rad_i + h.rad + c.discomfort_dist;
+                const bool coll_h = lane < H && lane != i && (norm2(gx - h.px, gy - h.py) < md || norm2(gx - h.gx, gy - h.gy) < md);
+                if (!(coll_r || wv_any(coll_h))) break;
+            }
+            if (lane == i) { h.gx = gx; h.gy = gy; }
+        }
+    }
+}
+
+// crowd_sim_var_num.py:233-279 generate_ob / crowd_sim_pred.py:62-97 / crowd_sim_pred_real_gst.py:76-93,
+// crowd_sim.py:558-572 get_num_human_in_fov, :243-273 update_last_human_states.
+__device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool reset, const Robot &rb, Lane &h, const cn_obs &ob)
+{
+    const cn_env_config &c = s.cfg;
+    const int H = s.H, D = s.D, P = s.P;
+    const bool isH = lane < H;
+    // robot FOV = 2*pi: visible iff not coincident and within sensor range (detect_visible, crowd_sim.py:513-552)
+    const double dx = rb.px - h.px, dy = rb.py - h.py;
+    const bool vis = isH && !(dx == 0.0 && dy == 0.0) && (norm2(dx, dy) - c.robot_radius - h.rad <= c.sensor_range);
+    const uint64_t vmask = __ballot(vis);
+    const int num_visible = __popcll(vmask);
+    const double prev_vx = h.l2, prev_vy = h.l3;
+    if (vis) { h.l0 = h.px; h.l1 = h.py; h.l2 = h.vx; h.l3 = h.vy; h.l4 = h.rad; }
+    else if (reset) { h.l0 = 15.0; h.l1 = 15.0; h.l2 = 0.0; h.l3 = 0.0; h.l4 = 0.3; }
+    else { h.l0 = h.l0 + h.l2 * c.time_step; h.l1 = h.l1 + h.l3 * c.time_step; }
+    if (lane == 0) {
+        float *rn = ob.robot_node + (size_t)e * 7;
+        rn[0] = (float)rb.px; rn[1] = (float)rb.py; rn[2] = (float)c.robot_radius; rn[3] = (float)rb.gx; rn[4] = (float)rb.gy;
+        rn[5] = (float)c.robot_v_pref; rn[6] = (float)rb.theta;
+        ob.temporal_edges[(size_t)e * 2] = (float)rb.vx; ob.temporal_edges[(size_t)e * 2 + 1] = (float)rb.vy;
+        ob.detected_human_num[e] = (float)(num_visible == 0 ? 1 : num_visible);
+    }
+    const double ex = h.l0 - rb.px, ey = h.l1 - rb.py; // == true relative position for visible humans
+    const bool do_sort = c.sort_humans && c.env_kind != CN_ENV_PRED_GST;
+    int row = lane;
+    if (do_sort) {
+        // sorted(key = norm(first two)) is stable, invisible rows (inf) keep index order and go last
+        const double key = vis ? sqrt(ex * ex + ey * ey) : INFINITY;
+        int rank = 0;
+        for (int m = 0; m < H; ++m) {
+            const double km = __shfl(key, m, 64);
+            rank += (km < key || (km == key && m < lane)) ? 1 : 0;
+        }
+        row = rank;
+    }
+    if (isH) {
+        float *se = ob.spatial_edges + ((size_t)e * H + row) * D;
+        if (c.env_kind == CN_ENV_VARNUM) {
+            se[0] = vis ? (float)ex : 15.0f;
+            se[1] = vis ? (float)ey : 15.0f;
+        } else {
+            double *ft = s.ftraj ? s.ftraj + (size_t)e * P * 2 * H : nullptr;
+            for (int k = 0; k <= P; ++k) {
+                double fx = 15.0, fy = 15.0;
+                if (vis) {
+                    const double t = (double)k * c.time_step * 1.0; // pred_interval == 1 (config.py:130-131)
+                    fx = h.px + t * prev_vx;
+                    fy = h.py + t * prev_vy;
+                }
+                if (ft && k >= 1) { ft[((k - 1) * 2 + 0) * H + lane] = fx; ft[((k - 1) * 2 + 1) * H + lane] = fy; }
+                if (c.env_kind == CN_ENV_PRED) {
+                    se[2 * k] = vis ? (float)(fx - rb.px) : 15.0f;
+                    se[2 * k + 1] = vis ? (float)(fy - rb.py) : 15.0f;
+                } else {
+                    se[2 * k] = vis ? (float)ex : 15.0f;
+                    se[2 * k + 1] = vis ? (float)ey : 15.0f;
+                }
+            }
+        }
+        if (ob.visible_masks) {
+            uint8_t *vm = ob.visible_masks + (size_t)e * H;
+            if (do_sort) vm[lane] = lane < num_visible ? 1 : 0;
+            else vm[lane] = vis ? 1 : 0;
+        }
+    }
+}
+
+// crowd_sim_var_num.py:303-363 reset (seed, robot, humans, potential, first observation)
+__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, const cn_obs &ob)
+{
+    const cn_env_config &c = s.cfg;
+    const uint64_t offset = c.phase == CN_PHASE_TRAIN ? 2000ull : (c.phase == CN_PHASE_VAL ? 0ull : 1000ull);
+    uint64_t cc = s.case_counter[e];
+    const uint64_t seed = offset + cc + (uint64_t)(s.seed_base + e);
+    rng_seed(R, (uint32_t)seed, lane);
+    double px, py, gx, gy;
+    for (;;) { // :97-100
+        px = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+        py = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+        gx = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+        gy = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+        if (norm2(px - gx, py - gy) >= 8.0) break;
+    }
+    rb.px = px; rb.py = py; rb.gx = gx; rb.gy = gy; rb.vx = 0.0; rb.vy = 0.0; rb.theta = M_PI / 2.0;
+    for (int i = 0; i < s.H; ++i) gen_human(s, R, lane, i, i, rb, h, shared_nd);
+    h.l0 = h.l1 = h.l2 = h.l3 = h.l4 = 0.0; // :108
+    const uint64_t case_size = c.phase == CN_PHASE_TRAIN ? (4294967295ull - 2000ull) : (c.phase == CN_PHASE_VAL ? c.val_size : c.test_size);
+    cc = (cc + (uint64_t)c.nenv) % case_size;
+    rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
+    if (lane == 0) { s.case_counter[e] = cc; s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0; }
+    write_obs(s, e, lane, true, rb, h, ob);
+}
+
+__device__ __forceinline__ void load_env(const EnvDev &s, int e, int lane, Robot &rb, Lane &h)
+{
+    const int H = s.H;
+    const int lj = lane < H ? lane : 0;
+    const double *hum = s.hum + (size_t)e * 8 * H;
+    h.px = hum[F_PX * H + lj]; h.py = hum[F_PY * H + lj]; h.vx = hum[F_VX * H + lj]; h.vy = hum[F_VY * H + lj];
+    h.gx = hum[F_GX * H + lj]; h.gy = hum[F_GY * H + lj]; h.rad = hum[F_RAD * H + lj]; h.vpref = hum[F_VPREF * H + lj];
+    const double *l = s.lhs + (size_t)e * 5 * H;
+    h.l0 = l[lj]; h.l1 = l[H + lj]; h.l2 = l[2 * H + lj]; h.l3 = l[3 * H + lj]; h.l4 = l[4 * H + lj];
+    h.simv = s.sim_valid[(size_t)e * H + lj];
+    const double *r = s.rob + (size_t)e * 8;
+    rb.px = r[R_PX]; rb.py = r[R_PY]; rb.vx = r[R_VX]; rb.vy = r[R_VY]; rb.gx = r[R_GX]; rb.gy = r[R_GY]; rb.theta = r[R_THETA]; rb.pot = r[R_POT];
+}
+__device__ __forceinline__ void store_env(const EnvDev &s, int e, int lane, const Robot &rb, const Lane &h)
+{
+    const int H = s.H;
+    if (lane < H) {
+        double *hum = s.hum + (size_t)e * 8 * H;
+        hum[F_PX * H + lane] = h.px; hum[F_PY * H + lane] = h.py; hum[F_VX * H + lane] = h.vx; hum[F_VY * H + lane] = h.vy;
+        hum[F_GX * H + lane] = h.gx; hum[F_GY * H + lane] = h.gy; hum[F_RAD * H + lane] = h.rad; hum[F_VPREF * H + lane] = h.vpref;
+        double *l = s.lhs + (size_t)e * 5 * H;
+        l[lane] = h.l0; l[H + lane] = h.l1; l[2 * H + lane] = h.l2; l[3 * H + lane] = h.l3; l[4 * H + lane] = h.l4;
+        s.sim_valid[(size_t)e * H + lane] = h.simv;
+    }
+    if (lane == 0) {
+        double *r = s.rob + (size_t)e * 8;
+        r[R_PX] = rb.px; r[R_PY] = rb.py; r[R_VX] = rb.vx; r[R_VY] = rb.vy; r[R_GX] = rb.gx; r[R_GY] = rb.gy; r[R_THETA] = rb.theta; r[R_POT] = rb.pot;
+    }
+}
+
+__global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob)
+{
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    Rng R{MT_N, false};
+    Robot rb{};
+    Lane h{};
+    h.rad = s.cfg.human_radius;
+    double shared_nd = s.cfg.orca_neighbor_dist;
+    do_reset(s, R, e, lane, rb, h, shared_nd, ob);
+    store_env(s, e, lane, rb, h);
+    if (lane == 0) s.shared_nd[e] = shared_nd;
+    rng_store(R, s, e, lane);
+}
+
+// crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
+// (rl/networks/shmem_vec_env.py:139-142).  ORCA velocities for this step were produced by orca_kernel.
+__global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
+                                                      uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out)
+{
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    const cn_env_config &c = s.cfg;
+    const int H = s.H;
+    const bool isH = lane < H;
+    Rng R{MT_N, false};
+    Robot rb;
+    Lane h;
+    load_env(s, e, lane, rb, h);
+    double shared_nd = s.shared_nd[e];
+    int step_counter = s.step_counter[e];
+
+    // srnn.clip_action (crowd_nav/policy/srnn.py:17-34), float32 like the numpy action array
+    float ax = actions[2 * e], ay = actions[2 * e + 1];
+    {
+        const float act_norm = sqrtf(ax * ax + ay * ay);
+        const float vp = (float)c.robot_v_pref;
+        if (act_norm > vp) { ax = ax / act_norm * vp; ay = ay / act_norm * vp; }
+    }
+    // calc_reward (crowd_sim_var_num.py:465-561), pre-move positions.  "first collision in list order, break":
+    // dmin is only consumed when there is no collision at all, so the lane-parallel min is equivalent.
+    const double cdx = h.px - rb.px, cdy = h.py - rb.py;
+    const double closest = isH ? sqrt(cdx * cdx + cdy * cdy) - h.rad - c.robot_radius : INFINITY;
+    const bool collision = wv_any(closest < 0.0);
+    const double dmin = wv_min(closest);
+    const double goal_dist = norm2(rb.px - rb.gx, rb.py - rb.gy);
+    const bool reaching_goal = goal_dist < c.robot_radius;
+    const double global_time = (double)step_counter * c.time_step;
+    double reward;
+    int done, info;
+    if (global_time >= c.time_limit - 1.0) { reward = 0.0; done = 1; info = CN_INFO_TIMEOUT; }
+    else if (collision) { reward = c.collision_penalty; done = 1; info = CN_INFO_COLLISION; }
+    else if (reaching_goal) { reward = c.success_reward; done = 1; info = CN_INFO_REACHGOAL; }
+    else if (dmin < c.discomfort_dist) {
+        reward = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * c.time_step;
+        done = 0; info = CN_INFO_DANGER;
+    } else {
+        reward = 2.0 * (-fabs(goal_dist) - rb.pot);
+        rb.pot = -fabs(goal_dist);
+        done = 0; info = CN_INFO_NOTHING;
+    }
+    if (c.env_kind == CN_ENV_PRED) {
+        // social reward from the predictions stored by the previous observation (crowd_sim_pred.py:216-233)
+        const double *ft = s.ftraj + (size_t)e * s.P * 2 * H;
+        double rf = 0.0;
+        for (int k = 1; k <= s.P; ++k) {
+            const double pen = c.collision_penalty / (double)(1 << (k + 1));
+            if (isH) {
+                const double fx = ft[((k - 1) * 2 + 0) * H + lane] - rb.px, fy = ft[((k - 1) * 2 + 1) * H + lane] - rb.py;
+                if (sqrt(fx * fx + fy * fy) < c.robot_radius + c.human_radius && pen < rf) rf = pen;
+            }
+        }
+        reward = reward + wv_min(rf);
+    }
+    // kinematics (crowd_sim/envs/utils/agent.py:170-183, holonomic)
+    rb.px = rb.px + (double)(ax * (float)c.time_step);
+    rb.py = rb.py + (double)(ay * (float)c.time_step);
+    rb.vx = (double)ax; rb.vy = (double)ay;
+    if (isH) {
+        const float hax = s.hact[(size_t)e * 2 * H + lane], hay = s.hact[(size_t)e * 2 * H + H + lane];
+        h.px = h.px + (double)hax * c.time_step;
+        h.py = h.py + (double)hay * c.time_step;
+        h.vx = (double)hax; h.vy = (double)hay;
+    }
+    step_counter += 1;
+    const double ep_ret = s.ep_ret[e] + reward;
+    const int ep_cnt = s.ep_cnt[e] + 1;
+    if (lane == 0) {
+        reward_out[e] = (float)reward; done_out[e] = (uint8_t)done; info_out[e] = (uint8_t)info;
+        ep_ret_out[e] = ep_ret; ep_len_out[e] = ep_cnt;
+    }
+    if (done) {
+        // vec-env auto-reset: the terminal observation is replaced by the first observation of the next episode.
+        // (The terminal step's own goal-change / respawn draws happen before np.random.seed and cannot be observed.)
+        do_reset(s, R, e, lane, rb, h, shared_nd, ob);
+    } else {
+        write_obs(s, e, lane, false, rb, h, ob);
+        // crowd_sim_var_num.py:446-448: every 5 s of simulated time
+        const int period = (int)(5.0 / c.time_step + 0.5);
+        if (c.random_goal_changing && (step_counter % period) == 0) {
+            rng_load(R, s, e, lane);
+            change_goals(s, R, lane, rb, h);
+        }
+        // :451-456: humans that reached their goal are replaced by freshly generated ones, in index order
+        if (c.end_goal_changing) {
+            uint64_t reached = __ballot(isH && norm2(h.gx - h.px, h.gy - h.py) < h.rad);
+            if (reached) rng_load(R, s, e, lane);
+            while (reached) {
+                const int i = __ffsll((unsigned long long)reached) - 1;
+                reached &= reached - 1;
+                gen_human(s, R, lane, i, H, rb, h, shared_nd);
+            }
+        }
+        if (lane == 0) { s.step_counter[e] = step_counter; s.ep_ret[e] = ep_ret; s.ep_cnt[e] = ep_cnt; }
+    }
+    store_env(s, e, lane, rb, h);
+    if (lane == 0) s.shared_nd[e] = shared_nd;
+    rng_store(R, s, e, lane);
+}
+
+__global__ void export_state_kernel(EnvDev s, double *humans, double *robot)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = s.H;
+    if (humans && idx < s.E * H * 8) {
+        const int e = idx / (H * 8), r = idx % (H * 8), j = r / 8, f = r % 8;
+        humans[idx] = s.hum[((size_t)e * 8 + f) * H + j];
+    }
+    if (robot && idx < s.E * 8) robot[idx] = s.rob[idx];
+}
+__global__ void export_hact_kernel(EnvDev s, float *out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = s.H;
+    if (idx < s.E * H * 2) {
+        const int e = idx / (H * 2), r = idx % (H * 2), j = r / 2, f = r % 2;
+        out[idx] = s.hact[((size_t)e * 2 + f) * H + j];
+    }
+}
+
+} // namespace
+
+struct cn_env_batch {
+    EnvDev d;
+    bool reset_done;
+    void *blob;
+};
+
+extern "C" void cn_env_config_default(cn_env_config *c)
+{
+    // crowd_nav/configs/config.py:16-120 with the non-randomised training preset (BASELINE configs[1])
+    *c = cn_env_config{};
+    c->human_num = 20; c->predict_steps = 5; c->env_kind = CN_ENV_VARNUM;
+    c->randomize_attributes = 0; c->random_goal_changing = 0; c->end_goal_changing = 1; c->sort_humans = 1;
+    c->phase = CN_PHASE_TRAIN; c->nenv = 1; c->val_size = 100; c->test_size = 500;
+    c->time_step = 0.25; c->time_limit = 50.0;
+    c->success_reward = 10.0; c->collision_penalty = -20.0; c->discomfort_dist = 0.25; c->discomfort_penalty_factor = 10.0;
+    c->circle_radius = 6.0 * std::sqrt(2.0); c->arena_size = 6.0;
+    c->human_radius = 0.3; c->human_v_pref = 1.0; c->robot_radius = 0.3; c->robot_v_pref = 1.0; c->sensor_range = 5.0;
+    c->goal_change_chance = 0.5; c->end_goal_change_chance = 1.0;
+    c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0; c->orca_time_horizon_obst = 5.0;
+}
+
+extern "C" int cn_env_obs_width(const cn_env_config *cfg)
+{
+    return cfg->env_kind == CN_ENV_VARNUM ? 2 : 2 * (cfg->predict_steps + 1);
+}
+
+extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t seed, int64_t first_env_index, cn_env_batch **out)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(cfg && out, "cn_env_create: null argument");
+    CN_REQUIRE(num_envs > 0, "cn_env_create: num_envs must be positive");
+    CN_REQUIRE(cfg->human_num >= 1 && cfg->human_num <= CN_MAX_HUMANS, "cn_env_create: human_num must be in [1,%d]", CN_MAX_HUMANS);
+    CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
+    CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_PRED_GST, "cn_env_create: unknown env_kind %d", cfg->env_kind);
+    CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN, "cn_env_create: only phase=train is implemented on the device (test phase needs the 'truth' predictor)");
+    CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
+    CN_REQUIRE(cfg->time_step > 0 && std::fabs(5.0 / cfg->time_step - std::round(5.0 / cfg->time_step)) < 1e-9,
+               "cn_env_create: time_step must divide 5 s");
+    cn_env_batch *b = new (std::nothrow) cn_env_batch{};
+    CN_REQUIRE(b, "cn_env_create: out of host memory");
+    EnvDev &d = b->d;
+    d.cfg = *cfg;
+    d.E = num_envs; d.H = cfg->human_num; d.D = cn_env_obs_width(cfg); d.P = cfg->predict_steps;
+    d.seed_base = seed + first_env_index;
+    const size_t E = num_envs, H = cfg->human_num;
+    // one allocation, carved (all sub-buffers 256-byte aligned)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
+    const size_t o_hum = carve(E * 8 * H * 8), o_rob = carve(E * 8 * 8), o_lhs = carve(E * 5 * H * 8);
+    const size_t o_ft = cfg->env_kind == CN_ENV_PRED ? carve(E * d.P * 2 * H * 8) : 0;
+    const size_t o_sc = carve(E * 4), o_cc = carve(E * 8), o_er = carve(E * 8), o_ec = carve(E * 4), o_nd = carve(E * 8);
+    const size_t o_sv = carve(E * H), o_snd = carve(E * H * 4), o_ssr = carve(E * H * 4), o_ssm = carve(E * H * 4);
+    const size_t o_seen = cfg->randomize_attributes ? carve(E * H * H * 4) : 0;
+    const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
+    char *base = nullptr;
+    hipError_t herr = hipMalloc((void **)&base, off);
+    if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
+    herr = hipMemset(base, 0, off);
+    if (herr != hipSuccess) { (void)hipFree(base); delete b; cn_set_error("cn_env_create: hipMemset failed: %s", hipGetErrorString(herr)); return CN_ERR_HIP; }
+    b->blob = base;
+    d.hum = (double *)(base + o_hum); d.rob = (double *)(base + o_rob); d.lhs = (double *)(base + o_lhs);
+    d.ftraj = cfg->env_kind == CN_ENV_PRED ? (double *)(base + o_ft) : nullptr;
+    d.step_counter = (int32_t *)(base + o_sc); d.case_counter = (uint64_t *)(base + o_cc);
+    d.ep_ret = (double *)(base + o_er); d.ep_cnt = (int32_t *)(base + o_ec); d.shared_nd = (double *)(base + o_nd);
+    d.sim_valid = (uint8_t *)(base + o_sv); d.sim_nd = (float *)(base + o_snd); d.sim_self_radius = (float *)(base + o_ssr);
+    d.sim_self_maxspeed = (float *)(base + o_ssm);
+    d.sim_seen = cfg->randomize_attributes ? (float *)(base + o_seen) : nullptr;
+    d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
+    b->reset_done = false;
+    *out = b;
+    return CN_OK;
+}
+
+extern "C" int cn_env_destroy(cn_env_batch *env)
+{
+    if (!env) return CN_OK;
+    if (env->blob) CN_HIP(hipFree(env->blob));
+    delete env;
+    return CN_OK;
+}
+
+static int check_obs(const cn_obs *obs)
+{
+    CN_REQUIRE(obs && obs->robot_node && obs->temporal_edges && obs->spatial_edges && obs->detected_human_num,
+               "observation pointers must be non-null (visible_masks may be null)");
+    return CN_OK;
+}
+
+extern "C" int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream)
+{
+    CN_REQUIRE(env, "cn_env_reset: null handle");
+    if (int rc = check_obs(obs)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // VecEnv.reset() resets every env; case counters keep running (crowd_sim_var_num.py:348)
+    hipLaunchKernelGGL(env_reset_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs);
+    CN_CHECK_LAUNCH();
+    env->reset_done = true;
+    return CN_OK;
+}
+
+extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done,
+                           uint8_t *info, double *ep_return, int32_t *ep_len, void *stream)
+{
+    CN_REQUIRE(env, "cn_env_step: null handle");
+    if (!env->reset_done) { cn_set_error("cn_env_step: call cn_env_reset first"); return CN_ERR_STATE; }
+    if (int rc = check_obs(obs)) return rc;
+    CN_REQUIRE(actions && reward && done && info && ep_return && ep_len, "cn_env_step: null output/input pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int agents = env->d.E * env->d.H;
+    hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, st, env->d);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(env_step_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream)
+{
+    CN_REQUIRE(env, "cn_env_get_state: null handle");
+    const int n = env->d.E * env->d.H * 8;
+    hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, humans, robot);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream)
+{
+    CN_REQUIRE(env && out, "cn_env_get_human_actions: null argument");
+    const int n = env->d.E * env->d.H * 2;
+    hipLaunchKernelGGL(export_hact_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, out);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_orca_solve(int B, int n_other, const float *self, const float *others, float neighbor_dist, int max_neighbors,
+                             float time_horizon, float time_step, float *out_vel, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(B >= 0 && n_other >= 0 && n_other <= 63, "cn_orca_solve: n_other must be in [0,63]");
+    CN_REQUIRE(self && out_vel && (others || n_other == 0), "cn_orca_solve: null pointer");
+    if (B == 0) return CN_OK;
+    hipLaunchKernelGGL(orca_solve_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, n_other, self, others,
+                       neighbor_dist, max_neighbors, time_horizon, time_step, out_vel);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

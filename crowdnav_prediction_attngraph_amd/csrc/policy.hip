@@ -1,0 +1,581 @@
+// policy.hip -- rollout-time forward of the attention-interaction-graph policy (selfAttn_merge_srnn + DiagGaussian)
+// on gfx950.  Reference: rl/networks/selfAttn_srnn_temp_node.py:360-449, rl/networks/model.py:56-80.
+//
+// Pipeline per call (E envs, H humans, M = E*H rows), all on the caller's stream, no host sync:
+//   embed0        [M,D]   -> [M,128]  ReLU                      (K = 2 or 12: VALU)
+//   gemm          [M,128] -> [M,512]  ReLU                      embedding_layer.2
+//   gemm          [M,512] -> [M,1536]                           folded (q|k|v)_linear ∘ in_proj, 1/sqrt(64) folded into q
+//   hh_attention  per (env, head): softmax(QK^T + key padding mask) V  -> [M,512]
+//   gemm          [M,512] -> [M,256]  ReLU                      folded out_proj ∘ spatial_linear
+//   gemm          [M,256] -> [M,64]                             attn.spatial_edge_layer
+//   robot_embed   [E,9]   -> [E,256]  ReLU ; gemm -> [E,64]     robot_linear, attn.temporal_edge_layer
+//   hr_attention  per env: masked softmax over humans, weighted sum of [H,256]
+//   gemms + gru_pointwise + gemms(tanh) + gauss_head            EndRNN, actor/critic, DiagGaussian
+// The dense contractions run on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32, 155 TF peak): the
+// reference computes in fp32 and the parity bar is 1e-4, which bf16 inputs cannot hold at K = 512.
+// The two affine pairs without a nonlinearity in between are folded once per weight snapshot (fp64 accumulation),
+// which removes 4 of the 9 [M,512]x[512,512] products (83.65 -> 52.2 MFLOP per env-step at H = 20).
+#include "common.h"
+
+#include <cmath>
+#include <new>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+constexpr int BM = 128, BK = 32, LDS_STRIDE = 36; // 36 floats = 144 B rows: conflict-free ds_read_b128
+
+// C[M,N] (ldc) = act(A[M,K] (lda) * W[N,K]^T + bias[N]); N % BN == 0, K % 32 == 0, M arbitrary.
+// 256 threads = 4 wavefronts in a 2x2 arrangement; each wavefront owns a 64 x (BN/2) tile = 2 x (BN/64) MFMA blocks.
+// K order inside a group of 8 is remapped so each lane feeds 4 consecutive MFMA steps from ONE 16-byte LDS read:
+// lanes 0-31 hold k = 8g+s, lanes 32-63 hold k = 8g+4+s at step s (same mapping for A and W, so the sum is unchanged).
+template <int BN, int ACT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                      const float *__restrict__ W, const float *__restrict__ bias,
+                                                      float *__restrict__ C, int ldc)
+{
+    constexpr int NB = BN / 64;        // MFMA column blocks per wavefront
+    constexpr int WLD = BN / 32;       // float4 loads of W per thread per K tile
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4; // staging: 8 lanes cover one 128-byte row segment
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 pa[4], pw[WLD];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = m_blk + lrow + 32 * p;
+            if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
+            else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < WLD; ++p) {
+            const int r = n_blk + lrow + 32 * p;
+            pw[p] = *reinterpret_cast<const f32x4 *>(W + (size_t)r * K + k0 + lcol);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(&As[(lrow + 32 * p) * LDS_STRIDE + lcol]) = pa[p];
+#pragma unroll
+        for (int p = 0; p < WLD; ++p) *reinterpret_cast<f32x4 *>(&Ws[(lrow + 32 * p) * LDS_STRIDE + lcol]) = pw[p];
+    };
+
+    load_tiles(0);
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads(); // previous tile fully consumed
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < K) load_tiles(k0 + BK); // prefetch next tile into registers while this one is multiplied
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 af[2], bf[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *reinterpret_cast<const f32x4 *>(&As[(wm * 64 + i * 32 + l31) * LDS_STRIDE + g * 8 + half * 4]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                bf[j] = *reinterpret_cast<const f32x4 *>(&Ws[(wn * (BN / 2) + j * 32 + l31) * LDS_STRIDE + g * 8 + half * 4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
+            const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    float v = acc[i][j][r] + b;
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+// embedding_layer.0 (K = D <= 16): out[m][n] = relu(sum_d x[m][d] * W[n][d] + b[n]), n < 128
+__global__ __launch_bounds__(256) void embed0_kernel(int M, int D, const float *__restrict__ x, const float *__restrict__ W,
+                                                     const float *__restrict__ b, float *__restrict__ out)
+{
+    __shared__ float Wl[128 * 16 + 128];
+    for (int i = threadIdx.x; i < 128 * D; i += 256) Wl[i] = W[i];
+    if (threadIdx.x < 128) Wl[128 * 16 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int n = threadIdx.x & 127;
+    for (int m = blockIdx.x * 2 + (threadIdx.x >> 7); m < M; m += gridDim.x * 2) {
+        float acc = Wl[128 * 16 + n];
+        for (int d = 0; d < D; ++d) acc += x[(size_t)m * D + d] * Wl[n * D + d];
+        out[(size_t)m * 128 + n] = fmaxf(acc, 0.0f);
+    }
+}
+
+// robot_linear.0: out[e][n] = relu(W[n][0:2] . temporal_edges[e] + W[n][2:9] . robot_node[e] + b[n]), n < 256
+// (torch.cat((temporal_edges, robot_node), -1), selfAttn_srnn_temp_node.py:397)
+__global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__restrict__ temporal, const float *__restrict__ robot_node,
+                                                          const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ out)
+{
+    const int n = threadIdx.x;
+    float w[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) w[d] = W[n * 9 + d];
+    const float bn = b[n];
+    for (int e = blockIdx.x; e < E; e += gridDim.x) {
+        float acc = bn;
+        acc += temporal[e * 2] * w[0];
+        acc += temporal[e * 2 + 1] * w[1];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) acc += robot_node[e * 7 + d] * w[2 + d];
+        out[(size_t)e * 256 + n] = fmaxf(acc, 0.0f);
+    }
+}
+
+// Human-human multi-head attention core (torch.nn.MultiheadAttention with key_padding_mask, 8 heads x 64):
+// one wavefront per (env, head); K and V of the env/head are staged in LDS; lane j scores key j, lane d owns output
+// dim d.  Query rows >= detected_human_num are padding: their outputs only ever meet an exactly-zero robot-human
+// attention weight, so zeros are written instead of computing them.
+__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const float *__restrict__ qkv, const float *__restrict__ det,
+                                                           float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * (blockDim.x >> 6) + wave; // (env, head)
+    if (unit >= E * 8) return;
+    const int e = unit >> 3, head = unit & 7;
+    float *Ks = smem + (size_t)wave * (3 * H * 65);
+    float *Vs = Ks + H * 65;
+    float *Qs = Vs + H * 65;
+    const float *base = qkv + (size_t)e * H * 1536 + head * 64;
+    for (int j = 0; j < H; ++j) {
+        Qs[j * 65 + lane] = base[(size_t)j * 1536 + lane];
+        Ks[j * 65 + lane] = base[(size_t)j * 1536 + 512 + lane];
+        Vs[j * 65 + lane] = base[(size_t)j * 1536 + 1024 + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wavefront visible to its own reads
+    int nd = (int)det[e];
+    nd = nd < 1 ? 1 : (nd > H ? H : nd);
+    const int jl = lane < H ? lane : 0;
+    for (int i = 0; i < H; ++i) {
+        float *orow = out + ((size_t)e * H + i) * 512 + head * 64;
+        if (i >= nd) { orow[lane] = 0.0f; continue; }
+        float s = 0.0f;
+#pragma unroll 16
+        for (int d = 0; d < 64; ++d) s += Qs[i * 65 + d] * Ks[jl * 65 + d];
+        s = lane < nd ? s : -INFINITY;
+        const float mx = wv_max(s);
+        const float p = lane < nd ? expf(s - mx) : 0.0f;
+        const float denom = wv_sum(p);
+        const float pn = p / denom;
+        float o = 0.0f;
+        for (int j = 0; j < nd; ++j) o += wv_readlane(pn, j) * Vs[j * 65 + lane];
+        orow[lane] = o;
+    }
+}
+
+// Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177): one wavefront per env.
+__global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ t_emb, const float *__restrict__ s_emb,
+                                                           const float *__restrict__ out_sp, const float *__restrict__ det,
+                                                           float *__restrict__ hr_out, float *__restrict__ hr_attn)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    if (e >= E) return;
+    float *Ss = smem + (size_t)wave * (H * 65 + 64);
+    float *Ts = Ss + H * 65;
+    for (int j = 0; j < H; ++j) Ss[j * 65 + lane] = s_emb[((size_t)e * H + j) * 64 + lane];
+    Ts[lane] = t_emb[(size_t)e * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    int nd = (int)det[e];
+    nd = nd < 1 ? 1 : (nd > H ? H : nd);
+    const int jl = lane < H ? lane : 0;
+    float s = 0.0f;
+#pragma unroll 16
+    for (int d = 0; d < 64; ++d) s += Ts[d] * Ss[jl * 65 + d];
+    s = s * ((float)H / 8.0f);                 // temperature = num_edges / sqrt(attention_size = 64)
+    s = lane < nd ? s : -1e9f;                 // masked_fill(attn_mask == 0, -1e9)
+    s = lane < H ? s : -INFINITY;
+    const float mx = wv_max(s);
+    const float p = lane < H ? expf(s - mx) : 0.0f;
+    const float denom = wv_sum(p);
+    const float a = p / denom;
+    if (hr_attn && lane < H) hr_attn[(size_t)e * H + lane] = a;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int j = 0; j < H; ++j) {
+        const float aj = wv_readlane(a, j);
+        const float *row = out_sp + ((size_t)e * H + j) * 256;
+        o0 += aj * row[lane]; o1 += aj * row[64 + lane]; o2 += aj * row[128 + lane]; o3 += aj * row[192 + lane];
+    }
+    float *o = hr_out + (size_t)e * 256;
+    o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
+}
+
+// GRU cell pointwise part (PyTorch formulation, gate order r,z,n) with the done mask applied to h
+// (rl/networks/srnn_model.py:43-46): gi = x W_ih^T + b_ih (bias already added), gh_raw = h W_hh^T (no bias, unmasked).
+__global__ __launch_bounds__(128) void gru_pointwise_kernel(int E, const float *__restrict__ gi, const float *__restrict__ gh_raw,
+                                                            const float *__restrict__ b_hh, const float *__restrict__ h_in,
+                                                            const float *__restrict__ masks, float *__restrict__ h_out)
+{
+    const int e = blockIdx.x, c = threadIdx.x;
+    if (e >= E) return;
+    const float m = masks[e];
+    const float *gie = gi + (size_t)e * 384, *ghe = gh_raw + (size_t)e * 384;
+    const float hr = m * ghe[c] + b_hh[c], hz = m * ghe[128 + c] + b_hh[128 + c], hn = m * ghe[256 + c] + b_hh[256 + c];
+    const float r = 1.0f / (1.0f + expf(-(gie[c] + hr)));
+    const float z = 1.0f / (1.0f + expf(-(gie[128 + c] + hz)));
+    const float n = tanhf(gie[256 + c] + r * hn);
+    const float h = m * h_in[(size_t)e * 128 + c];
+    h_out[(size_t)e * 128 + c] = (1.0f - z) * n + z * h;
+}
+
+// critic_linear + DiagGaussian head (model.py:64-72, distributions.py:36-44,76-95): one wavefront per env.
+// ac [E,512]: columns 0..255 actor features, 256..511 critic features.
+__global__ __launch_bounds__(256) void gauss_head_kernel(int E, const float *__restrict__ ac, int ld, const float *__restrict__ wv,
+                                                         const float *__restrict__ bv, const float *__restrict__ wm,
+                                                         const float *__restrict__ bm, const float *__restrict__ logstd,
+                                                         const float *__restrict__ eps, float *__restrict__ value,
+                                                         float *__restrict__ action, float *__restrict__ logp)
+{
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float *a = ac + (size_t)e * ld, *c = a + 256;
+    float sv = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = lane + 64 * k;
+        sv += c[d] * wv[d];
+        s0 += a[d] * wm[d];
+        s1 += a[d] * wm[256 + d];
+    }
+    sv = wv_sum(sv); s0 = wv_sum(s0); s1 = wv_sum(s1);
+    if (lane == 0) {
+        value[e] = sv + bv[0];
+        if (action) {
+            const float mean0 = s0 + bm[0], mean1 = s1 + bm[1];
+            const float ls0 = logstd[0], ls1 = logstd[1];
+            const float sd0 = expf(ls0), sd1 = expf(ls1);
+            const float a0 = eps ? mean0 + sd0 * eps[2 * e] : mean0;
+            const float a1 = eps ? mean1 + sd1 * eps[2 * e + 1] : mean1;
+            action[2 * e] = a0; action[2 * e + 1] = a1;
+            const float HALF_LOG_2PI = 0.91893853320467274178f;
+            const float d0 = a0 - mean0, d1 = a1 - mean1;
+            logp[e] = (-(d0 * d0) / (2.0f * sd0 * sd0) - ls0 - HALF_LOG_2PI) + (-(d1 * d1) / (2.0f * sd1 * sd1) - ls1 - HALF_LOG_2PI);
+        }
+    }
+}
+
+// Weight folding: C[n][k] = scale * sum_j A[n][j] * B[j][k]  (fp64 accumulation), A [N,J], B [J,K]
+__global__ void fold_mm_kernel(int N, int J, int K, const float *__restrict__ A, const float *__restrict__ B, float scale, float *__restrict__ C)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (k >= K || n >= N) return;
+    double acc = 0.0;
+    for (int j = 0; j < J; ++j) acc += (double)A[(size_t)n * J + j] * (double)B[(size_t)j * K + k];
+    C[(size_t)n * K + k] = (float)(acc * (double)scale);
+}
+// c[n] = scale * (sum_j A[n][j] * b[j] + b2[n])
+__global__ void fold_bias_kernel(int N, int J, const float *__restrict__ A, const float *__restrict__ b, const float *__restrict__ b2,
+                                 float scale, float *__restrict__ c)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double acc = b2[n];
+    for (int j = 0; j < J; ++j) acc += (double)A[(size_t)n * J + j] * (double)b[j];
+    c[n] = (float)(acc * (double)scale);
+}
+
+constexpr size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+} // namespace
+
+struct cn_policy {
+    int H, D, maxE;
+    bool weights_set;
+    char *blob;
+    // weight snapshot (device)
+    float *emb0_w, *emb0_b, *emb2_w, *emb2_b;
+    float *qkv_w, *qkv_b;   // folded [1536,512], [1536]
+    float *os_w, *os_b;     // folded out_proj∘spatial_linear [256,512], [256]
+    float *as_w, *as_b;     // attn.spatial_edge_layer [64,256]
+    float *at_w, *at_b;     // attn.temporal_edge_layer [64,256]
+    float *rl_w, *rl_b;     // robot_linear [256,9]
+    float *enc_w, *enc_b, *edge_w, *edge_b; // [64,256] each
+    float *wih, *whh, *bih, *bhh;           // GRU
+    float *out_w, *out_b;                   // [256,128]
+    float *ac0_w, *ac0_b;                   // concat(actor.0, critic.0) [512,256]
+    float *a2_w, *a2_b, *c2_w, *c2_b;       // [256,256]
+    float *cl_w, *cl_b, *fm_w, *fm_b, *logstd;
+    // activations
+    float *emb1, *emb2, *qkv, *attn, *out_sp, *s_emb;
+    float *robot_states, *t_emb, *hr_out, *hr_attn, *x, *gi, *gh, *hnew, *rnn_out, *ac1, *ac2;
+    // profiling of the dominant kernel (QKV projection)
+    bool profiling;
+    hipEvent_t ev[2];
+    bool ev_pending;
+    double prof_ms[8];
+    int64_t prof_n[8];
+};
+
+template <int BN, int ACT>
+static int launch_gemm(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st)
+{
+    CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    if (M == 0) return CN_OK;
+    dim3 grid(N / BN, (M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_policy **out)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(out, "cn_policy_create: null out");
+    CN_REQUIRE(human_num >= 1 && human_num <= CN_MAX_HUMANS, "cn_policy_create: human_num must be in [1,%d]", CN_MAX_HUMANS);
+    CN_REQUIRE(edge_width >= 1 && edge_width <= 16, "cn_policy_create: edge_width must be in [1,16]");
+    CN_REQUIRE(max_envs >= 1, "cn_policy_create: max_envs must be positive");
+    cn_policy *p = new (std::nothrow) cn_policy{};
+    CN_REQUIRE(p, "cn_policy_create: out of host memory");
+    p->H = human_num; p->D = edge_width; p->maxE = max_envs;
+    const size_t E = max_envs, M = E * human_num, D = edge_width;
+    size_t off = 0;
+    auto carve = [&](size_t nfloat) { size_t o = off; off += align_up(nfloat * sizeof(float)); return o; };
+    const size_t o_emb0w = carve(128 * D), o_emb0b = carve(128), o_emb2w = carve(512 * 128), o_emb2b = carve(512);
+    const size_t o_qkvw = carve(1536 * 512), o_qkvb = carve(1536), o_osw = carve(256 * 512), o_osb = carve(256);
+    const size_t o_asw = carve(64 * 256), o_asb = carve(64), o_atw = carve(64 * 256), o_atb = carve(64);
+    const size_t o_rlw = carve(256 * 9), o_rlb = carve(256);
+    const size_t o_encw = carve(64 * 256), o_encb = carve(64), o_edgew = carve(64 * 256), o_edgeb = carve(64);
+    const size_t o_wih = carve(384 * 128), o_whh = carve(384 * 128), o_bih = carve(384), o_bhh = carve(384);
+    const size_t o_outw = carve(256 * 128), o_outb = carve(256);
+    const size_t o_ac0w = carve(512 * 256), o_ac0b = carve(512);
+    const size_t o_a2w = carve(256 * 256), o_a2b = carve(256), o_c2w = carve(256 * 256), o_c2b = carve(256);
+    const size_t o_clw = carve(256), o_clb = carve(1), o_fmw = carve(512), o_fmb = carve(2), o_ls = carve(2);
+    const size_t o_emb1 = carve(M * 128), o_emb2 = carve(M * 512), o_qkv = carve(M * 1536), o_attn = carve(M * 512);
+    const size_t o_outsp = carve(M * 256), o_semb = carve(M * 64);
+    const size_t o_rs = carve(E * 256), o_temb = carve(E * 64), o_hr = carve(E * 256), o_hra = carve(M), o_x = carve(E * 128);
+    const size_t o_gi = carve(E * 384), o_gh = carve(E * 384), o_hn = carve(E * 128), o_ro = carve(E * 256);
+    const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
+    char *base = nullptr;
+    hipError_t herr = hipMalloc((void **)&base, off);
+    if (herr != hipSuccess) { delete p; cn_set_error("cn_policy_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
+    p->blob = base;
+    auto F = [&](size_t o) { return (float *)(base + o); };
+    p->emb0_w = F(o_emb0w); p->emb0_b = F(o_emb0b); p->emb2_w = F(o_emb2w); p->emb2_b = F(o_emb2b);
+    p->qkv_w = F(o_qkvw); p->qkv_b = F(o_qkvb); p->os_w = F(o_osw); p->os_b = F(o_osb);
+    p->as_w = F(o_asw); p->as_b = F(o_asb); p->at_w = F(o_atw); p->at_b = F(o_atb);
+    p->rl_w = F(o_rlw); p->rl_b = F(o_rlb); p->enc_w = F(o_encw); p->enc_b = F(o_encb); p->edge_w = F(o_edgew); p->edge_b = F(o_edgeb);
+    p->wih = F(o_wih); p->whh = F(o_whh); p->bih = F(o_bih); p->bhh = F(o_bhh); p->out_w = F(o_outw); p->out_b = F(o_outb);
+    p->ac0_w = F(o_ac0w); p->ac0_b = F(o_ac0b); p->a2_w = F(o_a2w); p->a2_b = F(o_a2b); p->c2_w = F(o_c2w); p->c2_b = F(o_c2b);
+    p->cl_w = F(o_clw); p->cl_b = F(o_clb); p->fm_w = F(o_fmw); p->fm_b = F(o_fmb); p->logstd = F(o_ls);
+    p->emb1 = F(o_emb1); p->emb2 = F(o_emb2); p->qkv = F(o_qkv); p->attn = F(o_attn); p->out_sp = F(o_outsp); p->s_emb = F(o_semb);
+    p->robot_states = F(o_rs); p->t_emb = F(o_temb); p->hr_out = F(o_hr); p->hr_attn = F(o_hra); p->x = F(o_x);
+    p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
+    p->weights_set = false;
+    p->profiling = false;
+    p->ev_pending = false;
+    if (hipEventCreate(&p->ev[0]) != hipSuccess || hipEventCreate(&p->ev[1]) != hipSuccess) {
+        (void)hipFree(base); delete p; cn_set_error("cn_policy_create: hipEventCreate failed"); return CN_ERR_HIP;
+    }
+    *out = p;
+    return CN_OK;
+}
+
+extern "C" int cn_policy_destroy(cn_policy *p)
+{
+    if (!p) return CN_OK;
+    (void)hipEventDestroy(p->ev[0]);
+    (void)hipEventDestroy(p->ev[1]);
+    if (p->blob) CN_HIP(hipFree(p->blob));
+    delete p;
+    return CN_OK;
+}
+
+#define CN_D2D(dst, src, n) CN_HIP(hipMemcpyAsync((dst), (src), (size_t)(n) * sizeof(float), hipMemcpyDeviceToDevice, st))
+
+extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, void *stream)
+{
+    CN_REQUIRE(p && w, "cn_policy_set_weights: null argument");
+    const float *const *ptrs = reinterpret_cast<const float *const *>(w);
+    for (size_t i = 0; i < sizeof(cn_policy_weights) / sizeof(const float *); ++i)
+        CN_REQUIRE(ptrs[i] != nullptr, "cn_policy_set_weights: weight pointer #%zu is null", i);
+    hipStream_t st = (hipStream_t)stream;
+    const int D = p->D;
+    CN_D2D(p->emb0_w, w->emb0_w, 128 * D); CN_D2D(p->emb0_b, w->emb0_b, 128);
+    CN_D2D(p->emb2_w, w->emb2_w, 512 * 128); CN_D2D(p->emb2_b, w->emb2_b, 512);
+    // fold (q|k|v)_linear into in_proj:  y = W_in (W_x e + b_x) + b_in ; q additionally scaled by 1/sqrt(head_dim) = 0.125
+    const float *xw[3] = {w->q_w, w->k_w, w->v_w}, *xb[3] = {w->q_b, w->k_b, w->v_b};
+    for (int s = 0; s < 3; ++s) {
+        const float scale = s == 0 ? 0.125f : 1.0f;
+        hipLaunchKernelGGL(fold_mm_kernel, dim3(2, 512), dim3(256), 0, st, 512, 512, 512, w->in_proj_w + (size_t)s * 512 * 512, xw[s], scale,
+                           p->qkv_w + (size_t)s * 512 * 512);
+        CN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(fold_bias_kernel, dim3(2), dim3(256), 0, st, 512, 512, w->in_proj_w + (size_t)s * 512 * 512, xb[s],
+                           w->in_proj_b + s * 512, scale, p->qkv_b + s * 512);
+        CN_CHECK_LAUNCH();
+    }
+    // fold out_proj into spatial_linear: y = W_sl (W_o a + b_o) + b_sl
+    hipLaunchKernelGGL(fold_mm_kernel, dim3(2, 256), dim3(256), 0, st, 256, 512, 512, w->spatial_linear_w, w->out_proj_w, 1.0f, p->os_w);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, st, 256, 512, w->spatial_linear_w, w->out_proj_b, w->spatial_linear_b, 1.0f, p->os_b);
+    CN_CHECK_LAUNCH();
+    CN_D2D(p->as_w, w->attn_spatial_w, 64 * 256); CN_D2D(p->as_b, w->attn_spatial_b, 64);
+    CN_D2D(p->at_w, w->attn_temporal_w, 64 * 256); CN_D2D(p->at_b, w->attn_temporal_b, 64);
+    CN_D2D(p->rl_w, w->robot_linear_w, 256 * 9); CN_D2D(p->rl_b, w->robot_linear_b, 256);
+    CN_D2D(p->enc_w, w->enc_w, 64 * 256); CN_D2D(p->enc_b, w->enc_b, 64);
+    CN_D2D(p->edge_w, w->edge_embed_w, 64 * 256); CN_D2D(p->edge_b, w->edge_embed_b, 64);
+    CN_D2D(p->wih, w->gru_w_ih, 384 * 128); CN_D2D(p->whh, w->gru_w_hh, 384 * 128);
+    CN_D2D(p->bih, w->gru_b_ih, 384); CN_D2D(p->bhh, w->gru_b_hh, 384);
+    CN_D2D(p->out_w, w->out_w, 256 * 128); CN_D2D(p->out_b, w->out_b, 256);
+    CN_D2D(p->ac0_w, w->actor0_w, 256 * 256); CN_D2D(p->ac0_w + 256 * 256, w->critic0_w, 256 * 256);
+    CN_D2D(p->ac0_b, w->actor0_b, 256); CN_D2D(p->ac0_b + 256, w->critic0_b, 256);
+    CN_D2D(p->a2_w, w->actor2_w, 256 * 256); CN_D2D(p->a2_b, w->actor2_b, 256);
+    CN_D2D(p->c2_w, w->critic2_w, 256 * 256); CN_D2D(p->c2_b, w->critic2_b, 256);
+    CN_D2D(p->cl_w, w->critic_linear_w, 256); CN_D2D(p->cl_b, w->critic_linear_b, 1);
+    CN_D2D(p->fm_w, w->fc_mean_w, 512); CN_D2D(p->fm_b, w->fc_mean_b, 2); CN_D2D(p->logstd, w->logstd, 2);
+    p->weights_set = true;
+    return CN_OK;
+}
+
+static int harvest_profile(cn_policy *p)
+{
+    if (p->ev_pending) {
+        CN_HIP(hipEventSynchronize(p->ev[1]));
+        float ms = 0.f;
+        CN_HIP(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+        p->prof_ms[0] += ms; p->prof_n[0] += 1;
+        p->ev_pending = false;
+    }
+    return CN_OK;
+}
+
+static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *hxs_in, const float *masks, const float *eps,
+                          float *value, float *action, float *logp, float *hxs_out, hipStream_t st)
+{
+    CN_REQUIRE(p, "policy: null handle");
+    if (!p->weights_set) { cn_set_error("policy: call cn_policy_set_weights first"); return CN_ERR_STATE; }
+    CN_REQUIRE(E >= 1 && E <= p->maxE, "policy: E=%d outside [1,%d]", E, p->maxE);
+    CN_REQUIRE(obs && obs->robot_node && obs->temporal_edges && obs->spatial_edges && obs->detected_human_num, "policy: null observation pointer");
+    CN_REQUIRE(hxs_in && masks && value, "policy: null pointer");
+    const int H = p->H, D = p->D, M = E * H;
+    int rc;
+    // ---- human-human block ----
+    {
+        int blocks = (M + 1) / 2; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(256), 0, st, M, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->emb1);
+        CN_CHECK_LAUNCH();
+    }
+    if ((rc = launch_gemm<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_w, p->emb2_b, p->emb2, 512, st))) return rc;
+    if (p->profiling) { if ((rc = harvest_profile(p))) return rc; CN_HIP(hipEventRecord(p->ev[0], st)); }
+    if ((rc = launch_gemm<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_w, p->qkv_b, p->qkv, 1536, st))) return rc;
+    if (p->profiling) { CN_HIP(hipEventRecord(p->ev[1], st)); p->ev_pending = true; }
+    {
+        const size_t per_wave = (size_t)3 * H * 65 * sizeof(float); // K, V, Q of one (env, head)
+        int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+        hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, H, p->qkv,
+                           obs->detected_human_num, p->attn);
+        CN_CHECK_LAUNCH();
+    }
+    if ((rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st))) return rc;
+    if ((rc = launch_gemm<64, ACT_NONE>(M, 64, 256, p->out_sp, 256, p->as_w, p->as_b, p->s_emb, 64, st))) return rc;
+    // ---- robot node, robot-human attention ----
+    {
+        int blocks = E < 2048 ? E : 2048;
+        hipLaunchKernelGGL(robot_embed_kernel, dim3(blocks), dim3(256), 0, st, E, obs->temporal_edges, obs->robot_node, p->rl_w, p->rl_b, p->robot_states);
+        CN_CHECK_LAUNCH();
+    }
+    if ((rc = launch_gemm<64, ACT_NONE>(E, 64, 256, p->robot_states, 256, p->at_w, p->at_b, p->t_emb, 64, st))) return rc;
+    {
+        const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
+        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->t_emb, p->s_emb, p->out_sp, obs->detected_human_num,
+                           p->hr_out, p->hr_attn);
+        CN_CHECK_LAUNCH();
+    }
+    // ---- EndRNN: encoders -> GRU -> output_linear ----
+    if ((rc = launch_gemm<64, ACT_RELU>(E, 64, 256, p->robot_states, 256, p->enc_w, p->enc_b, p->x, 128, st))) return rc;
+    if ((rc = launch_gemm<64, ACT_RELU>(E, 64, 256, p->hr_out, 256, p->edge_w, p->edge_b, p->x + 64, 128, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_NONE>(E, 384, 128, p->x, 128, p->wih, p->bih, p->gi, 384, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_NONE>(E, 384, 128, hxs_in, 128, p->whh, nullptr, p->gh, 384, st))) return rc;
+    float *hdst = hxs_out ? hxs_out : p->hnew;
+    hipLaunchKernelGGL(gru_pointwise_kernel, dim3(E), dim3(128), 0, st, E, p->gi, p->gh, p->bhh, hxs_in, masks, hdst);
+    CN_CHECK_LAUNCH();
+    if ((rc = launch_gemm<128, ACT_NONE>(E, 256, 128, hdst, 128, p->out_w, p->out_b, p->rnn_out, 256, st))) return rc;
+    // ---- actor / critic trunks (first layers batched), heads ----
+    if ((rc = launch_gemm<128, ACT_TANH>(E, 512, 256, p->rnn_out, 256, p->ac0_w, p->ac0_b, p->ac1, 512, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_TANH>(E, 256, 256, p->ac1, 512, p->a2_w, p->a2_b, p->ac2, 512, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_TANH>(E, 256, 256, p->ac1 + 256, 512, p->c2_w, p->c2_b, p->ac2 + 256, 512, st))) return rc;
+    hipLaunchKernelGGL(gauss_head_kernel, dim3((E + 3) / 4), dim3(256), 0, st, E, p->ac2, 512, p->cl_w, p->cl_b, p->fm_w, p->fm_b, p->logstd, eps,
+                       value, action, logp);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_policy_act(cn_policy *p, int E, const cn_obs *obs, const float *hxs_in, const float *masks, const float *eps,
+                             float *value, float *action, float *logp, float *hxs_out, void *stream)
+{
+    CN_REQUIRE(action && logp && hxs_out, "cn_policy_act: null output pointer");
+    CN_REQUIRE(hxs_out != hxs_in, "cn_policy_act: hxs_out must not alias hxs_in");
+    return policy_forward(p, E, obs, hxs_in, masks, eps, value, action, logp, hxs_out, (hipStream_t)stream);
+}
+
+extern "C" int cn_policy_get_value(cn_policy *p, int E, const cn_obs *obs, const float *hxs_in, const float *masks, float *value, void *stream)
+{
+    return policy_forward(p, E, obs, hxs_in, masks, nullptr, value, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float *hr_attn, float *hr_out, float *robot_emb, float *actor_feat, void *stream)
+{
+    CN_REQUIRE(p && E >= 1 && E <= p->maxE, "cn_policy_get_taps: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t M = (size_t)E * p->H;
+    if (spatial_lin) CN_D2D(spatial_lin, p->out_sp, M * 256);
+    if (hr_attn) CN_D2D(hr_attn, p->hr_attn, M);
+    if (hr_out) CN_D2D(hr_out, p->hr_out, (size_t)E * 256);
+    if (robot_emb) CN_D2D(robot_emb, p->robot_states, (size_t)E * 256);
+    if (actor_feat) CN_HIP(hipMemcpy2DAsync(actor_feat, 256 * sizeof(float), p->ac2, 512 * sizeof(float), 256 * sizeof(float), E, hipMemcpyDeviceToDevice, st));
+    return CN_OK;
+}
+
+extern "C" int cn_policy_set_profiling(cn_policy *p, int enabled)
+{
+    CN_REQUIRE(p, "cn_policy_set_profiling: null handle");
+    p->profiling = enabled != 0;
+    return CN_OK;
+}
+
+extern "C" int cn_policy_get_profile(cn_policy *p, double *ms_out, int64_t *launches_out)
+{
+    CN_REQUIRE(p && ms_out && launches_out, "cn_policy_get_profile: null argument");
+    if (int rc = harvest_profile(p)) return rc;
+    for (int i = 0; i < 8; ++i) { ms_out[i] = p->prof_ms[i]; launches_out[i] = p->prof_n[i]; }
+    return CN_OK;
+}

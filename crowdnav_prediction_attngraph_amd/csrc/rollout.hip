@@ -1,0 +1,95 @@
+// rollout.hip -- GAE scan and advantage normalisation (rl/networks/storage.py:123-132, rl/ppo/ppo.py:37-39).
+//
+// GAE has a serial dependence over T (30) and none over envs: one lane per env, lanes of a wavefront read
+// consecutive envs of a [T][N] row -> fully coalesced; values stay in registers across the scan.  fp32 with torch's
+// operation order (-ffp-contract=off), so it is bit-identical to the reference loop.
+// Advantage statistics are wavefront-shuffle reductions accumulated in fp64, one atomic per block; the three partial
+// sums are exposed so that data-parallel ranks can all-reduce them before normalising (global mean / unbiased std).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gae_kernel(int T, int N, const float *__restrict__ rewards, const float *__restrict__ values,
+                                                  const float *__restrict__ masks, float gamma, float gl, float *__restrict__ returns)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float gae = 0.0f;
+    float v_next = values[(size_t)T * N + n];
+    for (int t = T - 1; t >= 0; --t) {
+        const float m = masks[(size_t)(t + 1) * N + n];
+        const float v = values[(size_t)t * N + n];
+        const float delta = rewards[(size_t)t * N + n] + gamma * v_next * m - v;
+        gae = delta + gl * m * gae;
+        returns[(size_t)t * N + n] = gae + v;
+        v_next = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void adv_stats_kernel(int64_t n, const float *__restrict__ returns, const float *__restrict__ values,
+                                                        double *stats)
+{
+    __shared__ double part[2][4];
+    double s = 0.0, ss = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = (double)(returns[i] - values[i]); // fp32 subtraction like torch, accumulated in fp64
+        s += a; ss += a * a;
+    }
+    s = wv_sum(s); ss = wv_sum(ss);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[0][w] = s; part[1][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(&stats[1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        if (blockIdx.x == 0) atomicAdd(&stats[2], (double)n);
+    }
+}
+
+__global__ __launch_bounds__(256) void adv_norm_kernel(int64_t n, const float *__restrict__ returns, const float *__restrict__ values,
+                                                       const double *__restrict__ stats, float *__restrict__ adv)
+{
+    const double cnt = stats[2];
+    const double mean = stats[0] / cnt;
+    double var = (stats[1] - cnt * mean * mean) / (cnt - 1.0); // unbiased (torch.std default)
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, denom = (float)sqrt(var) + 1e-5f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        adv[i] = ((returns[i] - values[i]) - meanf) / denom;
+}
+
+} // namespace
+
+extern "C" int cn_gae(int T, int N, const float *rewards, const float *values, const float *masks, double gamma, double lam,
+                      float *returns, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(T > 0 && N > 0 && rewards && values && masks && returns, "cn_gae: bad argument");
+    hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, rewards, values, masks,
+                       (float)gamma, (float)(gamma * lam), returns);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_adv_stats(int64_t n, const float *returns, const float *values, double *stats, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(n > 0 && returns && values && stats, "cn_adv_stats: bad argument");
+    CN_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), (hipStream_t)stream));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(adv_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, returns, values, stats);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_adv_normalize(int64_t n, const float *returns, const float *values, const double *stats, float *adv, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(n > 0 && returns && values && stats && adv, "cn_adv_normalize: bad argument");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adv_norm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, returns, values, stats, adv);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

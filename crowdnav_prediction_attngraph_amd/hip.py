@@ -1,0 +1,191 @@
+"""Thin object wrappers over the C ABI handles (cn_env_batch, cn_policy) and the rollout-math entry points."""
+import ctypes as C
+
+import torch
+
+from . import _abi as A
+
+
+def _need_cuda():
+    if not torch.cuda.is_available():
+        raise A.CnError("no GPU visible: the crowd-sim / policy hot path only runs on MI355X (no CPU fallback)")
+
+
+class HipEnvBatch:
+    """E device-resident environments (cn_env_batch).  Mirrors VecEnv reset/step at tensor level; no host sync."""
+
+    def __init__(self, cfg, num_envs, seed, first_env_index=0, device=None):
+        _need_cuda()
+        self.cfg = cfg
+        self.E = int(num_envs)
+        self.H = int(cfg.human_num)
+        self.D = A.lib().cn_env_obs_width(C.byref(cfg))
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_create(C.byref(cfg), self.E, int(seed), int(first_env_index), C.byref(h)), "cn_env_create")
+        self._h = h
+        E, H, D, dev = self.E, self.H, self.D, self.device
+        self.obs = {
+            "robot_node": torch.zeros(E, 1, 7, device=dev), "temporal_edges": torch.zeros(E, 1, 2, device=dev),
+            "spatial_edges": torch.zeros(E, H, D, device=dev), "detected_human_num": torch.zeros(E, 1, device=dev),
+            "visible_masks": torch.zeros(E, H, dtype=torch.uint8, device=dev),
+        }
+        self.reward = torch.zeros(E, device=dev)
+        self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.info = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.ep_return = torch.zeros(E, dtype=torch.float64, device=dev)
+        self.ep_len = torch.zeros(E, dtype=torch.int32, device=dev)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            A.lib().cn_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, obs=None):
+        obs = self.obs if obs is None else obs
+        o = A.obs_struct(obs)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_reset(self._h, C.byref(o), A.stream_ptr()), "cn_env_reset")
+        return obs
+
+    def step(self, actions, obs=None):
+        """actions [E,2] float32 on the device -> (obs, reward [E], done [E] u8, info [E] u8, ep_return, ep_len)."""
+        obs = self.obs if obs is None else obs
+        if actions.dtype != torch.float32 or actions.shape != (self.E, 2):
+            raise A.CnError("actions must be float32 [%d,2]" % self.E)
+        actions = actions.contiguous()
+        o = A.obs_struct(obs)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_step(self._h, A.ptr(actions), C.byref(o), A.ptr(self.reward), A.ptr(self.done), A.ptr(self.info),
+                                        A.ptr(self.ep_return), A.ptr(self.ep_len), A.stream_ptr()), "cn_env_step")
+        return obs, self.reward, self.done, self.info, self.ep_return, self.ep_len
+
+    def get_state(self):
+        humans = torch.zeros(self.E, self.H, 8, dtype=torch.float64, device=self.device)
+        robot = torch.zeros(self.E, 8, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_get_state(self._h, A.ptr(humans), A.ptr(robot), A.stream_ptr()), "cn_env_get_state")
+        return humans, robot
+
+    def get_human_actions(self):
+        out = torch.zeros(self.E, self.H, 2, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_get_human_actions(self._h, A.ptr(out), A.stream_ptr()), "cn_env_get_human_actions")
+        return out
+
+
+def orca_solve(self_state, others, neighbor_dist=10.0, max_neighbors=None, time_horizon=5.0, time_step=0.25):
+    """Batched stand-alone ORCA (rvo2 replacement).  self_state [B,8], others [B,n,5] float32 device tensors -> [B,2]."""
+    _need_cuda()
+    B, n = others.shape[0], others.shape[1]
+    out = torch.zeros(B, 2, device=self_state.device)
+    A.check(A.lib().cn_orca_solve(B, n, A.ptr(self_state.contiguous()), A.ptr(others.contiguous()), float(neighbor_dist),
+                                  n if max_neighbors is None else int(max_neighbors), float(time_horizon), float(time_step),
+                                  A.ptr(out), A.stream_ptr()), "cn_orca_solve")
+    return out
+
+
+class HipPolicy:
+    """cn_policy handle: rollout-time forward (act / get_value) of the attention-graph policy."""
+
+    def __init__(self, human_num, edge_width, max_envs, device=None):
+        _need_cuda()
+        self.H, self.D, self.maxE = int(human_num), int(edge_width), int(max_envs)
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_policy_create(self.H, self.D, self.maxE, C.byref(h)), "cn_policy_create")
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            A.lib().cn_policy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, state_dict):
+        """state_dict: reference key -> float32 device tensor (the library snapshots + folds them)."""
+        w = A.PolicyWeights()
+        keep = []
+        for field, key in A.POLICY_WEIGHT_KEYS:
+            t = state_dict[key].detach()
+            if t.dtype != torch.float32 or not t.is_cuda:
+                t = t.to(device=self.device, dtype=torch.float32)
+            t = t.contiguous()
+            keep.append(t)
+            setattr(w, field, t.data_ptr())
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_policy_set_weights(self._h, C.byref(w), A.stream_ptr()), "cn_policy_set_weights")
+        self._keep = keep  # keep sources alive until the async copies are ordered behind later work on the stream
+
+    def act(self, obs, hxs, masks, eps=None, out=None):
+        E = obs["robot_node"].shape[0]
+        dev = self.device
+        if out is None:
+            out = dict(value=torch.empty(E, 1, device=dev), action=torch.empty(E, 2, device=dev),
+                       logp=torch.empty(E, 1, device=dev), hxs=torch.empty(E, 1, 128, device=dev))
+        o = A.obs_struct(obs)
+        with torch.cuda.device(dev):
+            A.check(A.lib().cn_policy_act(self._h, E, C.byref(o), A.ptr(hxs.contiguous()), A.ptr(masks.contiguous()),
+                                          A.ptr(None if eps is None else eps.contiguous()), A.ptr(out["value"]), A.ptr(out["action"]),
+                                          A.ptr(out["logp"]), A.ptr(out["hxs"]), A.stream_ptr()), "cn_policy_act")
+        return out
+
+    def get_value(self, obs, hxs, masks, out=None):
+        E = obs["robot_node"].shape[0]
+        if out is None:
+            out = torch.empty(E, 1, device=self.device)
+        o = A.obs_struct(obs)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_policy_get_value(self._h, E, C.byref(o), A.ptr(hxs.contiguous()), A.ptr(masks.contiguous()), A.ptr(out),
+                                                A.stream_ptr()), "cn_policy_get_value")
+        return out
+
+    def taps(self, E):
+        dev, H = self.device, self.H
+        t = dict(spatial_lin=torch.empty(E, H, 256, device=dev), hr_attn=torch.empty(E, H, device=dev),
+                 hr_out=torch.empty(E, 256, device=dev), robot_emb=torch.empty(E, 256, device=dev), actor_feat=torch.empty(E, 256, device=dev))
+        with torch.cuda.device(dev):
+            A.check(A.lib().cn_policy_get_taps(self._h, E, A.ptr(t["spatial_lin"]), A.ptr(t["hr_attn"]), A.ptr(t["hr_out"]),
+                                               A.ptr(t["robot_emb"]), A.ptr(t["actor_feat"]), A.stream_ptr()), "cn_policy_get_taps")
+        return t
+
+    def set_profiling(self, enabled):
+        A.check(A.lib().cn_policy_set_profiling(self._h, int(bool(enabled))), "cn_policy_set_profiling")
+
+    def get_profile(self):
+        ms = (C.c_double * 8)()
+        n = (C.c_int64 * 8)()
+        A.check(A.lib().cn_policy_get_profile(self._h, ms, n), "cn_policy_get_profile")
+        return list(ms), list(n)
+
+
+def gae(rewards, values, masks, gamma, lam, returns):
+    """rewards [T,N,1], values/masks/returns [T+1,N,1] contiguous float32 device tensors; fills returns[:T]."""
+    T, N = rewards.shape[0], rewards.shape[1]
+    A.check(A.lib().cn_gae(T, N, A.ptr(rewards), A.ptr(values), A.ptr(masks), float(gamma), float(lam), A.ptr(returns), A.stream_ptr()), "cn_gae")
+    return returns
+
+
+def adv_stats(returns, values, n):
+    stats = torch.zeros(3, dtype=torch.float64, device=returns.device)
+    A.check(A.lib().cn_adv_stats(int(n), A.ptr(returns), A.ptr(values), A.ptr(stats), A.stream_ptr()), "cn_adv_stats")
+    return stats
+
+
+def adv_normalize(returns, values, stats, n, out):
+    A.check(A.lib().cn_adv_normalize(int(n), A.ptr(returns), A.ptr(values), A.ptr(stats), A.ptr(out), A.stream_ptr()), "cn_adv_normalize")
+    return out

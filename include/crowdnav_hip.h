@@ -1,0 +1,175 @@
+/*
+ * crowdnav_hip.h -- C ABI of libcrowdnav_hip.so, the MI355X (gfx950) implementation of the CrowdNav++ hot path.
+ *
+ * The reference (Shuijing725/CrowdNav_Prediction_AttnGraph) is pure Python; its only native boundary on this path is
+ * the third-party `rvo2` module.  There is therefore no existing FFI to bind to: this header defines the boundary a
+ * maintainer would bind from the reference's Python (ctypes stub in INTEGRATION.md), one entry point per reference
+ * interface it replaces:
+ *
+ *   cn_env_create/destroy      <- rl/networks/envs.py:97-140 make_vec_envs (+ :36-94 make_env: thisSeed = seed + rank,
+ *                                 nenv, phase) and crowd_sim/envs/crowd_sim.py:88-202 configure()
+ *   cn_env_reset               <- VecEnv.reset(): rl/networks/shmem_vec_env.py:74-79 -> crowd_sim_var_num.py:303-363
+ *   cn_env_step                <- VecEnv.step(): shmem_vec_env.py:136-142 (auto-reset) -> crowd_sim_var_num.py:366-460
+ *                                 / crowd_sim_pred.py:100-214, incl. ORCA humans (crowd_nav/policy/orca.py:64-117,
+ *                                 i.e. rvo2.PyRVOSimulator.doStep) and bench.Monitor episode stats (envs.py:70-73)
+ *   cn_orca_solve              <- rvo2: PyRVOSimulator.addAgent / setAgentPosition,Velocity,PrefVelocity / doStep / getAgentVelocity(0) (orca.py:80-114)
+ *   cn_policy_create/destroy/set_weights <- rl/networks/model.py:16-46 Policy.__init__ / load_state_dict
+ *   cn_policy_act              <- rl/networks/model.py:56-74 Policy.act (-> selfAttn_srnn_temp_node.py:360-449)
+ *   cn_policy_get_value        <- rl/networks/model.py:76-80 Policy.get_value
+ *   cn_gae                     <- rl/networks/storage.py:123-132 RolloutStorage.compute_returns (use_gae branch)
+ *   cn_adv_stats / cn_adv_normalize <- rl/ppo/ppo.py:37-39 advantage normalisation (split so that N GPUs can
+ *                                 all-reduce the three partial sums in between)
+ *
+ * Conventions: every function returns 0 on success and a negative cn_status otherwise (no C++ exception crosses the
+ * ABI); cn_last_error() returns a thread-local message.  All tensor arguments are raw DEVICE pointers owned by the
+ * caller (PyTorch allocates them); the library owns only the opaque handles (persistent per-env simulator state incl.
+ * the numpy-compatible MT19937 streams, and the policy workspace / folded weights).  `stream` is a hipStream_t passed
+ * as void*; all work is enqueued on it and nothing synchronises with the host.  A handle is re-entrant across handles,
+ * not thread-safe on one handle.  There is no CPU fallback: every entry point fails if no gfx950 device is present.
+ */
+#ifndef CROWDNAV_HIP_H
+#define CROWDNAV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CN_OK = 0,
+    CN_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    CN_ERR_HIP = -2,       /* a HIP runtime call failed (see cn_last_error) */
+    CN_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
+    CN_ERR_STATE = -4      /* call sequence error (e.g. step before reset, weights not set) */
+} cn_status;
+
+enum { CN_ENV_VARNUM = 0, CN_ENV_PRED = 1, CN_ENV_PRED_GST = 2 };   /* gym ids CrowdSimVarNum-v0 / CrowdSimPred-v0 / CrowdSimPredRealGST-v0 */
+enum { CN_PHASE_TRAIN = 0, CN_PHASE_VAL = 1, CN_PHASE_TEST = 2 };
+enum { CN_INFO_NOTHING = 0, CN_INFO_TIMEOUT = 1, CN_INFO_COLLISION = 2, CN_INFO_REACHGOAL = 3, CN_INFO_DANGER = 4 }; /* crowd_sim/envs/utils/info.py */
+
+#define CN_MAX_HUMANS 64 /* one wavefront lane per human */
+#define CN_MAX_PRED 8
+
+/* Mirrors the fields of crowd_nav/configs/config.py that the path reads (same names, same meaning). */
+typedef struct {
+    int32_t human_num;            /* sim.human_num; sim.human_num_range must be 0 */
+    int32_t predict_steps;        /* sim.predict_steps */
+    int32_t env_kind;             /* CN_ENV_* */
+    int32_t randomize_attributes; /* env.randomize_attributes */
+    int32_t random_goal_changing; /* humans.random_goal_changing */
+    int32_t end_goal_changing;    /* humans.end_goal_changing */
+    int32_t sort_humans;          /* args.sort_humans */
+    int32_t phase;                /* CN_PHASE_* (only TRAIN is implemented on the device in this round) */
+    int32_t nenv;                 /* TOTAL number of envs across all GPUs: the case_counter stride (crowd_sim_var_num.py:348) */
+    uint32_t val_size, test_size;
+    double time_step, time_limit;
+    double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
+    double circle_radius, arena_size;
+    double human_radius, human_v_pref;
+    double robot_radius, robot_v_pref, sensor_range;
+    double goal_change_chance, end_goal_change_chance;
+    double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
+} cn_env_config;
+
+/* Observation tensors exactly as VecPyTorch returns them (float32, contiguous):
+ * robot_node [E,1,7], temporal_edges [E,1,2], spatial_edges [E,H,D] (D = 2 or 2*(predict_steps+1)),
+ * detected_human_num [E,1], visible_masks [E,H] (uint8 0/1; may be NULL). */
+typedef struct {
+    float *robot_node;
+    float *temporal_edges;
+    float *spatial_edges;
+    float *detected_human_num;
+    uint8_t *visible_masks;
+} cn_obs;
+
+typedef struct cn_env_batch cn_env_batch;
+typedef struct cn_policy cn_policy;
+
+const char *cn_last_error(void);
+int cn_version(void);
+int cn_device_count(void);
+
+void cn_env_config_default(cn_env_config *cfg);
+/* num_envs envs on the current device; env i gets thisSeed = seed + first_env_index + i (global env index, so that
+ * trajectories do not depend on how many GPUs the batch is sharded over). */
+int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t seed, int64_t first_env_index, cn_env_batch **out);
+int cn_env_destroy(cn_env_batch *env);
+int cn_env_obs_width(const cn_env_config *cfg);
+int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);
+/* actions [E,2] float32 (raw policy output; clipped inside like srnn.clip_action).  Outputs: reward [E] float32,
+ * done [E] uint8, info [E] uint8 (CN_INFO_*), ep_return [E] float64 and ep_len [E] int32 (valid where done: the
+ * bench.Monitor episode sum / length).  Envs that finish are reset in the same launch and `obs` holds the reset
+ * observation for them (shmem_vec_env.py:139-142). */
+int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done, uint8_t *info,
+                double *ep_return, int32_t *ep_len, void *stream);
+/* Debug/test access to the simulator state: copies humans [E,H,8] (px,py,vx,vy,gx,gy,radius,v_pref) and robot [E,8]
+ * (px,py,vx,vy,gx,gy,theta,potential) as float64 into caller DEVICE buffers (either may be NULL). */
+int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream);
+/* last ORCA velocities of the humans, [E,H,2] float32 device buffer */
+int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream);
+
+/* Stand-alone batched ORCA solve (the rvo2 replacement): B independent agents, each with n_other neighbours.
+ * self [B,8] = px,py,vx,vy,radius,max_speed,pref_vx,pref_vy ; others [B,n_other,5] = px,py,vx,vy,radius (float32);
+ * out_vel [B,2].  n_other <= 63.  Parameters as PyRVOSimulator.addAgent. */
+int cn_orca_solve(int B, int n_other, const float *self, const float *others, float neighbor_dist, int max_neighbors,
+                  float time_horizon, float time_step, float *out_vel, void *stream);
+
+/* ---- policy (selfAttn_merge_srnn + DiagGaussian head) ---- */
+/* Device pointers to the fp32 parameters, named after the reference state_dict keys (model.py / SURVEY.md 8a-P0). */
+typedef struct {
+    const float *robot_linear_w, *robot_linear_b;                 /* base.robot_linear.0 [256,9] */
+    const float *emb0_w, *emb0_b;                                 /* base.spatial_attn.embedding_layer.0 [128,D] */
+    const float *emb2_w, *emb2_b;                                 /* base.spatial_attn.embedding_layer.2 [512,128] */
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;               /* base.spatial_attn.{q,k,v}_linear [512,512] */
+    const float *in_proj_w, *in_proj_b;                           /* base.spatial_attn.multihead_attn.in_proj_* [1536,512] */
+    const float *out_proj_w, *out_proj_b;                         /* ...multihead_attn.out_proj [512,512] */
+    const float *spatial_linear_w, *spatial_linear_b;             /* base.spatial_linear.0 [256,512] */
+    const float *attn_temporal_w, *attn_temporal_b;               /* base.attn.temporal_edge_layer.0 [64,256] */
+    const float *attn_spatial_w, *attn_spatial_b;                 /* base.attn.spatial_edge_layer.0 [64,256] */
+    const float *enc_w, *enc_b;                                   /* base.humanNodeRNN.encoder_linear [64,256] */
+    const float *edge_embed_w, *edge_embed_b;                     /* base.humanNodeRNN.edge_attention_embed [64,256] */
+    const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;       /* base.humanNodeRNN.gru.* [384,128],[384,128],[384],[384] */
+    const float *out_w, *out_b;                                   /* base.humanNodeRNN.output_linear [256,128] */
+    const float *actor0_w, *actor0_b, *actor2_w, *actor2_b;       /* base.actor.{0,2} [256,256] */
+    const float *critic0_w, *critic0_b, *critic2_w, *critic2_b;   /* base.critic.{0,2} [256,256] */
+    const float *critic_linear_w, *critic_linear_b;               /* base.critic_linear [1,256] */
+    const float *fc_mean_w, *fc_mean_b;                           /* dist.fc_mean [2,256] */
+    const float *logstd;                                          /* dist.logstd._bias [2,1] */
+} cn_policy_weights;
+
+/* H humans, D = spatial edge width, max_envs = largest batch any later call will pass. */
+int cn_policy_create(int human_num, int edge_width, int max_envs, cn_policy **out);
+int cn_policy_destroy(cn_policy *p);
+/* Snapshot the weights (copies + pre-folds the affine pairs q/k/v_linear∘in_proj and out_proj∘spatial_linear).
+ * Call again after every optimiser step that changed them. */
+int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, void *stream);
+/* One rollout-time forward for E envs.  hxs_in/out [E,128] (human_node_rnn), masks [E,1].  eps [E,2] standard-normal
+ * noise or NULL for the deterministic mode() action.  Outputs value [E,1], action [E,2], logp [E,1]. */
+int cn_policy_act(cn_policy *p, int E, const cn_obs *obs, const float *hxs_in, const float *masks, const float *eps,
+                  float *value, float *action, float *logp, float *hxs_out, void *stream);
+int cn_policy_get_value(cn_policy *p, int E, const cn_obs *obs, const float *hxs_in, const float *masks, float *value,
+                        void *stream);
+/* Test taps of the last act/get_value call: hh_out [E,H,512] is not materialised by the folded pipeline, so the taps
+ * are spatial_lin [E,H,256], hr_attn [E,H], hr_out [E,256], robot_emb [E,256], actor_feat [E,256] (NULL to skip). */
+int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float *hr_attn, float *hr_out, float *robot_emb,
+                       float *actor_feat, void *stream);
+/* Dominant-kernel timing support for bench.py: number of HH-block launches so far and accumulated device time of the
+ * QKV projection kernel measured with hipEvents on `stream` when profiling is enabled. */
+int cn_policy_set_profiling(cn_policy *p, int enabled);
+int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launches_out /*[8]*/);
+
+/* ---- rollout math ---- */
+/* rewards [T,N], values [T+1,N], masks [T+1,N] -> returns[t][n] for t < T (row T untouched).  fp32, torch op order. */
+int cn_gae(int T, int N, const float *rewards, const float *values, const float *masks, double gamma, double lam,
+           float *returns, void *stream);
+/* stats[3] (float64, device) = {sum, sum of squares, count} of (returns - values) over n elements */
+int cn_adv_stats(int64_t n, const float *returns, const float *values, double *stats, void *stream);
+/* adv = ((returns - values) - mean) / (std_unbiased + 1e-5) with mean/std derived from stats (possibly all-reduced) */
+int cn_adv_normalize(int64_t n, const float *returns, const float *values, const double *stats, float *adv, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROWDNAV_HIP_H */
