@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of BASELINE.json on MI355X: env-steps/s of (policy forward -> crowd_sim step) at 20 humans.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole batch: the attention-graph policy's forward on the current
+observations (fp32, sampled action), the ORCA/crowd-sim step for all E envs with in-launch auto-reset, and the done
+mask for the next forward.  Inputs (env state, observations, weights) are resident in HBM before the timed region.
+Workload at N=1: BASELINE configs[1] -- CrowdSimVarNum-v0, 20 humans, 4096 envs, HH+HR attention on.  With N ranks
+every rank owns 4096 envs (weak scaling, global env indices rank*4096.., no data-path collective in the rollout).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic policy-forward FLOPs per env-step (unfolded reference graph) and compulsory HBM bytes
+def flops_per_env_step(H, D):
+    return 2 * (H * (D * 128 + 128 * 512 + 3 * 512 ** 2 + 3 * 512 ** 2 + 512 ** 2 + 512 * 256 + 256 * 64) + 2 * 8 * H * H * 64
+                + 9 * 256 + 256 * 64 * 3 + H * 64 + H * 256 + 3 * 128 * 256 + 128 * 256 + 4 * 256 ** 2 + 256 + 512)
+
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(H, envs=48, steps=60):
+    """The oracle (kind='port': scalar C sim + numpy policy forward) on ONE host core, bounded sample."""
+    import numpy as np
+    from oracle import oracle as O
+    from oracle import policy_oracle as P
+    from tests import policy_util as PU
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    shapes = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "policy_varnum_e4_h20.npz"))["meta"]))["shapes"]
+    sd = PU.formula_state_dict({k: tuple(v) for k, v in shapes.items()})
+    cfg = O.default_config(human_num=H, nenv=envs)
+    oenvs = [O.OracleEnv(cfg, 425 + i) for i in range(envs)]
+    obs = [e.reset() for e in oenvs]
+    h = np.zeros((envs, 128))
+    masks = np.ones((envs, 1))
+    rs = np.random.RandomState(0)
+    std = np.exp(sd["dist.logstd._bias"].astype(np.float64).reshape(1, 2))
+
+    def run(n):
+        nonlocal obs, h, masks
+        t_sim = t_pol = 0.0
+        for _ in range(n):
+            t0 = time.perf_counter()
+            batch = {k: np.stack([o[k] for o in obs]) for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+            _, mean, _, h, _ = P.act(sd, batch, h, masks)
+            act = (mean + std * rs.standard_normal((envs, 2))).astype(np.float32)
+            t1 = time.perf_counter()
+            dones = []
+            for i, e in enumerate(oenvs):
+                ob, _, d, _ = e.step(act[i], autoreset=True)
+                obs[i] = ob
+                dones.append(d)
+            masks = 1.0 - np.array(dones, dtype=np.float64).reshape(envs, 1)
+            t2 = time.perf_counter()
+            t_pol += t1 - t0
+            t_sim += t2 - t1
+        return t_sim, t_pol
+
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        run(2)
+        t_sim, t_pol = run(steps)
+    finally:
+        if ctx is not None:
+            ctx.unregister() if hasattr(ctx, "unregister") else None
+    n = envs * steps
+    return {"value": round(n / (t_sim + t_pol), 2), "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d steps of the same workload (H=%d): scalar C sim %.0f env-steps/s, numpy fp64 policy forward %.0f env-steps/s, 1 thread"
+                      % (envs, steps, H, n / t_sim, n / t_pol)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--humans", type=int, default=20)
+    ap.add_argument("--env-name", default="CrowdSimVarNum-v0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+
+    E, H = args.envs, args.humans
+    kind = A.ENV_KINDS[args.env_name]
+    cfg = A.default_env_config(human_num=H, env_kind=kind, nenv=E * world)
+    env = HipEnvBatch(cfg, E, 425, first_env_index=rank * E)
+    D = env.D
+    torch.manual_seed(425)
+    ob_space, act_space = make_spaces(H, D)
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name=args.env_name, num_processes=E), base="selfAttn_merge_srnn").cuda()
+    pol = HipPolicy(H, D, E)
+    pol.set_weights(net.state_dict())
+    obs = env.reset()
+    hxs = [torch.zeros(E, 1, 128, device="cuda"), torch.zeros(E, 1, 128, device="cuda")]
+    masks = torch.ones(E, 1, device="cuda")
+    out = dict(value=torch.empty(E, 1, device="cuda"), action=torch.empty(E, 2, device="cuda"), logp=torch.empty(E, 1, device="cuda"), hxs=hxs[1])
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    eps = torch.empty(E, 2, device="cuda")
+
+    def step(i):
+        nonlocal masks
+        eps.normal_(generator=gen)
+        out["hxs"] = hxs[(i + 1) & 1]
+        pol.act(obs, hxs[i & 1], masks, eps=eps, out=out)
+        _, _, done, _, _, _ = env.step(out["action"])
+        masks = (done == 0).to(torch.float32).view(E, 1)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    pol.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    pol.set_profiling(False)
+    prof_ms, prof_n = pol.get_profile()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    total_env_steps = E * world * args.steps
+    value = total_env_steps / elapsed
+    # dominant kernel: the folded QKV projection GEMM [M,512]x[512,1536] (fp32 MFMA), timed with HIP events on its stream
+    M = E * H
+    qkv_flops = 2.0 * M * 512 * 1536
+    qkv_ms = prof_ms[0] / max(prof_n[0], 1)
+    achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12 if qkv_ms > 0 else 0.0
+    F = flops_per_env_step(H, D)
+    line = {
+        "metric": "env-steps/sec (sim+policy fwd) at %d humans" % H, "value": round(value, 1), "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %s, %d humans, %d parallel envs per GPU, HH+HR attention on, "
+                               "policy forward + ORCA sim step + auto-reset per step" % (args.env_name, H, E),
+                   "envs_per_gpu": E, "humans": H, "parallelism": "dp%d (envs sharded, no rollout collective)" % world,
+                   "policy_init": "orthogonal, torch.manual_seed(425)", "sampled_actions": True},
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<128,NONE> (folded q|k|v projection, M=%d N=1536 K=512)" % M,
+                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "launch_ms": round(qkv_ms, 4), "launches": int(prof_n[0]),
+                     "whole_step": {"algorithmic_flops_per_env_step": F, "achieved_tflops_reference_graph": round(value / world * F / 1e12, 2),
+                                    "frac_of_f32_mfma_peak": round(value / world * F / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(H)
+        line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        line["gpu_over_cpu_1core"] = round(value / line["cpu_baseline"]["value"], 1)
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

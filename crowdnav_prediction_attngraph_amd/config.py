@@ -1,0 +1,89 @@
+"""Config -- the fields of crowd_nav/configs/config.py the hot path reads, same nesting and names
+(config.env.time_step, config.sim.human_num, config.humans.radius, config.orca.neighbor_dist, ...), so a reference
+Config instance and this one are interchangeable as the `config=` argument of make_vec_envs.
+Defaults follow crowd_nav/configs/config.py:16-120."""
+import copy
+import math
+import types
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+class Config(object):
+    def __init__(self, args=None, **overrides):
+        self.args = args if args is not None else _ns(sort_humans=True, env_name="CrowdSimVarNum-v0", num_processes=16, seed=425)
+        self.training = _ns(device="cuda:0")
+        self.env = _ns(time_limit=50, time_step=0.25, val_size=100, test_size=500, randomize_attributes=True,
+                       num_processes=getattr(self.args, "num_processes", 16), record=False, load_act=False, use_wrapper=False)
+        self.reward = _ns(success_reward=10, collision_penalty=-20, discomfort_dist=0.25, discomfort_penalty_factor=10, gamma=0.99)
+        self.sim = _ns(circle_radius=6 * math.sqrt(2), arena_size=6, human_num=20, human_num_range=0, predict_steps=5,
+                       predict_method="none", render=False)
+        self.humans = _ns(visible=True, policy="orca", radius=0.3, v_pref=1, sensor="coordinates", FOV=2.,
+                          random_goal_changing=True, goal_change_chance=0.5, end_goal_changing=True, end_goal_change_chance=1.0,
+                          random_radii=False, random_v_pref=False, random_unobservability=False, unobservable_chance=0.3,
+                          random_policy_changing=False)
+        self.robot = _ns(visible=False, policy="selfAttn_merge_srnn", radius=0.3, v_pref=1, sensor="coordinates", FOV=2, sensor_range=5)
+        self.action_space = _ns(kinematics="holonomic")
+        self.orca = _ns(neighbor_dist=10, safety_space=0.15, time_horizon=5, time_horizon_obst=5)
+        self.data = _ns(pred_timestep=0.25)
+        for k, v in overrides.items():
+            ns, attr = k.split(".")
+            setattr(getattr(self, ns), attr, v)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+
+def non_randomized(args=None, **overrides):
+    """The non-randomised preset of trained_models/GST_predictor_non_rand (BASELINE configs[1])."""
+    o = {"env.randomize_attributes": False, "humans.random_goal_changing": False, "humans.end_goal_changing": True}
+    o.update(overrides)
+    return Config(args, **o)
+
+
+def to_env_config(config, env_name, nenv_total, phase="train"):
+    """Reference-style Config -> cn_env_config, rejecting settings the device simulator does not implement."""
+    from . import _abi as A
+    if env_name not in A.ENV_KINDS:
+        raise NotImplementedError("env id %r is not on the accelerated path (supported: %s)" % (env_name, sorted(A.ENV_KINDS)))
+    g = lambda ns, name, default: getattr(getattr(config, ns, None), name, default)  # noqa: E731
+    unsupported = []
+    if g("sim", "human_num_range", 0) != 0:
+        unsupported.append("sim.human_num_range != 0")
+    if g("robot", "visible", False):
+        unsupported.append("robot.visible=True")
+    if g("action_space", "kinematics", "holonomic") != "holonomic":
+        unsupported.append("unicycle kinematics")
+    if g("humans", "policy", "orca") != "orca":
+        unsupported.append("humans.policy != 'orca'")
+    if float(g("humans", "FOV", 2.)) != 2.0 or float(g("robot", "FOV", 2)) != 2.0:
+        unsupported.append("FOV != 2*pi")
+    if env_name == "CrowdSimPred-v0" and g("sim", "predict_method", "const_vel") != "const_vel":
+        unsupported.append("sim.predict_method=%r (only const_vel)" % g("sim", "predict_method", None))
+    if phase != "train":
+        unsupported.append("phase=%r (test phase needs the 'truth' predictor: SURVEY.md 8f-1)" % phase)
+    if float(g("env", "time_step", 0.25)) != float(g("data", "pred_timestep", 0.25)):
+        unsupported.append("data.pred_timestep != env.time_step")
+    if unsupported:
+        raise NotImplementedError("not implemented on the device path yet: " + "; ".join(unsupported))
+    return A.default_env_config(
+        human_num=int(g("sim", "human_num", 20)), predict_steps=int(g("sim", "predict_steps", 5)), env_kind=A.ENV_KINDS[env_name],
+        randomize_attributes=int(bool(g("env", "randomize_attributes", True))),
+        random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
+        end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
+        sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
+        phase=0, nenv=int(nenv_total), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
+        time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),
+        success_reward=float(g("reward", "success_reward", 10)), collision_penalty=float(g("reward", "collision_penalty", -20)),
+        discomfort_dist=float(g("reward", "discomfort_dist", 0.25)),
+        discomfort_penalty_factor=float(g("reward", "discomfort_penalty_factor", 10)),
+        circle_radius=float(g("sim", "circle_radius", 6 * math.sqrt(2))), arena_size=float(g("sim", "arena_size", 6)),
+        human_radius=float(g("humans", "radius", 0.3)), human_v_pref=float(g("humans", "v_pref", 1)),
+        robot_radius=float(g("robot", "radius", 0.3)), robot_v_pref=float(g("robot", "v_pref", 1)),
+        sensor_range=float(g("robot", "sensor_range", 5)),
+        goal_change_chance=float(g("humans", "goal_change_chance", 0.5)),
+        end_goal_change_chance=float(g("humans", "end_goal_change_chance", 1.0)),
+        orca_neighbor_dist=float(g("orca", "neighbor_dist", 10)), orca_safety_space=float(g("orca", "safety_space", 0.15)),
+        orca_time_horizon=float(g("orca", "time_horizon", 5)), orca_time_horizon_obst=float(g("orca", "time_horizon_obst", 5)))

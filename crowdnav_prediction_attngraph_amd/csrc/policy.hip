@@ -340,8 +340,9 @@ struct cn_policy {
     float *robot_states, *t_emb, *hr_out, *hr_attn, *x, *gi, *gh, *hnew, *rnn_out, *ac1, *ac2;
     // profiling of the dominant kernel (QKV projection)
     bool profiling;
-    hipEvent_t ev[2];
-    bool ev_pending;
+    static constexpr int PROF_RING = 64;
+    hipEvent_t ev[PROF_RING][2]; // ring of (start, stop) pairs around the QKV projection launch
+    int ev_head, ev_tail;        // [tail, head) are recorded but not yet harvested
     double prof_ms[8];
     int64_t prof_n[8];
 };
@@ -402,10 +403,11 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
     p->weights_set = false;
     p->profiling = false;
-    p->ev_pending = false;
-    if (hipEventCreate(&p->ev[0]) != hipSuccess || hipEventCreate(&p->ev[1]) != hipSuccess) {
-        (void)hipFree(base); delete p; cn_set_error("cn_policy_create: hipEventCreate failed"); return CN_ERR_HIP;
-    }
+    p->ev_head = p->ev_tail = 0;
+    for (int i = 0; i < cn_policy::PROF_RING; ++i)
+        if (hipEventCreate(&p->ev[i][0]) != hipSuccess || hipEventCreate(&p->ev[i][1]) != hipSuccess) {
+            (void)hipFree(base); delete p; cn_set_error("cn_policy_create: hipEventCreate failed"); return CN_ERR_HIP;
+        }
     *out = p;
     return CN_OK;
 }
@@ -413,8 +415,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
 extern "C" int cn_policy_destroy(cn_policy *p)
 {
     if (!p) return CN_OK;
-    (void)hipEventDestroy(p->ev[0]);
-    (void)hipEventDestroy(p->ev[1]);
+    for (int i = 0; i < cn_policy::PROF_RING; ++i) { (void)hipEventDestroy(p->ev[i][0]); (void)hipEventDestroy(p->ev[i][1]); }
     if (p->blob) CN_HIP(hipFree(p->blob));
     delete p;
     return CN_OK;
@@ -466,14 +467,19 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
     return CN_OK;
 }
 
-static int harvest_profile(cn_policy *p)
+// Collect finished (start, stop) pairs.  `all` waits for everything recorded; otherwise only the oldest slot is waited
+// for, and only when the ring is full (it finished long ago: the host is at most a few launches ahead of the device).
+static int harvest_profile(cn_policy *p, bool all)
 {
-    if (p->ev_pending) {
-        CN_HIP(hipEventSynchronize(p->ev[1]));
+    constexpr int R = cn_policy::PROF_RING;
+    while (p->ev_tail != p->ev_head) {
+        const bool full = ((p->ev_head + 1) % R) == p->ev_tail;
+        if (!all && !full) break;
+        CN_HIP(hipEventSynchronize(p->ev[p->ev_tail][1]));
         float ms = 0.f;
-        CN_HIP(hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+        CN_HIP(hipEventElapsedTime(&ms, p->ev[p->ev_tail][0], p->ev[p->ev_tail][1]));
         p->prof_ms[0] += ms; p->prof_n[0] += 1;
-        p->ev_pending = false;
+        p->ev_tail = (p->ev_tail + 1) % R;
     }
     return CN_OK;
 }
@@ -495,9 +501,9 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         CN_CHECK_LAUNCH();
     }
     if ((rc = launch_gemm<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_w, p->emb2_b, p->emb2, 512, st))) return rc;
-    if (p->profiling) { if ((rc = harvest_profile(p))) return rc; CN_HIP(hipEventRecord(p->ev[0], st)); }
+    if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
     if ((rc = launch_gemm<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_w, p->qkv_b, p->qkv, 1536, st))) return rc;
-    if (p->profiling) { CN_HIP(hipEventRecord(p->ev[1], st)); p->ev_pending = true; }
+    if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
     {
         const size_t per_wave = (size_t)3 * H * 65 * sizeof(float); // K, V, Q of one (env, head)
         int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
@@ -575,7 +581,7 @@ extern "C" int cn_policy_set_profiling(cn_policy *p, int enabled)
 extern "C" int cn_policy_get_profile(cn_policy *p, double *ms_out, int64_t *launches_out)
 {
     CN_REQUIRE(p && ms_out && launches_out, "cn_policy_get_profile: null argument");
-    if (int rc = harvest_profile(p)) return rc;
+    if (int rc = harvest_profile(p, true)) return rc;
     for (int i = 0; i < 8; ++i) { ms_out[i] = p->prof_ms[i]; launches_out[i] = p->prof_n[i]; }
     return CN_OK;
 }

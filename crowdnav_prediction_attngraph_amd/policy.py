@@ -1,0 +1,300 @@
+"""Policy -- host-side mirror of the reference's `rl.networks.model.Policy` (selfAttn_merge_srnn base + DiagGaussian).
+
+Same constructor signature, `act` / `get_value` / `evaluate_actions` contracts and state-dict keys as
+/root/reference/rl/networks/model.py:14-90 and rl/networks/selfAttn_srnn_temp_node.py:287-449, so reference
+checkpoints load and `train.py` runs unchanged.  Two execution paths:
+
+  * rollout (`act`, `get_value`, no autograd) on a GPU -> hand-written HIP kernels through the C ABI
+    (cn_policy_act / cn_policy_get_value).  There is no fallback: on CUDA tensors a missing extension raises.
+  * training (`evaluate_actions`, needs gradients) -> the same math expressed in torch ops so autograd provides the
+    backward (hand-written backward kernels are the next step).  CPU tensors also take this path; it
+    exists for the CPU unit tests and the reference's `--no-cuda` plumbing mode, never silently on a GPU box.
+
+Parameter construction order follows the reference so that `torch.manual_seed(s); Policy(...)` yields bit-identical
+initial weights (tests/test_host_policy.py checks this against checksums captured from the reference).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Box:
+    """Minimal gym.spaces.Box stand-in (gym is not a dependency of the hot path)."""
+
+    def __init__(self, low=-np.inf, high=np.inf, shape=None, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    def __repr__(self):
+        return "Box%s" % (self.shape,)
+
+
+class Dict:
+    def __init__(self, spaces):
+        self.spaces = OrderedDict(sorted(spaces.items()))
+
+
+def make_spaces(human_num, edge_width, with_masks=True):
+    """Observation / action spaces of CrowdSimVarNum-v0 (crowd_sim_var_num.py:37-58) and the Pred variants."""
+    d = {"robot_node": Box(shape=(1, 7)), "temporal_edges": Box(shape=(1, 2)), "spatial_edges": Box(shape=(human_num, edge_width)),
+         "detected_human_num": Box(shape=(1,))}
+    if with_masks:
+        d["visible_masks"] = Box(shape=(human_num,), dtype=np.bool_)
+    return Dict(d), Box(shape=(2,))
+
+
+def _arg(args, name, default):
+    if args is None:
+        return default
+    if isinstance(args, dict):
+        return args.get(name, default)
+    return getattr(args, name, default)
+
+
+def _ortho(module, gain=1.0):
+    nn.init.orthogonal_(module.weight.data, gain=gain)
+    nn.init.constant_(module.bias.data, 0)
+    return module
+
+
+class _AddBias(nn.Module):
+    """rl/networks/network_utils.py:31-42 -- keeps the checkpoint key `dist.logstd._bias` ([2,1])."""
+
+    def __init__(self, bias):
+        super().__init__()
+        self._bias = nn.Parameter(bias.unsqueeze(1))
+
+    def forward(self, x):
+        return x + self._bias.t().view(1, -1)
+
+
+class _DiagGaussian(nn.Module):
+    def __init__(self, num_inputs, num_outputs):
+        super().__init__()
+        self.fc_mean = _ortho(nn.Linear(num_inputs, num_outputs))
+        self.logstd = _AddBias(torch.zeros(num_outputs))
+
+
+class _EndRNN(nn.Module):
+    def __init__(self, rnn_size, embedding_size, edge_rnn_size, output_size):
+        super().__init__()
+        self.gru = nn.GRU(embedding_size * 2, rnn_size)
+        for name, param in self.gru.named_parameters():
+            if "bias" in name:
+                nn.init.constant_(param, 0)
+            elif "weight" in name:
+                nn.init.orthogonal_(param)
+        self.encoder_linear = nn.Linear(256, embedding_size)
+        self.edge_attention_embed = nn.Linear(edge_rnn_size, embedding_size)
+        self.output_linear = nn.Linear(rnn_size, output_size)
+
+
+class _EdgeAttention(nn.Module):
+    def __init__(self, edge_rnn_size, attention_size):
+        super().__init__()
+        self.temporal_edge_layer = nn.ModuleList()
+        self.spatial_edge_layer = nn.ModuleList()
+        self.temporal_edge_layer.append(nn.Linear(edge_rnn_size, attention_size))
+        self.spatial_edge_layer.append(nn.Linear(edge_rnn_size, attention_size))
+
+
+class _SpatialSelfAttn(nn.Module):
+    def __init__(self, input_size):
+        super().__init__()
+        self.embedding_layer = nn.Sequential(nn.Linear(input_size, 128), nn.ReLU(), nn.Linear(128, 512), nn.ReLU())
+        self.q_linear = nn.Linear(512, 512)
+        self.v_linear = nn.Linear(512, 512)
+        self.k_linear = nn.Linear(512, 512)
+        self.multihead_attn = nn.MultiheadAttention(512, 8)
+
+
+class AttnGraphBase(nn.Module):
+    """The network body (`base`).  Hyper-parameters as in arguments.py:155-206."""
+
+    def __init__(self, obs_space_dict, args):
+        super().__init__()
+        self.is_recurrent = True
+        self.args = args
+        self.human_num = obs_space_dict["spatial_edges"].shape[0]
+        self.edge_width = obs_space_dict["spatial_edges"].shape[1]
+        self.seq_length = _arg(args, "seq_length", 30)
+        self.nenv = _arg(args, "num_processes", 16)
+        self.nminibatch = _arg(args, "num_mini_batch", 2)
+        self.human_node_rnn_size = _arg(args, "human_node_rnn_size", 128)
+        self.human_human_edge_rnn_size = _arg(args, "human_human_edge_rnn_size", 256)
+        self.output_size = _arg(args, "human_node_output_size", 256)
+        emb = _arg(args, "human_node_embedding_size", 64)
+        attention_size = _arg(args, "attention_size", 64)
+        if (self.human_node_rnn_size, self.human_human_edge_rnn_size, self.output_size, emb, attention_size) != (128, 256, 256, 64, 64):
+            raise NotImplementedError("the HIP kernels are specialised to the reference's network sizes (128/256/256/64/64)")
+        if not _arg(args, "use_self_attn", True) or not _arg(args, "sort_humans", True):
+            raise NotImplementedError("only use_self_attn=True, sort_humans=True (the configuration of every BASELINE config) is implemented")
+        env_name = _arg(args, "env_name", None)
+        expect = {"CrowdSimVarNum-v0": 2, "CrowdSimPred-v0": 12, "CrowdSimPredRealGST-v0": 12}.get(env_name)
+        if expect is not None and _arg(args, "predict_steps", 5) == 5 and expect != self.edge_width:
+            raise ValueError("env_name %s expects spatial edge width %d, observation space has %d" % (env_name, expect, self.edge_width))
+        gain = math.sqrt(2)
+        # construction order == reference (selfAttn_srnn_temp_node.py:309-343) so seeded inits are bit-identical
+        self.humanNodeRNN = _EndRNN(self.human_node_rnn_size, emb, self.human_human_edge_rnn_size, self.output_size)
+        self.attn = _EdgeAttention(self.human_human_edge_rnn_size, attention_size)
+        h = self.output_size
+        self.actor = nn.Sequential(_ortho(nn.Linear(h, h), gain), nn.Tanh(), _ortho(nn.Linear(h, h), gain), nn.Tanh())
+        self.critic = nn.Sequential(_ortho(nn.Linear(h, h), gain), nn.Tanh(), _ortho(nn.Linear(h, h), gain), nn.Tanh())
+        self.critic_linear = _ortho(nn.Linear(h, 1), gain)
+        self.robot_linear = nn.Sequential(_ortho(nn.Linear(9, 256), gain), nn.ReLU())
+        self.human_node_final_linear = _ortho(nn.Linear(self.output_size, 2), gain)
+        self.spatial_attn = _SpatialSelfAttn(self.edge_width)
+        self.spatial_linear = nn.Sequential(_ortho(nn.Linear(512, 256), gain), nn.ReLU())
+
+    # ---- training-time forward in torch ops (autograd) ----
+    def _hh_block(self, spatial_edges, det):
+        """[B,H,D] -> [B,H,256].  SpatialEdgeSelfAttn.forward + spatial_linear (selfAttn_srnn_temp_node.py:63-91,:408)."""
+        B, H, _ = spatial_edges.shape
+        sa = self.spatial_attn
+        e = sa.embedding_layer(spatial_edges)
+        q, k, v = sa.q_linear(e), sa.k_linear(e), sa.v_linear(e)
+        W, b = sa.multihead_attn.in_proj_weight, sa.multihead_attn.in_proj_bias
+        q = F.linear(q, W[:512], b[:512]).view(B, H, 8, 64).transpose(1, 2)
+        k = F.linear(k, W[512:1024], b[512:1024]).view(B, H, 8, 64).transpose(1, 2)
+        v = F.linear(v, W[1024:], b[1024:]).view(B, H, 8, 64).transpose(1, 2)
+        valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
+        scores = torch.matmul(q, k.transpose(-1, -2)) * 0.125
+        scores = scores.masked_fill(~valid.view(B, 1, 1, H), float("-inf"))
+        o = torch.matmul(torch.softmax(scores, dim=-1), v).transpose(1, 2).reshape(B, H, 512)
+        o = sa.multihead_attn.out_proj(o)
+        return self.spatial_linear(o), valid
+
+    def _hr_attention(self, robot_states, out_sp, valid):
+        """EdgeAttention_M (selfAttn_srnn_temp_node.py:145-223): [B,256],[B,H,256] -> [B,256]."""
+        H = out_sp.shape[1]
+        t = self.attn.temporal_edge_layer[0](robot_states)
+        s = self.attn.spatial_edge_layer[0](out_sp)
+        a = (t.unsqueeze(1) * s).sum(-1) * (H / math.sqrt(64.0))
+        a = torch.softmax(a.masked_fill(~valid, -1e9), dim=-1)
+        return torch.bmm(a.unsqueeze(1), out_sp).squeeze(1), a
+
+    def _gru_cell(self, gi, h):
+        g = self.humanNodeRNN.gru
+        gh = F.linear(h, g.weight_hh_l0, g.bias_hh_l0)
+        i_r, i_z, i_n = gi.chunk(3, -1)
+        h_r, h_z, h_n = gh.chunk(3, -1)
+        r = torch.sigmoid(i_r + h_r)
+        z = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        return (1.0 - z) * n + z * h
+
+    def forward_sequence(self, inputs, h0, masks, T, N):
+        """inputs: dict of [T*N, ...] (T-major), h0 [N,1,128] or [N,128], masks [T*N,1].
+        Returns value [T*N,1], actor features [T*N,256], h_T [N,128].  Masking h at every step is arithmetically the
+        reference's split-at-done trick (rl/networks/srnn_model.py:52-104)."""
+        B = T * N
+        robot_in = torch.cat((inputs["temporal_edges"].reshape(B, 2), inputs["robot_node"].reshape(B, 7)), dim=-1)
+        robot_states = self.robot_linear(robot_in)
+        det = inputs["detected_human_num"].reshape(B).to(torch.int64).clamp(min=1)
+        out_sp, valid = self._hh_block(inputs["spatial_edges"].reshape(B, self.human_num, self.edge_width), det)
+        hr, _ = self._hr_attention(robot_states, out_sp, valid)
+        rnn = self.humanNodeRNN
+        x = torch.cat((F.relu(rnn.encoder_linear(robot_states)), F.relu(rnn.edge_attention_embed(hr))), dim=-1)
+        gi = F.linear(x, rnn.gru.weight_ih_l0, rnn.gru.bias_ih_l0).view(T, N, -1)
+        m = masks.reshape(T, N, 1)
+        h = h0.reshape(N, -1)
+        hs = []
+        for t in range(T):
+            h = self._gru_cell(gi[t], h * m[t])
+            hs.append(h)
+        out = rnn.output_linear(torch.stack(hs, 0).view(B, -1))
+        value = self.critic_linear(self.critic(out))
+        return value, self.actor(out), h
+
+
+class Policy(nn.Module):
+    """Drop-in for rl.networks.model.Policy."""
+
+    def __init__(self, obs_shape, action_space, base=None, base_kwargs=None):
+        super().__init__()
+        if base not in ("selfAttn_merge_srnn", None):
+            raise NotImplementedError("only base='selfAttn_merge_srnn' is implemented (the DS-RNN baseline 'srnn' is out of scope)")
+        if action_space.__class__.__name__ != "Box":
+            raise NotImplementedError("only Box(2) action spaces (holonomic robot) are implemented")
+        self.base = AttnGraphBase(obs_shape, base_kwargs)
+        self.srnn = True
+        self.dist = _DiagGaussian(self.base.output_size, action_space.shape[0])
+        self._hip = None
+        self._hip_version = None
+        self._zero_edge = {}
+
+    @property
+    def is_recurrent(self):
+        return self.base.is_recurrent
+
+    # ---- HIP rollout path ----
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def _hip_policy(self, E, device):
+        from .hip import HipPolicy
+        if self._hip is None or self._hip.maxE < E or self._hip.device != device:
+            self._hip = HipPolicy(self.base.human_num, self.base.edge_width, E, device=device)
+            self._hip_version = None
+        ver = self._weights_version()
+        if ver != self._hip_version:
+            self._hip.set_weights(self.state_dict())
+            self._hip_version = ver
+        return self._hip
+
+    def _edge_zeros(self, E, device):
+        key = (E, str(device))
+        if key not in self._zero_edge:
+            self._zero_edge = {key: torch.zeros(1, 1, 1, device=device).expand(E, self.base.human_num + 1, self.base.human_human_edge_rnn_size)}
+        return self._zero_edge[key]
+
+    @staticmethod
+    def _obs32(inputs):
+        return {k: (v if v.dtype == torch.float32 else v.float()).contiguous() for k, v in inputs.items() if k != "visible_masks"}
+
+    def act(self, inputs, rnn_hxs, masks, deterministic=False):
+        E = inputs["robot_node"].shape[0]
+        hx = rnn_hxs["human_node_rnn"]
+        if hx.is_cuda:
+            pol = self._hip_policy(E, hx.device)
+            eps = None if deterministic else torch.randn(E, 2, device=hx.device)
+            out = pol.act(self._obs32(inputs), hx.reshape(E, 1, 128), masks.reshape(E, 1).float(), eps=eps)
+            value, action, logp, h = out["value"], out["action"], out["logp"], out["hxs"]
+        else:
+            with torch.no_grad():
+                value, feat, h = self.base.forward_sequence(inputs, hx, masks, 1, E)
+                mean = self.dist.fc_mean(feat)
+                std = self.dist.logstd(torch.zeros_like(mean)).exp()
+                action = mean if deterministic else mean + std * torch.randn_like(mean)
+                logp = self._log_prob(mean, std, action)
+            h = h.view(E, 1, 128)
+        return value, action, logp, {"human_node_rnn": h, "human_human_edge_rnn": self._edge_zeros(E, hx.device)}
+
+    def get_value(self, inputs, rnn_hxs, masks):
+        E = inputs["robot_node"].shape[0]
+        hx = rnn_hxs["human_node_rnn"]
+        if hx.is_cuda:
+            return self._hip_policy(E, hx.device).get_value(self._obs32(inputs), hx.reshape(E, 1, 128), masks.reshape(E, 1).float())
+        with torch.no_grad():
+            value, _, _ = self.base.forward_sequence(inputs, hx, masks, 1, E)
+        return value
+
+    @staticmethod
+    def _log_prob(mean, std, action):
+        var = std * std
+        return (-((action - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))).sum(-1, keepdim=True)
+
+    def evaluate_actions(self, inputs, rnn_hxs, masks, action):
+        """inputs [T*N,...] (T = seq_length, N = num_processes / num_mini_batch), rnn_hxs at t=0 ([N,...])."""
+        B = inputs["robot_node"].shape[0]
+        N = rnn_hxs["human_node_rnn"].shape[0]
+        T = B // N
+        value, feat, h = self.base.forward_sequence(inputs, rnn_hxs["human_node_rnn"], masks, T, N)
+        mean = self.dist.fc_mean(feat)
+        logstd = self.dist.logstd(torch.zeros_like(mean))
+        logp = self._log_prob(mean, logstd.exp(), action)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).mean()   # FixedNormal.entropy().mean(): over batch and dims
+        return value, logp, entropy, {"human_node_rnn": h.view(N, 1, -1), "human_human_edge_rnn": self._edge_zeros(N, h.device)}

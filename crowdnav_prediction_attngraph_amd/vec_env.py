@@ -1,0 +1,117 @@
+"""make_vec_envs / BatchedCrowdSim -- the vec-env object of rl/networks/envs.py:97-140, with all E envs resident on
+one GPU instead of one OS process per env (shmem_vec_env.py).
+
+Contract kept: `.observation_space.spaces`, `.action_space`, `.reset() -> {key: Tensor[E,...] on device}`,
+`.step(Tensor[E,2]) -> (obs, FloatTensor[E,1] on CPU, ndarray[E] bool, list[E] of dict)`, `.talk2Env`, `.render`, `.close`,
+per-env seeds thisSeed = seed + global_env_index, auto-reset on done with the reset observation returned, and the
+bench.Monitor `info['episode'] = {'r','l','t'}` at episode end.  `step_device()` is the zero-host-sync variant used by the
+fused rollout loop.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from . import info as I
+from .config import Config, to_env_config
+from .hip import HipEnvBatch
+from .policy import make_spaces
+
+_OBS_KEYS = ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks")
+
+
+class BatchedCrowdSim(object):
+    def __init__(self, env_name, seed, num_envs, device, config=None, phase=None):
+        if not torch.cuda.is_available():
+            raise A.CnError("the batched crowd simulator runs on MI355X only (no CPU fallback)")
+        self.env_name = env_name
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise A.CnError("device must be a GPU: the simulator has no CPU implementation (use the reference for --no-cuda)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        config = config if config is not None else Config()
+        if phase is None:
+            phase = "train" if num_envs > 1 else "test"   # rl/networks/envs.py:55-58
+        world, rank = 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world, rank = dist.get_world_size(), dist.get_rank()
+        except Exception:
+            pass
+        self.cfg = to_env_config(config, env_name, self.num_envs * world, phase)
+        self._env = HipEnvBatch(self.cfg, self.num_envs, int(seed if seed is not None else 0), first_env_index=rank * self.num_envs,
+                                device=self.device)
+        self.human_num, self.edge_width = self._env.H, self._env.D
+        has_masks = env_name != "CrowdSimPred-v0"     # crowd_sim_pred.py:38-58 has no visible_masks key
+        self.observation_space, self.action_space = make_spaces(self.human_num, self.edge_width, with_masks=has_masks)
+        self._keys = [k for k in _OBS_KEYS if k in self.observation_space.spaces]
+        self._t0 = time.time()
+        self._closed = False
+
+    # ---- device-level API (no host synchronisation) ----
+    def reset_device(self):
+        return self._env.reset()
+
+    def step_device(self, actions):
+        """-> obs dict (internal buffers, overwritten by the next step), reward [E], done [E] u8, info [E] u8, ep_return [E] f64, ep_len [E] i32"""
+        return self._env.step(actions)
+
+    # ---- reference-compatible API ----
+    def _export_obs(self, obs):
+        out = {}
+        for k in self._keys:
+            out[k] = obs[k].to(torch.bool) if k == "visible_masks" else obs[k].clone()
+        return out
+
+    def reset(self):
+        return self._export_obs(self._env.reset())
+
+    def step(self, actions):
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32)
+        actions = actions.to(self.device, dtype=torch.float32).reshape(self.num_envs, 2)
+        obs, reward, done, info, ep_ret, ep_len = self._env.step(actions)
+        out = self._export_obs(obs)
+        # one D2H transfer for everything the reference returns on the host (VecPyTorch.step_wait, envs.py:216-224)
+        reward_h, done_h, info_h, ret_h, len_h = (reward.cpu(), done.cpu().numpy().astype(bool), info.cpu().numpy(),
+                                                  ep_ret.cpu().numpy(), ep_len.cpu().numpy())
+        infos = [{"info": I.from_code(int(c))} for c in info_h]
+        if done_h.any():
+            now = round(time.time() - self._t0, 6)
+            for i in np.nonzero(done_h)[0]:
+                infos[i]["episode"] = {"r": round(float(ret_h[i]), 6), "l": int(len_h[i]), "t": now}
+        return out, reward_h.unsqueeze(1).float(), done_h, infos
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        return self.step(self._pending)
+
+    def talk2Env(self, data):
+        return [True] * self.num_envs       # render aid only in the reference (crowd_sim_pred_real_gst.py:64-74)
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is out of scope of the accelerated path (use the reference env to visualise)")
+
+    def close(self):
+        if not self._closed:
+            self._env.close()
+            self._closed = True
+
+
+def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_early_resets, num_frame_stack=None, config=None,
+                  ax=None, test_case=-1, wrap_pytorch=True, pretext_wrapper=False, phase=None):
+    """Same signature as rl/networks/envs.py:97-109 (+ optional `phase`)."""
+    if pretext_wrapper:
+        raise NotImplementedError("VecPretextNormalize (GST predictor in the loop, BASELINE configs[3]) is not implemented yet: "
+                                  "use CrowdSimPred-v0 / CrowdSimVarNum-v0 (DESIGN.md, scope table rows G1-G3)")
+    if ax is not None:
+        raise NotImplementedError("rendering (ax=...) is out of scope of the accelerated path")
+    if num_frame_stack is not None:
+        raise NotImplementedError("frame stacking applies to image observations only")
+    return BatchedCrowdSim(env_name, seed, num_processes, device, config=config, phase=phase)

@@ -166,8 +166,27 @@ def rollout_case(tag, env_name, E, H, D, T, nmb):
     print("rollout %-12s losses=%s -> %s (%.0f KB)" % (tag, out["losses"], os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+def init_case():
+    """Parameter checksums of the reference Policy right after construction under torch.manual_seed(0)."""
+    import torch
+    from rl.networks.model import Policy
+    out = {}
+    for tag, env_name, H, D in (("varnum_h20", "CrowdSimVarNum-v0", 20, 2), ("pred_h20", "CrowdSimPred-v0", 20, 12)):
+        args = ref_args(env_name, 16, 2, 30)
+        ob_space, act_space = spaces(H, D)
+        torch.manual_seed(0)
+        pol = Policy(ob_space.spaces, act_space, base_kwargs=args, base="selfAttn_merge_srnn")
+        for k, v in pol.state_dict().items():
+            a = v.detach().numpy().astype(np.float64)
+            out["%s/%s" % (tag, k)] = np.array([a.sum(), np.abs(a).sum(), float(a.ravel()[0]), float(a.ravel()[-1])])
+    path = os.path.join(HERE, "policy_init.npz")
+    np.savez_compressed(path, **out)
+    print("policy init checksums -> %s (%.0f KB)" % (os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 def main():
     R.install()
+    init_case()
     policy_case("varnum_e4_h20", "CrowdSimVarNum-v0", 4, 20, 2)
     policy_case("varnum_e1_h5", "CrowdSimVarNum-v0", 1, 5, 2)
     policy_case("pred_e4_h20", "CrowdSimPred-v0", 4, 20, 12)

@@ -1,0 +1,80 @@
+"""world_size-2 gloo test of the data-parallel PPO update (CPU): env shards per rank, one flat gradient all-reduce per
+optimiser step, global advantage statistics -> identical to a single-process update over the union of the shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+H, D, T = 5, 2, 4
+
+
+def _build(E_total, lo, hi):
+    """Policy (seeded) + rollout storage holding envs [lo, hi) of a deterministic synthetic rollout of E_total envs."""
+    sys.path.insert(0, ROOT)
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from crowdnav_prediction_attngraph_amd.storage import RolloutStorage
+    from tests import policy_util as PU
+    ob_space, act_space = make_spaces(H, D)
+    torch.manual_seed(7)
+    pol = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn",
+                 base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=hi - lo, num_mini_batch=1, seq_length=T))
+    E = hi - lo
+    ro = RolloutStorage(T, E, ob_space.spaces, act_space, 128, 256)
+    rs = np.random.RandomState(3)
+    full = dict(rewards=rs.uniform(-1, 1, (T, E_total, 1)), values=rs.uniform(-1, 1, (T + 1, E_total, 1)),
+                returns=rs.uniform(-1, 1, (T + 1, E_total, 1)), logp=rs.uniform(-3, -1, (T, E_total, 1)),
+                actions=rs.uniform(-1, 1, (T, E_total, 2)), masks=(rs.uniform(size=(T + 1, E_total, 1)) > 0.2).astype(np.float64),
+                hx=rs.uniform(-1, 1, (E_total, 1, 128)))
+    obs = [PU.synth_obs(E_total, H, D, seed=50 + s) for s in range(T + 1)]
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, lo:hi]).astype(np.float32))  # noqa: E731
+    for s in range(T + 1):
+        for k, v in obs[s].items():
+            ro.obs[k][s].copy_(torch.from_numpy(v[lo:hi]))
+    ro.rewards.copy_(f32(full["rewards"])); ro.value_preds.copy_(f32(full["values"])); ro.returns.copy_(f32(full["returns"]))
+    ro.action_log_probs.copy_(f32(full["logp"])); ro.actions.copy_(f32(full["actions"])); ro.masks.copy_(f32(full["masks"]))
+    ro.recurrent_hidden_states["human_node_rnn"][0].copy_(torch.from_numpy(full["hx"][lo:hi].astype(np.float32)))
+    return pol, ro
+
+
+def _update(pol, ro):
+    from crowdnav_prediction_attngraph_amd.ppo import PPO
+    agent = PPO(pol, 0.2, 2, 1, 0.5, 0.01, lr=1e-3, eps=1e-5, max_grad_norm=0.5)
+    torch.manual_seed(11)
+    losses = agent.update(ro)
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    return losses, flat
+
+
+def _worker(rank, world, port, E_total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = E_total // world
+    pol, ro = _build(E_total, rank * per, (rank + 1) * per)
+    losses, flat = _update(pol, ro)
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save(dict(losses=losses, flat=flat, same=all(torch.equal(gathered[0], g) for g in gathered)), out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_single_process_union(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    E_total = 4
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, E_total, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["same"], "ranks diverged after the all-reduced update"
+    torch.set_num_threads(1)
+    pol, ro = _build(E_total, 0, E_total)
+    losses, flat = _update(pol, ro)
+    np.testing.assert_allclose(got["losses"], losses, atol=2e-6)
+    np.testing.assert_allclose(got["flat"].numpy(), flat.numpy(), atol=2e-6)
