@@ -1,0 +1,108 @@
+"""PPO training loop over the device-resident simulator -- the flow of the reference's train.py:140-242 with the
+per-step host round trips removed.
+
+`collect_rollout` is the fused rollout: for each of the T steps the policy forward writes value / action / log-prob /
+next hidden state straight into the RolloutStorage rows and the simulator writes the next observation, reward and
+done mask straight into row t+1 -- no clones, no host synchronisation, no Python work proportional to E.
+(The reference-compatible `envs.step()` path, which returns CPU rewards / numpy dones / info dicts, still exists for
+an unmodified train.py; it costs one D2H sync and O(E) Python per step.)
+"""
+import time
+
+import torch
+
+from .policy import Policy
+from .ppo import PPO
+from .storage import RolloutStorage
+from .vec_env import make_vec_envs
+
+
+class EpisodeStats:
+    """Device-side bench.Monitor aggregate: sum of finished-episode returns / lengths / outcome counts."""
+
+    def __init__(self, device):
+        self.acc = torch.zeros(8, dtype=torch.float64, device=device)  # n_done, sum_ret, sum_len, timeout, collision, goal, -, -
+
+    def update(self, done, info, ep_return, ep_len):
+        d = done.to(torch.float64)
+        self.acc[0] += d.sum()
+        self.acc[1] += (ep_return * d).sum()
+        self.acc[2] += (ep_len.to(torch.float64) * d).sum()
+        for code in (1, 2, 3):
+            self.acc[2 + code] += ((info == code).to(torch.float64) * d).sum()
+
+    def pop(self):
+        a = self.acc.cpu().tolist()
+        self.acc.zero_()
+        n = max(a[0], 1.0)
+        return dict(episodes=int(a[0]), eprewmean=a[1] / n, eplenmean=a[2] / n, timeout=a[3] / n, collision=a[4] / n, success=a[5] / n)
+
+
+def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
+    """Fill `rollouts` (row 0 must hold the current observation / hidden state / mask).  Zero host syncs."""
+    env = envs._env
+    E, dev = envs.num_envs, envs.device
+    pol = actor_critic._hip_policy(E, dev)
+    T = rollouts.num_steps
+    hx = rollouts.recurrent_hidden_states["human_node_rnn"]
+    eps = torch.empty(E, 2, device=dev)
+    for t in range(T):
+        obs_t = {k: rollouts.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+        eps.normal_(generator=generator)
+        out = dict(value=rollouts.value_preds[t], action=rollouts.actions[t], logp=rollouts.action_log_probs[t], hxs=hx[t + 1])
+        pol.act(obs_t, hx[t], rollouts.masks[t], eps=eps, out=out)
+        obs_n = {k: rollouts.obs[k][t + 1] for k in obs_t}
+        obs_n["visible_masks"] = None
+        if "visible_masks" in rollouts.obs:
+            obs_n["visible_masks"] = rollouts.obs["visible_masks"][t + 1].view(torch.uint8)
+        _, reward, done, info, ep_ret, ep_len = env.step(rollouts.actions[t], obs=obs_n)
+        rollouts.rewards[t].copy_(reward.view(E, 1))
+        rollouts.masks[t + 1].copy_((done == 0).view(E, 1))
+        if stats is not None:
+            stats.update(done, info, ep_ret, ep_len)
+    rollouts.step = 0
+
+
+def bootstrap_value(actor_critic, rollouts):
+    obs = {k: rollouts.obs[k][-1] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+    hxs = {"human_node_rnn": rollouts.recurrent_hidden_states["human_node_rnn"][-1]}
+    return actor_critic.get_value(obs, hxs, rollouts.masks[-1])
+
+
+def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_updates=10, seed=425, config=None, ppo_epoch=5,
+          num_mini_batch=2, lr=4e-5, eps=1e-5, clip_param=0.2, value_loss_coef=0.5, entropy_coef=0.0, max_grad_norm=0.5, gamma=0.99,
+          gae_lambda=0.95, log=print, device=None):
+    """Returns a list of per-update dicts (losses, timings, episode stats).  Works single- or multi-GPU (one process per
+    GPU, torch.distributed initialised by the caller)."""
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(seed)
+    envs = make_vec_envs(env_name, seed, num_processes, gamma, None, device, False, config=config, phase="train")
+    base_kwargs = dict(env_name=env_name, num_processes=num_processes, num_mini_batch=num_mini_batch, seq_length=num_steps)
+    actor_critic = Policy(envs.observation_space.spaces, envs.action_space, base_kwargs=base_kwargs, base="selfAttn_merge_srnn").to(device)
+    rollouts = RolloutStorage(num_steps, num_processes, envs.observation_space.spaces, envs.action_space, 128, 256)
+    rollouts.to(device)
+    agent = PPO(actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, entropy_coef, lr=lr, eps=eps, max_grad_norm=max_grad_norm)
+    obs = envs.reset_device()
+    for k in rollouts.obs:
+        rollouts.obs[k][0].copy_(obs[k].view_as(rollouts.obs[k][0]) if k != "visible_masks" else obs[k].to(torch.bool))
+    stats = EpisodeStats(device)
+    history = []
+    for j in range(num_updates):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        collect_rollout(envs, actor_critic, rollouts, stats)
+        next_value = bootstrap_value(actor_critic, rollouts)
+        rollouts.compute_returns(next_value, True, gamma, gae_lambda, False)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        value_loss, action_loss, dist_entropy = agent.update(rollouts)
+        rollouts.after_update()
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        rec = dict(update=j, value_loss=value_loss, action_loss=action_loss, entropy=dist_entropy, rollout_s=t1 - t0, update_s=t2 - t1,
+                   samples_per_s=num_steps * num_processes / (t2 - t0), **stats.pop())
+        history.append(rec)
+        if log:
+            log(rec)
+    envs.close()
+    return history, actor_critic

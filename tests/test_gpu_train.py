@@ -1,0 +1,106 @@
+"""-m gpu: the host mirror end to end on the device -- reference-compatible vec-env API, fused rollout, PPO update."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_vec_env_api_contract():
+    from crowdnav_prediction_attngraph_amd import config as C, info as I
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    envs = make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.non_randomized())
+    assert envs.action_space.shape[0] == 2 and envs.action_space.__class__.__name__ == "Box"
+    assert envs.observation_space.spaces["spatial_edges"].shape == (20, 2)
+    obs = envs.reset()
+    assert obs["robot_node"].shape == (16, 1, 7) and obs["visible_masks"].dtype == torch.bool and obs["spatial_edges"].is_cuda
+    n_ep = 0
+    for t in range(230):
+        obs, reward, done, infos = envs.step(torch.full((16, 2), 0.05, device="cuda"))
+        assert reward.shape == (16, 1) and not reward.is_cuda and reward.dtype == torch.float32
+        assert isinstance(done, np.ndarray) and done.dtype == bool and len(infos) == 16
+        for d, inf in zip(done, infos):
+            assert ("episode" in inf) == bool(d)
+            if d:
+                n_ep += 1
+                assert isinstance(inf["info"], (I.Timeout, I.Collision, I.ReachGoal)) and inf["episode"]["l"] >= 1
+    assert n_ep >= 16        # everything times out after 197 steps at the latest
+    assert envs.talk2Env(None) == [True] * 16
+    envs.close()
+    with pytest.raises(NotImplementedError):
+        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"robot.visible": True}))
+    with pytest.raises(NotImplementedError):
+        make_vec_envs("CrowdSimVarNum-v0", 425, 1, 0.99, None, torch.device("cuda"), False)   # num_processes=1 -> phase 'test'
+
+
+def test_policy_module_uses_hip_for_act_and_tracks_weight_updates():
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from tests import policy_util as PU
+    torch.manual_seed(0)
+    ob_space, act_space = make_spaces(20, 2)
+    pol = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn", base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=32)).cuda()
+    obs = {k: torch.from_numpy(v).cuda() for k, v in PU.synth_obs(32, 20, 2, 1).items()}
+    hxs = {"human_node_rnn": torch.randn(32, 1, 128, device="cuda"), "human_human_edge_rnn": torch.zeros(32, 21, 256, device="cuda")}
+    masks = torch.ones(32, 1, device="cuda")
+    v1, a1, lp1, h1 = pol.act(obs, hxs, masks, deterministic=True)
+    with torch.no_grad():  # torch path (training graph) on the same inputs
+        v_t, feat, h_t = pol.base.forward_sequence(obs, hxs["human_node_rnn"], masks, 1, 32)
+        mean = pol.dist.fc_mean(feat)
+    assert torch.allclose(v1, v_t, atol=1e-4) and torch.allclose(a1, mean, atol=1e-4) and torch.allclose(h1["human_node_rnn"].view(32, 128), h_t, atol=1e-4)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    v2, _, _, _ = pol.act(obs, hxs, masks, deterministic=True)
+    with torch.no_grad():
+        v_t2, _, _ = pol.base.forward_sequence(obs, hxs["human_node_rnn"], masks, 1, 32)
+    assert not torch.allclose(v1, v2, atol=1e-5) and torch.allclose(v2, v_t2, atol=1e-4)   # the HIP snapshot was refreshed
+
+
+def test_fused_rollout_and_update_run_and_learn_signal_is_finite():
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.trainer import train
+    hist, pol = train("CrowdSimVarNum-v0", num_processes=64, num_steps=30, num_updates=3, config=C.non_randomized(**{"sim.human_num": 5}), log=None)
+    assert len(hist) == 3
+    for r in hist:
+        assert all(np.isfinite([r["value_loss"], r["action_loss"], r["entropy"]])) and r["samples_per_s"] > 0
+    assert abs(hist[0]["entropy"] - 1.4189385) < 1e-3          # 0.5 + 0.5 log(2 pi) with logstd = 0
+    assert sum(r["episodes"] for r in hist) > 0
+    hist2, _ = train("CrowdSimPred-v0", num_processes=32, num_steps=8, num_updates=1, config=C.Config(**{"sim.human_num": 6}), log=None)
+    assert np.isfinite(hist2[0]["value_loss"])
+
+
+def test_fused_rollout_equals_reference_style_stepping():
+    """collect_rollout (zero-copy, no sync) fills the storage exactly like act()/envs.step()/insert() does."""
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.policy import Policy
+    from crowdnav_prediction_attngraph_amd.storage import RolloutStorage
+    from crowdnav_prediction_attngraph_amd.trainer import collect_rollout
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    E, T = 24, 12
+    cfg = C.non_randomized(**{"sim.human_num": 8})
+    torch.manual_seed(1)
+    ea = make_vec_envs("CrowdSimVarNum-v0", 9, E, 0.99, None, torch.device("cuda"), False, config=cfg)
+    eb = make_vec_envs("CrowdSimVarNum-v0", 9, E, 0.99, None, torch.device("cuda"), False, config=cfg)
+    pol = Policy(ea.observation_space.spaces, ea.action_space, base="selfAttn_merge_srnn", base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E)).cuda()
+    ra = RolloutStorage(T, E, ea.observation_space.spaces, ea.action_space, 128, 256); ra.to("cuda")
+    rb = RolloutStorage(T, E, eb.observation_space.spaces, eb.action_space, 128, 256); rb.to("cuda")
+    oa, ob = ea.reset(), eb.reset()
+    for k in ra.obs:
+        ra.obs[k][0].copy_(oa[k]); rb.obs[k][0].copy_(ob[k])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    collect_rollout(ea, pol, ra, generator=g)
+    torch.manual_seed(0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    hip_pol = pol._hip_policy(E, torch.device("cuda", torch.cuda.current_device()))
+    for t in range(T):
+        obs_t = {k: rb.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+        eps = torch.empty(E, 2, device="cuda").normal_(generator=g)
+        out = hip_pol.act(obs_t, rb.recurrent_hidden_states["human_node_rnn"][t], rb.masks[t], eps=eps)
+        obs, reward, done, infos = eb.step(out["action"])
+        masks = torch.FloatTensor([[0.0] if d else [1.0] for d in done])
+        rb.insert(obs, {"human_node_rnn": out["hxs"]}, out["action"], out["logp"], out["value"], reward, masks, torch.ones(E, 1))
+    for name in ("rewards", "value_preds", "actions", "action_log_probs", "masks"):
+        assert torch.equal(getattr(ra, name), getattr(rb, name)), name
+    for k in ra.obs:
+        assert torch.equal(ra.obs[k], rb.obs[k]), k
+    assert torch.equal(ra.recurrent_hidden_states["human_node_rnn"], rb.recurrent_hidden_states["human_node_rnn"])
