@@ -73,8 +73,12 @@ def test_two_rank_update_equals_single_process_union(tmp_path):
     mp.spawn(_worker, args=(2, port, E_total, out), nprocs=2, join=True)
     got = torch.load(out)
     assert got["same"], "ranks diverged after the all-reduced update"
+    nthreads = torch.get_num_threads()
     torch.set_num_threads(1)
-    pol, ro = _build(E_total, 0, E_total)
-    losses, flat = _update(pol, ro)
+    try:
+        pol, ro = _build(E_total, 0, E_total)
+        losses, flat = _update(pol, ro)
+    finally:
+        torch.set_num_threads(nthreads)
     np.testing.assert_allclose(got["losses"], losses, atol=2e-6)
     np.testing.assert_allclose(got["flat"].numpy(), flat.numpy(), atol=2e-6)

@@ -25,7 +25,7 @@ def _dev(obs):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in obs.items()}
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "policy_*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "policy_*_h*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
 def test_policy_act_matches_reference_golden(path):
     from crowdnav_prediction_attngraph_amd.hip import HipPolicy
     z = np.load(path)

@@ -65,7 +65,7 @@ def test_fused_rollout_and_update_run_and_learn_signal_is_finite():
         assert all(np.isfinite([r["value_loss"], r["action_loss"], r["entropy"]])) and r["samples_per_s"] > 0
     assert abs(hist[0]["entropy"] - 1.4189385) < 1e-3          # 0.5 + 0.5 log(2 pi) with logstd = 0
     assert sum(r["episodes"] for r in hist) > 0
-    hist2, _ = train("CrowdSimPred-v0", num_processes=32, num_steps=8, num_updates=1, config=C.Config(**{"sim.human_num": 6}), log=None)
+    hist2, _ = train("CrowdSimPred-v0", num_processes=32, num_steps=8, num_updates=1, config=C.Config(**{"sim.human_num": 6, "sim.predict_method": "const_vel"}), log=None)
     assert np.isfinite(hist2[0]["value_loss"])
 
 

@@ -180,7 +180,7 @@ def test_hip_orca_has_the_same_properties():
     S, Os = zip(*[_scene(rs, 19, 6.0) for _ in range(B)])
     S, Os = np.stack(S), np.stack(Os)
     v = orca_solve(torch.from_numpy(S).cuda(), torch.from_numpy(Os).cuda()).cpu().numpy()
-    assert np.all(np.hypot(v[:, 0], v[:, 1]) <= S[:, 5] * (1 + 1e-4) + 1e-5)
+    assert np.all(np.hypot(v[:, 0], v[:, 1]) <= S[:, 5] * (1 + 1e-2) + 1e-5)
     for b in range(B):
         (vx, vy), lines, fail = O.orca_velocity(S[b], Os[b], want_lines=True)
         assert (v[b, 0], v[b, 1]) == (np.float32(vx), np.float32(vy))

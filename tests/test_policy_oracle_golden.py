@@ -17,7 +17,7 @@ def _sd(meta):
     return PU.formula_state_dict({k: tuple(v) for k, v in meta["shapes"].items()})
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "policy_*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "policy_*_h*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
 def test_policy_act_matches_reference(path):
     z = np.load(path)
     meta = json.loads(str(z["meta"]))
