@@ -33,11 +33,15 @@ constexpr int BM = 128, BK = 32, LDS_STRIDE = 36; // 36 floats = 144 B rows: con
 // 256 threads = 4 wavefronts in a 2x2 arrangement; each wavefront owns a 64 x (BN/2) tile = 2 x (BN/64) MFMA blocks.
 // K order inside a group of 8 is remapped so each lane feeds 4 consecutive MFMA steps from ONE 16-byte LDS read:
 // lanes 0-31 hold k = 8g+s, lanes 32-63 hold k = 8g+4+s at step s (same mapping for A and W, so the sum is unchanged).
+// m_dev (optional): device-side row count (<= M).  The HH block runs on the compacted set of detected humans whose
+// size is only known on the device; the grid is sized for the worst case and surplus row tiles exit immediately.
 template <int BN, int ACT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                      float *__restrict__ C, int ldc)
+                                                      float *__restrict__ C, int ldc, const int *__restrict__ m_dev)
 {
+    if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
+    if ((int)(blockIdx.y * BM) >= M) return;
     constexpr int NB = BN / 64;        // MFMA column blocks per wavefront
     constexpr int WLD = BN / 32;       // float4 loads of W per thread per K tile
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
@@ -121,19 +125,53 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
         }
 }
 
-// embedding_layer.0 (K = D <= 16): out[m][n] = relu(sum_d x[m][d] * W[n][d] + b[n]), n < 128
-__global__ __launch_bounds__(256) void embed0_kernel(int M, int D, const float *__restrict__ x, const float *__restrict__ W,
-                                                     const float *__restrict__ b, float *__restrict__ out)
+// Row compaction: row_off[e] = sum_{e' < e} nd(e'), nd = clamp(detected_human_num, 1, H); row_off[E] = number of live
+// (env, human) rows.  Padded humans (index >= nd) only ever meet an exactly-zero robot-human attention weight, so the
+// whole human-human block runs on live rows only.  Single block, Hillis-Steele scan over per-thread chunk sums.
+__global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const float *__restrict__ det, int *__restrict__ row_off)
 {
-    __shared__ float Wl[128 * 16 + 128];
-    for (int i = threadIdx.x; i < 128 * D; i += 256) Wl[i] = W[i];
-    if (threadIdx.x < 128) Wl[128 * 16 + threadIdx.x] = b[threadIdx.x];
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (E + 1023) / 1024;
+    const int lo = t * chunk, hi = min(lo + chunk, E);
+    int sum = 0;
+    for (int e = lo; e < hi; ++e) { int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd); sum += nd; }
+    part[t] = sum;
     __syncthreads();
-    const int n = threadIdx.x & 127;
-    for (int m = blockIdx.x * 2 + (threadIdx.x >> 7); m < M; m += gridDim.x * 2) {
-        float acc = Wl[128 * 16 + n];
-        for (int d = 0; d < D; ++d) acc += x[(size_t)m * D + d] * Wl[n * D + d];
-        out[(size_t)m * 128 + n] = fmaxf(acc, 0.0f);
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum; // exclusive prefix of this thread's chunk
+    for (int e = lo; e < hi; ++e) {
+        row_off[e] = run;
+        int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
+        run += nd;
+    }
+    if (t == 1023) row_off[E] = part[1023];
+}
+
+// embedding_layer.0 (K = D <= 16) on live rows: out[row_off[e] + j][n] = relu(sum_d x[e][j][d] * W[n][d] + b[n]), n < 128
+__global__ __launch_bounds__(128) void embed0_kernel(int E, int H, int D, const float *__restrict__ x, const float *__restrict__ W,
+                                                     const float *__restrict__ b, const int *__restrict__ row_off, float *__restrict__ out)
+{
+    const int n = threadIdx.x;
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) w[d] = d < D ? W[n * D + d] : 0.0f;
+    const float bn = b[n];
+    for (int e = blockIdx.x; e < E; e += gridDim.x) {
+        const int r0 = row_off[e], nd = row_off[e + 1] - r0;
+        for (int j = 0; j < nd; ++j) {
+            const float *xr = x + ((size_t)e * H + j) * D;
+            float acc = bn;
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d < D) acc += xr[d] * w[d];
+            out[(size_t)(r0 + j) * 128 + n] = fmaxf(acc, 0.0f);
+        }
     }
 }
 
@@ -157,11 +195,10 @@ __global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__
     }
 }
 
-// Human-human multi-head attention core (torch.nn.MultiheadAttention with key_padding_mask, 8 heads x 64):
-// one wavefront per (env, head); K and V of the env/head are staged in LDS; lane j scores key j, lane d owns output
-// dim d.  Query rows >= detected_human_num are padding: their outputs only ever meet an exactly-zero robot-human
-// attention weight, so zeros are written instead of computing them.
-__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const float *__restrict__ qkv, const float *__restrict__ det,
+// Human-human multi-head attention core (torch.nn.MultiheadAttention with key_padding_mask, 8 heads x 64) on the
+// compacted rows: one wavefront per (env, head); the nd live K/V/Q rows of the env/head are staged in LDS; lane j scores
+// key j, lane d owns output dim d.  Masked keys are simply absent (softmax over the nd live keys == softmax with -inf).
+__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const float *__restrict__ qkv, const int *__restrict__ row_off,
                                                            float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -169,23 +206,20 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const f
     const int unit = blockIdx.x * (blockDim.x >> 6) + wave; // (env, head)
     if (unit >= E * 8) return;
     const int e = unit >> 3, head = unit & 7;
+    const int r0 = row_off[e], nd = row_off[e + 1] - r0;
     float *Ks = smem + (size_t)wave * (3 * H * 65);
     float *Vs = Ks + H * 65;
     float *Qs = Vs + H * 65;
-    const float *base = qkv + (size_t)e * H * 1536 + head * 64;
-    for (int j = 0; j < H; ++j) {
+    const float *base = qkv + (size_t)r0 * 1536 + head * 64;
+    for (int j = 0; j < nd; ++j) {
         Qs[j * 65 + lane] = base[(size_t)j * 1536 + lane];
         Ks[j * 65 + lane] = base[(size_t)j * 1536 + 512 + lane];
         Vs[j * 65 + lane] = base[(size_t)j * 1536 + 1024 + lane];
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wavefront visible to its own reads
-    int nd = (int)det[e];
-    nd = nd < 1 ? 1 : (nd > H ? H : nd);
-    const int jl = lane < H ? lane : 0;
-    for (int i = 0; i < H; ++i) {
-        float *orow = out + ((size_t)e * H + i) * 512 + head * 64;
-        if (i >= nd) { orow[lane] = 0.0f; continue; }
+    const int jl = lane < nd ? lane : 0;
+    for (int i = 0; i < nd; ++i) {
         float s = 0.0f;
 #pragma unroll 16
         for (int d = 0; d < 64; ++d) s += Qs[i * 65 + d] * Ks[jl * 65 + d];
@@ -196,47 +230,56 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const f
         const float pn = p / denom;
         float o = 0.0f;
         for (int j = 0; j < nd; ++j) o += wv_readlane(pn, j) * Vs[j * 65 + lane];
-        orow[lane] = o;
+        out[(size_t)(r0 + i) * 512 + head * 64 + lane] = o;
     }
 }
 
-// Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177): one wavefront per env.
+// Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177) on the compacted rows: one
+// wavefront per env.  masked_fill(-1e9) + softmax gives padded humans exactly zero weight (exp underflows to 0), so the
+// softmax and the weighted sum run over the nd live rows only.
 __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ t_emb, const float *__restrict__ s_emb,
-                                                           const float *__restrict__ out_sp, const float *__restrict__ det,
+                                                           const float *__restrict__ out_sp, const int *__restrict__ row_off,
                                                            float *__restrict__ hr_out, float *__restrict__ hr_attn)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 4 + wave;
     if (e >= E) return;
+    const int r0 = row_off[e], nd = row_off[e + 1] - r0;
     float *Ss = smem + (size_t)wave * (H * 65 + 64);
     float *Ts = Ss + H * 65;
-    for (int j = 0; j < H; ++j) Ss[j * 65 + lane] = s_emb[((size_t)e * H + j) * 64 + lane];
+    for (int j = 0; j < nd; ++j) Ss[j * 65 + lane] = s_emb[(size_t)(r0 + j) * 64 + lane];
     Ts[lane] = t_emb[(size_t)e * 64 + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    int nd = (int)det[e];
-    nd = nd < 1 ? 1 : (nd > H ? H : nd);
-    const int jl = lane < H ? lane : 0;
+    const int jl = lane < nd ? lane : 0;
     float s = 0.0f;
 #pragma unroll 16
     for (int d = 0; d < 64; ++d) s += Ts[d] * Ss[jl * 65 + d];
     s = s * ((float)H / 8.0f);                 // temperature = num_edges / sqrt(attention_size = 64)
-    s = lane < nd ? s : -1e9f;                 // masked_fill(attn_mask == 0, -1e9)
-    s = lane < H ? s : -INFINITY;
+    s = lane < nd ? s : -INFINITY;
     const float mx = wv_max(s);
-    const float p = lane < H ? expf(s - mx) : 0.0f;
+    const float p = lane < nd ? expf(s - mx) : 0.0f;
     const float denom = wv_sum(p);
     const float a = p / denom;
     if (hr_attn && lane < H) hr_attn[(size_t)e * H + lane] = a;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int j = 0; j < H; ++j) {
+    for (int j = 0; j < nd; ++j) {
         const float aj = wv_readlane(a, j);
-        const float *row = out_sp + ((size_t)e * H + j) * 256;
+        const float *row = out_sp + (size_t)(r0 + j) * 256;
         o0 += aj * row[lane]; o1 += aj * row[64 + lane]; o2 += aj * row[128 + lane]; o3 += aj * row[192 + lane];
     }
     float *o = hr_out + (size_t)e * 256;
     o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
+}
+
+// test tap: scatter the compacted [rows,256] activations back to [E,H,256] (zeros on padded humans)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int E, int H, const float *__restrict__ src, const int *__restrict__ row_off,
+                                                           float *__restrict__ dst)
+{
+    const int e = blockIdx.x, c = threadIdx.x;
+    const int r0 = row_off[e], nd = row_off[e + 1] - r0;
+    for (int j = 0; j < H; ++j) dst[((size_t)e * H + j) * 256 + c] = j < nd ? src[(size_t)(r0 + j) * 256 + c] : 0.0f;
 }
 
 // GRU cell pointwise part (PyTorch formulation, gate order r,z,n) with the done mask applied to h
@@ -337,6 +380,7 @@ struct cn_policy {
     float *cl_w, *cl_b, *fm_w, *fm_b, *logstd;
     // activations
     float *emb1, *emb2, *qkv, *attn, *out_sp, *s_emb;
+    int *row_off; // [maxE + 1] exclusive prefix of live humans per env; row_off[E] = live rows
     float *robot_states, *t_emb, *hr_out, *hr_attn, *x, *gi, *gh, *hnew, *rnn_out, *ac1, *ac2;
     // profiling of the dominant kernel (QKV projection)
     bool profiling;
@@ -348,12 +392,13 @@ struct cn_policy {
 };
 
 template <int BN, int ACT>
-static int launch_gemm(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st)
+static int launch_gemm(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st,
+                       const int *m_dev = nullptr)
 {
     CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
     if (M == 0) return CN_OK;
     dim3 grid(N / BN, (M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc);
+    hipLaunchKernelGGL((gemm_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc, m_dev);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -386,6 +431,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_rs = carve(E * 256), o_temb = carve(E * 64), o_hr = carve(E * 256), o_hra = carve(M), o_x = carve(E * 128);
     const size_t o_gi = carve(E * 384), o_gh = carve(E * 384), o_hn = carve(E * 128), o_ro = carve(E * 256);
     const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
+    const size_t o_roff = carve(E + 1);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete p; cn_set_error("cn_policy_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -401,6 +447,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->emb1 = F(o_emb1); p->emb2 = F(o_emb2); p->qkv = F(o_qkv); p->attn = F(o_attn); p->out_sp = F(o_outsp); p->s_emb = F(o_semb);
     p->robot_states = F(o_rs); p->t_emb = F(o_temb); p->hr_out = F(o_hr); p->hr_attn = F(o_hra); p->x = F(o_x);
     p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
+    p->row_off = (int *)(base + o_roff);
     p->weights_set = false;
     p->profiling = false;
     p->ev_head = p->ev_tail = 0;
@@ -494,25 +541,27 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_REQUIRE(hxs_in && masks && value, "policy: null pointer");
     const int H = p->H, D = p->D, M = E * H;
     int rc;
-    // ---- human-human block ----
+    // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
+    const int *m_dev = p->row_off + E;
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off);
+    CN_CHECK_LAUNCH();
     {
-        int blocks = (M + 1) / 2; if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(256), 0, st, M, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->emb1);
+        int blocks = E < 4096 ? E : 4096;
+        hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(128), 0, st, E, H, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->row_off, p->emb1);
         CN_CHECK_LAUNCH();
     }
-    if ((rc = launch_gemm<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_w, p->emb2_b, p->emb2, 512, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_w, p->emb2_b, p->emb2, 512, st, m_dev))) return rc;
     if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
-    if ((rc = launch_gemm<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_w, p->qkv_b, p->qkv, 1536, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_w, p->qkv_b, p->qkv, 1536, st, m_dev))) return rc;
     if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
     {
         const size_t per_wave = (size_t)3 * H * 65 * sizeof(float); // K, V, Q of one (env, head)
         int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-        hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, H, p->qkv,
-                           obs->detected_human_num, p->attn);
+        hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, H, p->qkv, p->row_off, p->attn);
         CN_CHECK_LAUNCH();
     }
-    if ((rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st))) return rc;
-    if ((rc = launch_gemm<64, ACT_NONE>(M, 64, 256, p->out_sp, 256, p->as_w, p->as_b, p->s_emb, 64, st))) return rc;
+    if ((rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev))) return rc;
+    if ((rc = launch_gemm<64, ACT_NONE>(M, 64, 256, p->out_sp, 256, p->as_w, p->as_b, p->s_emb, 64, st, m_dev))) return rc;
     // ---- robot node, robot-human attention ----
     {
         int blocks = E < 2048 ? E : 2048;
@@ -522,7 +571,7 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     if ((rc = launch_gemm<64, ACT_NONE>(E, 64, 256, p->robot_states, 256, p->at_w, p->at_b, p->t_emb, 64, st))) return rc;
     {
         const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
-        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->t_emb, p->s_emb, p->out_sp, obs->detected_human_num,
+        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->t_emb, p->s_emb, p->out_sp, p->row_off,
                            p->hr_out, p->hr_attn);
         CN_CHECK_LAUNCH();
     }
@@ -563,7 +612,11 @@ extern "C" int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float
     CN_REQUIRE(p && E >= 1 && E <= p->maxE, "cn_policy_get_taps: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const size_t M = (size_t)E * p->H;
-    if (spatial_lin) CN_D2D(spatial_lin, p->out_sp, M * 256);
+    (void)M;
+    if (spatial_lin) {
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(E), dim3(256), 0, st, E, p->H, p->out_sp, p->row_off, spatial_lin);
+        CN_CHECK_LAUNCH();
+    }
     if (hr_attn) CN_D2D(hr_attn, p->hr_attn, M);
     if (hr_out) CN_D2D(hr_out, p->hr_out, (size_t)E * 256);
     if (robot_emb) CN_D2D(robot_emb, p->robot_states, (size_t)E * 256);
