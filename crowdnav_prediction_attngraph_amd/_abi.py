@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
     "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
-    "cn_policy_get_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
+    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def lib():
         L.cn_policy_get_value.argtypes = [vp, i32, C.POINTER(Obs), vp, vp, vp, vp]
         L.cn_policy_get_taps.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.cn_policy_set_profiling.argtypes = [vp, i32]
+        L.cn_policy_set_gemm_mode.argtypes = [vp, i32]
         L.cn_policy_get_profile.argtypes = [vp, C.POINTER(f64), C.POINTER(i64)]
         L.cn_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp]
         L.cn_adv_stats.argtypes = [i64, vp, vp, vp, vp]

@@ -38,17 +38,35 @@ __device__ __forceinline__ float wv_readlane(float x, int lane_uniform)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane_uniform));
 }
+// DPP reductions (gfx9 family): row_shr 1/2/4/8 leave each 16-lane row's result in its last lane, row_bcast:15 and
+// row_bcast:31 fold the rows, lane 63 holds the wave result, one v_readlane broadcasts it.  7 VALU ops instead of six
+// ds_bpermute round trips.  Lanes without a DPP source keep `identity` (bound_ctrl = 0 -> `old` operand).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float wv_dpp(float v, float identity)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wv_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float I = __builtin_inff();
+    v = fminf(v, wv_dpp<0x111, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x112, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x114, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x118, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x142, 0xa>(v, I));
+    v = fminf(v, wv_dpp<0x143, 0xc>(v, I));
+    return wv_readlane(v, 63);
 }
 __device__ __forceinline__ float wv_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float I = -__builtin_inff();
+    v = fmaxf(v, wv_dpp<0x111, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x112, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x114, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x118, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x142, 0xa>(v, I));
+    v = fmaxf(v, wv_dpp<0x143, 0xc>(v, I));
+    return wv_readlane(v, 63);
 }
 __device__ __forceinline__ float wv_sum(float v)
 {

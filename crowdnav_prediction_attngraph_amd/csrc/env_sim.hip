@@ -135,7 +135,9 @@ __device__ __forceinline__ bool lp1_wave(const LpLine &L, uint64_t valid, int i,
     return true;
 }
 
-// Returns n on success, else the index of the line that failed.
+// Returns n on success, else the index of the line that failed.  RVO2 walks the lines in order and re-optimises at every
+// line the current result violates; lines it does not violate are no-ops, so the walk jumps from violated line to
+// violated line: every lane tests its own line against the current result, a ballot + ffs finds the next one.
 __device__ __forceinline__ int lp2_wave(const LpLine &L, uint64_t valid, int n, float radius, float optx, float opty,
                                         bool dirOpt, int lane, float &rx, float &ry)
 {
@@ -147,47 +149,51 @@ __device__ __forceinline__ int lp2_wave(const LpLine &L, uint64_t valid, int n, 
     } else {
         rx = optx; ry = opty;
     }
-    for (int i = 0; i < n; ++i) {
-        if (!((valid >> i) & 1ull)) continue;
+    uint64_t todo = valid & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+    for (;;) {
+        const uint64_t vm = __ballot(L.dx * (L.py - ry) - L.dy * (L.px - rx) > 0.0f) & todo;
+        if (!vm) return n;
+        const int i = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)vm) - 1);
+        todo &= ~((2ull << i) - 1ull); // lines 0..i are behind us
         const float ipx = wv_readlane(L.px, i), ipy = wv_readlane(L.py, i);
         const float idx = wv_readlane(L.dx, i), idy = wv_readlane(L.dy, i);
-        if (idx * (ipy - ry) - idy * (ipx - rx) > 0.0f) {
-            const float tx = rx, ty = ry;
-            if (!lp1_wave(L, valid, i, ipx, ipy, idx, idy, radius, optx, opty, dirOpt, lane, rx, ry)) {
-                rx = tx; ry = ty;
-                return i;
-            }
+        const float tx = rx, ty = ry;
+        if (!lp1_wave(L, valid, i, ipx, ipy, idx, idy, radius, optx, opty, dirOpt, lane, rx, ry)) {
+            rx = tx; ry = ty;
+            return i;
         }
     }
-    return n;
 }
 
 __device__ __forceinline__ void lp3_wave(const LpLine &L, int n, int beginLine, float radius, int lane, float &rx, float &ry)
 {
     float distance = 0.0f;
-    for (int i = beginLine; i < n; ++i) {
+    uint64_t todo = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) & ~((1ull << beginLine) - 1ull);
+    for (;;) {
+        const uint64_t vm = __ballot(L.dx * (L.py - ry) - L.dy * (L.px - rx) > distance) & todo;
+        if (!vm) return;
+        const int i = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)vm) - 1);
+        todo &= ~((2ull << i) - 1ull);
         const float ipx = wv_readlane(L.px, i), ipy = wv_readlane(L.py, i);
         const float idx = wv_readlane(L.dx, i), idy = wv_readlane(L.dy, i);
-        if (idx * (ipy - ry) - idy * (ipx - rx) > distance) {
-            // every lane j < i projects its line onto line i (RVO2 builds projLines sequentially; same set, same order)
-            LpLine Pj;
-            const float determinant = idx * L.dy - idy * L.dx;
-            const bool par = fabsf(determinant) <= RVO_EPS;
-            const bool skip = par && (idx * L.dx + idy * L.dy > 0.0f);
-            if (par) {
-                Pj.px = 0.5f * (ipx + L.px); Pj.py = 0.5f * (ipy + L.py);
-            } else {
-                const float s = (L.dx * (ipy - L.py) - L.dy * (ipx - L.px)) / determinant;
-                Pj.px = ipx + s * idx; Pj.py = ipy + s * idy;
-            }
-            const float ddx = L.dx - idx, ddy = L.dy - idy;
-            const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
-            Pj.dx = ddx * inv; Pj.dy = ddy * inv;
-            const uint64_t pvalid = __ballot(lane < i && !skip);
-            const float tx = rx, ty = ry;
-            if (lp2_wave(Pj, pvalid, i, radius, -idy, idx, true, lane, rx, ry) < i) { rx = tx; ry = ty; }
-            distance = idx * (ipy - ry) - idy * (ipx - rx);
+        // every lane j < i projects its line onto line i (RVO2 builds projLines sequentially; same set, same order)
+        LpLine Pj;
+        const float determinant = idx * L.dy - idy * L.dx;
+        const bool par = fabsf(determinant) <= RVO_EPS;
+        const bool skip = par && (idx * L.dx + idy * L.dy > 0.0f);
+        if (par) {
+            Pj.px = 0.5f * (ipx + L.px); Pj.py = 0.5f * (ipy + L.py);
+        } else {
+            const float s = (L.dx * (ipy - L.py) - L.dy * (ipx - L.px)) / determinant;
+            Pj.px = ipx + s * idx; Pj.py = ipy + s * idy;
         }
+        const float ddx = L.dx - idx, ddy = L.dy - idy;
+        const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+        Pj.dx = ddx * inv; Pj.dy = ddy * inv;
+        const uint64_t pvalid = __ballot(lane < i && !skip);
+        const float tx = rx, ty = ry;
+        if (lp2_wave(Pj, pvalid, i, radius, -idy, idx, true, lane, rx, ry) < i) { rx = tx; ry = ty; }
+        distance = idx * (ipy - ry) - idy * (ipx - rx);
     }
 }
 

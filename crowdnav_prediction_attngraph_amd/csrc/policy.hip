@@ -125,6 +125,141 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
         }
 }
 
+// ---- split-precision GEMM: fp32 operands as (hi + lo) bf16 pairs, three bf16 MFMAs per product term ------------------
+// a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with hi = bf16(x), lo = bf16(x - hi): the dropped terms are <= 2^-16 relative,
+// accumulation is fp32 (measured end-to-end error on the HH block: 1.5e-5, bar 1e-4).  Runs on v_mfma_f32_32x32x16_bf16
+// (16x the fp32 MFMA rate, three passes -> 5.3x).  A is fp32 in HBM and split while it is staged into LDS
+// (v_cvt_pk_bf16_f32); W is split once per weight snapshot.  LDS rows are 32 bf16 padded to 40 (80 B): the 16-byte
+// fragment reads of 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int L3_STRIDE = 40;
+
+template <int BN, int ACT>
+__global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                       const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+                                                       const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                       const int *__restrict__ m_dev)
+{
+    if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
+    if ((int)(blockIdx.y * BM) >= M) return;
+    constexpr int NB = BN / 64;
+    constexpr int WCH = BN * 4 / 256; // 16-byte chunks of each W array per thread per K tile
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[BM * L3_STRIDE];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[BM * L3_STRIDE];
+    __shared__ __attribute__((aligned(16))) __bf16 Wh[BN * L3_STRIDE];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[BN * L3_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 pa[4];
+    bf16x8 pwh[WCH], pwl[WCH];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = m_blk + lrow + 32 * p;
+            if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
+            else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < WCH; ++p) {
+            const int c = tid + 256 * p, r = n_blk + (c >> 2), col = (c & 3) * 8;
+            pwh[p] = *reinterpret_cast<const bf16x8 *>(Whi + (size_t)r * K + k0 + col);
+            pwl[p] = *reinterpret_cast<const bf16x8 *>(Wlo + (size_t)r * K + k0 + col);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hi[q] = (__bf16)pa[p][q];
+                lo[q] = (__bf16)(pa[p][q] - (float)hi[q]);
+            }
+            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + 32 * p) * L3_STRIDE + lcol]) = hi;
+            *reinterpret_cast<bf16x4 *>(&Al[(lrow + 32 * p) * L3_STRIDE + lcol]) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < WCH; ++p) {
+            const int c = tid + 256 * p, r = c >> 2, col = (c & 3) * 8;
+            *reinterpret_cast<bf16x8 *>(&Wh[r * L3_STRIDE + col]) = pwh[p];
+            *reinterpret_cast<bf16x8 *>(&Wl[r * L3_STRIDE + col]) = pwl[p];
+        }
+    };
+
+    load_tiles(0);
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < K) load_tiles(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 64 + i * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
+                al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int o = (wn * (BN / 2) + j * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+                bh[j] = *reinterpret_cast<const bf16x8 *>(&Wh[o]);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(&Wl[o]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
+            const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    float v = acc[i][j][r] + b;
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+// split a fp32 weight matrix into bf16 hi / lo parts
+__global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const __bf16 h = (__bf16)w[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(w[i] - (float)h);
+    }
+}
+
 // Row compaction: row_off[e] = sum_{e' < e} nd(e'), nd = clamp(detected_human_num, 1, H); row_off[E] = number of live
 // (env, human) rows.  Padded humans (index >= nd) only ever meet an exactly-zero robot-human attention weight, so the
 // whole human-human block runs on live rows only.  Single block, Hillis-Steele scan over per-thread chunk sums.
@@ -196,8 +331,11 @@ __global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__
 }
 
 // Human-human multi-head attention core (torch.nn.MultiheadAttention with key_padding_mask, 8 heads x 64) on the
-// compacted rows: one wavefront per (env, head); the nd live K/V/Q rows of the env/head are staged in LDS; lane j scores
-// key j, lane d owns output dim d.  Masked keys are simply absent (softmax over the nd live keys == softmax with -inf).
+// compacted rows: one wavefront per (env, head); the nd live Q/K/V rows are staged in LDS (row stride 65 floats).
+//   scores  : lanes enumerate (query i, key j) pairs, 64 pairs per pass -> nd*nd dot products of length 64
+//   softmax : lane i owns row i of the nd x nd score matrix (kept in LDS, reusing the Q region)
+//   P*V     : lane d owns output dim d
+// Masked keys are simply absent (softmax over the nd live keys == softmax with -inf on the padded ones).
 __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const float *__restrict__ qkv, const int *__restrict__ row_off,
                                                            float *__restrict__ out)
 {
@@ -218,18 +356,38 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const f
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wavefront visible to its own reads
-    const int jl = lane < nd ? lane : 0;
-    for (int i = 0; i < nd; ++i) {
+    // ---- scores: pair q = (i, j), 64 pairs per pass.  S[q] is written over the Q region right after the pass that
+    // computed it: pass ps writes floats [64ps, 64ps+63] = Q rows <= ps, later passes read Q rows >= 64(ps+1)/nd >= ps+1.
+    const int npairs = nd * nd;
+    const int npass = (npairs + 63) >> 6;
+#pragma unroll 1
+    for (int ps = 0; ps < npass; ++ps) {
+        const int q = ps * 64 + lane;
+        const int qi = q < npairs ? q / nd : 0, qj = q < npairs ? q - qi * nd : 0;
         float s = 0.0f;
 #pragma unroll 16
-        for (int d = 0; d < 64; ++d) s += Qs[i * 65 + d] * Ks[jl * 65 + d];
-        s = lane < nd ? s : -INFINITY;
-        const float mx = wv_max(s);
-        const float p = lane < nd ? expf(s - mx) : 0.0f;
-        const float denom = wv_sum(p);
-        const float pn = p / denom;
+        for (int d = 0; d < 64; ++d) s += Qs[qi * 65 + d] * Ks[qj * 65 + d];
+        __builtin_amdgcn_wave_barrier();
+        if (q < npairs) Qs[q] = s; // dense S[i * nd + j]
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    // ---- softmax: lane i normalises row i in place ----
+    if (lane < nd) {
+        float *row = Qs + lane * nd;
+        float mx = -INFINITY;
+        for (int j = 0; j < nd; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.0f;
+        for (int j = 0; j < nd; ++j) { const float p = expf(row[j] - mx); row[j] = p; sum += p; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < nd; ++j) row[j] *= inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- P * V: lane d ----
+    for (int i = 0; i < nd; ++i) {
         float o = 0.0f;
-        for (int j = 0; j < nd; ++j) o += wv_readlane(pn, j) * Vs[j * 65 + lane];
+        for (int j = 0; j < nd; ++j) o += Qs[i * nd + j] * Vs[j * 65 + lane];
         out[(size_t)(r0 + i) * 512 + head * 64 + lane] = o;
     }
 }
@@ -380,6 +538,8 @@ struct cn_policy {
     float *cl_w, *cl_b, *fm_w, *fm_b, *logstd;
     // activations
     float *emb1, *emb2, *qkv, *attn, *out_sp, *s_emb;
+    __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
+    int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split (default)
     int *row_off; // [maxE + 1] exclusive prefix of live humans per env; row_off[E] = live rows
     float *robot_states, *t_emb, *hr_out, *hr_attn, *x, *gi, *gh, *hnew, *rnn_out, *ac1, *ac2;
     // profiling of the dominant kernel (QKV projection)
@@ -399,6 +559,18 @@ static int launch_gemm(int M, int N, int K, const float *A, int lda, const float
     if (M == 0) return CN_OK;
     dim3 grid(N / BN, (M + BM - 1) / BM);
     hipLaunchKernelGGL((gemm_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc, m_dev);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+template <int BN, int ACT>
+static int launch_gemm3(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
+                        hipStream_t st, const int *m_dev)
+{
+    CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    if (M == 0) return CN_OK;
+    dim3 grid(N / BN, (M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm3_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -432,6 +604,8 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_gi = carve(E * 384), o_gh = carve(E * 384), o_hn = carve(E * 128), o_ro = carve(E * 256);
     const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
     const size_t o_roff = carve(E + 1);
+    const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
+    const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete p; cn_set_error("cn_policy_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -448,6 +622,9 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->robot_states = F(o_rs); p->t_emb = F(o_temb); p->hr_out = F(o_hr); p->hr_attn = F(o_hra); p->x = F(o_x);
     p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
     p->row_off = (int *)(base + o_roff);
+    p->emb2_hi = (__bf16 *)(base + o_e2h); p->emb2_lo = (__bf16 *)(base + o_e2l); p->qkv_hi = (__bf16 *)(base + o_qh); p->qkv_lo = (__bf16 *)(base + o_ql);
+    p->os_hi = (__bf16 *)(base + o_osh); p->os_lo = (__bf16 *)(base + o_osl);
+    p->gemm_mode = 1;
     p->weights_set = false;
     p->profiling = false;
     p->ev_head = p->ev_tail = 0;
@@ -496,6 +673,15 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
     CN_CHECK_LAUNCH();
     hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, st, 256, 512, w->spatial_linear_w, w->out_proj_b, w->spatial_linear_b, 1.0f, p->os_b);
     CN_CHECK_LAUNCH();
+    {
+        struct { const float *w; __bf16 *hi, *lo; size_t n; } sp[3] = {{p->emb2_w, p->emb2_hi, p->emb2_lo, 512 * 128},
+                                                                       {p->qkv_w, p->qkv_hi, p->qkv_lo, 1536 * 512},
+                                                                       {p->os_w, p->os_hi, p->os_lo, 256 * 512}};
+        for (auto &x : sp) {
+            hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((x.n + 255) / 256)), dim3(256), 0, st, x.n, x.w, x.hi, x.lo);
+            CN_CHECK_LAUNCH();
+        }
+    }
     CN_D2D(p->as_w, w->attn_spatial_w, 64 * 256); CN_D2D(p->as_b, w->attn_spatial_b, 64);
     CN_D2D(p->at_w, w->attn_temporal_w, 64 * 256); CN_D2D(p->at_b, w->attn_temporal_b, 64);
     CN_D2D(p->rl_w, w->robot_linear_w, 256 * 9); CN_D2D(p->rl_b, w->robot_linear_b, 256);
@@ -550,9 +736,14 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(128), 0, st, E, H, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->row_off, p->emb1);
         CN_CHECK_LAUNCH();
     }
-    if ((rc = launch_gemm<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_w, p->emb2_b, p->emb2, 512, st, m_dev))) return rc;
+    const bool split = p->gemm_mode == 1;
+    if (split) rc = launch_gemm3<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_hi, p->emb2_lo, p->emb2_b, p->emb2, 512, st, m_dev);
+    else rc = launch_gemm<128, ACT_RELU>(M, 512, 128, p->emb1, 128, p->emb2_w, p->emb2_b, p->emb2, 512, st, m_dev);
+    if (rc) return rc;
     if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
-    if ((rc = launch_gemm<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_w, p->qkv_b, p->qkv, 1536, st, m_dev))) return rc;
+    if (split) rc = launch_gemm3<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_hi, p->qkv_lo, p->qkv_b, p->qkv, 1536, st, m_dev);
+    else rc = launch_gemm<128, ACT_NONE>(M, 1536, 512, p->emb2, 512, p->qkv_w, p->qkv_b, p->qkv, 1536, st, m_dev);
+    if (rc) return rc;
     if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
     {
         const size_t per_wave = (size_t)3 * H * 65 * sizeof(float); // K, V, Q of one (env, head)
@@ -560,7 +751,9 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, H, p->qkv, p->row_off, p->attn);
         CN_CHECK_LAUNCH();
     }
-    if ((rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev))) return rc;
+    if (split) rc = launch_gemm3<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
+    else rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
+    if (rc) return rc;
     if ((rc = launch_gemm<64, ACT_NONE>(M, 64, 256, p->out_sp, 256, p->as_w, p->as_b, p->s_emb, 64, st, m_dev))) return rc;
     // ---- robot node, robot-human attention ----
     {
@@ -621,6 +814,13 @@ extern "C" int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float
     if (hr_out) CN_D2D(hr_out, p->hr_out, (size_t)E * 256);
     if (robot_emb) CN_D2D(robot_emb, p->robot_states, (size_t)E * 256);
     if (actor_feat) CN_HIP(hipMemcpy2DAsync(actor_feat, 256 * sizeof(float), p->ac2, 512 * sizeof(float), 256 * sizeof(float), E, hipMemcpyDeviceToDevice, st));
+    return CN_OK;
+}
+
+extern "C" int cn_policy_set_gemm_mode(cn_policy *p, int mode)
+{
+    CN_REQUIRE(p && (mode == 0 || mode == 1), "cn_policy_set_gemm_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
+    p->gemm_mode = mode;
     return CN_OK;
 }
 

@@ -163,6 +163,10 @@ class HipPolicy:
                                                A.ptr(t["robot_emb"]), A.ptr(t["actor_feat"]), A.stream_ptr()), "cn_policy_get_taps")
         return t
 
+    def set_gemm_mode(self, mode):
+        """'bf16x3' (default: split-precision bf16 MFMA, ~2e-5 of fp32) or 'fp32' (exact fp32 MFMA)."""
+        A.check(A.lib().cn_policy_set_gemm_mode(self._h, {"fp32": 0, "bf16x3": 1}[mode]), "cn_policy_set_gemm_mode")
+
     def set_profiling(self, enabled):
         A.check(A.lib().cn_policy_set_profiling(self._h, int(bool(enabled))), "cn_policy_set_profiling")
 

@@ -155,6 +155,12 @@ int cn_policy_get_value(cn_policy *p, int E, const cn_obs *obs, const float *hxs
  * are spatial_lin [E,H,256], hr_attn [E,H], hr_out [E,256], robot_emb [E,256], actor_feat [E,256] (NULL to skip). */
 int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float *hr_attn, float *hr_out, float *robot_emb,
                        float *actor_feat, void *stream);
+/* Arithmetic of the three large human-human GEMMs (embedding_layer.2, folded q|k|v, folded out_proj∘spatial_linear):
+ *   1 (default) = split precision: each fp32 operand as bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 per term, fp32
+ *                 accumulation (products exact to ~2^-16 relative; outputs within 2e-5 of the fp32 path, bar 1e-4);
+ *   0           = exact fp32 on v_mfma_f32_32x32x2_f32.
+ * Everything else always runs in fp32. */
+int cn_policy_set_gemm_mode(cn_policy *p, int mode);
 /* Dominant-kernel timing support for bench.py: number of HH-block launches so far and accumulated device time of the
  * QKV projection kernel measured with hipEvents on `stream` when profiling is enabled. */
 int cn_policy_set_profiling(cn_policy *p, int enabled);

@@ -25,14 +25,16 @@ def _dev(obs):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in obs.items()}
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "policy_*_h*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
-def test_policy_act_matches_reference_golden(path):
+def test_policy_act_matches_reference_golden(path, mode):
     from crowdnav_prediction_attngraph_amd.hip import HipPolicy
     z = np.load(path)
     meta = json.loads(str(z["meta"]))
     E, H, D = meta["E"], meta["H"], meta["D"]
     _, sd = _sd_dev(meta["shapes"])
     pol = HipPolicy(H, D, max(E, 4))
+    pol.set_gemm_mode(mode)     # bf16x3 = split-precision MFMA (default), fp32 = exact fp32 MFMA: both must hold 1e-4
     pol.set_weights(sd)
     obs = _dev({k: z[k] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")})
     hxs, masks = torch.from_numpy(z["hxs_node"]).cuda(), torch.from_numpy(z["masks"]).cuda()
@@ -62,8 +64,9 @@ def test_policy_act_matches_reference_golden(path):
     np.testing.assert_allclose(v.cpu().numpy(), z["value"], atol=TOL)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("E,H,D", [(257, 20, 2), (130, 20, 12), (64, 5, 2), (40, 50, 2), (3, 64, 2), (1, 1, 2)])
-def test_policy_act_matches_numpy_oracle(E, H, D):
+def test_policy_act_matches_numpy_oracle(E, H, D, mode):
     """Sizes with ragged tiles (E*H not a multiple of 128), random-looking weights, random detected counts."""
     from crowdnav_prediction_attngraph_amd.hip import HipPolicy
     from oracle import policy_oracle as P
@@ -71,6 +74,7 @@ def test_policy_act_matches_numpy_oracle(E, H, D):
     shapes["base.spatial_attn.embedding_layer.0.weight"] = [128, D]
     sd, sdd = _sd_dev(shapes)
     pol = HipPolicy(H, D, E)
+    pol.set_gemm_mode(mode)
     pol.set_weights(sdd)
     obs = PU.synth_obs(E, H, D, seed=E + H)
     rs = np.random.RandomState(1)
