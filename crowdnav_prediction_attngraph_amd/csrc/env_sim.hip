@@ -781,7 +781,24 @@ struct cn_env_batch {
     EnvDev d;
     bool reset_done;
     void *blob;
+    // ORCA of step t+1 only needs the simulator state left by step t, not the robot's next action: it is launched on a
+    // side stream as soon as step t (or a reset) is enqueued and overlaps the caller's policy forward.
+    hipStream_t side;
+    hipEvent_t ev_state, ev_orca;
+    bool orca_ready; // hact for the current state has been enqueued on `side`
 };
+
+static int prefetch_orca(cn_env_batch *env, hipStream_t main)
+{
+    CN_HIP(hipEventRecord(env->ev_state, main));
+    CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
+    const int agents = env->d.E * env->d.H;
+    hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
+    CN_CHECK_LAUNCH();
+    CN_HIP(hipEventRecord(env->ev_orca, env->side));
+    env->orca_ready = true;
+    return CN_OK;
+}
 
 extern "C" void cn_env_config_default(cn_env_config *c)
 {
@@ -846,6 +863,11 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.sim_seen = cfg->randomize_attributes ? (float *)(base + o_seen) : nullptr;
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
     b->reset_done = false;
+    b->orca_ready = false;
+    if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->ev_state, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(base); delete b; cn_set_error("cn_env_create: stream/event creation failed"); return CN_ERR_HIP;
+    }
     *out = b;
     return CN_OK;
 }
@@ -853,6 +875,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
 extern "C" int cn_env_destroy(cn_env_batch *env)
 {
     if (!env) return CN_OK;
+    (void)hipStreamSynchronize(env->side);
+    (void)hipEventDestroy(env->ev_state); (void)hipEventDestroy(env->ev_orca); (void)hipStreamDestroy(env->side);
     if (env->blob) CN_HIP(hipFree(env->blob));
     delete env;
     return CN_OK;
@@ -871,10 +895,11 @@ extern "C" int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream)
     if (int rc = check_obs(obs)) return rc;
     hipStream_t st = (hipStream_t)stream;
     // VecEnv.reset() resets every env; case counters keep running (crowd_sim_var_num.py:348)
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // an in-flight prefetch reads the old state
     hipLaunchKernelGGL(env_reset_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs);
     CN_CHECK_LAUNCH();
     env->reset_done = true;
-    return CN_OK;
+    return prefetch_orca(env, st);
 }
 
 extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done,
@@ -885,17 +910,17 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     if (int rc = check_obs(obs)) return rc;
     CN_REQUIRE(actions && reward && done && info && ep_return && ep_len, "cn_env_step: null output/input pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int agents = env->d.E * env->d.H;
-    hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, st, env->d);
-    CN_CHECK_LAUNCH();
+    if (!env->orca_ready) { if (int rc = prefetch_orca(env, st)) return rc; }
+    CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // human velocities for the current state (computed on the side stream)
     hipLaunchKernelGGL(env_step_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len);
     CN_CHECK_LAUNCH();
-    return CN_OK;
+    return prefetch_orca(env, st); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
 }
 
 extern "C" int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream)
 {
     CN_REQUIRE(env, "cn_env_get_state: null handle");
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent((hipStream_t)stream, env->ev_orca, 0)); // ORCA also (re)builds sim_* lazily
     const int n = env->d.E * env->d.H * 8;
     hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, humans, robot);
     CN_CHECK_LAUNCH();
@@ -905,6 +930,9 @@ extern "C" int cn_env_get_state(cn_env_batch *env, double *humans, double *robot
 extern "C" int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream)
 {
     CN_REQUIRE(env && out, "cn_env_get_human_actions: null argument");
+    // the velocities applied by the LAST step were overwritten by the prefetch for the next one: report the prefetched
+    // ones (= the velocities the next step will apply), ordered behind the side stream
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent((hipStream_t)stream, env->ev_orca, 0));
     const int n = env->d.E * env->d.H * 2;
     hipLaunchKernelGGL(export_hact_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, out);
     CN_CHECK_LAUNCH();

@@ -35,34 +35,43 @@ constexpr int BM = 128, BK = 32, LDS_STRIDE = 36; // 36 floats = 144 B rows: con
 // lanes 0-31 hold k = 8g+s, lanes 32-63 hold k = 8g+4+s at step s (same mapping for A and W, so the sum is unchanged).
 // m_dev (optional): device-side row count (<= M).  The HH block runs on the compacted set of detected humans whose
 // size is only known on the device; the grid is sized for the worst case and surplus row tiles exit immediately.
-template <int BN, int ACT>
+// blockIdx.z batches independent problems that share the shape (strides in floats; e.g. actor.2 / critic.2).
+// relu_from: columns >= relu_from get a ReLU on top of ACT (lets one launch produce [t_emb | relu(enc)]).
+struct GemmBatch { long long sA, sW, sB, sC; };
+
+template <int TBM, int BN, int ACT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                      float *__restrict__ C, int ldc, const int *__restrict__ m_dev)
+                                                      float *__restrict__ C, int ldc, const int *__restrict__ m_dev,
+                                                      GemmBatch gb, int relu_from)
 {
     if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
-    if ((int)(blockIdx.y * BM) >= M) return;
+    if ((int)(blockIdx.y * TBM) >= M) return;
+    A += blockIdx.z * gb.sA; W += blockIdx.z * gb.sW; C += blockIdx.z * gb.sC;
+    if (bias) bias += blockIdx.z * gb.sB;
+    constexpr int MI = TBM / 64;       // 32-row MFMA blocks per wavefront
     constexpr int NB = BN / 64;        // MFMA column blocks per wavefront
+    constexpr int ALD = TBM / 32;      // float4 loads of A per thread per K tile
     constexpr int WLD = BN / 32;       // float4 loads of W per thread per K tile
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float As[TBM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
+    const int m_blk = blockIdx.y * TBM, n_blk = blockIdx.x * BN;
     const int lrow = tid >> 3, lcol = (tid & 7) * 4; // staging: 8 lanes cover one 128-byte row segment
 
-    f32x16 acc[2][NB];
+    f32x16 acc[MI][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    f32x4 pa[4], pw[WLD];
+    f32x4 pa[ALD], pw[WLD];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < ALD; ++p) {
             const int r = m_blk + lrow + 32 * p;
             if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
             else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(&As[(lrow + 32 * p) * LDS_STRIDE + lcol]) = pa[p];
+        for (int p = 0; p < ALD; ++p) *reinterpret_cast<f32x4 *>(&As[(lrow + 32 * p) * LDS_STRIDE + lcol]) = pa[p];
 #pragma unroll
         for (int p = 0; p < WLD; ++p) *reinterpret_cast<f32x4 *>(&Ws[(lrow + 32 * p) * LDS_STRIDE + lcol]) = pw[p];
     };
@@ -89,17 +98,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
         if (k0 + BK < K) load_tiles(k0 + BK); // prefetch next tile into registers while this one is multiplied
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[2], bf[NB];
+            f32x4 af[MI], bf[NB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = *reinterpret_cast<const f32x4 *>(&As[(wm * 64 + i * 32 + l31) * LDS_STRIDE + g * 8 + half * 4]);
+            for (int i = 0; i < MI; ++i)
+                af[i] = *reinterpret_cast<const f32x4 *>(&As[(wm * (TBM / 2) + i * 32 + l31) * LDS_STRIDE + g * 8 + half * 4]);
 #pragma unroll
             for (int j = 0; j < NB; ++j)
                 bf[j] = *reinterpret_cast<const f32x4 *>(&Ws[(wn * (BN / 2) + j * 32 + l31) * LDS_STRIDE + g * 8 + half * 4]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
@@ -107,17 +116,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
             const float b = bias ? bias[col] : 0.0f;
+            const bool extra_relu = col >= relu_from;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = m_blk + wm * (TBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < M) {
                     float v = acc[i][j][r] + b;
-                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_RELU || extra_relu) v = fmaxf(v, 0.0f);
                     if (ACT == ACT_TANH) v = tanhf(v);
                     C[(size_t)row * ldc + col] = v;
                 }
@@ -336,8 +346,11 @@ __global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__
 //   softmax : lane i owns row i of the nd x nd score matrix (kept in LDS, reusing the Q region)
 //   P*V     : lane d owns output dim d
 // Masked keys are simply absent (softmax over the nd live keys == softmax with -inf on the padded ones).
-__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const float *__restrict__ qkv, const int *__restrict__ row_off,
-                                                           float *__restrict__ out)
+// Size classes share the launch grid: (0,8] is the common case (~6 detected humans) with a 6 KB LDS footprint per
+// wavefront (high occupancy), then (8,16], (16,32], (32,64] as far as H requires; a wavefront whose unit belongs to
+// another class exits at once.  All global loads of a unit are issued before the first LDS write (24 in flight).
+__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, int cap, const float *__restrict__ qkv,
+                                                           const int *__restrict__ row_off, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -345,14 +358,22 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const f
     if (unit >= E * 8) return;
     const int e = unit >> 3, head = unit & 7;
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
-    float *Ks = smem + (size_t)wave * (3 * H * 65);
-    float *Vs = Ks + H * 65;
-    float *Qs = Vs + H * 65;
-    const float *base = qkv + (size_t)r0 * 1536 + head * 64;
-    for (int j = 0; j < nd; ++j) {
-        Qs[j * 65 + lane] = base[(size_t)j * 1536 + lane];
-        Ks[j * 65 + lane] = base[(size_t)j * 1536 + 512 + lane];
-        Vs[j * 65 + lane] = base[(size_t)j * 1536 + 1024 + lane];
+    if (nd <= cap_lo || nd > cap) return; // another size class handles this unit
+    float *Ks = smem + (size_t)wave * (3 * cap * 65);
+    float *Vs = Ks + cap * 65;
+    float *Qs = Vs + cap * 65;
+    const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
+    for (int j0 = 0; j0 < nd; j0 += 8) {
+        float q[8], k[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool live = j0 + u < nd;
+            const float *row = base + (size_t)(live ? j0 + u : 0) * 1536;
+            q[u] = row[0]; k[u] = row[512]; v[u] = row[1024];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u < nd) { Qs[(j0 + u) * 65 + lane] = q[u]; Ks[(j0 + u) * 65 + lane] = k[u]; Vs[(j0 + u) * 65 + lane] = v[u]; }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wavefront visible to its own reads
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int H, const f
 // Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177) on the compacted rows: one
 // wavefront per env.  masked_fill(-1e9) + softmax gives padded humans exactly zero weight (exp underflows to 0), so the
 // softmax and the weighted sum run over the nd live rows only.
-__global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ t_emb, const float *__restrict__ s_emb,
+__global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ t_emb, int t_ld, const float *__restrict__ s_emb,
                                                            const float *__restrict__ out_sp, const int *__restrict__ row_off,
                                                            float *__restrict__ hr_out, float *__restrict__ hr_attn)
 {
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const f
     float *Ss = smem + (size_t)wave * (H * 65 + 64);
     float *Ts = Ss + H * 65;
     for (int j = 0; j < nd; ++j) Ss[j * 65 + lane] = s_emb[(size_t)(r0 + j) * 64 + lane];
-    Ts[lane] = t_emb[(size_t)e * 64 + lane];
+    Ts[lane] = t_emb[(size_t)e * t_ld + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     const int jl = lane < nd ? lane : 0;
@@ -536,6 +557,9 @@ struct cn_policy {
     float *ac0_w, *ac0_b;                   // concat(actor.0, critic.0) [512,256]
     float *a2_w, *a2_b, *c2_w, *c2_b;       // [256,256]
     float *cl_w, *cl_b, *fm_w, *fm_b, *logstd;
+    float *te_w, *te_b;       // [attn.temporal_edge_layer ; encoder_linear] stacked [128,256]
+    float *ac0f_w, *ac0f_b;   // (actor.0 ; critic.0) folded with output_linear [512,128]
+    float *z;                 // [E,192] = [t_emb | relu(enc) | relu(edge)]
     // activations
     float *emb1, *emb2, *qkv, *attn, *out_sp, *s_emb;
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
@@ -551,16 +575,30 @@ struct cn_policy {
     int64_t prof_n[8];
 };
 
+template <int TBM, int BN, int ACT>
+static int launch_gemm_t(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st,
+                         const int *m_dev, int nbatch, GemmBatch gb, int relu_from)
+{
+    CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    if (M == 0) return CN_OK;
+    dim3 grid(N / BN, (M + TBM - 1) / TBM, nbatch);
+    hipLaunchKernelGGL((gemm_nt_kernel<TBM, BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc, m_dev, gb, relu_from);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+// big-M GEMMs (rows = live humans): 128-row tiles
 template <int BN, int ACT>
 static int launch_gemm(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st,
                        const int *m_dev = nullptr)
 {
-    CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
-    if (M == 0) return CN_OK;
-    dim3 grid(N / BN, (M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc, m_dev);
-    CN_CHECK_LAUNCH();
-    return CN_OK;
+    return launch_gemm_t<128, BN, ACT>(M, N, K, A, lda, W, bias, C, ldc, st, m_dev, 1, GemmBatch{0, 0, 0, 0}, 1 << 30);
+}
+// per-env GEMMs (rows = envs, a few thousand): 64 x 64 tiles so that the launch still fills the 256 CUs
+template <int ACT>
+static int launch_gemm_env(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st,
+                           int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0, 0}, int relu_from = 1 << 30)
+{
+    return launch_gemm_t<64, 64, ACT>(M, N, K, A, lda, W, bias, C, ldc, st, nullptr, nbatch, gb, relu_from);
 }
 
 template <int BN, int ACT>
@@ -604,6 +642,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_gi = carve(E * 384), o_gh = carve(E * 384), o_hn = carve(E * 128), o_ro = carve(E * 256);
     const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
     const size_t o_roff = carve(E + 1);
+    const size_t o_tew = carve(128 * 256), o_teb = carve(128), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 192);
     const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
     const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
     char *base = nullptr;
@@ -625,6 +664,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->emb2_hi = (__bf16 *)(base + o_e2h); p->emb2_lo = (__bf16 *)(base + o_e2l); p->qkv_hi = (__bf16 *)(base + o_qh); p->qkv_lo = (__bf16 *)(base + o_ql);
     p->os_hi = (__bf16 *)(base + o_osh); p->os_lo = (__bf16 *)(base + o_osl);
     p->gemm_mode = 1;
+    p->te_w = F(o_tew); p->te_b = F(o_teb); p->ac0f_w = F(o_acfw); p->ac0f_b = F(o_acfb); p->z = F(o_z);
     p->weights_set = false;
     p->profiling = false;
     p->ev_head = p->ev_tail = 0;
@@ -694,6 +734,13 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
     CN_D2D(p->ac0_b, w->actor0_b, 256); CN_D2D(p->ac0_b + 256, w->critic0_b, 256);
     CN_D2D(p->a2_w, w->actor2_w, 256 * 256); CN_D2D(p->a2_b, w->actor2_b, 256);
     CN_D2D(p->c2_w, w->critic2_w, 256 * 256); CN_D2D(p->c2_b, w->critic2_b, 256);
+    CN_D2D(p->te_w, w->attn_temporal_w, 64 * 256); CN_D2D(p->te_w + 64 * 256, w->enc_w, 64 * 256);
+    CN_D2D(p->te_b, w->attn_temporal_b, 64); CN_D2D(p->te_b + 64, w->enc_b, 64);
+    // fold output_linear into the first actor / critic layers: tanh(W0 (Wo h + bo) + b0) = tanh((W0 Wo) h + (W0 bo + b0))
+    hipLaunchKernelGGL(fold_mm_kernel, dim3(1, 512), dim3(128), 0, st, 512, 256, 128, p->ac0_w, w->out_w, 1.0f, p->ac0f_w);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_bias_kernel, dim3(2), dim3(256), 0, st, 512, 256, p->ac0_w, w->out_b, p->ac0_b, 1.0f, p->ac0f_b);
+    CN_CHECK_LAUNCH();
     CN_D2D(p->cl_w, w->critic_linear_w, 256); CN_D2D(p->cl_b, w->critic_linear_b, 1);
     CN_D2D(p->fm_w, w->fc_mean_w, 512); CN_D2D(p->fm_b, w->fc_mean_b, 2); CN_D2D(p->logstd, w->logstd, 2);
     p->weights_set = true;
@@ -746,10 +793,16 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     if (rc) return rc;
     if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
     {
-        const size_t per_wave = (size_t)3 * H * 65 * sizeof(float); // K, V, Q of one (env, head)
-        int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-        hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, H, p->qkv, p->row_off, p->attn);
-        CN_CHECK_LAUNCH();
+        int lo = 0;
+        for (int cap = 8; lo < H; cap *= 2) {
+            const int c = cap < H ? cap : H;
+            const size_t per_wave = (size_t)3 * c * 65 * sizeof(float);
+            int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+            hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, lo, c, p->qkv, p->row_off,
+                               p->attn);
+            CN_CHECK_LAUNCH();
+            lo = c;
+        }
     }
     if (split) rc = launch_gemm3<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
     else rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
@@ -761,26 +814,25 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         hipLaunchKernelGGL(robot_embed_kernel, dim3(blocks), dim3(256), 0, st, E, obs->temporal_edges, obs->robot_node, p->rl_w, p->rl_b, p->robot_states);
         CN_CHECK_LAUNCH();
     }
-    if ((rc = launch_gemm<64, ACT_NONE>(E, 64, 256, p->robot_states, 256, p->at_w, p->at_b, p->t_emb, 64, st))) return rc;
+    // [t_emb | relu(enc)] in one launch (both read robot_states); z = [t_emb | enc | edge], x = z + 64
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 128, 256, p->robot_states, 256, p->te_w, p->te_b, p->z, 192, st, 1, GemmBatch{0, 0, 0, 0}, 64))) return rc;
     {
         const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
-        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->t_emb, p->s_emb, p->out_sp, p->row_off,
+        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->z, 192, p->s_emb, p->out_sp, p->row_off,
                            p->hr_out, p->hr_attn);
         CN_CHECK_LAUNCH();
     }
-    // ---- EndRNN: encoders -> GRU -> output_linear ----
-    if ((rc = launch_gemm<64, ACT_RELU>(E, 64, 256, p->robot_states, 256, p->enc_w, p->enc_b, p->x, 128, st))) return rc;
-    if ((rc = launch_gemm<64, ACT_RELU>(E, 64, 256, p->hr_out, 256, p->edge_w, p->edge_b, p->x + 64, 128, st))) return rc;
-    if ((rc = launch_gemm<128, ACT_NONE>(E, 384, 128, p->x, 128, p->wih, p->bih, p->gi, 384, st))) return rc;
-    if ((rc = launch_gemm<128, ACT_NONE>(E, 384, 128, hxs_in, 128, p->whh, nullptr, p->gh, 384, st))) return rc;
+    // ---- EndRNN: edge encoder -> GRU (output_linear is folded into the actor / critic trunks) ----
+    if ((rc = launch_gemm_env<ACT_RELU>(E, 64, 256, p->hr_out, 256, p->edge_w, p->edge_b, p->z + 128, 192, st))) return rc;
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, p->z + 64, 192, p->wih, p->bih, p->gi, 384, st))) return rc;
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, hxs_in, 128, p->whh, nullptr, p->gh, 384, st))) return rc;
     float *hdst = hxs_out ? hxs_out : p->hnew;
     hipLaunchKernelGGL(gru_pointwise_kernel, dim3(E), dim3(128), 0, st, E, p->gi, p->gh, p->bhh, hxs_in, masks, hdst);
     CN_CHECK_LAUNCH();
-    if ((rc = launch_gemm<128, ACT_NONE>(E, 256, 128, hdst, 128, p->out_w, p->out_b, p->rnn_out, 256, st))) return rc;
-    // ---- actor / critic trunks (first layers batched), heads ----
-    if ((rc = launch_gemm<128, ACT_TANH>(E, 512, 256, p->rnn_out, 256, p->ac0_w, p->ac0_b, p->ac1, 512, st))) return rc;
-    if ((rc = launch_gemm<128, ACT_TANH>(E, 256, 256, p->ac1, 512, p->a2_w, p->a2_b, p->ac2, 512, st))) return rc;
-    if ((rc = launch_gemm<128, ACT_TANH>(E, 256, 256, p->ac1 + 256, 512, p->c2_w, p->c2_b, p->ac2 + 256, 512, st))) return rc;
+    // ---- actor / critic trunks: first layers stacked (+ folded output_linear), second layers as one batched launch ----
+    if ((rc = launch_gemm_env<ACT_TANH>(E, 512, 128, hdst, 128, p->ac0f_w, p->ac0f_b, p->ac1, 512, st))) return rc;
+    if ((rc = launch_gemm_env<ACT_TANH>(E, 256, 256, p->ac1, 512, p->a2_w, p->a2_b, p->ac2, 512, st, 2,
+                                        GemmBatch{256, (long long)(p->c2_w - p->a2_w), (long long)(p->c2_b - p->a2_b), 256}))) return rc;
     hipLaunchKernelGGL(gauss_head_kernel, dim3((E + 3) / 4), dim3(256), 0, st, E, p->ac2, 512, p->cl_w, p->cl_b, p->fm_w, p->fm_b, p->logstd, eps,
                        value, action, logp);
     CN_CHECK_LAUNCH();

@@ -151,21 +151,31 @@ class AttnGraphBase(nn.Module):
 
     # ---- training-time forward in torch ops (autograd) ----
     def _hh_block(self, spatial_edges, det):
-        """[B,H,D] -> [B,H,256].  SpatialEdgeSelfAttn.forward + spatial_linear (selfAttn_srnn_temp_node.py:63-91,:408)."""
-        B, H, _ = spatial_edges.shape
+        """[B,H,D] -> [B,H,256].  SpatialEdgeSelfAttn.forward + spatial_linear (selfAttn_srnn_temp_node.py:63-91,:408).
+
+        Only the detected humans (index < det) are pushed through the linear layers: padded humans are masked as keys
+        and their own outputs only ever meet an exactly-zero robot-human attention weight, so values and gradients are
+        identical to the dense computation while the dominant GEMMs shrink by H / mean(det) (~3.4x at 20 humans).
+        The tiny per-env attention itself runs on zero-padded [B,8,H,64] tensors."""
+        B, H, D = spatial_edges.shape
         sa = self.spatial_attn
-        e = sa.embedding_layer(spatial_edges)
-        q, k, v = sa.q_linear(e), sa.k_linear(e), sa.v_linear(e)
-        W, b = sa.multihead_attn.in_proj_weight, sa.multihead_attn.in_proj_bias
-        q = F.linear(q, W[:512], b[:512]).view(B, H, 8, 64).transpose(1, 2)
-        k = F.linear(k, W[512:1024], b[512:1024]).view(B, H, 8, 64).transpose(1, 2)
-        v = F.linear(v, W[1024:], b[1024:]).view(B, H, 8, 64).transpose(1, 2)
         valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
-        scores = torch.matmul(q, k.transpose(-1, -2)) * 0.125
+        idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
+        e = sa.embedding_layer(spatial_edges.reshape(B * H, D).index_select(0, idx))
+        W, b = sa.multihead_attn.in_proj_weight, sa.multihead_attn.in_proj_bias
+        q = F.linear(sa.q_linear(e), W[:512], b[:512])
+        k = F.linear(sa.k_linear(e), W[512:1024], b[512:1024])
+        v = F.linear(sa.v_linear(e), W[1024:], b[1024:])
+
+        def pad(x):
+            return x.new_zeros(B * H, 512).index_copy(0, idx, x).view(B, H, 8, 64).transpose(1, 2)
+
+        scores = torch.matmul(pad(q), pad(k).transpose(-1, -2)) * 0.125
         scores = scores.masked_fill(~valid.view(B, 1, 1, H), float("-inf"))
-        o = torch.matmul(torch.softmax(scores, dim=-1), v).transpose(1, 2).reshape(B, H, 512)
-        o = sa.multihead_attn.out_proj(o)
-        return self.spatial_linear(o), valid
+        o = torch.matmul(torch.softmax(scores, dim=-1), pad(v)).transpose(1, 2).reshape(B * H, 512)
+        o = self.spatial_linear(sa.multihead_attn.out_proj(o.index_select(0, idx)))
+        out_sp = o.new_zeros(B * H, o.shape[1]).index_copy(0, idx, o).view(B, H, -1)
+        return out_sp, valid
 
     def _hr_attention(self, robot_states, out_sp, valid):
         """EdgeAttention_M (selfAttn_srnn_temp_node.py:145-223): [B,256],[B,H,256] -> [B,256]."""

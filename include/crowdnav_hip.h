@@ -107,7 +107,8 @@ int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, floa
 /* Debug/test access to the simulator state: copies humans [E,H,8] (px,py,vx,vy,gx,gy,radius,v_pref) and robot [E,8]
  * (px,py,vx,vy,gx,gy,theta,potential) as float64 into caller DEVICE buffers (either may be NULL). */
 int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream);
-/* last ORCA velocities of the humans, [E,H,2] float32 device buffer */
+/* ORCA velocities of the humans for the CURRENT state (the ones the next cn_env_step will apply; they are computed
+ * ahead of time on an internal side stream, overlapped with the caller's policy forward), [E,H,2] float32 */
 int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream);
 
 /* Stand-alone batched ORCA solve (the rvo2 replacement): B independent agents, each with n_other neighbours.
