@@ -27,6 +27,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 
+// XCD-aware tile mapping.  Workgroups are dispatched round-robin over the 8 XCDs (linear id L -> XCD L % 8), each with a
+// private L2.  With the natural (x = column tile fastest) order the N/BN workgroups that share one A row-tile land on
+// 8 different XCDs and every L2 fetches that tile again (rocprof: FETCH_SIZE 5-9x the algorithmic bytes).  Remap so
+// that XCD x owns row tiles {x, x+8, ...} and walks their column tiles consecutively: q = L / 8 -> (row = (q / nbx) * 8
+// + x, col = q % nbx).  gridDim.y must be a multiple of 8 (the launcher pads; surplus row tiles exit on the M check).
+__device__ __forceinline__ void xcd_tile(int &row_tile, int &col_tile)
+{
+    const int nbx = gridDim.x;
+    const int L = blockIdx.y * nbx + blockIdx.x;
+    const int x = L & 7, q = L >> 3;
+    col_tile = q % nbx;
+    row_tile = (q / nbx) * 8 + x;
+}
+
 constexpr int BM = 128, BK = 32, LDS_STRIDE = 36; // 36 floats = 144 B rows: conflict-free ds_read_b128
 
 // C[M,N] (ldc) = act(A[M,K] (lda) * W[N,K]^T + bias[N]); N % BN == 0, K % 32 == 0, M arbitrary.
@@ -46,7 +60,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
                                                       GemmBatch gb, int relu_from)
 {
     if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
-    if ((int)(blockIdx.y * TBM) >= M) return;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    if (row_tile * TBM >= M) return;
     A += blockIdx.z * gb.sA; W += blockIdx.z * gb.sW; C += blockIdx.z * gb.sC;
     if (bias) bias += blockIdx.z * gb.sB;
     constexpr int MI = TBM / 64;       // 32-row MFMA blocks per wavefront
@@ -57,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
     __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m_blk = blockIdx.y * TBM, n_blk = blockIdx.x * BN;
+    const int m_blk = row_tile * TBM, n_blk = col_tile * BN;
     const int lrow = tid >> 3, lcol = (tid & 7) * 4; // staging: 8 lanes cover one 128-byte row segment
 
     f32x16 acc[MI][NB];
@@ -143,7 +159,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
 // fragment reads of 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int L3_STRIDE = 40;
+constexpr int BK3 = 64;        // K tile of the split kernel: 4 MFMA k-steps (48 MFMAs per wavefront) between barriers
+constexpr int L3_STRIDE = 72;  // 64 bf16 + 8 pad = 144 B rows: 16-byte fragment reads of 16 consecutive rows are conflict-free
 
 template <int BN, int ACT>
 __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
@@ -152,17 +169,21 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
                                                        const int *__restrict__ m_dev)
 {
     if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
-    if ((int)(blockIdx.y * BM) >= M) return;
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    if (row_tile * BM >= M) return;
     constexpr int NB = BN / 64;
-    constexpr int WCH = BN * 4 / 256; // 16-byte chunks of each W array per thread per K tile
-    __shared__ __attribute__((aligned(16))) __bf16 Ah[BM * L3_STRIDE];
-    __shared__ __attribute__((aligned(16))) __bf16 Al[BM * L3_STRIDE];
-    __shared__ __attribute__((aligned(16))) __bf16 Wh[BN * L3_STRIDE];
-    __shared__ __attribute__((aligned(16))) __bf16 Wl[BN * L3_STRIDE];
+    constexpr int ALD = BM * BK3 / 4 / 256;  // float4 loads of A per thread per K tile (8)
+    constexpr int WCH = BN * BK3 / 8 / 256;  // 16-byte chunks of each W array per thread per K tile (4)
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    __bf16 *Ah = reinterpret_cast<__bf16 *>(smem3);
+    __bf16 *Al = Ah + BM * L3_STRIDE;
+    __bf16 *Wh = Al + BM * L3_STRIDE;
+    __bf16 *Wl = Wh + BN * L3_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m_blk = blockIdx.y * BM, n_blk = blockIdx.x * BN;
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    const int m_blk = row_tile * BM, n_blk = col_tile * BN;
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4; // A staging: 16 lanes cover one 256-byte row segment
 
     f32x16 acc[2][NB];
 #pragma unroll
@@ -172,37 +193,37 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    f32x4 pa[4];
+    f32x4 pa[ALD];
     bf16x8 pwh[WCH], pwl[WCH];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int r = m_blk + lrow + 32 * p;
+        for (int p = 0; p < ALD; ++p) {
+            const int r = m_blk + lrow + 16 * p;
             if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
             else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int p = 0; p < WCH; ++p) {
-            const int c = tid + 256 * p, r = n_blk + (c >> 2), col = (c & 3) * 8;
+            const int c = tid + 256 * p, r = n_blk + (c >> 3), col = (c & 7) * 8;
             pwh[p] = *reinterpret_cast<const bf16x8 *>(Whi + (size_t)r * K + k0 + col);
             pwl[p] = *reinterpret_cast<const bf16x8 *>(Wlo + (size_t)r * K + k0 + col);
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < ALD; ++p) {
             bf16x4 hi, lo;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 hi[q] = (__bf16)pa[p][q];
                 lo[q] = (__bf16)(pa[p][q] - (float)hi[q]);
             }
-            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + 32 * p) * L3_STRIDE + lcol]) = hi;
-            *reinterpret_cast<bf16x4 *>(&Al[(lrow + 32 * p) * L3_STRIDE + lcol]) = lo;
+            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + 16 * p) * L3_STRIDE + lcol]) = hi;
+            *reinterpret_cast<bf16x4 *>(&Al[(lrow + 16 * p) * L3_STRIDE + lcol]) = lo;
         }
 #pragma unroll
         for (int p = 0; p < WCH; ++p) {
-            const int c = tid + 256 * p, r = c >> 2, col = (c & 3) * 8;
+            const int c = tid + 256 * p, r = c >> 3, col = (c & 7) * 8;
             *reinterpret_cast<bf16x8 *>(&Wh[r * L3_STRIDE + col]) = pwh[p];
             *reinterpret_cast<bf16x8 *>(&Wl[r * L3_STRIDE + col]) = pwl[p];
         }
@@ -210,13 +231,13 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
 
     load_tiles(0);
     const int half = lane >> 5, l31 = lane & 31;
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    for (int k0 = 0; k0 < K; k0 += BK3) {
         __syncthreads();
         store_tiles();
         __syncthreads();
-        if (k0 + BK < K) load_tiles(k0 + BK);
+        if (k0 + BK3 < K) load_tiles(k0 + BK3);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < BK3 / 16; ++ks) {
             bf16x8 ah[2], al[2], bh[NB], bl[NB];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -230,14 +251,19 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
                 bh[j] = *reinterpret_cast<const bf16x8 *>(&Wh[o]);
                 bl[j] = *reinterpret_cast<const bf16x8 *>(&Wl[o]);
             }
+            // term-major issue order: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -341,76 +367,98 @@ __global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__
 }
 
 // Human-human multi-head attention core (torch.nn.MultiheadAttention with key_padding_mask, 8 heads x 64) on the
-// compacted rows: one wavefront per (env, head); the nd live Q/K/V rows are staged in LDS (row stride 65 floats).
-//   scores  : lanes enumerate (query i, key j) pairs, 64 pairs per pass -> nd*nd dot products of length 64
-//   softmax : lane i owns row i of the nd x nd score matrix (kept in LDS, reusing the Q region)
-//   P*V     : lane d owns output dim d
+// compacted rows: one wavefront per (env, head).
+//   load    : lane d reads element d of every live row: Q, K rows go to LDS (row stride 68 floats = 16-byte aligned and
+//             conflict-free for ds_read_b128), V stays in registers (lane d only ever needs column d of V)
+//   scores  : lanes enumerate (query i, key j) pairs, 64 pairs per pass; each dot product is 16 x (2 b128 reads + 4 FMA)
+//   softmax : lane i owns row i of S (LDS, row stride CAP, zero padded so P*V can read float4s)
+//   P*V     : lane d: o[i][d] = sum_j S[i][j] * v[j]
 // Masked keys are simply absent (softmax over the nd live keys == softmax with -inf on the padded ones).
-// Size classes share the launch grid: (0,8] is the common case (~6 detected humans) with a 6 KB LDS footprint per
-// wavefront (high occupancy), then (8,16], (16,32], (32,64] as far as H requires; a wavefront whose unit belongs to
-// another class exits at once.  All global loads of a unit are issued before the first LDS write (24 in flight).
-__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, int cap, const float *__restrict__ qkv,
-                                                           const int *__restrict__ row_off, float *__restrict__ out)
+// CAP in {8,16,32,64} are size classes sharing one launch grid: class (cap_lo, CAP] handles the units with that many
+// detected humans (the common case of ~6 uses 4.6 KB of LDS per wavefront -> high occupancy); other units exit at once.
+template <int CAP>
+__global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, const float *__restrict__ qkv, const int *__restrict__ row_off,
+                                                           float *__restrict__ out)
 {
+    constexpr int RS = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = blockIdx.x * (blockDim.x >> 6) + wave; // (env, head)
     if (unit >= E * 8) return;
     const int e = unit >> 3, head = unit & 7;
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
-    if (nd <= cap_lo || nd > cap) return; // another size class handles this unit
-    float *Ks = smem + (size_t)wave * (3 * cap * 65);
-    float *Vs = Ks + cap * 65;
-    float *Qs = Vs + cap * 65;
+    if (nd <= cap_lo || nd > CAP) return; // another size class handles this unit
+    float *Ks = smem + (size_t)wave * (2 * CAP * RS + CAP * CAP);
+    float *Qs = Ks + CAP * RS;
+    float *S = Qs + CAP * RS;
     const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
-    for (int j0 = 0; j0 < nd; j0 += 8) {
-        float q[8], k[8], v[8];
+    float v[CAP];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool live = j0 + u < nd;
-            const float *row = base + (size_t)(live ? j0 + u : 0) * 1536;
-            q[u] = row[0]; k[u] = row[512]; v[u] = row[1024];
+    for (int j0 = 0; j0 < CAP; j0 += 8) {
+        if (j0 < nd) { // wave-uniform
+            float q[8], k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *row = base + (size_t)(j0 + u < nd ? j0 + u : 0) * 1536;
+                q[u] = row[0]; k[u] = row[512]; v[j0 + u] = row[1024];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < nd) { Qs[(j0 + u) * RS + lane] = q[u]; Ks[(j0 + u) * RS + lane] = k[u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[j0 + u] = 0.0f;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (j0 + u < nd) { Qs[(j0 + u) * 65 + lane] = q[u]; Ks[(j0 + u) * 65 + lane] = k[u]; Vs[(j0 + u) * 65 + lane] = v[u]; }
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wavefront visible to its own reads
-    // ---- scores: pair q = (i, j), 64 pairs per pass.  S[q] is written over the Q region right after the pass that
-    // computed it: pass ps writes floats [64ps, 64ps+63] = Q rows <= ps, later passes read Q rows >= 64(ps+1)/nd >= ps+1.
     const int npairs = nd * nd;
-    const int npass = (npairs + 63) >> 6;
-#pragma unroll 1
-    for (int ps = 0; ps < npass; ++ps) {
-        const int q = ps * 64 + lane;
-        const int qi = q < npairs ? q / nd : 0, qj = q < npairs ? q - qi * nd : 0;
+    for (int q = lane; q < npairs; q += 64) {
+        const int qi = q / nd, qj = q - qi * nd;
+        const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qs + qi * RS);
+        const f32x4 *kp = reinterpret_cast<const f32x4 *>(Ks + qj * RS);
         float s = 0.0f;
-#pragma unroll 16
-        for (int d = 0; d < 64; ++d) s += Qs[qi * 65 + d] * Ks[qj * 65 + d];
-        __builtin_amdgcn_wave_barrier();
-        if (q < npairs) Qs[q] = s; // dense S[i * nd + j]
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const f32x4 a = qp[d], b = kp[d];
+            s += a[0] * b[0]; s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3];
+        }
+        S[qi * CAP + qj] = s;
     }
-    // ---- softmax: lane i normalises row i in place ----
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     if (lane < nd) {
-        float *row = Qs + lane * nd;
+        float *row = S + lane * CAP;
         float mx = -INFINITY;
         for (int j = 0; j < nd; ++j) mx = fmaxf(mx, row[j]);
         float sum = 0.0f;
         for (int j = 0; j < nd; ++j) { const float p = expf(row[j] - mx); row[j] = p; sum += p; }
         const float inv = 1.0f / sum;
         for (int j = 0; j < nd; ++j) row[j] *= inv;
+        for (int j = nd; j < CAP; ++j) row[j] = 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    // ---- P * V: lane d ----
     for (int i = 0; i < nd; ++i) {
+        const f32x4 *prow = reinterpret_cast<const f32x4 *>(S + i * CAP);
         float o = 0.0f;
-        for (int j = 0; j < nd; ++j) o += Qs[i * nd + j] * Vs[j * 65 + lane];
+#pragma unroll
+        for (int j4 = 0; j4 < CAP / 4; ++j4) {
+            const f32x4 p = prow[j4];
+            o += p[0] * v[4 * j4]; o += p[1] * v[4 * j4 + 1]; o += p[2] * v[4 * j4 + 2]; o += p[3] * v[4 * j4 + 3];
+        }
         out[(size_t)(r0 + i) * 512 + head * 64 + lane] = o;
     }
+}
+
+template <int CAP>
+static int launch_hh_attention(int E, int cap_lo, const float *qkv, const int *row_off, float *out, hipStream_t st)
+{
+    const size_t per_wave = (size_t)(2 * CAP * 68 + CAP * CAP) * sizeof(float);
+    int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+    hipLaunchKernelGGL(hh_attention_kernel<CAP>, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, cap_lo, qkv, row_off, out);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }
 
 // Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177) on the compacted rows: one
@@ -581,7 +629,7 @@ static int launch_gemm_t(int M, int N, int K, const float *A, int lda, const flo
 {
     CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
     if (M == 0) return CN_OK;
-    dim3 grid(N / BN, (M + TBM - 1) / TBM, nbatch);
+    dim3 grid(N / BN, (((M + TBM - 1) / TBM) + 7) & ~7, nbatch); // rows padded to a multiple of 8 for the XCD mapping
     hipLaunchKernelGGL((gemm_nt_kernel<TBM, BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, W, bias, C, ldc, m_dev, gb, relu_from);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -605,10 +653,16 @@ template <int BN, int ACT>
 static int launch_gemm3(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
                         hipStream_t st, const int *m_dev)
 {
-    CN_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    CN_REQUIRE(N % BN == 0 && K % BK3 == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
     if (M == 0) return CN_OK;
-    dim3 grid(N / BN, (M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm3_nt_kernel<BN, ACT>), grid, dim3(256), 0, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
+    dim3 grid(N / BN, (((M + BM - 1) / BM) + 7) & ~7);
+    constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB: needs the opt-in above 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm3_nt_kernel<BN, ACT>), grid, dim3(256), lds, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -793,16 +847,10 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     if (rc) return rc;
     if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
     {
-        int lo = 0;
-        for (int cap = 8; lo < H; cap *= 2) {
-            const int c = cap < H ? cap : H;
-            const size_t per_wave = (size_t)3 * c * 65 * sizeof(float);
-            int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-            hipLaunchKernelGGL(hh_attention_kernel, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, lo, c, p->qkv, p->row_off,
-                               p->attn);
-            CN_CHECK_LAUNCH();
-            lo = c;
-        }
+        if ((rc = launch_hh_attention<8>(E, 0, p->qkv, p->row_off, p->attn, st))) return rc;
+        if (H > 8 && (rc = launch_hh_attention<16>(E, 8, p->qkv, p->row_off, p->attn, st))) return rc;
+        if (H > 16 && (rc = launch_hh_attention<32>(E, 16, p->qkv, p->row_off, p->attn, st))) return rc;
+        if (H > 32 && (rc = launch_hh_attention<64>(E, 32, p->qkv, p->row_off, p->attn, st))) return rc;
     }
     if (split) rc = launch_gemm3<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
     else rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
