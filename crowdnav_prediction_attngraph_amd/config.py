@@ -28,6 +28,7 @@ class Config(object):
         self.action_space = _ns(kinematics="holonomic")
         self.orca = _ns(neighbor_dist=10, safety_space=0.15, time_horizon=5, time_horizon_obst=5)
         self.data = _ns(pred_timestep=0.25)
+        self.pred = _ns(model_dir="gst_updated/results/100-gumbel_social_transformer-faster_lstm-lr_0.001-init_temp_0.5-edge_head_0-ebd_64-snl_1-snh_8-seed_1000_rand/sj")
         for k, v in overrides.items():
             ns, attr = k.split(".")
             setattr(getattr(self, ns), attr, v)

@@ -162,10 +162,14 @@ class AttnGraphBase(nn.Module):
         valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
         idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
         e = sa.embedding_layer(spatial_edges.reshape(B * H, D).index_select(0, idx))
+        # (q|k|v)_linear followed by in_proj is an affine pair with no nonlinearity in between: compose the two weight
+        # matrices first (a 512^3 product, differentiable, so both factors still receive their exact gradients) and run ONE
+        # [rows,512]x[512,1536] GEMM instead of six [rows,512]x[512,512] ones, in the forward and in the backward pass.
         W, b = sa.multihead_attn.in_proj_weight, sa.multihead_attn.in_proj_bias
-        q = F.linear(sa.q_linear(e), W[:512], b[:512])
-        k = F.linear(sa.k_linear(e), W[512:1024], b[512:1024])
-        v = F.linear(sa.v_linear(e), W[1024:], b[1024:])
+        lins = (sa.q_linear, sa.k_linear, sa.v_linear)
+        Wc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].weight for i in range(3)], 0)
+        bc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].bias + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
+        q, k, v = F.linear(e, Wc, bc).split(512, dim=-1)
 
         def pad(x):
             return x.new_zeros(B * H, 512).index_copy(0, idx, x).view(B, H, 8, 64).transpose(1, 2)
@@ -173,7 +177,9 @@ class AttnGraphBase(nn.Module):
         scores = torch.matmul(pad(q), pad(k).transpose(-1, -2)) * 0.125
         scores = scores.masked_fill(~valid.view(B, 1, 1, H), float("-inf"))
         o = torch.matmul(torch.softmax(scores, dim=-1), pad(v)).transpose(1, 2).reshape(B * H, 512)
-        o = self.spatial_linear(sa.multihead_attn.out_proj(o.index_select(0, idx)))
+        # same composition for out_proj followed by spatial_linear (Linear -> Linear -> ReLU)
+        op, sl = sa.multihead_attn.out_proj, self.spatial_linear[0]
+        o = F.relu(F.linear(o.index_select(0, idx), sl.weight @ op.weight, sl.weight @ op.bias + sl.bias))
         out_sp = o.new_zeros(B * H, o.shape[1]).index_copy(0, idx, o).view(B, H, -1)
         return out_sp, valid
 

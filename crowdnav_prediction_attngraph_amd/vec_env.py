@@ -22,7 +22,7 @@ _OBS_KEYS = ("robot_node", "temporal_edges", "spatial_edges", "detected_human_nu
 
 
 class BatchedCrowdSim(object):
-    def __init__(self, env_name, seed, num_envs, device, config=None, phase=None):
+    def __init__(self, env_name, seed, num_envs, device, config=None, phase=None, pretext_wrapper=False, predictor=None):
         if not torch.cuda.is_available():
             raise A.CnError("the batched crowd simulator runs on MI355X only (no CPU fallback)")
         self.env_name = env_name
@@ -51,14 +51,37 @@ class BatchedCrowdSim(object):
         self._keys = [k for k in _OBS_KEYS if k in self.observation_space.spaces]
         self._t0 = time.time()
         self._closed = False
+        # VecPretextNormalize (GST predictions written into spatial_edges[:, :, 2:], social penalty, distance sort)
+        self._pretext = None
+        if pretext_wrapper:
+            if env_name != "CrowdSimPredRealGST-v0":
+                raise ValueError("pretext_wrapper=True goes with CrowdSimPredRealGST-v0 (config.py:162-165)")
+            from .gst import PretextProcessor, load_predictor
+            pred = predictor if predictor is not None else load_predictor(config, self.device)
+            self._pretext = PretextProcessor(pred.to(self.device), self.num_envs, self.human_num, int(self.cfg.predict_steps), float(self.cfg.robot_radius),
+                                             float(self.cfg.human_radius), float(self.cfg.collision_penalty), self.device)
 
     # ---- device-level API (no host synchronisation) ----
+    def _apply_pretext(self, obs, reward):
+        se, reward = self._pretext.process(obs, reward)
+        obs = dict(obs)
+        obs["spatial_edges"] = se
+        return obs, reward
+
     def reset_device(self):
-        return self._env.reset()
+        obs = self._env.reset()
+        if self._pretext is not None:
+            self._pretext.reset_buffers()
+            obs, _ = self._apply_pretext(obs, torch.zeros(self.num_envs, device=self.device))
+        return obs
 
     def step_device(self, actions):
-        """-> obs dict (internal buffers, overwritten by the next step), reward [E], done [E] u8, info [E] u8, ep_return [E] f64, ep_len [E] i32"""
-        return self._env.step(actions)
+        """-> obs dict (internal buffers, overwritten by the next step), reward [E], done [E] u8, info [E] u8, ep_return [E] f64, ep_len [E] i32.
+        The Monitor episode return sums the raw env reward (before the GST social penalty), like the reference's wrapper order."""
+        obs, reward, done, info, ep_ret, ep_len = self._env.step(actions)
+        if self._pretext is not None:
+            obs, reward = self._apply_pretext(obs, reward)
+        return obs, reward, done, info, ep_ret, ep_len
 
     # ---- reference-compatible API ----
     def _export_obs(self, obs):
@@ -68,13 +91,13 @@ class BatchedCrowdSim(object):
         return out
 
     def reset(self):
-        return self._export_obs(self._env.reset())
+        return self._export_obs(self.reset_device())
 
     def step(self, actions):
         if not torch.is_tensor(actions):
             actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32)
         actions = actions.to(self.device, dtype=torch.float32).reshape(self.num_envs, 2)
-        obs, reward, done, info, ep_ret, ep_len = self._env.step(actions)
+        obs, reward, done, info, ep_ret, ep_len = self.step_device(actions)
         out = self._export_obs(obs)
         # one D2H transfer for everything the reference returns on the host (VecPyTorch.step_wait, envs.py:216-224)
         reward_h, done_h, info_h, ret_h, len_h = (reward.cpu(), done.cpu().numpy().astype(bool), info.cpu().numpy(),
@@ -105,13 +128,11 @@ class BatchedCrowdSim(object):
 
 
 def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_early_resets, num_frame_stack=None, config=None,
-                  ax=None, test_case=-1, wrap_pytorch=True, pretext_wrapper=False, phase=None):
-    """Same signature as rl/networks/envs.py:97-109 (+ optional `phase`)."""
-    if pretext_wrapper:
-        raise NotImplementedError("VecPretextNormalize (GST predictor in the loop, BASELINE configs[3]) is not implemented yet: "
-                                  "use CrowdSimPred-v0 / CrowdSimVarNum-v0 (DESIGN.md, scope table rows G1-G3)")
+                  ax=None, test_case=-1, wrap_pytorch=True, pretext_wrapper=False, phase=None, predictor=None):
+    """Same signature as rl/networks/envs.py:97-109 (+ optional `phase`, and `predictor` to inject a GSTPredictor instead of
+    loading config.pred.model_dir)."""
     if ax is not None:
         raise NotImplementedError("rendering (ax=...) is out of scope of the accelerated path")
     if num_frame_stack is not None:
         raise NotImplementedError("frame stacking applies to image observations only")
-    return BatchedCrowdSim(env_name, seed, num_processes, device, config=config, phase=phase)
+    return BatchedCrowdSim(env_name, seed, num_processes, device, config=config, phase=phase, pretext_wrapper=pretext_wrapper, predictor=predictor)

@@ -1,0 +1,91 @@
+"""The product's GST predictor + wrapper logic (torch ops; CPU here, the same code runs on the GPU) against the reference goldens."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from crowdnav_prediction_attngraph_amd.gst import GSTPredictor, PretextProcessor
+from tests.golden_util import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from make_golden_gst import gst_formula_state_dict  # noqa: E402
+
+
+def _model(meta, device="cpu"):
+    sd = gst_formula_state_dict({k: tuple(v) for k, v in meta["shapes"].items()})
+    m = GSTPredictor().to(device)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(v)) for k, v in meta["shapes"].items()]  # checkpoint-compatible
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m
+
+
+def _check(device):
+    z = np.load(os.path.join(GOLDEN, "gst_e4_h20.npz"))
+    meta = json.loads(str(z["meta"]))
+    m = _model(meta, device)
+    for case in ("a", "b"):
+        out, mask = m(torch.from_numpy(z["in_traj_" + case]).to(device), torch.from_numpy(z["in_mask_" + case]).to(device))
+        np.testing.assert_array_equal(mask.cpu().numpy(), z["out_mask_" + case])
+        valid = z["out_mask_" + case][..., 0] > 0
+        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=2e-4, atol=2e-4)
+        assert np.all(out.cpu().numpy()[~valid][..., :2] == -999.0)
+    E, H, T = meta["E"], meta["H"], meta["T"]
+    w = PretextProcessor(m, E, H, 5, 0.3, 0.3, -20.0, torch.device(device))
+    for t in range(T):
+        obs = {"robot_node": torch.from_numpy(z["w_in_robot_node_%d" % t]).to(device), "spatial_edges": torch.from_numpy(z["w_in_spatial_edges_%d" % t]).to(device),
+               "visible_masks": torch.from_numpy(z["w_in_visible_masks_%d" % t]).to(device)}
+        se, rews = w.process(obs, torch.from_numpy(z["w_in_rews_%d" % t]).to(device))
+        np.testing.assert_allclose(se.cpu().numpy(), z["w_out_spatial_edges_%d" % t], rtol=2e-4, atol=2e-4, err_msg="edges @%d" % t)
+        np.testing.assert_allclose(rews.cpu().numpy().reshape(E, 1), z["w_out_rews_%d" % t], atol=1e-5, err_msg="rews @%d" % t)
+
+
+def test_gst_predictor_and_wrapper_match_reference_cpu():
+    _check("cpu")
+
+
+def test_reference_checkpoint_loads_when_available():
+    path = "/root/reference/gst_updated/results/100-gumbel_social_transformer-faster_lstm-lr_0.001-init_temp_0.5-edge_head_0-ebd_64-snl_1-snh_8-seed_1000_rand/sj/checkpoint/epoch_100.pt"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present (GPU box)")
+    m = GSTPredictor.from_checkpoint(path, "cpu")
+    assert sum(p.numel() for p in m.parameters()) == 67269   # SURVEY.md 8a-G3 [probed]
+
+
+@pytest.mark.gpu
+def test_gst_predictor_and_wrapper_match_reference_gpu():
+    _check("cuda")
+
+
+@pytest.mark.gpu
+def test_predrealgst_env_with_wrapper_steps_on_device():
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    z = np.load(os.path.join(GOLDEN, "gst_e4_h20.npz"))
+    meta = json.loads(str(z["meta"]))
+    pred = _model(meta, "cuda")
+    cfg = C.non_randomized(**{"sim.human_num": 20, "sim.predict_method": "inferred"})
+    envs = make_vec_envs("CrowdSimPredRealGST-v0", 425, 32, 0.99, None, torch.device("cuda"), False, config=cfg, pretext_wrapper=True, predictor=pred)
+    obs = envs.reset()
+    assert obs["spatial_edges"].shape == (32, 20, 12)
+    for t in range(12):
+        obs, rew, done, infos = envs.step(torch.full((32, 2), 0.3, device="cuda"))
+        se = obs["spatial_edges"]
+        d = se[:, :, :2].norm(dim=-1)
+        assert torch.all(d[:, 1:] >= d[:, :-1])               # sorted by current distance
+        assert torch.isfinite(se).all() and rew.shape == (32, 1)
+    envs.close()
+    # and through the fused trainer loop
+    from crowdnav_prediction_attngraph_amd.trainer import train
+    import crowdnav_prediction_attngraph_amd.vec_env as V
+    orig = V.make_vec_envs
+    try:
+        V_make = lambda *a, **k: orig(*a, **dict(k, pretext_wrapper=True, predictor=pred))  # noqa: E731
+        import crowdnav_prediction_attngraph_amd.trainer as TR
+        TR.make_vec_envs = V_make
+        hist, _ = train("CrowdSimPredRealGST-v0", num_processes=16, num_steps=6, num_updates=1, config=cfg, log=None)
+        assert np.isfinite(hist[0]["value_loss"])
+    finally:
+        TR.make_vec_envs = orig
