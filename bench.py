@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--humans", type=int, default=20)
     ap.add_argument("--env-name", default="CrowdSimVarNum-v0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--same-gpu", action="store_true", help="plumbing test: put every rank on GPU 0 (use with --dist-backend gloo)")
     ap.add_argument("--gemm", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="arithmetic of the three large HH GEMMs: split-precision bf16 MFMA (3 passes, within 2e-5 of fp32; default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -105,12 +107,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    dev_index = 0 if args.same_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from crowdnav_prediction_attngraph_amd import _abi as A
     from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
@@ -163,7 +169,7 @@ def main():
     pol.set_profiling(False)
     prof_ms, prof_n = pol.get_profile()
     if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cuda" if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if rank != 0:

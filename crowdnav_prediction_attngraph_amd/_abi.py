@@ -71,6 +71,28 @@ POLICY_WEIGHT_KEYS = [
 ]
 
 
+# order == field order of cn_gst_weights; values == keys of the reference's GST checkpoint
+GST_WEIGHT_KEYS = [
+    ("node_embedding_w", "gumbel_social_transformer.node_embedding.weight"), ("node_embedding_b", "gumbel_social_transformer.node_embedding.bias"),
+    ("in_proj_w", "gumbel_social_transformer.node_encoder_layers.0.self_attn.in_proj_weight"),
+    ("in_proj_b", "gumbel_social_transformer.node_encoder_layers.0.self_attn.in_proj_bias"),
+    ("out_proj_w", "gumbel_social_transformer.node_encoder_layers.0.self_attn.out_proj.weight"),
+    ("out_proj_b", "gumbel_social_transformer.node_encoder_layers.0.self_attn.out_proj.bias"),
+    ("norm_node_w", "gumbel_social_transformer.node_encoder_layers.0.norm_node.weight"),
+    ("norm_node_b", "gumbel_social_transformer.node_encoder_layers.0.norm_node.bias"),
+    ("norm1_node_w", "gumbel_social_transformer.node_encoder_layers.0.norm1_node.weight"),
+    ("norm1_node_b", "gumbel_social_transformer.node_encoder_layers.0.norm1_node.bias"),
+    ("linear1_w", "gumbel_social_transformer.node_encoder_layers.0.linear1.weight"), ("linear1_b", "gumbel_social_transformer.node_encoder_layers.0.linear1.bias"),
+    ("linear2_w", "gumbel_social_transformer.node_encoder_layers.0.linear2.weight"), ("linear2_b", "gumbel_social_transformer.node_encoder_layers.0.linear2.bias"),
+    ("lstm_w_ih", "lstm.weight_ih_l0"), ("lstm_w_hh", "lstm.weight_hh_l0"), ("lstm_b_ih", "lstm.bias_ih_l0"), ("lstm_b_hh", "lstm.bias_hh_l0"),
+    ("hidden2pos_w", "hidden2pos.weight"), ("hidden2pos_b", "hidden2pos.bias"),
+]
+
+
+class GstWeights(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in GST_WEIGHT_KEYS]
+
+
 class PolicyWeights(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _ in POLICY_WEIGHT_KEYS]
 
@@ -80,7 +102,8 @@ ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
     "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
-    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
+    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
+    "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
 ]
 
 _lib = None
@@ -115,6 +138,12 @@ def lib():
         L.cn_policy_set_profiling.argtypes = [vp, i32]
         L.cn_policy_set_gemm_mode.argtypes = [vp, i32]
         L.cn_policy_get_profile.argtypes = [vp, C.POINTER(f64), C.POINTER(i64)]
+        L.cn_gst_create.argtypes = [i32, i32, C.POINTER(vp)]
+        L.cn_gst_destroy.argtypes = [vp]
+        L.cn_gst_set_weights.argtypes = [vp, C.POINTER(GstWeights), vp]
+        L.cn_gst_predict.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.cn_gst_wrapper_reset.argtypes = [vp, i32, vp]
+        L.cn_gst_wrapper_step.argtypes = [vp, i32, C.POINTER(Obs), f32, f32, vp, vp, vp]
         L.cn_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp]
         L.cn_adv_stats.argtypes = [i64, vp, vp, vp, vp]
         L.cn_adv_normalize.argtypes = [i64, vp, vp, vp, vp, vp]

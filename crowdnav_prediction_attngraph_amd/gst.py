@@ -1,8 +1,9 @@
 """GST trajectory predictor + the VecPretextNormalize wrapper logic (BASELINE configs[3]), batched
 over all envs on the device with no host synchronisation and no per-env Python loop.
 
-STATUS: this path is expressed in torch ops (rocBLAS GEMMs), not yet in hand-written HIP kernels -- see DESIGN.md.
-It mirrors, with the same state-dict keys as the shipped checkpoints (so `epoch_100.pt` loads unchanged):
+On a GPU the predictor and the wrapper processing run as hand-written HIP kernels (csrc/gst.hip through cn_gst_predict /
+cn_gst_wrapper_step); the torch-op expression of the same math below is what CPU tensors use (unit tests) and doubles
+as an independent cross-check of the kernels.  Same state-dict keys as the shipped checkpoints (`epoch_100.pt` loads unchanged):
   gst_updated/src/gumbel_social_transformer/st_model.py:271-455 (faster_lstm, recursive decode, fully connected edges)
   gst_updated/scripts/wrapper/crowd_nav_interface_parallel.py:45-114
   rl/vec_env/vec_pretext_normalize.py:85-191
@@ -133,15 +134,26 @@ class GSTPredictor(nn.Module):
 class PretextProcessor:
     """State and per-step processing of VecPretextNormalize (rl/vec_env/vec_pretext_normalize.py:85-191)."""
 
-    def __init__(self, predictor, num_envs, human_num, predict_steps, robot_radius, human_radius, collision_penalty, device):
+    def __init__(self, predictor, num_envs, human_num, predict_steps, robot_radius, human_radius, collision_penalty, device, use_hip=None):
         self.pred, self.E, self.H, self.P = predictor, num_envs, human_num, predict_steps
-        self.dist, self.device = robot_radius + human_radius, device
+        self.dist, self.device = robot_radius + human_radius, torch.device(device)
+        self.collision_penalty = float(collision_penalty)
         self.pen = (collision_penalty / 2.0 ** torch.arange(2, predict_steps + 2, device=device, dtype=torch.float32)).view(1, 1, predict_steps)
+        self.hip = None
+        if use_hip if use_hip is not None else self.device.type == "cuda":
+            if predict_steps != 5:
+                raise NotImplementedError("the GST kernels are specialised to the shipped predictor (5 observed / 5 predicted steps)")
+            from .hip import HipGST
+            self.hip = HipGST(human_num, num_envs, device=self.device)     # raises if the extension is missing: no fallback on a GPU
+            self.hip.set_weights(predictor.state_dict())
         self.reset_buffers()
 
     def reset_buffers(self):
         """VecPretextNormalize.reset(): dummy history.  (NOT called when a single env auto-resets: the reference keeps the
         stale history of the finished episode, :112 `done` is unused.)"""
+        if self.hip is not None:
+            self.hip.wrapper_reset(self.E)
+            return
         self.traj = torch.full((5, self.E, self.H, 2), INVALID, device=self.device)
         self.mask = torch.zeros(5, self.E, self.H, 1, dtype=torch.bool, device=self.device)
 
@@ -150,6 +162,10 @@ class PretextProcessor:
         """obs: dict with robot_node [E,1,7], spatial_edges [E,H,2(P+1)] (unsorted, by human id), visible_masks [E,H] bool.
         rews [E] or [E,1] device tensor.  Returns (new spatial_edges [E,H,2(P+1)] sorted by distance, rews + social penalty)."""
         E, H, P = self.E, self.H, self.P
+        if self.hip is not None:
+            rews = rews.reshape(E).float().contiguous()
+            se = self.hip.wrapper_step(obs, rews, self.dist, self.collision_penalty)
+            return se, rews
         robot_xy = obs["robot_node"][:, :, :2]
         se = obs["spatial_edges"].clone()
         human_pos = robot_xy + se[:, :, :2]

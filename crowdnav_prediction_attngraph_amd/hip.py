@@ -177,6 +177,72 @@ class HipPolicy:
         return list(ms), list(n)
 
 
+class HipGST:
+    """cn_gst handle: GST predictor (cn_gst_predict) and the VecPretextNormalize processing (cn_gst_wrapper_*)."""
+
+    def __init__(self, human_num, max_envs, device=None):
+        _need_cuda()
+        self.H, self.maxE = int(human_num), int(max_envs)
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_create(self.H, self.maxE, C.byref(h)), "cn_gst_create")
+        self._h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            A.lib().cn_gst_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, state_dict):
+        w = A.GstWeights()
+        keep = []
+        for field, key in A.GST_WEIGHT_KEYS:
+            t = state_dict[key].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            setattr(w, field, t.data_ptr())
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_set_weights(self._h, C.byref(w), A.stream_ptr()), "cn_gst_set_weights")
+        self._keep = keep
+
+    def predict(self, in_traj, in_mask):
+        """in_traj [E,H,5,2], in_mask [E,H,5] or [E,H,5,1] float -> (out_traj [E,H,5,5], out_mask [E,H,1])."""
+        E = in_traj.shape[0]
+        out = torch.empty(E, self.H, 5, 5, device=self.device)
+        om = torch.empty(E, self.H, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_predict(self._h, E, A.ptr(in_traj.float().contiguous()), A.ptr(in_mask.float().reshape(E, self.H, 5).contiguous()),
+                                           A.ptr(out), A.ptr(om), A.stream_ptr()), "cn_gst_predict")
+        return out, om.unsqueeze(-1)
+
+    def wrapper_reset(self, E):
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_wrapper_reset(self._h, int(E), A.stream_ptr()), "cn_gst_wrapper_reset")
+
+    def wrapper_step(self, obs, rewards, dist, collision_penalty, out=None):
+        """obs: raw env observation (spatial_edges [E,H,12] by human id, visible_masks u8/bool); rewards [E] float32 updated in place."""
+        E = obs["robot_node"].shape[0]
+        if out is None:
+            out = torch.empty(E, self.H, 12, device=self.device)
+        o = A.Obs()
+        o.robot_node = A.ptr(obs["robot_node"])
+        o.spatial_edges = A.ptr(obs["spatial_edges"])
+        vm = obs["visible_masks"]
+        vm = vm.view(torch.uint8) if vm.dtype == torch.bool else vm
+        o.visible_masks = A.ptr(vm.contiguous())
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_wrapper_step(self._h, E, C.byref(o), float(dist), float(collision_penalty), A.ptr(rewards), A.ptr(out), A.stream_ptr()),
+                    "cn_gst_wrapper_step")
+        return out
+
+
 def gae(rewards, values, masks, gamma, lam, returns):
     """rewards [T,N,1], values/masks/returns [T+1,N,1] contiguous float32 device tensors; fills returns[:T]."""
     T, N = rewards.shape[0], rewards.shape[1]

@@ -167,6 +167,38 @@ int cn_policy_set_gemm_mode(cn_policy *p, int mode);
 int cn_policy_set_profiling(cn_policy *p, int enabled);
 int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launches_out /*[8]*/);
 
+/* ---- GST trajectory predictor + VecPretextNormalize (CrowdSimPredRealGST-v0, BASELINE configs[3]) ----
+ * cn_gst_predict          <- gst_updated/scripts/wrapper/crowd_nav_interface_parallel.py:45-114 CrowdNavPredInterfaceMultiEnv.forward
+ *                            (st_model.forward, gst_updated/src/gumbel_social_transformer/st_model.py:271-455, shipped hyper-parameters)
+ * cn_gst_wrapper_reset    <- rl/vec_env/vec_pretext_normalize.py:85-101 VecPretextNormalize.reset (history buffers)
+ * cn_gst_wrapper_step     <- rl/vec_env/vec_pretext_normalize.py:112-191 process_obs_rew
+ * Device pointers to the fp32 parameters, named after the checkpoint's state_dict keys (epoch_100.pt). */
+typedef struct {
+    const float *node_embedding_w, *node_embedding_b;      /* gumbel_social_transformer.node_embedding [64,2] */
+    const float *in_proj_w, *in_proj_b;                    /* ...node_encoder_layers.0.self_attn.in_proj_* [192,64] */
+    const float *out_proj_w, *out_proj_b;                  /* ...self_attn.out_proj [64,64] */
+    const float *norm_node_w, *norm_node_b;                /* ...norm_node [64] */
+    const float *norm1_node_w, *norm1_node_b;              /* ...norm1_node [64] */
+    const float *linear1_w, *linear1_b;                    /* ...linear1 [128,64] */
+    const float *linear2_w, *linear2_b;                    /* ...linear2 [64,128] */
+    const float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh; /* lstm.*_l0 [256,64],[256,64],[256],[256] */
+    const float *hidden2pos_w, *hidden2pos_b;              /* hidden2pos [5,64] */
+} cn_gst_weights;
+typedef struct cn_gst cn_gst;
+int cn_gst_create(int human_num, int max_envs, cn_gst **out);
+int cn_gst_destroy(cn_gst *g);
+int cn_gst_set_weights(cn_gst *g, const cn_gst_weights *w, void *stream);
+/* in_traj [E,H,5,2] world positions, in_mask [E,H,5] (0/1 float) -> out_traj [E,H,5,5] = cumulative (mu_x, mu_y, sigma_x,
+ * sigma_y, corr), positions -999 where the pedestrian is not predicted; out_mask [E,H] (0/1 float). */
+int cn_gst_predict(cn_gst *g, int E, const float *in_traj, const float *in_mask, float *out_traj, float *out_mask, void *stream);
+int cn_gst_wrapper_reset(cn_gst *g, int E, void *stream);
+/* obs: the raw CrowdSimPredRealGST-v0 observation (robot_node, spatial_edges [E,H,12] by human id, visible_masks).  Pushes the
+ * new positions into the 5-deep history, runs the predictor, adds the social penalty min_{h,k}(collision * penalty / 2^(k+2))
+ * to rewards [E] (in place, may be NULL) and writes spatial_edges_out [E,H,12]: predictions in the robot frame where valid,
+ * rows sorted by current distance. */
+int cn_gst_wrapper_step(cn_gst *g, int E, const cn_obs *obs, float robot_plus_human_radius, float collision_penalty, float *rewards,
+                        float *spatial_edges_out, void *stream);
+
 /* ---- rollout math ---- */
 /* rewards [T,N], values [T+1,N], masks [T+1,N] -> returns[t][n] for t < T (row T untouched).  fp32, torch op order. */
 int cn_gae(int T, int N, const float *rewards, const float *values, const float *masks, double gamma, double lam,
