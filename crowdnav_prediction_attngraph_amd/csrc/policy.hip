@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__
 // detected humans (the common case of ~6 uses 4.6 KB of LDS per wavefront -> high occupancy); other units exit at once.
 template <int CAP>
 __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, const float *__restrict__ qkv, const int *__restrict__ row_off,
-                                                           float *__restrict__ out)
+                                                           float *__restrict__ out, float scale)
 {
     constexpr int RS = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, co
             const f32x4 a = qp[d], b = kp[d];
             s += a[0] * b[0]; s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3];
         }
-        S[qi * CAP + qj] = s;
+        S[qi * CAP + qj] = s * scale;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -324,13 +324,82 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, co
 }
 
 template <int CAP>
-static int launch_hh_attention(int E, int cap_lo, const float *qkv, const int *row_off, float *out, hipStream_t st)
+static int launch_hh_attention(int E, int cap_lo, const float *qkv, const int *row_off, float *out, hipStream_t st, float scale = 1.0f)
 {
     const size_t per_wave = (size_t)(2 * CAP * 68 + CAP * CAP) * sizeof(float);
     int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-    hipLaunchKernelGGL(hh_attention_kernel<CAP>, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, cap_lo, qkv, row_off, out);
+    hipLaunchKernelGGL(hh_attention_kernel<CAP>, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, cap_lo, qkv, row_off, out, scale);
     CN_CHECK_LAUNCH();
     return CN_OK;
+}
+
+// Backward of the attention core for training (PPO update): per (sample, head) on the compacted rows.
+//   S = scale * Q K^T, P = softmax(S), O = P V ;   given dO:
+//   dV = P^T dO ; dP = dO V^T ; dS = scale * P .* (dP - rowsum(dP .* P)) ; dQ = dS K ; dK = dS^T Q
+// One wavefront per unit; Q, K, V, dO rows in LDS (stride 68), P and dS as nd x nd matrices (stride H) in LDS.
+__global__ __launch_bounds__(128) void hh_attention_bwd_kernel(int B, int H, const float *__restrict__ qkv, const int *__restrict__ row_off,
+                                                               const float *__restrict__ d_out, float *__restrict__ d_qkv, float scale)
+{
+    constexpr int RS = 68;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (unit >= B * 8) return;
+    const int b = unit >> 3, head = unit & 7;
+    const int r0 = row_off[b], nd = row_off[b + 1] - r0;
+    float *Qs = smem + (size_t)wave * (4 * H * RS + 2 * H * H);
+    float *Ks = Qs + H * RS, *Vs = Ks + H * RS, *Gs = Vs + H * RS; // Gs = dO rows
+    float *P = Gs + H * RS, *dS = P + H * H;
+    const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
+    const float *gbase = d_out + (size_t)r0 * 512 + head * 64 + lane;
+    for (int j = 0; j < nd; ++j) {
+        Qs[j * RS + lane] = base[(size_t)j * 1536];
+        Ks[j * RS + lane] = base[(size_t)j * 1536 + 512];
+        Vs[j * RS + lane] = base[(size_t)j * 1536 + 1024];
+        Gs[j * RS + lane] = gbase[(size_t)j * 512];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int npairs = nd * nd;
+    for (int q = lane; q < npairs; q += 64) {
+        const int qi = q / nd, qj = q - qi * nd;
+        const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qs + qi * RS), *kp = reinterpret_cast<const f32x4 *>(Ks + qj * RS);
+        const f32x4 *gp = reinterpret_cast<const f32x4 *>(Gs + qi * RS), *vp = reinterpret_cast<const f32x4 *>(Vs + qj * RS);
+        float s = 0.0f, dp = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const f32x4 a = qp[d], bb = kp[d], g = gp[d], v = vp[d];
+            s += a[0] * bb[0]; s += a[1] * bb[1]; s += a[2] * bb[2]; s += a[3] * bb[3];
+            dp += g[0] * v[0]; dp += g[1] * v[1]; dp += g[2] * v[2]; dp += g[3] * v[3];
+        }
+        P[qi * H + qj] = s * scale;
+        dS[qi * H + qj] = dp;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane < nd) {
+        float *prow = P + lane * H, *drow = dS + lane * H;
+        float mx = -INFINITY;
+        for (int j = 0; j < nd; ++j) mx = fmaxf(mx, prow[j]);
+        float sum = 0.0f;
+        for (int j = 0; j < nd; ++j) { const float e = expf(prow[j] - mx); prow[j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        float rd = 0.0f;
+        for (int j = 0; j < nd; ++j) { prow[j] *= inv; rd += drow[j] * prow[j]; }
+        for (int j = 0; j < nd; ++j) drow[j] = scale * prow[j] * (drow[j] - rd);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float *ob = d_qkv + (size_t)r0 * 1536 + head * 64 + lane;
+    for (int j = 0; j < nd; ++j) {
+        float dq = 0.0f, dk = 0.0f, dv = 0.0f; // row j of dQ, dK, dV, column `lane`
+        for (int i = 0; i < nd; ++i) {
+            dq += dS[j * H + i] * Ks[i * RS + lane];
+            dk += dS[i * H + j] * Qs[i * RS + lane];
+            dv += P[i * H + j] * Gs[i * RS + lane];
+        }
+        ob[(size_t)j * 1536] = dq; ob[(size_t)j * 1536 + 512] = dk; ob[(size_t)j * 1536 + 1024] = dv;
+    }
 }
 
 // Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177) on the compacted rows: one
@@ -797,5 +866,39 @@ extern "C" int cn_policy_get_profile(cn_policy *p, double *ms_out, int64_t *laun
     CN_REQUIRE(p && ms_out && launches_out, "cn_policy_get_profile: null argument");
     if (int rc = harvest_profile(p, true)) return rc;
     for (int i = 0; i < 8; ++i) { ms_out[i] = p->prof_ms[i]; launches_out[i] = p->prof_n[i]; }
+    return CN_OK;
+}
+
+// ---- stand-alone attention core (training path: autograd Function in the host mirror) ----
+extern "C" int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && qkv && row_off && out, "cn_hh_attention_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = launch_hh_attention<8>(B, 0, qkv, row_off, out, st, scale))) return rc;
+    if (H > 8 && (rc = launch_hh_attention<16>(B, 8, qkv, row_off, out, st, scale))) return rc;
+    if (H > 16 && (rc = launch_hh_attention<32>(B, 16, qkv, row_off, out, st, scale))) return rc;
+    if (H > 32 && (rc = launch_hh_attention<64>(B, 32, qkv, row_off, out, st, scale))) return rc;
+    return CN_OK;
+}
+
+extern "C" int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && qkv && row_off && d_out && d_qkv, "cn_hh_attention_bwd: bad argument");
+    const size_t per_wave = (size_t)(4 * H * 68 + 2 * H * H) * sizeof(float);
+    int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 2 ? 2 : wpb);
+    CN_REQUIRE(per_wave <= 160 * 1024, "cn_hh_attention_bwd: H too large for the LDS working set");
+    if (per_wave > 65536) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(hh_attention_bwd_kernel, dim3((B * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, (hipStream_t)stream, B, H, qkv, row_off,
+                       d_out, d_qkv, scale);
+    CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -243,6 +243,29 @@ class HipGST:
         return out
 
 
+class HHAttention(torch.autograd.Function):
+    """softmax(scale * q k^T) v per (sample, head) on compacted rows, forward and backward as HIP kernels
+    (cn_hh_attention_fwd / cn_hh_attention_bwd).  qkv [R,1536] float32 cuda, row_off [B+1] int32 cuda."""
+
+    @staticmethod
+    def forward(ctx, qkv, row_off, B, H, scale):
+        qkv = qkv.contiguous()
+        out = torch.empty(qkv.shape[0], 512, device=qkv.device)
+        A.check(A.lib().cn_hh_attention_fwd(int(B), int(H), A.ptr(qkv), A.ptr(row_off), float(scale), A.ptr(out), A.stream_ptr()), "cn_hh_attention_fwd")
+        ctx.save_for_backward(qkv, row_off)
+        ctx.meta = (int(B), int(H), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, row_off = ctx.saved_tensors
+        B, H, scale = ctx.meta
+        d_qkv = torch.empty_like(qkv)
+        A.check(A.lib().cn_hh_attention_bwd(B, H, A.ptr(qkv), A.ptr(row_off), A.ptr(d_out.contiguous()), scale, A.ptr(d_qkv), A.stream_ptr()),
+                "cn_hh_attention_bwd")
+        return d_qkv, None, None, None, None
+
+
 def gae(rewards, values, masks, gamma, lam, returns):
     """rewards [T,N,1], values/masks/returns [T+1,N,1] contiguous float32 device tensors; fills returns[:T]."""
     T, N = rewards.shape[0], rewards.shape[1]

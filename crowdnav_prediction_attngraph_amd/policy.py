@@ -169,17 +169,27 @@ class AttnGraphBase(nn.Module):
         lins = (sa.q_linear, sa.k_linear, sa.v_linear)
         Wc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].weight for i in range(3)], 0)
         bc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].bias + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
-        q, k, v = F.linear(e, Wc, bc).split(512, dim=-1)
+        qkv = F.linear(e, Wc, bc)                                                           # [rows, 1536] = [q | k | v]
+        if qkv.is_cuda:
+            # attention core on the compacted rows, forward AND backward as hand-written HIP kernels
+            from .hip import HHAttention
+            nd = det.clamp(max=H).to(torch.int32)
+            row_off = torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
+            o_live = HHAttention.apply(qkv, row_off, B, H, 0.125)
+        else:
+            # CPU tensors (unit tests): the same math on zero-padded [B,8,H,64] tensors in torch ops
+            q, k, v = qkv.split(512, dim=-1)
 
-        def pad(x):
-            return x.new_zeros(B * H, 512).index_copy(0, idx, x).view(B, H, 8, 64).transpose(1, 2)
+            def pad(x):
+                return x.new_zeros(B * H, 512).index_copy(0, idx, x).view(B, H, 8, 64).transpose(1, 2)
 
-        scores = torch.matmul(pad(q), pad(k).transpose(-1, -2)) * 0.125
-        scores = scores.masked_fill(~valid.view(B, 1, 1, H), float("-inf"))
-        o = torch.matmul(torch.softmax(scores, dim=-1), pad(v)).transpose(1, 2).reshape(B * H, 512)
+            scores = torch.matmul(pad(q), pad(k).transpose(-1, -2)) * 0.125
+            scores = scores.masked_fill(~valid.view(B, 1, 1, H), float("-inf"))
+            o = torch.matmul(torch.softmax(scores, dim=-1), pad(v)).transpose(1, 2).reshape(B * H, 512)
+            o_live = o.index_select(0, idx)
         # same composition for out_proj followed by spatial_linear (Linear -> Linear -> ReLU)
         op, sl = sa.multihead_attn.out_proj, self.spatial_linear[0]
-        o = F.relu(F.linear(o.index_select(0, idx), sl.weight @ op.weight, sl.weight @ op.bias + sl.bias))
+        o = F.relu(F.linear(o_live, sl.weight @ op.weight, sl.weight @ op.bias + sl.bias))
         out_sp = o.new_zeros(B * H, o.shape[1]).index_copy(0, idx, o).view(B, H, -1)
         return out_sp, valid
 

@@ -167,6 +167,13 @@ int cn_policy_set_gemm_mode(cn_policy *p, int mode);
 int cn_policy_set_profiling(cn_policy *p, int enabled);
 int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launches_out /*[8]*/);
 
+/* ---- human-human attention core, stand-alone (training path) ----
+ * The (env, head) units of torch.nn.MultiheadAttention's scaled-dot-product core (selfAttn_srnn_temp_node.py:89) on COMPACTED
+ * rows: sample b owns rows row_off[b] .. row_off[b+1]-1 (its detected humans); qkv [R,1536] = [q | k | v] (8 heads x 64).
+ * fwd: out [R,512] = softmax(scale * q k^T) v per unit.  bwd: d_qkv [R,1536] from d_out [R,512] (softmax recomputed). */
+int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, void *stream);
+int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, void *stream);
+
 /* ---- GST trajectory predictor + VecPretextNormalize (CrowdSimPredRealGST-v0, BASELINE configs[3]) ----
  * cn_gst_predict          <- gst_updated/scripts/wrapper/crowd_nav_interface_parallel.py:45-114 CrowdNavPredInterfaceMultiEnv.forward
  *                            (st_model.forward, gst_updated/src/gumbel_social_transformer/st_model.py:271-455, shipped hyper-parameters)

@@ -104,3 +104,37 @@ def test_fused_rollout_equals_reference_style_stepping():
     for k in ra.obs:
         assert torch.equal(ra.obs[k], rb.obs[k]), k
     assert torch.equal(ra.recurrent_hidden_states["human_node_rnn"], rb.recurrent_hidden_states["human_node_rnn"])
+
+
+def test_hip_attention_forward_backward_matches_torch_autograd():
+    """evaluate_actions on the GPU (HH attention core = cn_hh_attention_fwd/bwd) vs the pure torch-op graph on CPU:
+    same values, log-probs and parameter gradients."""
+    import copy
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from tests import policy_util as PU
+    torch.manual_seed(3)
+    H, D, T, N = 20, 2, 5, 6
+    ob_space, act_space = make_spaces(H, D)
+    pol_c = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn", base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=N, num_mini_batch=1, seq_length=T))
+    pol_g = copy.deepcopy(pol_c).cuda()
+    obs = PU.synth_obs(T * N, H, D, seed=4)
+    obs_c = {k: torch.from_numpy(v) for k, v in obs.items()}
+    h0 = torch.randn(N, 1, 128)
+    masks = (torch.rand(T * N, 1) > 0.2).float()
+    actions = torch.randn(T * N, 2)
+
+    def run(pol, dev):
+        o = {k: v.to(dev) for k, v in obs_c.items()}
+        v, lp, ent, _ = pol.evaluate_actions(o, {"human_node_rnn": h0.to(dev)}, masks.to(dev), actions.to(dev))
+        loss = (v * torch.linspace(-1, 1, T * N, device=dev).view(-1, 1)).sum() + (lp * 0.3).sum() + ent
+        pol.zero_grad()
+        loss.backward()
+        return v.detach().cpu(), lp.detach().cpu(), {k: p.grad.detach().cpu() for k, p in pol.named_parameters() if p.grad is not None}
+
+    v_c, lp_c, g_c = run(pol_c, "cpu")
+    v_g, lp_g, g_g = run(pol_g, "cuda")
+    assert torch.allclose(v_c, v_g, atol=1e-4) and torch.allclose(lp_c, lp_g, atol=1e-4)
+    assert set(g_c) == set(g_g)
+    for k in g_c:
+        scale = max(float(g_c[k].abs().max()), 1e-3)
+        assert float((g_c[k] - g_g[k]).abs().max()) <= 2e-4 * scale + 1e-5, (k, float((g_c[k] - g_g[k]).abs().max()), scale)
