@@ -70,9 +70,14 @@ __device__ __forceinline__ float wv_max(float v)
 }
 __device__ __forceinline__ float wv_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    // Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8), then fold the rows; total lands in lane 63
+    v += wv_dpp<0x111, 0xf>(v, 0.0f);
+    v += wv_dpp<0x112, 0xf>(v, 0.0f);
+    v += wv_dpp<0x114, 0xf>(v, 0.0f);
+    v += wv_dpp<0x118, 0xf>(v, 0.0f);
+    v += wv_dpp<0x142, 0xa>(v, 0.0f);
+    v += wv_dpp<0x143, 0xc>(v, 0.0f);
+    return wv_readlane(v, 63);
 }
 __device__ __forceinline__ double wv_min(double v)
 {
