@@ -46,6 +46,15 @@ struct EnvDev {
     uint32_t *mt;    // [E][624]
     int32_t *mt_pos; // [E]
     float *hact;     // [E][2][H] ORCA velocities of this step
+    // next-episode staging: episode k+1 of env e is a pure function of (seed, e, k), so it is generated ahead of time on
+    // the side stream (env_pregen_kernel) and a finishing env only copies it in (the serial MT19937 seeding + rejection
+    // sampling of 20 humans would otherwise be the tail of env_step_kernel)
+    double *nx_hum;     // [E][8][H]
+    double *nx_rob;     // [E][8]
+    double *nx_shared_nd; // [E]
+    uint32_t *nx_mt;    // [E][624]
+    int32_t *nx_mt_pos; // [E]
+    uint8_t *nx_ready;  // [E]
 };
 
 enum { F_PX = 0, F_PY, F_VX, F_VY, F_GX, F_GY, F_RAD, F_VPREF };
@@ -580,12 +589,12 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool
 }
 
 // crowd_sim_var_num.py:303-363 reset (seed, robot, humans, potential, first observation)
-__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, const cn_obs &ob)
+// the RNG-consuming part of reset(): seed, robot, humans (crowd_sim_var_num.py:333-340, :64-146)
+__device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd)
 {
     const cn_env_config &c = s.cfg;
     const uint64_t offset = c.phase == CN_PHASE_TRAIN ? 2000ull : (c.phase == CN_PHASE_VAL ? 0ull : 1000ull);
-    uint64_t cc = s.case_counter[e];
-    const uint64_t seed = offset + cc + (uint64_t)(s.seed_base + e);
+    const uint64_t seed = offset + s.case_counter[e] + (uint64_t)(s.seed_base + e);
     rng_seed(R, (uint32_t)seed, lane);
     double px, py, gx, gy;
     for (;;) { // :97-100
@@ -597,12 +606,45 @@ __device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lan
     }
     rb.px = px; rb.py = py; rb.gx = gx; rb.gy = gy; rb.vx = 0.0; rb.vy = 0.0; rb.theta = M_PI / 2.0;
     for (int i = 0; i < s.H; ++i) gen_human(s, R, lane, i, i, rb, h, shared_nd);
-    h.l0 = h.l1 = h.l2 = h.l3 = h.l4 = 0.0; // :108
-    const uint64_t case_size = c.phase == CN_PHASE_TRAIN ? (4294967295ull - 2000ull) : (c.phase == CN_PHASE_VAL ? c.val_size : c.test_size);
-    cc = (cc + (uint64_t)c.nenv) % case_size;
     rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
-    if (lane == 0) { s.case_counter[e] = cc; s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0; }
+}
+
+// the rest of reset(): belief cleared (:108), case counter advanced (:348), episode statistics, first observation
+__device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, Robot &rb, Lane &h, const cn_obs &ob)
+{
+    const cn_env_config &c = s.cfg;
+    h.l0 = h.l1 = h.l2 = h.l3 = h.l4 = 0.0;
+    const uint64_t case_size = c.phase == CN_PHASE_TRAIN ? (4294967295ull - 2000ull) : (c.phase == CN_PHASE_VAL ? c.val_size : c.test_size);
+    if (lane == 0) {
+        s.case_counter[e] = (s.case_counter[e] + (uint64_t)c.nenv) % case_size;
+        s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0;
+    }
     write_obs(s, e, lane, true, rb, h, ob);
+}
+
+// crowd_sim_var_num.py:303-363 reset.  Uses the pre-generated episode when the side stream has one ready.
+__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, const cn_obs &ob)
+{
+    if (s.nx_ready[e]) {
+        const int H = s.H;
+        const int lj = lane < H ? lane : 0;
+        const double *hum = s.nx_hum + (size_t)e * 8 * H;
+        h.px = hum[F_PX * H + lj]; h.py = hum[F_PY * H + lj]; h.vx = 0.0; h.vy = 0.0;
+        h.gx = hum[F_GX * H + lj]; h.gy = hum[F_GY * H + lj]; h.rad = hum[F_RAD * H + lj]; h.vpref = hum[F_VPREF * H + lj];
+        h.simv = 0;
+        const double *r = s.nx_rob + (size_t)e * 8;
+        rb.px = r[R_PX]; rb.py = r[R_PY]; rb.vx = 0.0; rb.vy = 0.0; rb.gx = r[R_GX]; rb.gy = r[R_GY]; rb.theta = r[R_THETA]; rb.pot = r[R_POT];
+        shared_nd = s.nx_shared_nd[e];
+        __syncthreads();
+        for (int k = lane; k < MT_N; k += 64) g_mt_lds[k] = s.nx_mt[(size_t)e * MT_N + k];
+        R.pos = s.nx_mt_pos[e];
+        R.loaded = true;
+        __syncthreads();
+        if (lane == 0) s.nx_ready[e] = 0;
+    } else {
+        gen_episode(s, R, e, lane, rb, h, shared_nd);
+    }
+    finish_reset(s, e, lane, rb, h, ob);
 }
 
 __device__ __forceinline__ void load_env(const EnvDev &s, int e, int lane, Robot &rb, Lane &h)
@@ -648,6 +690,36 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob)
     store_env(s, e, lane, rb, h);
     if (lane == 0) s.shared_nd[e] = shared_nd;
     rng_store(R, s, e, lane);
+}
+
+// Generates the NEXT episode of every env whose staging slot is empty (side stream, overlapped with the policy forward).
+__global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
+{
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    if (s.nx_ready[e]) return;
+    Rng R{MT_N, false};
+    Robot rb{};
+    Lane h{};
+    h.rad = s.cfg.human_radius;
+    double shared_nd = s.shared_nd[e]; // overwritten by the first Human() when randomised, unused otherwise
+    gen_episode(s, R, e, lane, rb, h, shared_nd);
+    const int H = s.H;
+    if (lane < H) {
+        double *hum = s.nx_hum + (size_t)e * 8 * H;
+        hum[F_PX * H + lane] = h.px; hum[F_PY * H + lane] = h.py; hum[F_GX * H + lane] = h.gx; hum[F_GY * H + lane] = h.gy;
+        hum[F_RAD * H + lane] = h.rad; hum[F_VPREF * H + lane] = h.vpref;
+    }
+    if (lane == 0) {
+        double *r = s.nx_rob + (size_t)e * 8;
+        r[R_PX] = rb.px; r[R_PY] = rb.py; r[R_GX] = rb.gx; r[R_GY] = rb.gy; r[R_THETA] = rb.theta; r[R_POT] = rb.pot;
+        s.nx_shared_nd[e] = shared_nd;
+        s.nx_mt_pos[e] = R.pos;
+    }
+    __syncthreads();
+    for (int k = lane; k < MT_N; k += 64) s.nx_mt[(size_t)e * MT_N + k] = g_mt_lds[k];
+    __syncthreads();
+    if (lane == 0) s.nx_ready[e] = 1;
 }
 
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
@@ -795,6 +867,9 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
     const int agents = env->d.E * env->d.H;
     hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
     CN_CHECK_LAUNCH();
+    // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step)
+    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
+    CN_CHECK_LAUNCH();
     CN_HIP(hipEventRecord(env->ev_orca, env->side));
     env->orca_ready = true;
     return CN_OK;
@@ -848,6 +923,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_sv = carve(E * H), o_snd = carve(E * H * 4), o_ssr = carve(E * H * 4), o_ssm = carve(E * H * 4);
     const size_t o_seen = cfg->randomize_attributes ? carve(E * H * H * 4) : 0;
     const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
+    const size_t o_nh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -862,6 +938,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.sim_self_maxspeed = (float *)(base + o_ssm);
     d.sim_seen = cfg->randomize_attributes ? (float *)(base + o_seen) : nullptr;
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
+    d.nx_hum = (double *)(base + o_nh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
+    d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
     b->reset_done = false;
     b->orca_ready = false;
     if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->ev_state, hipEventDisableTiming) != hipSuccess ||
