@@ -149,23 +149,19 @@ def main():
     else:
         pol_obs = obs
     hxs = [torch.zeros(E, 1, 128, device="cuda"), torch.zeros(E, 1, 128, device="cuda")]
-    masks = torch.ones(E, 1, device="cuda")
     out = dict(value=torch.empty(E, 1, device="cuda"), action=torch.empty(E, 2, device="cuda"), logp=torch.empty(E, 1, device="cuda"), hxs=hxs[1])
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     eps = torch.empty(E, 2, device="cuda")
 
-    live_rows = torch.zeros((), dtype=torch.float64, device="cuda")   # sum over steps of detected humans (rows the HH block runs on)
+    masks2 = [torch.ones(E, 1, device="cuda"), torch.ones(E, 1, device="cuda")]
 
     def step(i):
-        nonlocal masks
-        live_rows.add_(obs["detected_human_num"].sum(dtype=torch.float64))
         eps.normal_(generator=gen)
         out["hxs"] = hxs[(i + 1) & 1]
-        pol.act(pol_obs, hxs[i & 1], masks, eps=eps, out=out)
-        _, reward, done, _, _, _ = env.step(out["action"])
+        pol.act(pol_obs, hxs[i & 1], masks2[i & 1], eps=eps, out=out)
+        _, reward, done, _, _, _ = env.step(out["action"], not_done=masks2[(i + 1) & 1])   # done mask for the next forward
         if gst is not None:
             gst.wrapper_step(obs, reward, 0.6, -20.0, out=pol_obs["spatial_edges"])
-        masks = (done == 0).to(torch.float32).view(E, 1)
 
     for i in range(args.warmup):
         step(i)
@@ -173,7 +169,6 @@ def main():
     if dist is not None:
         dist.barrier()
     pol.set_profiling(True)
-    live_rows.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -195,7 +190,7 @@ def main():
     total_env_steps = E * world * args.steps
     value = total_env_steps / elapsed
     # dominant kernel: the folded QKV projection GEMM [M,512]x[512,1536] (fp32 MFMA), timed with HIP events on its stream
-    M = live_rows.item() / args.steps      # mean live (env, human) rows per step: padded humans are not computed
+    M = prof_n[1] / max(prof_n[0], 1)      # mean live (env, human) rows per step (device-side counter): padded humans are not computed
     qkv_flops = 2.0 * M * 512 * 1536
     qkv_ms = prof_ms[0] / max(prof_n[0], 1)
     achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12 if qkv_ms > 0 else 0.0

@@ -125,7 +125,7 @@ def lib():
         L.cn_env_destroy.argtypes = [vp]
         L.cn_env_obs_width.argtypes = [C.POINTER(EnvConfig)]
         L.cn_env_reset.argtypes = [vp, C.POINTER(Obs), vp]
-        L.cn_env_step.argtypes = [vp, vp, C.POINTER(Obs), vp, vp, vp, vp, vp, vp]
+        L.cn_env_step.argtypes = [vp, vp, C.POINTER(Obs), vp, vp, vp, vp, vp, vp, vp]
         L.cn_env_get_state.argtypes = [vp, vp, vp, vp]
         L.cn_env_get_human_actions.argtypes = [vp, vp, vp]
         L.cn_orca_solve.argtypes = [i32, i32, vp, vp, f32, i32, f32, f32, vp, vp]

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
 // (rl/networks/shmem_vec_env.py:139-142).  ORCA velocities for this step were produced by orca_kernel.
 __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
-                                                      uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out)
+                                                      uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
@@ -797,6 +797,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     if (lane == 0) {
         reward_out[e] = (float)reward; done_out[e] = (uint8_t)done; info_out[e] = (uint8_t)info;
         ep_ret_out[e] = ep_ret; ep_len_out[e] = ep_cnt;
+        if (not_done_out) not_done_out[e] = done ? 0.0f : 1.0f; // the `masks` tensor of train.py:185-186
     }
     if (done) {
         // vec-env auto-reset: the terminal observation is replaced by the first observation of the next episode.
@@ -981,7 +982,7 @@ extern "C" int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream)
 }
 
 extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done,
-                           uint8_t *info, double *ep_return, int32_t *ep_len, void *stream)
+                           uint8_t *info, double *ep_return, int32_t *ep_len, float *not_done, void *stream)
 {
     CN_REQUIRE(env, "cn_env_step: null handle");
     if (!env->reset_done) { cn_set_error("cn_env_step: call cn_env_reset first"); return CN_ERR_STATE; }
@@ -990,7 +991,7 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     hipStream_t st = (hipStream_t)stream;
     if (!env->orca_ready) { if (int rc = prefetch_orca(env, st)) return rc; }
     CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // human velocities for the current state (computed on the side stream)
-    hipLaunchKernelGGL(env_step_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len);
+    hipLaunchKernelGGL(env_step_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
     CN_CHECK_LAUNCH();
     return prefetch_orca(env, st); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
 }

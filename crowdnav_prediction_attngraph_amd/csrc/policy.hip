@@ -171,7 +171,8 @@ __global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 
 // Row compaction: row_off[e] = sum_{e' < e} nd(e'), nd = clamp(detected_human_num, 1, H); row_off[E] = number of live
 // (env, human) rows.  Padded humans (index >= nd) only ever meet an exactly-zero robot-human attention weight, so the
 // whole human-human block runs on live rows only.  Single block, Hillis-Steele scan over per-thread chunk sums.
-__global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const float *__restrict__ det, int *__restrict__ row_off)
+__global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const float *__restrict__ det, int *__restrict__ row_off,
+                                                           unsigned long long *__restrict__ live_total)
 {
     __shared__ int part[1024];
     const int t = threadIdx.x;
@@ -193,7 +194,10 @@ __global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const f
         int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
         run += nd;
     }
-    if (t == 1023) row_off[E] = part[1023];
+    if (t == 1023) {
+        row_off[E] = part[1023];
+        if (live_total) *live_total += (unsigned long long)part[1023]; // measurement aid: total live rows over the profiled launches
+    }
 }
 
 // embedding_layer.0 (K = D <= 16) on live rows: out[row_off[e] + j][n] = relu(sum_d x[e][j][d] * W[n][d] + b[n]), n < 128
@@ -553,6 +557,7 @@ struct cn_policy {
     float *emb1, *emb2, *qkv, *attn, *out_sp, *s_emb;
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
     int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split (default)
+    unsigned long long *live_total; // device counter: sum of live rows over the profiled forwards
     int *row_off; // [maxE + 1] exclusive prefix of live humans per env; row_off[E] = live rows
     float *robot_states, *t_emb, *hr_out, *hr_attn, *x, *gi, *gh, *hnew, *rnn_out, *ac1, *ac2;
     // profiling of the dominant kernel (QKV projection)
@@ -626,6 +631,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_gi = carve(E * 384), o_gh = carve(E * 384), o_hn = carve(E * 128), o_ro = carve(E * 256);
     const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
     const size_t o_roff = carve(E + 1);
+    const size_t o_live = carve(2);
     const size_t o_tew = carve(128 * 256), o_teb = carve(128), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 192);
     const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
     const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
@@ -645,6 +651,8 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->robot_states = F(o_rs); p->t_emb = F(o_temb); p->hr_out = F(o_hr); p->hr_attn = F(o_hra); p->x = F(o_x);
     p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
     p->row_off = (int *)(base + o_roff);
+    p->live_total = (unsigned long long *)(base + o_live);
+    (void)hipMemset(p->live_total, 0, 8);
     p->emb2_hi = (__bf16 *)(base + o_e2h); p->emb2_lo = (__bf16 *)(base + o_e2l); p->qkv_hi = (__bf16 *)(base + o_qh); p->qkv_lo = (__bf16 *)(base + o_ql);
     p->os_hi = (__bf16 *)(base + o_osh); p->os_lo = (__bf16 *)(base + o_osl);
     p->gemm_mode = 1;
@@ -760,7 +768,8 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     int rc;
     // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
     const int *m_dev = p->row_off + E;
-    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off);
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
+                       p->profiling ? p->live_total : (unsigned long long *)nullptr);
     CN_CHECK_LAUNCH();
     {
         int blocks = E < 4096 ? E : 4096;
@@ -865,6 +874,9 @@ extern "C" int cn_policy_get_profile(cn_policy *p, double *ms_out, int64_t *laun
 {
     CN_REQUIRE(p && ms_out && launches_out, "cn_policy_get_profile: null argument");
     if (int rc = harvest_profile(p, true)) return rc;
+    unsigned long long live = 0;
+    CN_HIP(hipMemcpy(&live, p->live_total, 8, hipMemcpyDeviceToHost)); // synchronising: measurement aid only
+    p->prof_n[1] = (int64_t)live;                                        // [1] = live (env, human) rows summed over the profiled forwards
     for (int i = 0; i < 8; ++i) { ms_out[i] = p->prof_ms[i]; launches_out[i] = p->prof_n[i]; }
     return CN_OK;
 }

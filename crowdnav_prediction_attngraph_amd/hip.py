@@ -55,17 +55,23 @@ class HipEnvBatch:
             A.check(A.lib().cn_env_reset(self._h, C.byref(o), A.stream_ptr()), "cn_env_reset")
         return obs
 
-    def step(self, actions, obs=None):
-        """actions [E,2] float32 on the device -> (obs, reward [E], done [E] u8, info [E] u8, ep_return, ep_len)."""
+    def step(self, actions, obs=None, not_done=None, reward=None):
+        """actions [E,2] float32 on the device -> (obs, reward [E], done [E] u8, info [E] u8, ep_return, ep_len).
+        not_done: optional float32 [E] / [E,1] tensor that receives 1 - done (the rollout `masks`);
+        reward: optional float32 [E] / [E,1] tensor written instead of the internal reward buffer."""
         obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        for name, t in (("not_done", not_done), ("reward", reward)):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != self.E or not t.is_contiguous()):
+                raise A.CnError("%s must be a contiguous float32 tensor of %d elements" % (name, self.E))
         if actions.dtype != torch.float32 or actions.shape != (self.E, 2):
             raise A.CnError("actions must be float32 [%d,2]" % self.E)
         actions = actions.contiguous()
         o = A.obs_struct(obs)
         with torch.cuda.device(self.device):
-            A.check(A.lib().cn_env_step(self._h, A.ptr(actions), C.byref(o), A.ptr(self.reward), A.ptr(self.done), A.ptr(self.info),
-                                        A.ptr(self.ep_return), A.ptr(self.ep_len), A.stream_ptr()), "cn_env_step")
-        return obs, self.reward, self.done, self.info, self.ep_return, self.ep_len
+            A.check(A.lib().cn_env_step(self._h, A.ptr(actions), C.byref(o), A.ptr(reward), A.ptr(self.done), A.ptr(self.info),
+                                        A.ptr(self.ep_return), A.ptr(self.ep_len), A.ptr(not_done), A.stream_ptr()), "cn_env_step")
+        return obs, reward, self.done, self.info, self.ep_return, self.ep_len
 
     def get_state(self):
         humans = torch.zeros(self.E, self.H, 8, dtype=torch.float64, device=self.device)

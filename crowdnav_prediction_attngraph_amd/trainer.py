@@ -56,7 +56,8 @@ def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
         if "visible_masks" in rollouts.obs:
             obs_n["visible_masks"] = rollouts.obs["visible_masks"][t + 1].view(torch.uint8)
         if envs._pretext is None:
-            _, reward, done, info, ep_ret, ep_len = env.step(rollouts.actions[t], obs=obs_n)   # simulator writes row t+1 in place
+            _, reward, done, info, ep_ret, ep_len = env.step(rollouts.actions[t], obs=obs_n, not_done=rollouts.masks[t + 1],
+                                                             reward=rollouts.rewards[t])   # rows written in place
         else:
             # GST wrapper in the loop: predictions / sort / social penalty post-process the raw observation
             o, reward, done, info, ep_ret, ep_len = envs.step_device(rollouts.actions[t])
@@ -64,8 +65,9 @@ def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
                 rollouts.obs[k][t + 1].copy_(o[k].view_as(rollouts.obs[k][t + 1]))
             if "visible_masks" in rollouts.obs:
                 rollouts.obs["visible_masks"][t + 1].copy_(o["visible_masks"].to(torch.bool))
-        rollouts.rewards[t].copy_(reward.view(E, 1))
-        rollouts.masks[t + 1].copy_((done == 0).view(E, 1))
+        if envs._pretext is not None:
+            rollouts.rewards[t].copy_(reward.view(E, 1))
+            rollouts.masks[t + 1].copy_((done == 0).view(E, 1))
         if stats is not None:
             stats.update(done, info, ep_ret, ep_len)
     rollouts.step = 0

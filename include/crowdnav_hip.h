@@ -100,10 +100,10 @@ int cn_env_obs_width(const cn_env_config *cfg);
 int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);
 /* actions [E,2] float32 (raw policy output; clipped inside like srnn.clip_action).  Outputs: reward [E] float32,
  * done [E] uint8, info [E] uint8 (CN_INFO_*), ep_return [E] float64 and ep_len [E] int32 (valid where done: the
- * bench.Monitor episode sum / length).  Envs that finish are reset in the same launch and `obs` holds the reset
- * observation for them (shmem_vec_env.py:139-142). */
+ * bench.Monitor episode sum / length), not_done [E] float32 = 1 - done (the `masks` of train.py:185-186; may be NULL).
+ * Envs that finish are reset in the same launch and `obs` holds the reset observation for them (shmem_vec_env.py:139-142). */
 int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done, uint8_t *info,
-                double *ep_return, int32_t *ep_len, void *stream);
+                double *ep_return, int32_t *ep_len, float *not_done, void *stream);
 /* Debug/test access to the simulator state: copies humans [E,H,8] (px,py,vx,vy,gx,gy,radius,v_pref) and robot [E,8]
  * (px,py,vx,vy,gx,gy,theta,potential) as float64 into caller DEVICE buffers (either may be NULL). */
 int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream);

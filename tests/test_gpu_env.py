@@ -63,7 +63,9 @@ def test_hip_env_matches_oracle_bit_exact(name):
     infos_seen = set()
     for t in range(T):
         act = _actions(host, t, E)
-        obs, rew, done, info, epr, epl = env.step(torch.from_numpy(act).to(env.device))
+        nd = torch.full((E, 1), -1.0, device=env.device)
+        obs, rew, done, info, epr, epl = env.step(torch.from_numpy(act).to(env.device), not_done=nd)
+        assert torch.equal(nd.view(-1), (done == 0).to(torch.float32)), "not_done mask t=%d" % t
         host = {k: obs[k].cpu().numpy() for k in keys}
         rew_h, done_h, info_h, epr_h, epl_h = rew.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), epr.cpu().numpy(), epl.cpu().numpy()
         for i, oe in enumerate(oenvs):
