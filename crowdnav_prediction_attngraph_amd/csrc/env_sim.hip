@@ -943,7 +943,9 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
     b->reset_done = false;
     b->orca_ready = false;
-    if (hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->ev_state, hipEventDisableTiming) != hipSuccess ||
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest); // side work yields to the caller's stream (critical path)
+    if (hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio_least) != hipSuccess || hipEventCreateWithFlags(&b->ev_state, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(base); delete b; cn_set_error("cn_env_create: stream/event creation failed"); return CN_ERR_HIP;
     }

@@ -171,11 +171,16 @@ __global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 
 // Row compaction: row_off[e] = sum_{e' < e} nd(e'), nd = clamp(detected_human_num, 1, H); row_off[E] = number of live
 // (env, human) rows.  Padded humans (index >= nd) only ever meet an exactly-zero robot-human attention weight, so the
 // whole human-human block runs on live rows only.  Single block, Hillis-Steele scan over per-thread chunk sums.
+// cls_cnt[2] / cls_list[2][E] (optional): the envs of the two rare big attention size classes (16 < nd <= 32, nd > 32);
+// the order inside a bin is arbitrary (LDS atomics) and has no effect on any result (a unit writes only its own rows).
 __global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const float *__restrict__ det, int *__restrict__ row_off,
-                                                           unsigned long long *__restrict__ live_total)
+                                                           unsigned long long *__restrict__ live_total, int *__restrict__ cls_cnt,
+                                                           int *__restrict__ cls_list)
 {
     __shared__ int part[1024];
+    __shared__ int cnt[2];
     const int t = threadIdx.x;
+    if (t < 2) cnt[t] = 0;
     const int chunk = (E + 1023) / 1024;
     const int lo = t * chunk, hi = min(lo + chunk, E);
     int sum = 0;
@@ -193,6 +198,14 @@ __global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const f
         row_off[e] = run;
         int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
         run += nd;
+        if (cls_list && nd > 16) {
+            const int c = nd <= 32 ? 0 : 1;
+            cls_list[(size_t)c * E + atomicAdd(&cnt[c], 1)] = e;
+        }
+    }
+    if (cls_cnt) {
+        __syncthreads();
+        if (t < 2) cls_cnt[t] = cnt[t];
     }
     if (t == 1023) {
         row_off[E] = part[1023];
@@ -254,16 +267,20 @@ __global__ __launch_bounds__(256) void robot_embed_kernel(int E, const float *__
 // detected humans (the common case of ~6 uses 4.6 KB of LDS per wavefront -> high occupancy); other units exit at once.
 template <int CAP>
 __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, const float *__restrict__ qkv, const int *__restrict__ row_off,
+                                                           const int *__restrict__ cls_cnt, const int *__restrict__ cls_list,
                                                            float *__restrict__ out, float scale)
 {
     constexpr int RS = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int unit = blockIdx.x * (blockDim.x >> 6) + wave; // (env, head)
-    if (unit >= E * 8) return;
-    const int e = unit >> 3, head = unit & 7;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    // wavefronts walk (env, head) units.  Without a class list every unit is inspected in env order and filtered by nd
+    // (grid = one unit per wavefront); with one (the rare big classes, whose 39-65 KB blocks would otherwise queue up
+    // just to exit) a resident-sized grid walks only that class's envs.
+    const int n_units = (cls_list ? *cls_cnt : E) * 8;
+    for (int unit = blockIdx.x * wpb + wave; unit < n_units; unit += gridDim.x * wpb) {
+    const int e = cls_list ? cls_list[unit >> 3] : unit >> 3, head = unit & 7;
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
-    if (nd <= cap_lo || nd > CAP) return; // another size class handles this unit
+    if (nd <= cap_lo || nd > CAP) continue; // another size class handles this unit
     float *Ks = smem + (size_t)wave * (2 * CAP * RS + CAP * CAP);
     float *Qs = Ks + CAP * RS;
     float *S = Qs + CAP * RS;
@@ -325,14 +342,20 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, co
         }
         out[(size_t)(r0 + i) * 512 + head * 64 + lane] = o;
     }
+    __builtin_amdgcn_wave_barrier(); // the next unit reuses this wavefront's LDS slices
+    }
 }
 
 template <int CAP>
-static int launch_hh_attention(int E, int cap_lo, const float *qkv, const int *row_off, float *out, hipStream_t st, float scale = 1.0f)
+static int launch_hh_attention(int E, int cap_lo, const float *qkv, const int *row_off, float *out, hipStream_t st, float scale = 1.0f,
+                               const int *cls_cnt = nullptr, const int *cls_list = nullptr)
 {
     const size_t per_wave = (size_t)(2 * CAP * 68 + CAP * CAP) * sizeof(float);
     int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-    hipLaunchKernelGGL(hh_attention_kernel<CAP>, dim3((E * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, E, cap_lo, qkv, row_off, out, scale);
+    int per_cu = (int)((160 * 1024) / (per_wave * wpb)); per_cu = per_cu > 8 ? 8 : per_cu; // resident blocks per CU (LDS / 32-wave cap)
+    int blocks = (E * 8 + wpb - 1) / wpb;
+    if (cls_list && blocks > 256 * per_cu) blocks = 256 * per_cu;
+    hipLaunchKernelGGL(hh_attention_kernel<CAP>, dim3(blocks), dim3(64 * wpb), per_wave * wpb, st, E, cap_lo, qkv, row_off, cls_cnt, cls_list, out, scale);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -558,8 +581,12 @@ struct cn_policy {
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
     int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split (default)
     unsigned long long *live_total; // device counter: sum of live rows over the profiled forwards
-    int *row_off; // [maxE + 1] exclusive prefix of live humans per env; row_off[E] = live rows
+    int *row_off; // [maxE + 1]
+    int *cls_cnt, *cls_list; // big attention size classes: [2] counts, [2][E] env lists exclusive prefix of live humans per env; row_off[E] = live rows
     float *robot_states, *t_emb, *hr_out, *hr_attn, *x, *gi, *gh, *hnew, *rnn_out, *ac1, *ac2;
+    // robot-side launches that do not depend on the human-human block run on this stream, beside the big GEMMs
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
     // profiling of the dominant kernel (QKV projection)
     bool profiling;
     static constexpr int PROF_RING = 64;
@@ -632,6 +659,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
     const size_t o_roff = carve(E + 1);
     const size_t o_live = carve(2);
+    const size_t o_ccnt = carve(2), o_clist = carve(2 * E);
     const size_t o_tew = carve(128 * 256), o_teb = carve(128), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 192);
     const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
     const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
@@ -652,6 +680,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
     p->row_off = (int *)(base + o_roff);
     p->live_total = (unsigned long long *)(base + o_live);
+    p->cls_cnt = (int *)(base + o_ccnt); p->cls_list = (int *)(base + o_clist);
     (void)hipMemset(p->live_total, 0, 8);
     p->emb2_hi = (__bf16 *)(base + o_e2h); p->emb2_lo = (__bf16 *)(base + o_e2l); p->qkv_hi = (__bf16 *)(base + o_qh); p->qkv_lo = (__bf16 *)(base + o_ql);
     p->os_hi = (__bf16 *)(base + o_osh); p->os_lo = (__bf16 *)(base + o_osl);
@@ -660,6 +689,12 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->weights_set = false;
     p->profiling = false;
     p->ev_head = p->ev_tail = 0;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest); // side work yields to the caller's stream (critical path)
+    if (hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_least) != hipSuccess || hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(base); delete p; cn_set_error("cn_policy_create: side stream / event creation failed"); return CN_ERR_HIP;
+    }
     for (int i = 0; i < cn_policy::PROF_RING; ++i)
         if (hipEventCreate(&p->ev[i][0]) != hipSuccess || hipEventCreate(&p->ev[i][1]) != hipSuccess) {
             (void)hipFree(base); delete p; cn_set_error("cn_policy_create: hipEventCreate failed"); return CN_ERR_HIP;
@@ -672,6 +707,7 @@ extern "C" int cn_policy_destroy(cn_policy *p)
 {
     if (!p) return CN_OK;
     for (int i = 0; i < cn_policy::PROF_RING; ++i) { (void)hipEventDestroy(p->ev[i][0]); (void)hipEventDestroy(p->ev[i][1]); }
+    (void)hipEventDestroy(p->ev_fork); (void)hipEventDestroy(p->ev_join); (void)hipStreamDestroy(p->side);
     if (p->blob) CN_HIP(hipFree(p->blob));
     delete p;
     return CN_OK;
@@ -766,10 +802,22 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_REQUIRE(hxs_in && masks && value, "policy: null pointer");
     const int H = p->H, D = p->D, M = E * H;
     int rc;
+    // ---- robot node: nothing here depends on the human-human block, so it runs beside it on the side stream ----
+    CN_HIP(hipEventRecord(p->ev_fork, st)); // inputs (and the previous forward's readers of z / gh) are ordered before this point
+    CN_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+    {
+        int blocks = E < 2048 ? E : 2048;
+        hipLaunchKernelGGL(robot_embed_kernel, dim3(blocks), dim3(256), 0, p->side, E, obs->temporal_edges, obs->robot_node, p->rl_w, p->rl_b, p->robot_states);
+        CN_CHECK_LAUNCH();
+    }
+    // [t_emb | relu(enc)] in one launch (both read robot_states); z = [t_emb | enc | edge], x = z + 64
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 128, 256, p->robot_states, 256, p->te_w, p->te_b, p->z, 192, p->side, 1, GemmBatch{0, 0, 0, 0}, 64))) return rc;
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, hxs_in, 128, p->whh, nullptr, p->gh, 384, p->side))) return rc; // GRU hidden-side gates
+    CN_HIP(hipEventRecord(p->ev_join, p->side));
     // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
     const int *m_dev = p->row_off + E;
     hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
-                       p->profiling ? p->live_total : (unsigned long long *)nullptr);
+                       p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
     CN_CHECK_LAUNCH();
     {
         int blocks = E < 4096 ? E : 4096;
@@ -788,21 +836,15 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     {
         if ((rc = launch_hh_attention<8>(E, 0, p->qkv, p->row_off, p->attn, st))) return rc;
         if (H > 8 && (rc = launch_hh_attention<16>(E, 8, p->qkv, p->row_off, p->attn, st))) return rc;
-        if (H > 16 && (rc = launch_hh_attention<32>(E, 16, p->qkv, p->row_off, p->attn, st))) return rc;
-        if (H > 32 && (rc = launch_hh_attention<64>(E, 32, p->qkv, p->row_off, p->attn, st))) return rc;
+        if (H > 16 && (rc = launch_hh_attention<32>(E, 16, p->qkv, p->row_off, p->attn, st, 1.0f, p->cls_cnt, p->cls_list))) return rc;
+        if (H > 32 && (rc = launch_hh_attention<64>(E, 32, p->qkv, p->row_off, p->attn, st, 1.0f, p->cls_cnt + 1, p->cls_list + (size_t)E))) return rc;
     }
     if (split) rc = launch_gemm3<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
     else rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
     if (rc) return rc;
     if ((rc = launch_gemm<64, ACT_NONE>(M, 64, 256, p->out_sp, 256, p->as_w, p->as_b, p->s_emb, 64, st, m_dev))) return rc;
-    // ---- robot node, robot-human attention ----
-    {
-        int blocks = E < 2048 ? E : 2048;
-        hipLaunchKernelGGL(robot_embed_kernel, dim3(blocks), dim3(256), 0, st, E, obs->temporal_edges, obs->robot_node, p->rl_w, p->rl_b, p->robot_states);
-        CN_CHECK_LAUNCH();
-    }
-    // [t_emb | relu(enc)] in one launch (both read robot_states); z = [t_emb | enc | edge], x = z + 64
-    if ((rc = launch_gemm_env<ACT_NONE>(E, 128, 256, p->robot_states, 256, p->te_w, p->te_b, p->z, 192, st, 1, GemmBatch{0, 0, 0, 0}, 64))) return rc;
+    // ---- robot-human attention (robot node embeddings arrive from the side stream) ----
+    CN_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
     {
         const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
         hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->z, 192, p->s_emb, p->out_sp, p->row_off,
@@ -812,7 +854,6 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     // ---- EndRNN: edge encoder -> GRU (output_linear is folded into the actor / critic trunks) ----
     if ((rc = launch_gemm_env<ACT_RELU>(E, 64, 256, p->hr_out, 256, p->edge_w, p->edge_b, p->z + 128, 192, st))) return rc;
     if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, p->z + 64, 192, p->wih, p->bih, p->gi, 384, st))) return rc;
-    if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, hxs_in, 128, p->whh, nullptr, p->gh, 384, st))) return rc;
     float *hdst = hxs_out ? hxs_out : p->hnew;
     hipLaunchKernelGGL(gru_pointwise_kernel, dim3(E), dim3(128), 0, st, E, p->gi, p->gh, p->bhh, hxs_in, masks, hdst);
     CN_CHECK_LAUNCH();
