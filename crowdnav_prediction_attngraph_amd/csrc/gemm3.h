@@ -1,0 +1,322 @@
+// gemm3.h -- split-precision ("bf16x3") MFMA GEMMs shared by policy.hip (rollout forward) and linear.hip (PPO update).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+// ---- split-precision GEMM: fp32 operands as (hi + lo) bf16 pairs, three bf16 MFMAs per product term ------------------
+// a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with hi = bf16(x), lo = bf16(x - hi): the dropped terms are <= 2^-16 relative,
+// accumulation is fp32 (measured end-to-end error on the HH block: 1.5e-5, bar 1e-4).  Runs on v_mfma_f32_32x32x16_bf16
+// (16x the fp32 MFMA rate, three passes -> 5.3x).  A is fp32 in HBM and split while it is staged into LDS
+// (v_cvt_pk_bf16_f32); W is split once per weight snapshot.  LDS rows are 32 bf16 padded to 40 (80 B): the 16-byte
+// fragment reads of 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK3 = 64;        // K tile of the split kernel: 4 MFMA k-steps (48 MFMAs per wavefront) between barriers
+constexpr int L3_STRIDE = 72;  // 64 bf16 + 8 pad = 144 B rows: 16-byte fragment reads of 16 consecutive rows are conflict-free
+
+template <int BN, int ACT>
+__global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                       const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+                                                       const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                       const int *__restrict__ m_dev)
+{
+    if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
+    int row_tile, col_tile;
+    xcd_tile(row_tile, col_tile);
+    if (row_tile * BM >= M) return;
+    constexpr int NB = BN / 64;
+    constexpr int ALD = BM * BK3 / 4 / 256;  // float4 loads of A per thread per K tile (8)
+    constexpr int WCH = BN * BK3 / 8 / 256;  // 16-byte chunks of each W array per thread per K tile (4)
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    __bf16 *Ah = reinterpret_cast<__bf16 *>(smem3);
+    __bf16 *Al = Ah + BM * L3_STRIDE;
+    __bf16 *Wh = Al + BM * L3_STRIDE;
+    __bf16 *Wl = Wh + BN * L3_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_blk = row_tile * BM, n_blk = col_tile * BN;
+    const int lrow = tid >> 4, lcol = (tid & 15) * 4; // A staging: 16 lanes cover one 256-byte row segment
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 pa[ALD];
+    bf16x8 pwh[WCH], pwl[WCH];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < ALD; ++p) {
+            const int r = m_blk + lrow + 16 * p;
+            if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
+            else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < WCH; ++p) {
+            const int c = tid + 256 * p, r = n_blk + (c >> 3), col = (c & 7) * 8;
+            pwh[p] = *reinterpret_cast<const bf16x8 *>(Whi + (size_t)r * K + k0 + col);
+            pwl[p] = *reinterpret_cast<const bf16x8 *>(Wlo + (size_t)r * K + k0 + col);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < ALD; ++p) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hi[q] = (__bf16)pa[p][q];
+                lo[q] = (__bf16)(pa[p][q] - (float)hi[q]);
+            }
+            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + 16 * p) * L3_STRIDE + lcol]) = hi;
+            *reinterpret_cast<bf16x4 *>(&Al[(lrow + 16 * p) * L3_STRIDE + lcol]) = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < WCH; ++p) {
+            const int c = tid + 256 * p, r = c >> 3, col = (c & 7) * 8;
+            *reinterpret_cast<bf16x8 *>(&Wh[r * L3_STRIDE + col]) = pwh[p];
+            *reinterpret_cast<bf16x8 *>(&Wl[r * L3_STRIDE + col]) = pwl[p];
+        }
+    };
+
+    load_tiles(0);
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = 0; k0 < K; k0 += BK3) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK3 < K) load_tiles(k0 + BK3);
+#pragma unroll
+        for (int ks = 0; ks < BK3 / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 64 + i * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
+                al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int o = (wn * (BN / 2) + j * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+                bh[j] = *reinterpret_cast<const bf16x8 *>(&Wh[o]);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(&Wl[o]);
+            }
+            // term-major issue order: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
+            const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    float v = acc[i][j][r] + b;
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+// split a fp32 weight matrix into bf16 hi / lo parts
+__global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const __bf16 h = (__bf16)w[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(w[i] - (float)h);
+    }
+}
+
+template <int BN, int ACT>
+static int launch_gemm3(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
+                        hipStream_t st, const int *m_dev)
+{
+    CN_REQUIRE(N % BN == 0 && K % BK3 == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    if (M == 0) return CN_OK;
+    dim3 grid(N / BN, (((M + BM - 1) / BM) + 7) & ~7);
+    constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB: needs the opt-in above 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm3_nt_kernel<BN, ACT>), grid, dim3(256), lds, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+
+// hi/lo split of W^T: w [rows, cols] row-major -> hi, lo [cols, rows].  Lets the NT kernel compute dX = dY * W
+// (the "weight" operand of that product is W^T).  Sizes are a few hundred KB: no tiling needed.
+__global__ void split_bf16_t_kernel(int rows, int cols, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // index into the transposed output
+    if (i < (size_t)rows * cols) {
+        const int c = (int)(i / rows), r = (int)(i % rows);
+        const float x = w[(size_t)r * cols + c];
+        const __bf16 h = (__bf16)x;
+        hi[i] = h;
+        lo[i] = (__bf16)(x - (float)h);
+    }
+}
+
+// Weight-gradient GEMM (TN): P[s][n][k] = sum_{m in split s} dY[m][n] * X[m][k], both operands fp32 activations with the
+// reduction index m as the SLOW axis in memory.  The MFMA wants 8 consecutive reduction elements per lane, so the tiles
+// are transposed on their way into LDS: thread (column c, group g) loads 8 rows m of its column with 8 coalesced dword
+// loads (64 lanes = 256 contiguous bytes each), splits them into bf16 hi/lo and writes ONE 16-byte LDS word per plane
+// at [c][8g .. 8g+7].  Consecutive lanes hit rows 144 B apart -> conflict-free ds_write_b128, and the LDS image is
+// exactly the NT kernel's, so the MFMA section is shared.  The m range is cut into `gridDim.z` splits (partials summed
+// by reduce_partials_kernel in a fixed order: deterministic).  Blocks of k tile 0 also produce the column sums of dY
+// (the bias gradient) from the registers they stage anyway.
+__global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+                                                       int rows_per_split, float *__restrict__ partials, float *__restrict__ db_part)
+{
+    constexpr int BN = 128;
+    constexpr int NB = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    __bf16 *Ah = reinterpret_cast<__bf16 *>(smem3);
+    __bf16 *Al = Ah + BM * L3_STRIDE;
+    __bf16 *Wh = Al + BM * L3_STRIDE;
+    __bf16 *Wl = Wh + BN * L3_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_blk = blockIdx.x * BM, k_blk = blockIdx.y * BN, split = blockIdx.z;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int c = tid & 127, g0 = tid >> 7;
+    const bool want_db = db_part != nullptr && blockIdx.y == 0;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float pa[4][8], pb[4][8];
+    const float *a_col = dY + n_blk + c, *b_col = X + k_blk + c;
+    auto load_chunk = [&](int m0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = m0 + (g0 + 2 * p) * 8 + u;
+                const bool ok = m < m_end;
+                pa[p][u] = ok ? a_col[(size_t)m * ldy] : 0.0f;
+                pb[p][u] = ok ? b_col[(size_t)m * ldx] : 0.0f;
+            }
+    };
+    float colsum = 0.0f;
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            bf16x8 ahi, alo, bhi, blo;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ahi[u] = (__bf16)pa[p][u];
+                alo[u] = (__bf16)(pa[p][u] - (float)ahi[u]);
+                bhi[u] = (__bf16)pb[p][u];
+                blo[u] = (__bf16)(pb[p][u] - (float)bhi[u]);
+                colsum += pa[p][u];
+            }
+            const int o = c * L3_STRIDE + (g0 + 2 * p) * 8;
+            *reinterpret_cast<bf16x8 *>(&Ah[o]) = ahi;
+            *reinterpret_cast<bf16x8 *>(&Al[o]) = alo;
+            *reinterpret_cast<bf16x8 *>(&Wh[o]) = bhi;
+            *reinterpret_cast<bf16x8 *>(&Wl[o]) = blo;
+        }
+    };
+
+    load_chunk(m_begin);
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int m0 = m_begin; m0 < m_end; m0 += BK3) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (m0 + BK3 < m_end) load_chunk(m0 + BK3);
+#pragma unroll
+        for (int ks = 0; ks < BK3 / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 64 + i * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
+                al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int o = (wn * (BN / 2) + j * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+                bh[j] = *reinterpret_cast<const bf16x8 *>(&Wh[o]);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(&Wl[o]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float *P = partials + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = k_blk + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                P[(size_t)row * K + col] = acc[i][j][r];
+            }
+        }
+    if (want_db) { // uniform per block
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem3);
+        red[tid] = colsum;
+        __syncthreads();
+        if (tid < 128) db_part[(size_t)split * N + n_blk + tid] = red[tid] + red[tid + 128];
+    }
+}
+
+// out[i] = sum_s part[s][i] in split order (deterministic)
+__global__ void reduce_partials_kernel(size_t n, int splits, const float *__restrict__ part, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float acc = 0.0f;
+        for (int s = 0; s < splits; ++s) acc += part[(size_t)s * n + i];
+        out[i] = acc;
+    }
+}
+
+} // namespace

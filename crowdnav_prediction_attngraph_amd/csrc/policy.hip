@@ -17,156 +17,12 @@
 // which removes 4 of the 9 [M,512]x[512,512] products (83.65 -> 52.2 MFLOP per env-step at H = 20).
 #include "common.h"
 #include "gemm.h"
+#include "gemm3.h"
 
 #include <cmath>
 #include <new>
 
 namespace {
-
-// ---- split-precision GEMM: fp32 operands as (hi + lo) bf16 pairs, three bf16 MFMAs per product term ------------------
-// a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with hi = bf16(x), lo = bf16(x - hi): the dropped terms are <= 2^-16 relative,
-// accumulation is fp32 (measured end-to-end error on the HH block: 1.5e-5, bar 1e-4).  Runs on v_mfma_f32_32x32x16_bf16
-// (16x the fp32 MFMA rate, three passes -> 5.3x).  A is fp32 in HBM and split while it is staged into LDS
-// (v_cvt_pk_bf16_f32); W is split once per weight snapshot.  LDS rows are 32 bf16 padded to 40 (80 B): the 16-byte
-// fragment reads of 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int BK3 = 64;        // K tile of the split kernel: 4 MFMA k-steps (48 MFMAs per wavefront) between barriers
-constexpr int L3_STRIDE = 72;  // 64 bf16 + 8 pad = 144 B rows: 16-byte fragment reads of 16 consecutive rows are conflict-free
-
-template <int BN, int ACT>
-__global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
-                                                       const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
-                                                       const float *__restrict__ bias, float *__restrict__ C, int ldc,
-                                                       const int *__restrict__ m_dev)
-{
-    if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
-    int row_tile, col_tile;
-    xcd_tile(row_tile, col_tile);
-    if (row_tile * BM >= M) return;
-    constexpr int NB = BN / 64;
-    constexpr int ALD = BM * BK3 / 4 / 256;  // float4 loads of A per thread per K tile (8)
-    constexpr int WCH = BN * BK3 / 8 / 256;  // 16-byte chunks of each W array per thread per K tile (4)
-    extern __shared__ __attribute__((aligned(16))) char smem3[];
-    __bf16 *Ah = reinterpret_cast<__bf16 *>(smem3);
-    __bf16 *Al = Ah + BM * L3_STRIDE;
-    __bf16 *Wh = Al + BM * L3_STRIDE;
-    __bf16 *Wl = Wh + BN * L3_STRIDE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m_blk = row_tile * BM, n_blk = col_tile * BN;
-    const int lrow = tid >> 4, lcol = (tid & 15) * 4; // A staging: 16 lanes cover one 256-byte row segment
-
-    f32x16 acc[2][NB];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    f32x4 pa[ALD];
-    bf16x8 pwh[WCH], pwl[WCH];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < ALD; ++p) {
-            const int r = m_blk + lrow + 16 * p;
-            if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
-            else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int p = 0; p < WCH; ++p) {
-            const int c = tid + 256 * p, r = n_blk + (c >> 3), col = (c & 7) * 8;
-            pwh[p] = *reinterpret_cast<const bf16x8 *>(Whi + (size_t)r * K + k0 + col);
-            pwl[p] = *reinterpret_cast<const bf16x8 *>(Wlo + (size_t)r * K + k0 + col);
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int p = 0; p < ALD; ++p) {
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                hi[q] = (__bf16)pa[p][q];
-                lo[q] = (__bf16)(pa[p][q] - (float)hi[q]);
-            }
-            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + 16 * p) * L3_STRIDE + lcol]) = hi;
-            *reinterpret_cast<bf16x4 *>(&Al[(lrow + 16 * p) * L3_STRIDE + lcol]) = lo;
-        }
-#pragma unroll
-        for (int p = 0; p < WCH; ++p) {
-            const int c = tid + 256 * p, r = c >> 3, col = (c & 7) * 8;
-            *reinterpret_cast<bf16x8 *>(&Wh[r * L3_STRIDE + col]) = pwh[p];
-            *reinterpret_cast<bf16x8 *>(&Wl[r * L3_STRIDE + col]) = pwl[p];
-        }
-    };
-
-    load_tiles(0);
-    const int half = lane >> 5, l31 = lane & 31;
-    for (int k0 = 0; k0 < K; k0 += BK3) {
-        __syncthreads();
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK3 < K) load_tiles(k0 + BK3);
-#pragma unroll
-        for (int ks = 0; ks < BK3 / 16; ++ks) {
-            bf16x8 ah[2], al[2], bh[NB], bl[NB];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int o = (wm * 64 + i * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
-                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
-                al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int o = (wn * (BN / 2) + j * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
-                bh[j] = *reinterpret_cast<const bf16x8 *>(&Wh[o]);
-                bl[j] = *reinterpret_cast<const bf16x8 *>(&Wl[o]);
-            }
-            // term-major issue order: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
-            const float b = bias ? bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) {
-                    float v = acc[i][j][r] + b;
-                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
-                    if (ACT == ACT_TANH) v = tanhf(v);
-                    C[(size_t)row * ldc + col] = v;
-                }
-            }
-        }
-}
-
-// split a fp32 weight matrix into bf16 hi / lo parts
-__global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const __bf16 h = (__bf16)w[i];
-        hi[i] = h;
-        lo[i] = (__bf16)(w[i] - (float)h);
-    }
-}
 
 // Row compaction: row_off[e] = sum_{e' < e} nd(e'), nd = clamp(detected_human_num, 1, H); row_off[E] = number of live
 // (env, human) rows.  Padded humans (index >= nd) only ever meet an exactly-zero robot-human attention weight, so the
@@ -468,6 +324,43 @@ __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const f
     o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
 }
 
+// Backward of hr_attention_kernel for the PPO update: one wavefront per sample on the compacted rows.
+//   a_j = T (t . s_j), p = softmax(a), hr = sum_j p_j o_j         (T = H / 8)
+//   dp_j = d_hr . o_j ; g_j = T p_j (dp_j - sum_k p_k dp_k) ; d_t = sum_j g_j s_j ; d_s_j = g_j t ; d_o_j = p_j d_hr
+// (d_o is only the direct weighted-sum path; the s = Linear(o) path is differentiated by the caller's graph.)
+__global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, const float *__restrict__ t_emb, const float *__restrict__ s_emb,
+                                                               const float *__restrict__ out_sp, const int *__restrict__ row_off,
+                                                               const float *__restrict__ attn, const float *__restrict__ d_hr,
+                                                               float *__restrict__ d_t, float *__restrict__ d_s, float *__restrict__ d_o)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    if (e >= B) return;
+    const int r0 = row_off[e], nd = row_off[e + 1] - r0;
+    const float a = lane < nd ? attn[(size_t)e * H + lane] : 0.0f; // lanes = humans
+    const float *g = d_hr + (size_t)e * 256;
+    const float g0 = g[lane], g1 = g[64 + lane], g2 = g[128 + lane], g3 = g[192 + lane];
+    float dp = 0.0f;
+    for (int j = 0; j < nd; ++j) {
+        const float *row = out_sp + (size_t)(r0 + j) * 256;
+        const float tot = wv_sum(g0 * row[lane] + g1 * row[64 + lane] + g2 * row[128 + lane] + g3 * row[192 + lane]);
+        if (lane == j) dp = tot;
+        float *dor = d_o + (size_t)(r0 + j) * 256;
+        const float aj = wv_readlane(a, j);
+        dor[lane] = aj * g0; dor[64 + lane] = aj * g1; dor[128 + lane] = aj * g2; dor[192 + lane] = aj * g3;
+    }
+    const float dot = wv_sum(a * dp);
+    const float gg = a * (dp - dot) * ((float)H / 8.0f);
+    const float tl = t_emb[(size_t)e * 64 + lane];
+    float dt = 0.0f;
+    for (int j = 0; j < nd; ++j) {
+        const float gj = wv_readlane(gg, j);
+        dt += gj * s_emb[(size_t)(r0 + j) * 64 + lane];
+        d_s[(size_t)(r0 + j) * 64 + lane] = gj * tl;
+    }
+    d_t[(size_t)e * 64 + lane] = dt;
+}
+
 // test tap: scatter the compacted [rows,256] activations back to [E,H,256] (zeros on padded humans)
 __global__ __launch_bounds__(256) void scatter_rows_kernel(int E, int H, const float *__restrict__ src, const int *__restrict__ row_off,
                                                            float *__restrict__ dst)
@@ -609,24 +502,6 @@ static int launch_gemm_env(int M, int N, int K, const float *A, int lda, const f
                            int nbatch = 1, GemmBatch gb = GemmBatch{0, 0, 0, 0}, int relu_from = 1 << 30)
 {
     return launch_gemm_t<64, 64, ACT>(M, N, K, A, lda, W, bias, C, ldc, st, nullptr, nbatch, gb, relu_from);
-}
-
-template <int BN, int ACT>
-static int launch_gemm3(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
-                        hipStream_t st, const int *m_dev)
-{
-    CN_REQUIRE(N % BN == 0 && K % BK3 == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
-    if (M == 0) return CN_OK;
-    dim3 grid(N / BN, (((M + BM - 1) / BM) + 7) & ~7);
-    constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB: needs the opt-in above 64 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm3_nt_kernel<BN, ACT>), grid, dim3(256), lds, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
-    CN_CHECK_LAUNCH();
-    return CN_OK;
 }
 
 extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_policy **out)
@@ -933,6 +808,30 @@ extern "C" int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *ro
     if (H > 8 && (rc = launch_hh_attention<16>(B, 8, qkv, row_off, out, st, scale))) return rc;
     if (H > 16 && (rc = launch_hh_attention<32>(B, 16, qkv, row_off, out, st, scale))) return rc;
     if (H > 32 && (rc = launch_hh_attention<64>(B, 32, qkv, row_off, out, st, scale))) return rc;
+    return CN_OK;
+}
+
+extern "C" int cn_hr_attention_fwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off, float *hr_out,
+                                   float *attn, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && t_emb && s_emb && out_sp && row_off && hr_out && attn, "cn_hr_attention_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
+    hipLaunchKernelGGL(hr_attention_kernel, dim3((B + 3) / 4), dim3(256), lds, st, B, H, t_emb, 64, s_emb, out_sp, row_off, hr_out, attn);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_hr_attention_bwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off, const float *attn,
+                                   const float *d_hr, float *d_t, float *d_s, float *d_o, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && t_emb && s_emb && out_sp && row_off && attn && d_hr && d_t && d_s && d_o,
+               "cn_hr_attention_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, t_emb, s_emb, out_sp, row_off, attn, d_hr, d_t, d_s, d_o);
+    CN_CHECK_LAUNCH();
     return CN_OK;
 }
 

@@ -272,6 +272,92 @@ class HHAttention(torch.autograd.Function):
         return d_qkv, None, None, None, None
 
 
+class HRAttention(torch.autograd.Function):
+    """Robot-human attention on compacted rows (cn_hr_attention_fwd / cn_hr_attention_bwd): t [B,64], s [R,64], o [R,256],
+    row_off [B+1] int32 -> hr [B,256].  The returned d_o is the weighted-sum path only (s = Linear(o) is the caller's graph)."""
+
+    @staticmethod
+    def forward(ctx, t, s, o, row_off, H):
+        t, s, o = t.contiguous(), s.contiguous(), o.contiguous()
+        B = t.shape[0]
+        hr = torch.empty(B, 256, device=t.device)
+        attn = torch.empty(B, H, device=t.device)
+        A.check(A.lib().cn_hr_attention_fwd(B, int(H), A.ptr(t), A.ptr(s), A.ptr(o), A.ptr(row_off), A.ptr(hr), A.ptr(attn), A.stream_ptr()),
+                "cn_hr_attention_fwd")
+        ctx.save_for_backward(t, s, o, row_off, attn)
+        ctx.H = int(H)
+        return hr
+
+    @staticmethod
+    def backward(ctx, d_hr):
+        t, s, o, row_off, attn = ctx.saved_tensors
+        d_t, d_s, d_o = torch.empty_like(t), torch.empty_like(s), torch.empty_like(o)
+        A.check(A.lib().cn_hr_attention_bwd(t.shape[0], ctx.H, A.ptr(t), A.ptr(s), A.ptr(o), A.ptr(row_off), A.ptr(attn), A.ptr(d_hr.contiguous()),
+                                            A.ptr(d_t), A.ptr(d_s), A.ptr(d_o), A.stream_ptr()), "cn_hr_attention_bwd")
+        return d_t, d_s, d_o, None, None
+
+
+def split_bf16(w, transpose=False):
+    """fp32 matrix -> (hi, lo) bf16 planes (int16 storage) of w, or of w^T when transpose is set."""
+    w = w.contiguous()
+    rows, cols = w.shape
+    shape = (cols, rows) if transpose else (rows, cols)
+    hi = torch.empty(shape, dtype=torch.int16, device=w.device)
+    lo = torch.empty(shape, dtype=torch.int16, device=w.device)
+    A.check(A.lib().cn_split_bf16(A.ptr(w), rows, cols, int(bool(transpose)), A.ptr(hi), A.ptr(lo), A.stream_ptr()), "cn_split_bf16")
+    return hi, lo
+
+
+def linear_supported(x, w):
+    """Shapes the split-precision training kernels cover (the three large human-human Linear layers)."""
+    N, K = w.shape
+    return x.is_cuda and x.dtype == torch.float32 and N % 128 == 0 and K % 128 == 0
+
+
+class HipLinear(torch.autograd.Function):
+    """y = [relu](x w^T + b) with forward, input gradient and weight/bias gradient on the bf16x3 MFMA kernels
+    (cn_linear_fwd / cn_linear_wgrad).  x [M,K], w [N,K], b [N]; N, K multiples of 128."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x = x.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=x.device)
+        if M:
+            hi, lo = split_bf16(w.detach())
+            A.check(A.lib().cn_linear_fwd(M, N, K, A.ptr(x), K, A.ptr(hi), A.ptr(lo), A.ptr(b.detach().contiguous()), int(bool(relu)), A.ptr(y), N,
+                                          A.stream_ptr()), "cn_linear_fwd")
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if M == 0:
+            return torch.zeros_like(x), torch.zeros_like(w), x.new_zeros(N), None
+        if ctx.needs_input_grad[0]:
+            hi_t, lo_t = split_bf16(w.detach(), transpose=True)              # [K,N]: dX = dY W as an NT product with W^T
+            dx = torch.empty(M, K, device=x.device)
+            A.check(A.lib().cn_linear_fwd(M, K, N, A.ptr(dy), N, A.ptr(hi_t), A.ptr(lo_t), None, 0, A.ptr(dx), K, A.stream_ptr()), "cn_linear_fwd(dX)")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            splits = A.lib().cn_linear_wgrad_splits(M, N, K)
+            part = torch.empty(splits, N, K, device=x.device)
+            dbp = torch.empty(splits, N, device=x.device)
+            dw = torch.empty(N, K, device=x.device)
+            db = torch.empty(N, device=x.device)
+            A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
+                    "cn_linear_wgrad")
+        return dx, dw, db, None
+
+
 def gae(rewards, values, masks, gamma, lam, returns):
     """rewards [T,N,1], values/masks/returns [T+1,N,1] contiguous float32 device tensors; fills returns[:T]."""
     T, N = rewards.shape[0], rewards.shape[1]

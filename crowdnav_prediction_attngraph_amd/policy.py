@@ -150,6 +150,18 @@ class AttnGraphBase(nn.Module):
         self.spatial_linear = nn.Sequential(_ortho(nn.Linear(512, 256), gain), nn.ReLU())
 
     # ---- training-time forward in torch ops (autograd) ----
+    # arithmetic of the three large human-human Linear layers in the PPO update on the GPU: 'bf16x3' = split-precision MFMA
+    # kernels (forward, dX, dW; same arithmetic as the rollout forward), 'fp32' = torch / rocBLAS fp32
+    train_gemm_mode = "bf16x3"
+
+    def _big_linear(self, x, w, b, relu=False):
+        if x.is_cuda and self.train_gemm_mode == "bf16x3":
+            from . import hip
+            if hip.linear_supported(x, w):
+                return hip.HipLinear.apply(x, w, b, relu)
+        y = F.linear(x, w, b)
+        return F.relu(y) if relu else y
+
     def _hh_block(self, spatial_edges, det):
         """[B,H,D] -> [B,H,256].  SpatialEdgeSelfAttn.forward + spatial_linear (selfAttn_srnn_temp_node.py:63-91,:408).
 
@@ -161,7 +173,8 @@ class AttnGraphBase(nn.Module):
         sa = self.spatial_attn
         valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
         idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
-        e = sa.embedding_layer(spatial_edges.reshape(B * H, D).index_select(0, idx))
+        emb0, emb2 = sa.embedding_layer[0], sa.embedding_layer[2]
+        e = self._big_linear(F.relu(emb0(spatial_edges.reshape(B * H, D).index_select(0, idx))), emb2.weight, emb2.bias, relu=True)
         # (q|k|v)_linear followed by in_proj is an affine pair with no nonlinearity in between: compose the two weight
         # matrices first (a 512^3 product, differentiable, so both factors still receive their exact gradients) and run ONE
         # [rows,512]x[512,1536] GEMM instead of six [rows,512]x[512,512] ones, in the forward and in the backward pass.
@@ -169,7 +182,7 @@ class AttnGraphBase(nn.Module):
         lins = (sa.q_linear, sa.k_linear, sa.v_linear)
         Wc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].weight for i in range(3)], 0)
         bc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].bias + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
-        qkv = F.linear(e, Wc, bc)                                                           # [rows, 1536] = [q | k | v]
+        qkv = self._big_linear(e, Wc, bc)                                                   # [rows, 1536] = [q | k | v]
         if qkv.is_cuda:
             # attention core on the compacted rows, forward AND backward as hand-written HIP kernels
             from .hip import HHAttention
@@ -189,7 +202,9 @@ class AttnGraphBase(nn.Module):
             o_live = o.index_select(0, idx)
         # same composition for out_proj followed by spatial_linear (Linear -> Linear -> ReLU)
         op, sl = sa.multihead_attn.out_proj, self.spatial_linear[0]
-        o = F.relu(F.linear(o_live, sl.weight @ op.weight, sl.weight @ op.bias + sl.bias))
+        o = self._big_linear(o_live, sl.weight @ op.weight, sl.weight @ op.bias + sl.bias, relu=True)
+        if o.is_cuda:
+            return o, row_off                     # stays compacted: the robot-human attention kernels index rows through row_off
         out_sp = o.new_zeros(B * H, o.shape[1]).index_copy(0, idx, o).view(B, H, -1)
         return out_sp, valid
 
@@ -221,7 +236,13 @@ class AttnGraphBase(nn.Module):
         robot_states = self.robot_linear(robot_in)
         det = inputs["detected_human_num"].reshape(B).to(torch.int64).clamp(min=1)
         out_sp, valid = self._hh_block(inputs["spatial_edges"].reshape(B, self.human_num, self.edge_width), det)
-        hr, _ = self._hr_attention(robot_states, out_sp, valid)
+        if out_sp.is_cuda:
+            # compacted rows [R,256] + row offsets: HIP robot-human attention forward/backward (no dense [B,H,256] tensors)
+            from .hip import HRAttention
+            hr = HRAttention.apply(self.attn.temporal_edge_layer[0](robot_states), self.attn.spatial_edge_layer[0](out_sp), out_sp, valid,
+                                   self.human_num)
+        else:
+            hr, _ = self._hr_attention(robot_states, out_sp, valid)
         rnn = self.humanNodeRNN
         x = torch.cat((F.relu(rnn.encoder_linear(robot_states)), F.relu(rnn.edge_attention_embed(hr))), dim=-1)
         gi = F.linear(x, rnn.gru.weight_ih_l0, rnn.gru.bias_ih_l0).view(T, N, -1)

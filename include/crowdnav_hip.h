@@ -174,6 +174,35 @@ int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launche
 int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, void *stream);
 int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, void *stream);
 
+/* ---- robot-human attention, stand-alone (training path) ----
+ * EdgeAttention_M.att_func (rl/networks/selfAttn_srnn_temp_node.py:145-177) on COMPACTED rows: sample b owns rows
+ * row_off[b] .. row_off[b+1]-1.  t_emb [B,64] = temporal_edge_layer output, s_emb [R,64] = spatial_edge_layer output,
+ * out_sp [R,256] = the attended values.  fwd: attn [B,H] (zero on padded humans), hr_out [B,256] = sum_j attn_j out_sp_j
+ * with attn = softmax((H / 8) t . s_j).  bwd: d_t [B,64], d_s [R,64] and the direct-path d_o [R,256] from d_hr [B,256]. */
+int cn_hr_attention_fwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off,
+                        float *hr_out, float *attn, void *stream);
+int cn_hr_attention_bwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off,
+                        const float *attn, const float *d_hr, float *d_t, float *d_s, float *d_o, void *stream);
+
+/* ---- large Linear layers of the PPO update (training path), split-precision bf16x3 MFMA like the rollout forward ----
+ * Replace torch.nn.Linear forward/backward of embedding_layer.2, the folded (q|k|v)_linear∘in_proj and the folded
+ * out_proj∘spatial_linear (rl/networks/selfAttn_srnn_temp_node.py:63-91,408) as autograd runs them inside PPO.update
+ * (rl/ppo.py:60-95).  All pointers are device pointers; hi/lo are bf16 planes (uint16 storage) of the weight.
+ * cn_split_bf16:   w [rows,cols] fp32 -> hi, lo (bf16) of w (transpose = 0) or of w^T [cols,rows] (transpose = 1).
+ * cn_linear_fwd:   Y[M,N] = act(X[M,K] W^T + bias), W given as hi/lo [N,K]; act 0 = none, 1 = ReLU; bias may be NULL.
+ *                  With the transposed split of W [N,K] passed as a [K,N] weight it computes dX = dY W (no bias).
+ *                  N % 128 == 0, K % 64 == 0.
+ * cn_linear_wgrad: dW[N,K] = dY[M,N]^T X[M,K] and (optional) db[N] = column sums of dY.  The M reduction is cut into
+ *                  `splits` ranges whose partial products land in partials [splits,N,K] (db_partials [splits,N]) and are
+ *                  summed in split order (deterministic).  N % 128 == 0, K % 128 == 0.
+ * cn_linear_wgrad_splits: the split count the library would pick for (M,N,K); 0 if the shape is unsupported. */
+int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream);
+int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act,
+                  float *Y, int ldy, void *stream);
+int cn_linear_wgrad_splits(int M, int N, int K);
+int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, int splits, float *partials,
+                    float *db_partials, float *dW, float *db, void *stream);
+
 /* ---- GST trajectory predictor + VecPretextNormalize (CrowdSimPredRealGST-v0, BASELINE configs[3]) ----
  * cn_gst_predict          <- gst_updated/scripts/wrapper/crowd_nav_interface_parallel.py:45-114 CrowdNavPredInterfaceMultiEnv.forward
  *                            (st_model.forward, gst_updated/src/gumbel_social_transformer/st_model.py:271-455, shipped hyper-parameters)

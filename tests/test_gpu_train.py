@@ -106,8 +106,10 @@ def test_fused_rollout_equals_reference_style_stepping():
     assert torch.equal(ra.recurrent_hidden_states["human_node_rnn"], rb.recurrent_hidden_states["human_node_rnn"])
 
 
-def test_hip_attention_forward_backward_matches_torch_autograd():
-    """evaluate_actions on the GPU (HH attention core = cn_hh_attention_fwd/bwd) vs the pure torch-op graph on CPU:
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_hip_attention_forward_backward_matches_torch_autograd(mode):
+    """evaluate_actions on the GPU (HH attention core = cn_hh_attention_fwd/bwd; the three large Linear layers =
+    cn_linear_fwd / cn_linear_wgrad in 'bf16x3' mode, rocBLAS fp32 in 'fp32' mode) vs the pure torch-op graph on CPU:
     same values, log-probs and parameter gradients."""
     import copy
     from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
@@ -117,6 +119,7 @@ def test_hip_attention_forward_backward_matches_torch_autograd():
     ob_space, act_space = make_spaces(H, D)
     pol_c = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn", base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=N, num_mini_batch=1, seq_length=T))
     pol_g = copy.deepcopy(pol_c).cuda()
+    pol_g.base.train_gemm_mode = mode
     obs = PU.synth_obs(T * N, H, D, seed=4)
     obs_c = {k: torch.from_numpy(v) for k, v in obs.items()}
     h0 = torch.randn(N, 1, 128)
@@ -138,3 +141,79 @@ def test_hip_attention_forward_backward_matches_torch_autograd():
     for k in g_c:
         scale = max(float(g_c[k].abs().max()), 1e-3)
         assert float((g_c[k] - g_g[k]).abs().max()) <= 2e-4 * scale + 1e-5, (k, float((g_c[k] - g_g[k]).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 512, 128, True), (4097, 1536, 512, False), (300, 256, 512, True), (64, 128, 128, False),
+                                         (20000, 512, 128, True)])
+def test_hip_linear_forward_and_gradients_match_fp64(M, N, K, relu):
+    """cn_linear_fwd / cn_linear_wgrad (bf16x3 split precision) against an fp64 torch graph: outputs and all three
+    gradients within 1e-4 of the largest reference magnitude (the fp32 reference itself sits at ~1e-6)."""
+    from crowdnav_prediction_attngraph_amd import hip
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(M, N, generator=g)
+    xg, wg, bg = (t.cuda().requires_grad_() for t in (x, w, b))
+    assert hip.linear_supported(xg, wg)
+    y = hip.HipLinear.apply(xg, wg, bg, relu)
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    if relu:
+        # ReLU is discontinuous in its gradient: outputs within rounding of zero may land on either side, so the reference
+        # uses the kernel's own active set (and checks it only disagrees with the fp64 one where |y| is at rounding level)
+        act = (y.detach().cpu() > 0)
+        flipped = yr.detach()[act != (yr.detach() > 0)].abs()
+        assert flipped.numel() == 0 or float(flipped.max()) < 1e-4
+        yr = yr * act.double()
+    yr.backward(dy.double())
+
+    def close(a, ref, what):
+        ref = ref.float()
+        err = float((a.cpu() - ref).abs().max())
+        assert err <= 1e-4 * max(float(ref.abs().max()), 1e-3), (what, err, float(ref.abs().max()))
+
+    close(y.detach(), yr.detach(), "y")
+    close(xg.grad, xr.grad, "dx")
+    close(wg.grad, wr.grad, "dw")
+    close(bg.grad, br.grad, "db")
+    # deterministic: a second backward gives bit-identical gradients
+    xg2, wg2, bg2 = (t.cuda().requires_grad_() for t in (x, w, b))
+    hip.HipLinear.apply(xg2, wg2, bg2, relu).backward(dy.cuda())
+    assert torch.equal(wg.grad, wg2.grad) and torch.equal(bg.grad, bg2.grad) and torch.equal(xg.grad, xg2.grad)
+
+
+@pytest.mark.gpu
+def test_hr_attention_forward_backward_matches_dense_torch():
+    """cn_hr_attention_fwd/bwd on compacted rows vs the reference's dense masked formulation (att_func,
+    selfAttn_srnn_temp_node.py:145-177: scores * H/8, masked_fill(-1e9), softmax, bmm) under torch autograd in fp64."""
+    from crowdnav_prediction_attngraph_amd import hip
+    g = torch.Generator().manual_seed(11)
+    B, H = 37, 20
+    nd = torch.randint(1, H + 1, (B,), generator=g)
+    nd[0], nd[1] = 1, H
+    row_off = torch.cat([torch.zeros(1, dtype=torch.int64), nd.cumsum(0)]).to(torch.int32)
+    R = int(row_off[-1])
+    t = torch.randn(B, 64, generator=g)
+    s = torch.randn(R, 64, generator=g) * 0.3
+    o = torch.randn(R, 256, generator=g)
+    d_hr = torch.randn(B, 256, generator=g)
+    tg, sg, og = (x.cuda().requires_grad_() for x in (t, s, o))
+    hr = hip.HRAttention.apply(tg, sg, og, row_off.cuda(), H)
+    hr.backward(d_hr.cuda())
+    # dense fp64 reference
+    tr, sr, orr = (x.double().requires_grad_() for x in (t, s, o))
+    idx = torch.cat([torch.arange(int(n)) + b * H for b, n in enumerate(nd)])
+    S = torch.zeros(B * H, 64, dtype=torch.float64).index_copy(0, idx, sr).view(B, H, 64)
+    O = torch.zeros(B * H, 256, dtype=torch.float64).index_copy(0, idx, orr).view(B, H, 256)
+    valid = torch.arange(H).view(1, H) < nd.view(B, 1)
+    a = (tr.unsqueeze(1) * S).sum(-1) * (H / 8.0)
+    a = torch.softmax(a.masked_fill(~valid, -1e9), dim=-1)
+    ref = torch.bmm(a.unsqueeze(1), O).squeeze(1)
+    ref.backward(d_hr.double())
+    for got, want, what in ((hr.detach(), ref.detach(), "hr"), (tg.grad, tr.grad, "d_t"), (sg.grad, sr.grad, "d_s"), (og.grad, orr.grad, "d_o")):
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 2e-5 * max(float(want.abs().max()), 1.0), (what, err)
