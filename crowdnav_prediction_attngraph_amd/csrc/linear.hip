@@ -6,6 +6,63 @@
 #include "common.h"
 #include "gemm3.h"
 
+namespace {
+
+// GRU cell, pointwise part, for the PPO update (torch.nn.GRU gate order r,z,n; rl/networks/srnn_model.py:35-105 runs the
+// cell per time step with the hidden state multiplied by the done mask first).  gi = x W_ih^T + b_ih, gh = hm W_hh^T + b_hh
+// (hm = masked previous hidden state).  The forward keeps (r, z, n, gh_n) for the backward.
+__global__ __launch_bounds__(128) void gru_cell_fwd_kernel(int N, const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ hm,
+                                                           float *__restrict__ h_out, float *__restrict__ gates)
+{
+    const int e = blockIdx.x, c = threadIdx.x;
+    const float *gie = gi + (size_t)e * 384, *ghe = gh + (size_t)e * 384;
+    const float hn = ghe[256 + c];
+    const float r = 1.0f / (1.0f + expf(-(gie[c] + ghe[c])));
+    const float z = 1.0f / (1.0f + expf(-(gie[128 + c] + ghe[128 + c])));
+    const float n = tanhf(gie[256 + c] + r * hn);
+    h_out[(size_t)e * 128 + c] = (1.0f - z) * n + z * hm[(size_t)e * 128 + c];
+    float *g = gates + (size_t)e * 512;
+    g[c] = r; g[128 + c] = z; g[256 + c] = n; g[384 + c] = hn;
+}
+
+// dh' -> d(gi) [N,384], d(gh) [N,384] and the direct path d(hm) = dh' * z
+__global__ __launch_bounds__(128) void gru_cell_bwd_kernel(int N, const float *__restrict__ gates, const float *__restrict__ hm,
+                                                           const float *__restrict__ dh, float *__restrict__ dgi, float *__restrict__ dgh,
+                                                           float *__restrict__ dhm)
+{
+    const int e = blockIdx.x, c = threadIdx.x;
+    const float *g = gates + (size_t)e * 512;
+    const float r = g[c], z = g[128 + c], n = g[256 + c], hn = g[384 + c];
+    const float d = dh[(size_t)e * 128 + c], h = hm[(size_t)e * 128 + c];
+    const float din = d * (1.0f - z) * (1.0f - n * n); // d(i_n)
+    const float dr = din * hn * r * (1.0f - r);          // d(i_r) = d(h_r)
+    const float dz = d * (h - n) * z * (1.0f - z);       // d(i_z) = d(h_z)
+    float *a = dgi + (size_t)e * 384, *b = dgh + (size_t)e * 384;
+    a[c] = dr; a[128 + c] = dz; a[256 + c] = din;
+    b[c] = dr; b[128 + c] = dz; b[256 + c] = din * r;
+    dhm[(size_t)e * 128 + c] = d * z;
+}
+
+} // namespace
+
+extern "C" int cn_gru_cell_fwd(int N, const float *gi, const float *gh, const float *hm, float *h_out, float *gates, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(N >= 1 && gi && gh && hm && h_out && gates, "cn_gru_cell_fwd: bad argument");
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, N, gi, gh, hm, h_out, gates);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_gru_cell_bwd(int N, const float *gates, const float *hm, const float *dh, float *dgi, float *dgh, float *dhm, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(N >= 1 && gates && hm && dh && dgi && dgh && dhm, "cn_gru_cell_bwd: bad argument");
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, N, gates, hm, dh, dgi, dgh, dhm);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 extern "C" int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream)
 {
     if (int rc = cn_require_device()) return rc;

@@ -248,11 +248,17 @@ class AttnGraphBase(nn.Module):
         gi = F.linear(x, rnn.gru.weight_ih_l0, rnn.gru.bias_ih_l0).view(T, N, -1)
         m = masks.reshape(T, N, 1)
         h = h0.reshape(N, -1)
-        hs = []
-        for t in range(T):
-            h = self._gru_cell(gi[t], h * m[t])
-            hs.append(h)
-        out = rnn.output_linear(torch.stack(hs, 0).view(B, -1))
+        if gi.is_cuda:
+            from .hip import GRUSequence
+            hs_all = GRUSequence.apply(gi, h, m, rnn.gru.weight_hh_l0, rnn.gru.bias_hh_l0)
+            h = hs_all[-1]
+        else:
+            hs = []
+            for gi_t, m_t in zip(gi.unbind(0), m.unbind(0)):
+                h = self._gru_cell(gi_t, h * m_t)
+                hs.append(h)
+            hs_all = torch.stack(hs, 0)
+        out = rnn.output_linear(hs_all.view(B, -1))
         value = self.critic_linear(self.critic(out))
         return value, self.actor(out), h
 

@@ -184,6 +184,16 @@ int cn_hr_attention_fwd(int B, int H, const float *t_emb, const float *s_emb, co
 int cn_hr_attention_bwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off,
                         const float *attn, const float *d_hr, float *d_t, float *d_s, float *d_o, void *stream);
 
+/* ---- GRU cell of the human node RNN, pointwise part (training path) ----
+ * torch.nn.GRU (gate order r,z,n) as EndRNN drives it one step at a time with h * done-mask
+ * (rl/networks/srnn_model.py:35-105, selfAttn_srnn_temp_node.py:262-285), under autograd in PPO.update.
+ * gi [N,384] = x W_ih^T + b_ih, gh [N,384] = hm W_hh^T + b_hh, hm [N,128] = masked previous hidden state.
+ * fwd: h_out [N,128] and gates [N,512] = (r, z, n, gh_n) kept for the backward.
+ * bwd: from dh [N,128]: dgi [N,384], dgh [N,384] and the direct path dhm [N,128] = dh * z. */
+int cn_gru_cell_fwd(int N, const float *gi, const float *gh, const float *hm, float *h_out, float *gates, void *stream);
+int cn_gru_cell_bwd(int N, const float *gates, const float *hm, const float *dh, float *dgi, float *dgh, float *dhm,
+                    void *stream);
+
 /* ---- large Linear layers of the PPO update (training path), split-precision bf16x3 MFMA like the rollout forward ----
  * Replace torch.nn.Linear forward/backward of embedding_layer.2, the folded (q|k|v)_linear∘in_proj and the folded
  * out_proj∘spatial_linear (rl/networks/selfAttn_srnn_temp_node.py:63-91,408) as autograd runs them inside PPO.update
