@@ -141,8 +141,8 @@ def lib():
         L.cn_policy_get_profile.argtypes = [vp, C.POINTER(f64), C.POINTER(i64)]
         L.cn_hh_attention_fwd.argtypes = [i32, i32, vp, vp, f32, vp, vp]
         L.cn_hh_attention_bwd.argtypes = [i32, i32, vp, vp, vp, f32, vp, vp]
-        L.cn_hr_attention_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
-        L.cn_hr_attention_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.cn_hr_attention_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
+        L.cn_hr_attention_bwd.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.cn_gru_cell_fwd.argtypes = [i32, vp, vp, vp, vp, vp, vp]
         L.cn_gru_cell_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
         L.cn_split_bf16.argtypes = [vp, i32, i32, i32, vp, vp, vp]

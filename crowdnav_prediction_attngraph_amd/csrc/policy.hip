@@ -7,9 +7,8 @@
 //   gemm          [M,512] -> [M,1536]                           folded (q|k|v)_linear ∘ in_proj, 1/sqrt(64) folded into q
 //   hh_attention  per (env, head): softmax(QK^T + key padding mask) V  -> [M,512]
 //   gemm          [M,512] -> [M,256]  ReLU                      folded out_proj ∘ spatial_linear
-//   gemm          [M,256] -> [M,64]                             attn.spatial_edge_layer
-//   robot_embed   [E,9]   -> [E,256]  ReLU ; gemm -> [E,64]     robot_linear, attn.temporal_edge_layer
-//   hr_attention  per env: masked softmax over humans, weighted sum of [H,256]
+//   robot_embed   [E,9]   -> [E,256]  ReLU ; gemm -> [E,256]    robot_linear, u = spatial_edge_layer^T temporal_edge_layer(.)
+//   hr_attention  per env: scores u . out_sp_j, masked softmax over humans, weighted sum of [H,256]
 //   gemms + gru_pointwise + gemms(tanh) + gauss_head            EndRNN, actor/critic, DiagGaussian
 // The dense contractions run on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32, 155 TF peak): the
 // reference computes in fp32 and the parity bar is 1e-4, which bf16 inputs cannot hold at K = 512.
@@ -286,29 +285,27 @@ __global__ __launch_bounds__(128) void hh_attention_bwd_kernel(int B, int H, con
 }
 
 // Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177) on the compacted rows: one
-// wavefront per env.  masked_fill(-1e9) + softmax gives padded humans exactly zero weight (exp underflows to 0), so the
+// wavefront per env.  The reference scores are t . s_j with t = temporal_edge_layer(robot) [64] and s_j =
+// spatial_edge_layer(o_j) = Ws o_j + bs [64].  Since t . (Ws o_j + bs) = (Ws^T t) . o_j + t . bs and the softmax is
+// invariant to the per-env constant t . bs, the kernel takes u = Ws^T t [256] and scores u . o_j directly: the
+// [rows,256]x[256,64] projection of every human row (and its two backward products) is replaced by a [E,64]x[64,256]
+// product per env.  masked_fill(-1e9) + softmax gives padded humans exactly zero weight (exp underflows to 0), so the
 // softmax and the weighted sum run over the nd live rows only.
-__global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ t_emb, int t_ld, const float *__restrict__ s_emb,
-                                                           const float *__restrict__ out_sp, const int *__restrict__ row_off,
-                                                           float *__restrict__ hr_out, float *__restrict__ hr_attn)
+__global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ u, int u_ld, const float *__restrict__ out_sp,
+                                                           const int *__restrict__ row_off, float *__restrict__ hr_out, float *__restrict__ hr_attn)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 4 + wave;
     if (e >= E) return;
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
-    float *Ss = smem + (size_t)wave * (H * 65 + 64);
-    float *Ts = Ss + H * 65;
-    for (int j = 0; j < nd; ++j) Ss[j * 65 + lane] = s_emb[(size_t)(r0 + j) * 64 + lane];
-    Ts[lane] = t_emb[(size_t)e * t_ld + lane];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    const int jl = lane < nd ? lane : 0;
-    float s = 0.0f;
-#pragma unroll 16
-    for (int d = 0; d < 64; ++d) s += Ts[d] * Ss[jl * 65 + d];
-    s = s * ((float)H / 8.0f);                 // temperature = num_edges / sqrt(attention_size = 64)
-    s = lane < nd ? s : -INFINITY;
+    const float *ue = u + (size_t)e * u_ld;
+    const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
+    float s = -INFINITY; // lane j holds the score of human j
+    for (int j = 0; j < nd; ++j) {
+        const float *row = out_sp + (size_t)(r0 + j) * 256;
+        const float tot = wv_sum(u0 * row[lane] + u1 * row[64 + lane] + u2 * row[128 + lane] + u3 * row[192 + lane]);
+        if (lane == j) s = tot * ((float)H / 8.0f); // temperature = num_edges / sqrt(attention_size = 64)
+    }
     const float mx = wv_max(s);
     const float p = lane < nd ? expf(s - mx) : 0.0f;
     const float denom = wv_sum(p);
@@ -325,40 +322,38 @@ __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const f
 }
 
 // Backward of hr_attention_kernel for the PPO update: one wavefront per sample on the compacted rows.
-//   a_j = T (t . s_j), p = softmax(a), hr = sum_j p_j o_j         (T = H / 8)
-//   dp_j = d_hr . o_j ; g_j = T p_j (dp_j - sum_k p_k dp_k) ; d_t = sum_j g_j s_j ; d_s_j = g_j t ; d_o_j = p_j d_hr
-// (d_o is only the direct weighted-sum path; the s = Linear(o) path is differentiated by the caller's graph.)
-__global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, const float *__restrict__ t_emb, const float *__restrict__ s_emb,
-                                                               const float *__restrict__ out_sp, const int *__restrict__ row_off,
-                                                               const float *__restrict__ attn, const float *__restrict__ d_hr,
-                                                               float *__restrict__ d_t, float *__restrict__ d_s, float *__restrict__ d_o)
+//   a_j = T (u . o_j), p = softmax(a), hr = sum_j p_j o_j         (T = H / 8)
+//   dp_j = d_hr . o_j ; g_j = T p_j (dp_j - sum_k p_k dp_k) ; d_u = sum_j g_j o_j ; d_o_j = p_j d_hr + g_j u
+__global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, const float *__restrict__ u, const float *__restrict__ out_sp,
+                                                               const int *__restrict__ row_off, const float *__restrict__ attn,
+                                                               const float *__restrict__ d_hr, float *__restrict__ d_u, float *__restrict__ d_o)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 4 + wave;
     if (e >= B) return;
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
     const float a = lane < nd ? attn[(size_t)e * H + lane] : 0.0f; // lanes = humans
-    const float *g = d_hr + (size_t)e * 256;
+    const float *g = d_hr + (size_t)e * 256, *ue = u + (size_t)e * 256;
     const float g0 = g[lane], g1 = g[64 + lane], g2 = g[128 + lane], g3 = g[192 + lane];
+    const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
     float dp = 0.0f;
     for (int j = 0; j < nd; ++j) {
         const float *row = out_sp + (size_t)(r0 + j) * 256;
         const float tot = wv_sum(g0 * row[lane] + g1 * row[64 + lane] + g2 * row[128 + lane] + g3 * row[192 + lane]);
         if (lane == j) dp = tot;
-        float *dor = d_o + (size_t)(r0 + j) * 256;
-        const float aj = wv_readlane(a, j);
-        dor[lane] = aj * g0; dor[64 + lane] = aj * g1; dor[128 + lane] = aj * g2; dor[192 + lane] = aj * g3;
     }
     const float dot = wv_sum(a * dp);
     const float gg = a * (dp - dot) * ((float)H / 8.0f);
-    const float tl = t_emb[(size_t)e * 64 + lane];
-    float dt = 0.0f;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     for (int j = 0; j < nd; ++j) {
-        const float gj = wv_readlane(gg, j);
-        dt += gj * s_emb[(size_t)(r0 + j) * 64 + lane];
-        d_s[(size_t)(r0 + j) * 64 + lane] = gj * tl;
+        const float aj = wv_readlane(a, j), gj = wv_readlane(gg, j);
+        const float *row = out_sp + (size_t)(r0 + j) * 256;
+        float *dor = d_o + (size_t)(r0 + j) * 256;
+        d0 += gj * row[lane]; d1 += gj * row[64 + lane]; d2 += gj * row[128 + lane]; d3 += gj * row[192 + lane];
+        dor[lane] = aj * g0 + gj * u0; dor[64 + lane] = aj * g1 + gj * u1; dor[128 + lane] = aj * g2 + gj * u2; dor[192 + lane] = aj * g3 + gj * u3;
     }
-    d_t[(size_t)e * 64 + lane] = dt;
+    float *du = d_u + (size_t)e * 256;
+    du[lane] = d0; du[64 + lane] = d1; du[128 + lane] = d2; du[192 + lane] = d3;
 }
 
 // test tap: scatter the compacted [rows,256] activations back to [E,H,256] (zeros on padded humans)
@@ -445,6 +440,24 @@ __global__ void fold_bias_kernel(int N, int J, const float *__restrict__ A, cons
     c[n] = (float)(acc * (double)scale);
 }
 
+// C[N,K] = A^T B with A [J,N], B [J,K];  c[n] = sum_j A[j][n] * b[j]
+__global__ void fold_mm_tn_kernel(int N, int J, int K, const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (k >= K || n >= N) return;
+    double acc = 0.0;
+    for (int j = 0; j < J; ++j) acc += (double)A[(size_t)j * N + n] * (double)B[(size_t)j * K + k];
+    C[(size_t)n * K + k] = (float)acc;
+}
+__global__ void fold_bias_tn_kernel(int N, int J, const float *__restrict__ A, const float *__restrict__ b, float *__restrict__ c)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double acc = 0.0;
+    for (int j = 0; j < J; ++j) acc += (double)A[(size_t)j * N + n] * (double)b[j];
+    c[n] = (float)acc;
+}
+
 constexpr size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 } // namespace
@@ -466,11 +479,11 @@ struct cn_policy {
     float *ac0_w, *ac0_b;                   // concat(actor.0, critic.0) [512,256]
     float *a2_w, *a2_b, *c2_w, *c2_b;       // [256,256]
     float *cl_w, *cl_b, *fm_w, *fm_b, *logstd;
-    float *te_w, *te_b;       // [attn.temporal_edge_layer ; encoder_linear] stacked [128,256]
+    float *te_w, *te_b;       // [spatial_edge_layer^T * temporal_edge_layer (u, 256 rows) ; encoder_linear (64 rows)] stacked [320,256]
     float *ac0f_w, *ac0f_b;   // (actor.0 ; critic.0) folded with output_linear [512,128]
     float *z;                 // [E,192] = [t_emb | relu(enc) | relu(edge)]
     // activations
-    float *emb1, *emb2, *qkv, *attn, *out_sp, *s_emb;
+    float *emb1, *emb2, *qkv, *attn, *out_sp;
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
     int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split (default)
     unsigned long long *live_total; // device counter: sum of live rows over the profiled forwards
@@ -528,14 +541,14 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_a2w = carve(256 * 256), o_a2b = carve(256), o_c2w = carve(256 * 256), o_c2b = carve(256);
     const size_t o_clw = carve(256), o_clb = carve(1), o_fmw = carve(512), o_fmb = carve(2), o_ls = carve(2);
     const size_t o_emb1 = carve(M * 128), o_emb2 = carve(M * 512), o_qkv = carve(M * 1536), o_attn = carve(M * 512);
-    const size_t o_outsp = carve(M * 256), o_semb = carve(M * 64);
+    const size_t o_outsp = carve(M * 256);
     const size_t o_rs = carve(E * 256), o_temb = carve(E * 64), o_hr = carve(E * 256), o_hra = carve(M), o_x = carve(E * 128);
     const size_t o_gi = carve(E * 384), o_gh = carve(E * 384), o_hn = carve(E * 128), o_ro = carve(E * 256);
     const size_t o_ac1 = carve(E * 512), o_ac2 = carve(E * 512);
     const size_t o_roff = carve(E + 1);
     const size_t o_live = carve(2);
     const size_t o_ccnt = carve(2), o_clist = carve(2 * E);
-    const size_t o_tew = carve(128 * 256), o_teb = carve(128), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 192);
+    const size_t o_tew = carve(320 * 256), o_teb = carve(320), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 384);
     const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
     const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
     char *base = nullptr;
@@ -550,7 +563,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->wih = F(o_wih); p->whh = F(o_whh); p->bih = F(o_bih); p->bhh = F(o_bhh); p->out_w = F(o_outw); p->out_b = F(o_outb);
     p->ac0_w = F(o_ac0w); p->ac0_b = F(o_ac0b); p->a2_w = F(o_a2w); p->a2_b = F(o_a2b); p->c2_w = F(o_c2w); p->c2_b = F(o_c2b);
     p->cl_w = F(o_clw); p->cl_b = F(o_clb); p->fm_w = F(o_fmw); p->fm_b = F(o_fmb); p->logstd = F(o_ls);
-    p->emb1 = F(o_emb1); p->emb2 = F(o_emb2); p->qkv = F(o_qkv); p->attn = F(o_attn); p->out_sp = F(o_outsp); p->s_emb = F(o_semb);
+    p->emb1 = F(o_emb1); p->emb2 = F(o_emb2); p->qkv = F(o_qkv); p->attn = F(o_attn); p->out_sp = F(o_outsp);
     p->robot_states = F(o_rs); p->t_emb = F(o_temb); p->hr_out = F(o_hr); p->hr_attn = F(o_hra); p->x = F(o_x);
     p->gi = F(o_gi); p->gh = F(o_gh); p->hnew = F(o_hn); p->rnn_out = F(o_ro); p->ac1 = F(o_ac1); p->ac2 = F(o_ac2);
     p->row_off = (int *)(base + o_roff);
@@ -637,8 +650,13 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
     CN_D2D(p->ac0_b, w->actor0_b, 256); CN_D2D(p->ac0_b + 256, w->critic0_b, 256);
     CN_D2D(p->a2_w, w->actor2_w, 256 * 256); CN_D2D(p->a2_b, w->actor2_b, 256);
     CN_D2D(p->c2_w, w->critic2_w, 256 * 256); CN_D2D(p->c2_b, w->critic2_b, 256);
-    CN_D2D(p->te_w, w->attn_temporal_w, 64 * 256); CN_D2D(p->te_w + 64 * 256, w->enc_w, 64 * 256);
-    CN_D2D(p->te_b, w->attn_temporal_b, 64); CN_D2D(p->te_b + 64, w->enc_b, 64);
+    // u = Ws^T (Wt r + bt): the robot-human scores become u . o_j (see hr_attention_kernel)
+    hipLaunchKernelGGL(fold_mm_tn_kernel, dim3(1, 256), dim3(256), 0, st, 256, 64, 256, w->attn_spatial_w, w->attn_temporal_w, p->te_w);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(fold_bias_tn_kernel, dim3(1), dim3(256), 0, st, 256, 64, w->attn_spatial_w, w->attn_temporal_b, p->te_b);
+    CN_CHECK_LAUNCH();
+    CN_D2D(p->te_w + 256 * 256, w->enc_w, 64 * 256);
+    CN_D2D(p->te_b + 256, w->enc_b, 64);
     // fold output_linear into the first actor / critic layers: tanh(W0 (Wo h + bo) + b0) = tanh((W0 Wo) h + (W0 bo + b0))
     hipLaunchKernelGGL(fold_mm_kernel, dim3(1, 512), dim3(128), 0, st, 512, 256, 128, p->ac0_w, w->out_w, 1.0f, p->ac0f_w);
     CN_CHECK_LAUNCH();
@@ -685,8 +703,8 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         hipLaunchKernelGGL(robot_embed_kernel, dim3(blocks), dim3(256), 0, p->side, E, obs->temporal_edges, obs->robot_node, p->rl_w, p->rl_b, p->robot_states);
         CN_CHECK_LAUNCH();
     }
-    // [t_emb | relu(enc)] in one launch (both read robot_states); z = [t_emb | enc | edge], x = z + 64
-    if ((rc = launch_gemm_env<ACT_NONE>(E, 128, 256, p->robot_states, 256, p->te_w, p->te_b, p->z, 192, p->side, 1, GemmBatch{0, 0, 0, 0}, 64))) return rc;
+    // [u | relu(enc)] in one launch (both read robot_states); z = [u (256) | enc (64) | edge (64)], GRU input x = z + 256
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 320, 256, p->robot_states, 256, p->te_w, p->te_b, p->z, 384, p->side, 1, GemmBatch{0, 0, 0, 0}, 256))) return rc;
     if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, hxs_in, 128, p->whh, nullptr, p->gh, 384, p->side))) return rc; // GRU hidden-side gates
     CN_HIP(hipEventRecord(p->ev_join, p->side));
     // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
@@ -717,18 +735,15 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     if (split) rc = launch_gemm3<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
     else rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
     if (rc) return rc;
-    if ((rc = launch_gemm<64, ACT_NONE>(M, 64, 256, p->out_sp, 256, p->as_w, p->as_b, p->s_emb, 64, st, m_dev))) return rc;
     // ---- robot-human attention (robot node embeddings arrive from the side stream) ----
     CN_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
     {
-        const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
-        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), lds, st, E, H, p->z, 192, p->s_emb, p->out_sp, p->row_off,
-                           p->hr_out, p->hr_attn);
+        hipLaunchKernelGGL(hr_attention_kernel, dim3((E + 3) / 4), dim3(256), 0, st, E, H, p->z, 384, p->out_sp, p->row_off, p->hr_out, p->hr_attn);
         CN_CHECK_LAUNCH();
     }
     // ---- EndRNN: edge encoder -> GRU (output_linear is folded into the actor / critic trunks) ----
-    if ((rc = launch_gemm_env<ACT_RELU>(E, 64, 256, p->hr_out, 256, p->edge_w, p->edge_b, p->z + 128, 192, st))) return rc;
-    if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, p->z + 64, 192, p->wih, p->bih, p->gi, 384, st))) return rc;
+    if ((rc = launch_gemm_env<ACT_RELU>(E, 64, 256, p->hr_out, 256, p->edge_w, p->edge_b, p->z + 320, 384, st))) return rc;
+    if ((rc = launch_gemm_env<ACT_NONE>(E, 384, 128, p->z + 256, 384, p->wih, p->bih, p->gi, 384, st))) return rc;
     float *hdst = hxs_out ? hxs_out : p->hnew;
     hipLaunchKernelGGL(gru_pointwise_kernel, dim3(E), dim3(128), 0, st, E, p->gi, p->gh, p->bhh, hxs_in, masks, hdst);
     CN_CHECK_LAUNCH();
@@ -811,26 +826,21 @@ extern "C" int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *ro
     return CN_OK;
 }
 
-extern "C" int cn_hr_attention_fwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off, float *hr_out,
-                                   float *attn, void *stream)
+extern "C" int cn_hr_attention_fwd(int B, int H, const float *u, const float *out_sp, const int *row_off, float *hr_out, float *attn, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
-    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && t_emb && s_emb && out_sp && row_off && hr_out && attn, "cn_hr_attention_fwd: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)4 * (H * 65 + 64) * sizeof(float);
-    hipLaunchKernelGGL(hr_attention_kernel, dim3((B + 3) / 4), dim3(256), lds, st, B, H, t_emb, 64, s_emb, out_sp, row_off, hr_out, attn);
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && u && out_sp && row_off && hr_out && attn, "cn_hr_attention_fwd: bad argument");
+    hipLaunchKernelGGL(hr_attention_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, H, u, 256, out_sp, row_off, hr_out, attn);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
 
-extern "C" int cn_hr_attention_bwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off, const float *attn,
-                                   const float *d_hr, float *d_t, float *d_s, float *d_o, void *stream)
+extern "C" int cn_hr_attention_bwd(int B, int H, const float *u, const float *out_sp, const int *row_off, const float *attn, const float *d_hr,
+                                   float *d_u, float *d_o, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
-    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && t_emb && s_emb && out_sp && row_off && attn && d_hr && d_t && d_s && d_o,
-               "cn_hr_attention_bwd: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, t_emb, s_emb, out_sp, row_off, attn, d_hr, d_t, d_s, d_o);
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && u && out_sp && row_off && attn && d_hr && d_u && d_o, "cn_hr_attention_bwd: bad argument");
+    hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, H, u, out_sp, row_off, attn, d_hr, d_u, d_o);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

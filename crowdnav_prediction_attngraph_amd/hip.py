@@ -273,28 +273,28 @@ class HHAttention(torch.autograd.Function):
 
 
 class HRAttention(torch.autograd.Function):
-    """Robot-human attention on compacted rows (cn_hr_attention_fwd / cn_hr_attention_bwd): t [B,64], s [R,64], o [R,256],
-    row_off [B+1] int32 -> hr [B,256].  The returned d_o is the weighted-sum path only (s = Linear(o) is the caller's graph)."""
+    """Robot-human attention on compacted rows (cn_hr_attention_fwd / cn_hr_attention_bwd): u [B,256] = Ws^T t (the
+    spatial_edge_layer projection moved to the robot side, see include/crowdnav_hip.h), o [R,256], row_off [B+1] int32
+    -> hr [B,256]."""
 
     @staticmethod
-    def forward(ctx, t, s, o, row_off, H):
-        t, s, o = t.contiguous(), s.contiguous(), o.contiguous()
-        B = t.shape[0]
-        hr = torch.empty(B, 256, device=t.device)
-        attn = torch.empty(B, H, device=t.device)
-        A.check(A.lib().cn_hr_attention_fwd(B, int(H), A.ptr(t), A.ptr(s), A.ptr(o), A.ptr(row_off), A.ptr(hr), A.ptr(attn), A.stream_ptr()),
-                "cn_hr_attention_fwd")
-        ctx.save_for_backward(t, s, o, row_off, attn)
+    def forward(ctx, u, o, row_off, H):
+        u, o = u.contiguous(), o.contiguous()
+        B = u.shape[0]
+        hr = torch.empty(B, 256, device=u.device)
+        attn = torch.empty(B, H, device=u.device)
+        A.check(A.lib().cn_hr_attention_fwd(B, int(H), A.ptr(u), A.ptr(o), A.ptr(row_off), A.ptr(hr), A.ptr(attn), A.stream_ptr()), "cn_hr_attention_fwd")
+        ctx.save_for_backward(u, o, row_off, attn)
         ctx.H = int(H)
         return hr
 
     @staticmethod
     def backward(ctx, d_hr):
-        t, s, o, row_off, attn = ctx.saved_tensors
-        d_t, d_s, d_o = torch.empty_like(t), torch.empty_like(s), torch.empty_like(o)
-        A.check(A.lib().cn_hr_attention_bwd(t.shape[0], ctx.H, A.ptr(t), A.ptr(s), A.ptr(o), A.ptr(row_off), A.ptr(attn), A.ptr(d_hr.contiguous()),
-                                            A.ptr(d_t), A.ptr(d_s), A.ptr(d_o), A.stream_ptr()), "cn_hr_attention_bwd")
-        return d_t, d_s, d_o, None, None
+        u, o, row_off, attn = ctx.saved_tensors
+        d_u, d_o = torch.empty_like(u), torch.empty_like(o)
+        A.check(A.lib().cn_hr_attention_bwd(u.shape[0], ctx.H, A.ptr(u), A.ptr(o), A.ptr(row_off), A.ptr(attn), A.ptr(d_hr.contiguous()), A.ptr(d_u), A.ptr(d_o),
+                                            A.stream_ptr()), "cn_hr_attention_bwd")
+        return d_u, d_o, None, None
 
 
 class GRUSequence(torch.autograd.Function):

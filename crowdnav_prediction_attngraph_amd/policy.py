@@ -238,9 +238,12 @@ class AttnGraphBase(nn.Module):
         out_sp, valid = self._hh_block(inputs["spatial_edges"].reshape(B, self.human_num, self.edge_width), det)
         if out_sp.is_cuda:
             # compacted rows [R,256] + row offsets: HIP robot-human attention forward/backward (no dense [B,H,256] tensors)
+            # t . (Ws o_j + bs) = (Ws^T t) . o_j + const: the spatial_edge_layer projection moves to the robot side (B rows
+            # instead of ~6B) and its bias, which the softmax cannot see, keeps an exactly-zero gradient
             from .hip import HRAttention
-            hr = HRAttention.apply(self.attn.temporal_edge_layer[0](robot_states), self.attn.spatial_edge_layer[0](out_sp), out_sp, valid,
-                                   self.human_num)
+            sl = self.attn.spatial_edge_layer[0]
+            u = self.attn.temporal_edge_layer[0](robot_states) @ sl.weight + 0.0 * sl.bias.sum()
+            hr = HRAttention.apply(u, out_sp, valid, self.human_num)
         else:
             hr, _ = self._hr_attention(robot_states, out_sp, valid)
         rnn = self.humanNodeRNN

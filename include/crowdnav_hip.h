@@ -176,13 +176,15 @@ int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, cons
 
 /* ---- robot-human attention, stand-alone (training path) ----
  * EdgeAttention_M.att_func (rl/networks/selfAttn_srnn_temp_node.py:145-177) on COMPACTED rows: sample b owns rows
- * row_off[b] .. row_off[b+1]-1.  t_emb [B,64] = temporal_edge_layer output, s_emb [R,64] = spatial_edge_layer output,
- * out_sp [R,256] = the attended values.  fwd: attn [B,H] (zero on padded humans), hr_out [B,256] = sum_j attn_j out_sp_j
- * with attn = softmax((H / 8) t . s_j).  bwd: d_t [B,64], d_s [R,64] and the direct-path d_o [R,256] from d_hr [B,256]. */
-int cn_hr_attention_fwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off,
-                        float *hr_out, float *attn, void *stream);
-int cn_hr_attention_bwd(int B, int H, const float *t_emb, const float *s_emb, const float *out_sp, const int *row_off,
-                        const float *attn, const float *d_hr, float *d_t, float *d_s, float *d_o, void *stream);
+ * row_off[b] .. row_off[b+1]-1 of out_sp [R,256] (the attended values).  The reference scores t . s_j with
+ * t = temporal_edge_layer(robot) and s_j = spatial_edge_layer(out_sp_j) = Ws out_sp_j + bs equal (Ws^T t) . out_sp_j up
+ * to a per-sample constant the softmax ignores, so the op takes u [B,256] = Ws^T t instead of t and s.
+ * fwd: attn [B,H] = softmax((H / 8) u . out_sp_j) (zero on padded humans), hr_out [B,256] = sum_j attn_j out_sp_j.
+ * bwd: d_u [B,256] and d_o [R,256] from d_hr [B,256]. */
+int cn_hr_attention_fwd(int B, int H, const float *u, const float *out_sp, const int *row_off, float *hr_out, float *attn,
+                        void *stream);
+int cn_hr_attention_bwd(int B, int H, const float *u, const float *out_sp, const int *row_off, const float *attn,
+                        const float *d_hr, float *d_u, float *d_o, void *stream);
 
 /* ---- GRU cell of the human node RNN, pointwise part (training path) ----
  * torch.nn.GRU (gate order r,z,n) as EndRNN drives it one step at a time with h * done-mask

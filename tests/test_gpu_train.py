@@ -188,8 +188,9 @@ def test_hip_linear_forward_and_gradients_match_fp64(M, N, K, relu):
 
 @pytest.mark.gpu
 def test_hr_attention_forward_backward_matches_dense_torch():
-    """cn_hr_attention_fwd/bwd on compacted rows vs the reference's dense masked formulation (att_func,
-    selfAttn_srnn_temp_node.py:145-177: scores * H/8, masked_fill(-1e9), softmax, bmm) under torch autograd in fp64."""
+    """cn_hr_attention_fwd/bwd on compacted rows, in the u = Ws^T t form, vs the reference's dense masked formulation
+    (att_func, selfAttn_srnn_temp_node.py:145-177: t . (Ws o + bs) * H/8, masked_fill(-1e9), softmax, bmm) under torch
+    autograd in fp64: same output and same gradients for t, Ws and o (bs gets zero: the softmax cannot see it)."""
     from crowdnav_prediction_attngraph_amd import hip
     g = torch.Generator().manual_seed(11)
     B, H = 37, 20
@@ -198,22 +199,24 @@ def test_hr_attention_forward_backward_matches_dense_torch():
     row_off = torch.cat([torch.zeros(1, dtype=torch.int64), nd.cumsum(0)]).to(torch.int32)
     R = int(row_off[-1])
     t = torch.randn(B, 64, generator=g)
-    s = torch.randn(R, 64, generator=g) * 0.3
+    Ws = torch.randn(64, 256, generator=g) * 0.05
+    bs = torch.randn(64, generator=g)
     o = torch.randn(R, 256, generator=g)
     d_hr = torch.randn(B, 256, generator=g)
-    tg, sg, og = (x.cuda().requires_grad_() for x in (t, s, o))
-    hr = hip.HRAttention.apply(tg, sg, og, row_off.cuda(), H)
+    tg, wg, og = (x.cuda().requires_grad_() for x in (t, Ws, o))
+    hr = hip.HRAttention.apply(tg @ wg, og, row_off.cuda(), H)
     hr.backward(d_hr.cuda())
     # dense fp64 reference
-    tr, sr, orr = (x.double().requires_grad_() for x in (t, s, o))
+    tr, wr, br, orr = (x.double().requires_grad_() for x in (t, Ws, bs, o))
     idx = torch.cat([torch.arange(int(n)) + b * H for b, n in enumerate(nd)])
-    S = torch.zeros(B * H, 64, dtype=torch.float64).index_copy(0, idx, sr).view(B, H, 64)
     O = torch.zeros(B * H, 256, dtype=torch.float64).index_copy(0, idx, orr).view(B, H, 256)
+    S = torch.nn.functional.linear(O, wr, br)
     valid = torch.arange(H).view(1, H) < nd.view(B, 1)
     a = (tr.unsqueeze(1) * S).sum(-1) * (H / 8.0)
     a = torch.softmax(a.masked_fill(~valid, -1e9), dim=-1)
     ref = torch.bmm(a.unsqueeze(1), O).squeeze(1)
     ref.backward(d_hr.double())
-    for got, want, what in ((hr.detach(), ref.detach(), "hr"), (tg.grad, tr.grad, "d_t"), (sg.grad, sr.grad, "d_s"), (og.grad, orr.grad, "d_o")):
+    assert float(br.grad.abs().max()) < 1e-9
+    for got, want, what in ((hr.detach(), ref.detach(), "hr"), (tg.grad, tr.grad, "d_t"), (wg.grad, wr.grad, "d_Ws"), (og.grad, orr.grad, "d_o")):
         err = float((got.cpu().double() - want).abs().max())
         assert err <= 2e-5 * max(float(want.abs().max()), 1.0), (what, err)
