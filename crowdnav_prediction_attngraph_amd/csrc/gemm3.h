@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, cons
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
     const int c = tid & 127, g0 = tid >> 7;
+    const bool n_ok = n_blk + c < N; // N may end inside the tile (64-wide layers): the surplus columns stay zero
     const bool want_db = db_part != nullptr && blockIdx.y == 0;
 
     f32x16 acc[2][NB];
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, cons
             for (int u = 0; u < 8; ++u) {
                 const int m = m0 + (g0 + 2 * p) * 8 + u;
                 const bool ok = m < m_end;
-                pa[p][u] = ok ? a_col[(size_t)m * ldy] : 0.0f;
+                pa[p][u] = ok && n_ok ? a_col[(size_t)m * ldy] : 0.0f;
                 pb[p][u] = ok ? b_col[(size_t)m * ldx] : 0.0f;
             }
     };
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                P[(size_t)row * K + col] = acc[i][j][r];
+                if (row < N) P[(size_t)row * K + col] = acc[i][j][r];
             }
         }
     if (want_db) { // uniform per block
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, cons
         float *red = reinterpret_cast<float *>(smem3);
         red[tid] = colsum;
         __syncthreads();
-        if (tid < 128) db_part[(size_t)split * N + n_blk + tid] = red[tid] + red[tid + 128];
+        if (tid < 128 && n_blk + tid < N) db_part[(size_t)split * N + n_blk + tid] = red[tid] + red[tid + 128];
     }
 }
 

@@ -43,7 +43,76 @@ __global__ __launch_bounds__(128) void gru_cell_bwd_kernel(int N, const float *_
     dhm[(size_t)e * 128 + c] = d * z;
 }
 
+// embedding_layer.0 of the human-human block in the update: Linear(D -> 128) + ReLU with D = 2 or 12 input features
+// (selfAttn_srnn_temp_node.py:33-36).  K is far too small for the matrix cores and its weight gradient is a reduction of
+// several hundred thousand rows into a [128, D] matrix: thread n owns output column n; rows are walked grid-stride
+// (coalesced 512-byte row reads of y / dy, broadcast reads of the D inputs); per-block partial sums are reduced in
+// block order afterwards (deterministic).
+__global__ __launch_bounds__(128) void embed0_fwd_kernel(int R, int D, const float *__restrict__ x, const float *__restrict__ W,
+                                                         const float *__restrict__ b, float *__restrict__ y)
+{
+    const int n = threadIdx.x;
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) w[d] = d < D ? W[n * D + d] : 0.0f;
+    const float bn = b[n];
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const float *xr = x + (size_t)r * D;
+        float acc = bn;
+#pragma unroll
+        for (int d = 0; d < 16; ++d)
+            if (d < D) acc += xr[d] * w[d];
+        y[(size_t)r * 128 + n] = fmaxf(acc, 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(128) void embed0_bwd_kernel(int R, int D, const float *__restrict__ x, const float *__restrict__ y,
+                                                         const float *__restrict__ dy, float *__restrict__ part)
+{
+    const int n = threadIdx.x;
+    float acc[17];
+#pragma unroll
+    for (int d = 0; d < 17; ++d) acc[d] = 0.0f;
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const float g = y[(size_t)r * 128 + n] > 0.0f ? dy[(size_t)r * 128 + n] : 0.0f;
+        const float *xr = x + (size_t)r * D;
+#pragma unroll
+        for (int d = 0; d < 16; ++d)
+            if (d < D) acc[d] += g * xr[d];
+        acc[16] += g;
+    }
+    float *p = part + ((size_t)blockIdx.x * 128 + n) * (D + 1); // [block][n][D weights | bias]
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+        if (d < D) p[d] = acc[d];
+    p[D] = acc[16];
+}
+
 } // namespace
+
+extern "C" int cn_embed0_fwd(int R, int D, const float *x, const float *W, const float *b, float *y, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(R >= 1 && D >= 1 && D <= 16 && x && W && b && y, "cn_embed0_fwd: bad argument (D must be in [1,16])");
+    const int blocks = R < 8192 ? R : 8192;
+    hipLaunchKernelGGL(embed0_fwd_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, R, D, x, W, b, y);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_embed0_bwd(int R, int D, const float *x, const float *y, const float *dy, int blocks, float *partials, float *dWb, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(R >= 1 && D >= 1 && D <= 16 && x && y && dy && partials && dWb && blocks >= 1, "cn_embed0_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (blocks > R) blocks = R;
+    hipLaunchKernelGGL(embed0_bwd_kernel, dim3(blocks), dim3(128), 0, st, R, D, x, y, dy, partials);
+    CN_CHECK_LAUNCH();
+    const size_t n = (size_t)128 * (D + 1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, blocks, partials, dWb);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 extern "C" int cn_gru_cell_fwd(int N, const float *gi, const float *gh, const float *hm, float *h_out, float *gates, void *stream)
 {
@@ -90,8 +159,8 @@ extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const
 
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {
-    if (M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 128) return 0;
-    const long long tiles = (long long)(N / 128) * (K / 128);
+    if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 128) return 0;
+    const long long tiles = (long long)((N + 127) / 128) * (K / 128);
     long long s = (768 + tiles - 1) / tiles;             // ~3 resident waves of blocks on 256 CUs
     const long long chunks = ((long long)M + BK3 - 1) / BK3;
     if (s > chunks) s = chunks;
@@ -103,7 +172,7 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(dY && X && partials && dW && M > 0 && splits >= 1, "cn_linear_wgrad: bad argument");
-    CN_REQUIRE(N % 128 == 0 && K % 128 == 0, "cn_linear_wgrad: N=%d and K=%d must be multiples of 128", N, K);
+    CN_REQUIRE(N % 64 == 0 && K % 128 == 0, "cn_linear_wgrad: N=%d must be a multiple of 64 and K=%d of 128", N, K);
     CN_REQUIRE((db == nullptr) == (db_partials == nullptr), "cn_linear_wgrad: db and db_partials go together");
     CN_REQUIRE(ldy >= N && ldx >= K, "cn_linear_wgrad: leading dimension smaller than the row length");
     hipStream_t st = (hipStream_t)stream;
@@ -116,7 +185,7 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm3_tn_kernel, dim3(N / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, X, ldx, rows, partials, db_partials);
+    hipLaunchKernelGGL(gemm3_tn_kernel, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, X, ldx, rows, partials, db_partials);
     CN_CHECK_LAUNCH();
     const size_t nk = (size_t)N * K;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, nk, used, partials, dW);

@@ -358,6 +358,64 @@ def linear_supported(x, w):
     return x.is_cuda and x.dtype == torch.float32 and N % 128 == 0 and K % 128 == 0
 
 
+class Embed0(torch.autograd.Function):
+    """relu(x w^T + b) for the D -> 128 input embedding of the human-human block (cn_embed0_fwd / cn_embed0_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        R, D = x.shape
+        y = torch.empty(R, 128, device=x.device)
+        if R:
+            A.check(A.lib().cn_embed0_fwd(R, D, A.ptr(x), A.ptr(w.detach().contiguous()), A.ptr(b.detach().contiguous()), A.ptr(y), A.stream_ptr()), "cn_embed0_fwd")
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        R, D = x.shape
+        if R == 0:
+            return None, x.new_zeros(128, D), x.new_zeros(128)
+        blocks = min(R, 1024)
+        part = torch.empty(blocks, 128, D + 1, device=x.device)
+        dwb = torch.empty(128, D + 1, device=x.device)
+        A.check(A.lib().cn_embed0_bwd(R, D, A.ptr(x), A.ptr(y), A.ptr(dy.contiguous()), blocks, A.ptr(part), A.ptr(dwb), A.stream_ptr()), "cn_embed0_bwd")
+        return None, dwb[:, :D].contiguous(), dwb[:, D].contiguous()
+
+
+def wgrad_supported(x, w):
+    N, K = w.shape
+    return x.is_cuda and x.dtype == torch.float32 and N % 64 == 0 and K % 128 == 0
+
+
+class WgradLinear(torch.autograd.Function):
+    """y = x w^T + b for the per-sample layers (a few hundred output columns, tens of thousands of rows): forward and input
+    gradient are ordinary library products; the weight/bias gradient, a reduction over all rows into a tiny matrix that the
+    BLAS heuristics leave on a handful of workgroups, runs on the split-K TN kernel (cn_linear_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        x, dy = x.contiguous(), dy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        splits = A.lib().cn_linear_wgrad_splits(M, N, K)
+        part = torch.empty(splits, N, K, device=x.device)
+        dbp = torch.empty(splits, N, device=x.device)
+        dw = torch.empty(N, K, device=x.device)
+        db = torch.empty(N, device=x.device)
+        A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
+                "cn_linear_wgrad")
+        return dx, dw, db
+
+
 class HipLinear(torch.autograd.Function):
     """y = [relu](x w^T + b) with forward, input gradient and weight/bias gradient on the bf16x3 MFMA kernels
     (cn_linear_fwd / cn_linear_wgrad).  x [M,K], w [N,K], b [N]; N, K multiples of 128."""

@@ -162,6 +162,19 @@ class AttnGraphBase(nn.Module):
         y = F.linear(x, w, b)
         return F.relu(y) if relu else y
 
+    def _lin(self, x, w, b):
+        """Per-sample Linear layer of the update: on the GPU the weight gradient (a reduction over all T*N rows into a small
+        matrix) goes to the split-K TN kernel, everything else stays a library product."""
+        if x.is_cuda and self.train_gemm_mode == "bf16x3":
+            from . import hip
+            if hip.wgrad_supported(x, w):
+                return hip.WgradLinear.apply(x, w, b)
+        return F.linear(x, w, b)
+
+    def _mlp2(self, seq, x):
+        """Sequential(Linear, Tanh, Linear, Tanh) (actor / critic trunks)."""
+        return torch.tanh(self._lin(torch.tanh(self._lin(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias))
+
     def _hh_block(self, spatial_edges, det):
         """[B,H,D] -> [B,H,256].  SpatialEdgeSelfAttn.forward + spatial_linear (selfAttn_srnn_temp_node.py:63-91,:408).
 
@@ -174,7 +187,13 @@ class AttnGraphBase(nn.Module):
         valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
         idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
         emb0, emb2 = sa.embedding_layer[0], sa.embedding_layer[2]
-        e = self._big_linear(F.relu(emb0(spatial_edges.reshape(B * H, D).index_select(0, idx))), emb2.weight, emb2.bias, relu=True)
+        x_live = spatial_edges.reshape(B * H, D).index_select(0, idx)
+        if x_live.is_cuda and D <= 16 and emb0.weight.shape[0] == 128:
+            from .hip import Embed0
+            e0 = Embed0.apply(x_live, emb0.weight, emb0.bias)
+        else:
+            e0 = F.relu(emb0(x_live))
+        e = self._big_linear(e0, emb2.weight, emb2.bias, relu=True)
         # (q|k|v)_linear followed by in_proj is an affine pair with no nonlinearity in between: compose the two weight
         # matrices first (a 512^3 product, differentiable, so both factors still receive their exact gradients) and run ONE
         # [rows,512]x[512,1536] GEMM instead of six [rows,512]x[512,512] ones, in the forward and in the backward pass.
@@ -242,13 +261,15 @@ class AttnGraphBase(nn.Module):
             # instead of ~6B) and its bias, which the softmax cannot see, keeps an exactly-zero gradient
             from .hip import HRAttention
             sl = self.attn.spatial_edge_layer[0]
-            u = self.attn.temporal_edge_layer[0](robot_states) @ sl.weight + 0.0 * sl.bias.sum()
+            tl = self.attn.temporal_edge_layer[0]
+            u = self._lin(robot_states, tl.weight, tl.bias) @ sl.weight + 0.0 * sl.bias.sum()
             hr = HRAttention.apply(u, out_sp, valid, self.human_num)
         else:
             hr, _ = self._hr_attention(robot_states, out_sp, valid)
         rnn = self.humanNodeRNN
-        x = torch.cat((F.relu(rnn.encoder_linear(robot_states)), F.relu(rnn.edge_attention_embed(hr))), dim=-1)
-        gi = F.linear(x, rnn.gru.weight_ih_l0, rnn.gru.bias_ih_l0).view(T, N, -1)
+        x = torch.cat((F.relu(self._lin(robot_states, rnn.encoder_linear.weight, rnn.encoder_linear.bias)),
+                       F.relu(self._lin(hr, rnn.edge_attention_embed.weight, rnn.edge_attention_embed.bias))), dim=-1)
+        gi = self._lin(x, rnn.gru.weight_ih_l0, rnn.gru.bias_ih_l0).view(T, N, -1)
         m = masks.reshape(T, N, 1)
         h = h0.reshape(N, -1)
         if gi.is_cuda:
@@ -261,9 +282,9 @@ class AttnGraphBase(nn.Module):
                 h = self._gru_cell(gi_t, h * m_t)
                 hs.append(h)
             hs_all = torch.stack(hs, 0)
-        out = rnn.output_linear(hs_all.view(B, -1))
-        value = self.critic_linear(self.critic(out))
-        return value, self.actor(out), h
+        out = self._lin(hs_all.view(B, -1), rnn.output_linear.weight, rnn.output_linear.bias)
+        value = self.critic_linear(self._mlp2(self.critic, out))
+        return value, self._mlp2(self.actor, out), h
 
 
 class Policy(nn.Module):

@@ -186,6 +186,15 @@ int cn_hr_attention_fwd(int B, int H, const float *u, const float *out_sp, const
 int cn_hr_attention_bwd(int B, int H, const float *u, const float *out_sp, const int *row_off, const float *attn,
                         const float *d_hr, float *d_u, float *d_o, void *stream);
 
+/* ---- embedding_layer.0 of the human-human block (training path) ----
+ * Linear(D -> 128) + ReLU on the compacted rows (rl/networks/selfAttn_srnn_temp_node.py:33-36), D = 2 (VarNum) or 12
+ * (Pred envs).  fwd: y [R,128] = relu(x [R,D] W^T + b).  bwd: dWb [128, D+1] = per output column the D weight
+ * gradients followed by the bias gradient, from dy [R,128] masked by y > 0; `blocks` row-strided partial sums land in
+ * partials [blocks,128,D+1] and are reduced in block order (deterministic).  The inputs are observations: no dx. */
+int cn_embed0_fwd(int R, int D, const float *x, const float *W, const float *b, float *y, void *stream);
+int cn_embed0_bwd(int R, int D, const float *x, const float *y, const float *dy, int blocks, float *partials, float *dWb,
+                  void *stream);
+
 /* ---- GRU cell of the human node RNN, pointwise part (training path) ----
  * torch.nn.GRU (gate order r,z,n) as EndRNN drives it one step at a time with h * done-mask
  * (rl/networks/srnn_model.py:35-105, selfAttn_srnn_temp_node.py:262-285), under autograd in PPO.update.
@@ -206,7 +215,7 @@ int cn_gru_cell_bwd(int N, const float *gates, const float *hm, const float *dh,
  *                  N % 128 == 0, K % 64 == 0.
  * cn_linear_wgrad: dW[N,K] = dY[M,N]^T X[M,K] and (optional) db[N] = column sums of dY.  The M reduction is cut into
  *                  `splits` ranges whose partial products land in partials [splits,N,K] (db_partials [splits,N]) and are
- *                  summed in split order (deterministic).  N % 128 == 0, K % 128 == 0.
+ *                  summed in split order (deterministic).  N % 64 == 0, K % 128 == 0.
  * cn_linear_wgrad_splits: the split count the library would pick for (M,N,K); 0 if the shape is unsupported. */
 int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream);
 int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act,
