@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--humans", type=int, default=20)
     ap.add_argument("--env-name", default="CrowdSimVarNum-v0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: put every rank on GPU 0 (use with --dist-backend gloo)")
     ap.add_argument("--gemm", choices=["bf16x3", "fp32"], default="bf16x3",
@@ -183,6 +184,28 @@ def main():
         tmax = torch.tensor([elapsed], device="cuda" if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # second half of BASELINE.json's metric: PPO samples/sec = T * E_total / wall time of (rollout + GAE + update), the
+    # reference's train.py loop (rl/ppo.py defaults: T = 30, 5 epochs x 2 recurrent minibatches); every rank runs it,
+    # gradients are all-reduced once per optimiser step (one flat bucket), time = max over ranks of the last update
+    ppo = None
+    if not args.no_ppo and args.env_name != "CrowdSimPredRealGST-v0":
+        del env, pol, net
+        torch.cuda.empty_cache()
+        from crowdnav_prediction_attngraph_amd.trainer import train
+        from crowdnav_prediction_attngraph_amd import config as CFG
+        over = {"sim.human_num": H}
+        if args.env_name == "CrowdSimPred-v0":
+            over["sim.predict_method"] = "const_vel"
+        tcfg = CFG.non_randomized(**over)
+        hist, _ = train(env_name=args.env_name, num_processes=E, num_steps=30, num_updates=3, seed=425, config=tcfg, log=None)
+        last = hist[-1]
+        tt = torch.tensor([last["rollout_s"], last["update_s"]], device="cuda" if (dist is None or args.dist_backend == "nccl") else "cpu", dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        r_s, u_s = float(tt[0]), float(tt[1])
+        ppo = {"samples_per_s": round(30 * E * world / (r_s + u_s), 1), "rollout_s": round(r_s, 5), "update_s": round(u_s, 5),
+               "config": "T=30 steps x %d envs per GPU, ppo_epoch 5, num_mini_batch 2, Adam; 3 updates run, the last one timed" % E,
+               "value_loss": round(last["value_loss"], 6)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -225,6 +248,8 @@ def main():
                                     "note": "env-steps/s x the FLOPs of the reference's dense, unfolded forward; NOT a hardware utilisation "
                                             "(padded humans are not computed and affine pairs are folded)"}},
     }
+    if ppo is not None:
+        line["ppo"] = ppo
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(H)
         line["cpu_baseline"]["host_cores_available"] = os.cpu_count()

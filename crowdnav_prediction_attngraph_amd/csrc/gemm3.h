@@ -16,7 +16,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK3 = 64;        // K tile of the split kernel: 4 MFMA k-steps (48 MFMAs per wavefront) between barriers
 constexpr int L3_STRIDE = 72;  // 64 bf16 + 8 pad = 144 B rows: 16-byte fragment reads of 16 consecutive rows are conflict-free
 
-template <int BN, int ACT>
+template <int TBM, int BN, int ACT>
 __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
                                                        const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
@@ -25,23 +25,24 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
     if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
     int row_tile, col_tile;
     xcd_tile(row_tile, col_tile);
-    if (row_tile * BM >= M) return;
+    if (row_tile * TBM >= M) return;
+    constexpr int MI = TBM / 64;             // 32-row MFMA blocks per wavefront (2 x 2 wavefronts: TBM/2 rows each)
     constexpr int NB = BN / 64;
-    constexpr int ALD = BM * BK3 / 4 / 256;  // float4 loads of A per thread per K tile (8)
+    constexpr int ALD = TBM * BK3 / 4 / 256;  // float4 loads of A per thread per K tile (8)
     constexpr int WCH = BN * BK3 / 8 / 256;  // 16-byte chunks of each W array per thread per K tile (4)
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     __bf16 *Ah = reinterpret_cast<__bf16 *>(smem3);
-    __bf16 *Al = Ah + BM * L3_STRIDE;
-    __bf16 *Wh = Al + BM * L3_STRIDE;
+    __bf16 *Al = Ah + TBM * L3_STRIDE;
+    __bf16 *Wh = Al + TBM * L3_STRIDE;
     __bf16 *Wl = Wh + BN * L3_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m_blk = row_tile * BM, n_blk = col_tile * BN;
+    const int m_blk = row_tile * TBM, n_blk = col_tile * BN;
     const int lrow = tid >> 4, lcol = (tid & 15) * 4; // A staging: 16 lanes cover one 256-byte row segment
 
-    f32x16 acc[2][NB];
+    f32x16 acc[MI][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
         if (k0 + BK3 < K) load_tiles(k0 + BK3);
 #pragma unroll
         for (int ks = 0; ks < BK3 / 16; ++ks) {
-            bf16x8 ah[2], al[2], bh[NB], bl[NB];
+            bf16x8 ah[MI], al[MI], bh[NB], bl[NB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int o = (wm * 64 + i * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
+            for (int i = 0; i < MI; ++i) {
+                const int o = (wm * (TBM / 2) + i * 32 + l31) * L3_STRIDE + ks * 16 + half * 8;
                 ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[o]);
                 al[i] = *reinterpret_cast<const bf16x8 *>(&Al[o]);
             }
@@ -107,28 +108,28 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
             }
             // term-major issue order: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
             const float b = bias ? bias[col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = m_blk + wm * (TBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < M) {
                     float v = acc[i][j][r] + b;
                     if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
@@ -150,24 +151,29 @@ __global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 
     }
 }
 
+template <int TBM, int BN, int ACT>
+static int launch_gemm3_t(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
+                          hipStream_t st, const int *m_dev)
+{
+    CN_REQUIRE(N % BN == 0 && K % BK3 == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    if (M == 0) return CN_OK;
+    dim3 grid(N / BN, (((M + TBM - 1) / TBM) + 7) & ~7);
+    constexpr size_t lds = (size_t)(2 * TBM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB at 128 x 128: needs the opt-in above 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<TBM, BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm3_nt_kernel<TBM, BN, ACT>), grid, dim3(256), lds, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 template <int BN, int ACT>
 static int launch_gemm3(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
                         hipStream_t st, const int *m_dev)
 {
-    CN_REQUIRE(N % BN == 0 && K % BK3 == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
-    if (M == 0) return CN_OK;
-    dim3 grid(N / BN, (((M + BM - 1) / BM) + 7) & ~7);
-    constexpr size_t lds = (size_t)(2 * BM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB: needs the opt-in above 64 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm3_nt_kernel<BN, ACT>), grid, dim3(256), lds, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
-    CN_CHECK_LAUNCH();
-    return CN_OK;
+    return launch_gemm3_t<BM, BN, ACT>(M, N, K, A, lda, Whi, Wlo, bias, C, ldc, st, m_dev);
 }
-
 
 // hi/lo split of W^T: w [rows, cols] row-major -> hi, lo [cols, rows].  Lets the NT kernel compute dX = dY * W
 // (the "weight" operand of that product is W^T).  Sizes are a few hundred KB: no tiling needed.
