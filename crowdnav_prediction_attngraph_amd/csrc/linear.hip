@@ -161,7 +161,8 @@ extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 128) return 0;
     const long long tiles = (long long)((N + 127) / 128) * (K / 128);
-    long long s = (768 + tiles - 1) / tiles;             // ~3 resident waves of blocks on 256 CUs
+    long long s = (768 + tiles - 1) / tiles;             // 1.5 resident rounds of blocks on 256 CUs (shorter blocks, small tail) ...
+    if (s > 64) s = 64;                                  // ... but bounded: every split costs an [N,K] partial to write and re-read
     const long long chunks = ((long long)M + BK3 - 1) / BK3;
     if (s > chunks) s = chunks;
     return (int)(s < 1 ? 1 : s);
