@@ -539,6 +539,52 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
                       (float)c->orca_time_horizon, (float)c->time_step, n, opx, opy, ovx, ovy, orad, avx, avy, 0, 0);
 }
 
+/* calc_human_future_traj(method='truth'), crowd_sim_var_num.py:152-227 (test phase, :386-388): roll every human forward
+ * predict_steps times with its own ORCA policy on the states predicted by the previous roll (act_joint_state ->
+ * ORCA.predict on the human's private simulator, so the frozen radii / neighbour distance of human_orca_action apply;
+ * the other humans' states are passed as they are, without the FOV / dummy substitution of get_human_actions), then
+ * blank the humans the robot does not currently see (:222-224).  Only positions are kept (future_traj). */
+static void truth_future_traj(OrcEnv *e)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = c->human_num, P = c->predict_steps;
+    double cur[ORC_MAX_HUMANS][4], nxt[ORC_MAX_HUMANS][4];
+    for (int i = 0; i < H; ++i) {
+        cur[i][0] = e->humans[i].px; cur[i][1] = e->humans[i].py; cur[i][2] = e->humans[i].vx; cur[i][3] = e->humans[i].vy;
+        e->future_traj[0][i][0] = cur[i][0]; e->future_traj[0][i][1] = cur[i][1];
+    }
+    for (int k = 1; k <= P; ++k) {
+        for (int i = 0; i < H; ++i) {
+            const OrcHuman *me = &e->humans[i];
+            float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
+            int n = 0;
+            for (int j = 0; j < H; ++j) {
+                if (j == i) continue;
+                opx[n] = (float)cur[j][0]; opy[n] = (float)cur[j][1]; ovx[n] = (float)cur[j][2]; ovy[n] = (float)cur[j][3];
+                orad[n] = e->sim_seen_radius[i][j];
+                ++n;
+            }
+            double vx = me->gx - cur[i][0], vy = me->gy - cur[i][1];
+            const double speed = norm2(vx, vy);
+            if (speed > 1.0) { vx = vx / speed; vy = vy / speed; }
+            float ax, ay;
+            orc_orca_velocity((float)cur[i][0], (float)cur[i][1], (float)cur[i][2], (float)cur[i][3], e->sim_self_radius[i],
+                              e->sim_self_maxspeed[i], (float)vx, (float)vy, e->sim_nd[i], H - 1, (float)c->orca_time_horizon,
+                              (float)c->time_step, n, opx, opy, ovx, ovy, orad, &ax, &ay, 0, 0);
+            /* one_step_lookahead, agent.py:185-192 */
+            nxt[i][0] = cur[i][0] + (double)ax * c->time_step; nxt[i][1] = cur[i][1] + (double)ay * c->time_step;
+            nxt[i][2] = (double)ax; nxt[i][3] = (double)ay;
+        }
+        for (int i = 0; i < H; ++i) {
+            for (int q = 0; q < 4; ++q) cur[i][q] = nxt[i][q];
+            e->future_traj[k][i][0] = cur[i][0]; e->future_traj[k][i][1] = cur[i][1];
+        }
+    }
+    for (int i = 0; i < H; ++i)
+        if (!e->human_visibility[i])
+            for (int k = 0; k <= P; ++k) { e->future_traj[k][i][0] = 15.0; e->future_traj[k][i][1] = 15.0; }
+}
+
 /* crowd_sim.py:415-450 */
 static void update_human_goals_randomly(OrcEnv *e)
 {
@@ -593,7 +639,9 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         human_orca_action(e, i, &hax[i], &hay[i]);
         e->last_human_actions[i][0] = hax[i]; e->last_human_actions[i][1] = hay[i];
     }
-    /* calc_reward, crowd_sim_var_num.py:465-561 (train phase: danger zone = circle) */
+    /* test phase (:386-388): the true future positions decide the Danger flag (and, for CrowdSimPred, the social reward) */
+    if (c->phase == ORC_PHASE_TEST) truth_future_traj(e);
+    /* calc_reward, crowd_sim_var_num.py:465-561 (train / val phase: danger zone = circle; test: future trajectories) */
     double dmin = INFINITY;
     int collision = 0;
     for (int i = 0; i < H; ++i) {
@@ -605,10 +653,20 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     const int reaching_goal = norm2(e->rpx - e->rgx, e->rpy - e->rgy) < c->robot_radius;
     const double global_time = (double)e->step_counter * c->time_step;
     double reward; int done, info; double mind = 0.0;
+    int danger_cond = dmin < c->discomfort_dist; /* :496-498 */
+    if (c->phase == ORC_PHASE_TEST) { /* :499-511 intrusion into the humans' future positions (np.amin over the hits) */
+        danger_cond = 0;
+        for (int k = 1; k <= c->predict_steps; ++k)
+            for (int i = 0; i < H; ++i) {
+                const double dx = e->future_traj[k][i][0] - e->rpx, dy = e->future_traj[k][i][1] - e->rpy;
+                const double d = sqrt(dx * dx + dy * dy);
+                if (d < c->robot_radius + c->human_radius) { if (!danger_cond || d < mind) mind = d; danger_cond = 1; }
+            }
+    }
     if (global_time >= c->time_limit - 1.0) { reward = 0.0; done = 1; info = ORC_INFO_TIMEOUT; }
     else if (collision) { reward = c->collision_penalty; done = 1; info = ORC_INFO_COLLISION; }
     else if (reaching_goal) { reward = c->success_reward; done = 1; info = ORC_INFO_REACHGOAL; }
-    else if (dmin < c->discomfort_dist) {
+    else if (danger_cond) {
         reward = (dmin - c->discomfort_dist) * c->discomfort_penalty_factor * c->time_step;
         done = 0; info = ORC_INFO_DANGER;
     } else {
@@ -618,7 +676,8 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         done = 0; info = ORC_INFO_NOTHING;
     }
     if (c->env_kind == ORC_ENV_PRED) {
-        /* social reward, crowd_sim_pred.py:216-233; future_traj is the one stored by the previous generate_ob */
+        /* social reward, crowd_sim_pred.py:216-233; future_traj is the one stored by the previous generate_ob (in the
+         * test phase it was just overwritten by the 'truth' roll-out above, as in the reference) */
         double rf = 0.0; /* np.min over products collision_idx * penalty (0 where no collision) */
         for (int k = 1; k <= c->predict_steps; ++k) {
             const double pen = c->collision_penalty / ldexp(1.0, k + 1);
@@ -652,14 +711,14 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     }
     e->ep_return += reward; e->ep_len += 1;
     *reward_out = reward; *info_out = info;
-    if (danger_min_dist) *danger_min_dist = mind;
+    if (danger_min_dist) *danger_min_dist = info == ORC_INFO_DANGER ? mind : 0.0; /* Danger(min_dist) is the only info that carries it */
     return done;
 }
 
 int orc_env_step_autoreset(OrcEnv *e, const float action[2], OrcObs *obs, double *reward, int *info,
-                           double *ep_return, int *ep_len)
+                           double *ep_return, int *ep_len, double *danger_min_dist)
 {
-    const int done = orc_env_step(e, action, obs, reward, info, 0);
+    const int done = orc_env_step(e, action, obs, reward, info, danger_min_dist);
     if (done) {
         /* bench.Monitor: info['episode'] = {'r': round(sum, 6), 'l': steps}; shmem_vec_env.py:139-142 auto-reset */
         if (ep_return) *ep_return = e->ep_return;
@@ -688,7 +747,7 @@ void orc_env_batch_step(OrcEnv **envs, int n, const float *actions, float *robot
         OrcObs obs;
         double r; int info;
         const int H = envs[i]->cfg.human_num, D = orc_obs_width(&envs[i]->cfg);
-        const int done = orc_env_step_autoreset(envs[i], actions + 2 * i, &obs, &r, &info, 0, 0);
+        const int done = orc_env_step_autoreset(envs[i], actions + 2 * i, &obs, &r, &info, 0, 0, 0);
         memcpy(robot_node + 7 * i, obs.robot_node, 7 * sizeof(float));
         memcpy(temporal_edges + 2 * i, obs.temporal_edges, 2 * sizeof(float));
         memcpy(spatial_edges + (size_t)i * H * D, obs.spatial_edges, (size_t)H * D * sizeof(float));

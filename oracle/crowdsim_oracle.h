@@ -144,7 +144,7 @@ void orc_env_reset(OrcEnv *env, OrcObs *obs);
 int orc_env_step(OrcEnv *env, const float action[2], OrcObs *obs, double *reward, int *info, double *danger_min_dist);
 /* vec-env style step: auto-reset on done, obs replaced by reset obs; ep_* receive Monitor output */
 int orc_env_step_autoreset(OrcEnv *env, const float action[2], OrcObs *obs, double *reward, int *info,
-                           double *ep_return, int *ep_len);
+                           double *ep_return, int *ep_len, double *danger_min_dist);
 int orc_obs_width(const OrcConfig *cfg);
 
 /* flat helpers for ctypes */

@@ -69,7 +69,7 @@ def lib():
                                    C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_env_step_autoreset.restype = C.c_int
         L.orc_env_step_autoreset.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(OrcObs), C.POINTER(C.c_double),
-                                             C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+                                             C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_config_default.argtypes = [C.POINTER(OrcConfig)]
         L.orc_mt_seed.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_mt_double.restype = C.c_double
@@ -136,14 +136,15 @@ class OracleEnv:
         a = (C.c_float * 2)(float(np.float32(action[0])), float(np.float32(action[1])))
         r, info = C.c_double(), C.c_int()
         if autoreset:
-            epr, epl = C.c_double(), C.c_int()
+            epr, epl, md = C.c_double(), C.c_int(), C.c_double()
             done = self._L.orc_env_step_autoreset(self._h, a, C.byref(self._obs), C.byref(r), C.byref(info),
-                                                  C.byref(epr), C.byref(epl))
+                                                  C.byref(epr), C.byref(epl), C.byref(md))
             extra = {"episode": {"r": round(epr.value, 6), "l": epl.value}} if done else {}
+            extra["min_dist"] = md.value
         else:
             md = C.c_double()
             done = self._L.orc_env_step(self._h, a, C.byref(self._obs), C.byref(r), C.byref(info), C.byref(md))
-            extra = {}
+            extra = {"min_dist": md.value}
         return _obs_to_dict(self._obs, self.cfg), r.value, bool(done), dict(info=info.value, **extra)
 
     # raw state access for tests (layout of OrcEnv is private; expose via small helpers instead)

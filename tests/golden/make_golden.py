@@ -79,7 +79,7 @@ def trace(env_name, over, seed, rank, nenv, steps, tag):
     H = cfg.sim.human_num
     rec = {k: [] for k in ("actions", "reward", "done", "info", "ep_return", "ep_len", "robot_state", "human_state",
                            "robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks",
-                           "human_action")}
+                           "human_action", "min_dist")}
     ob0 = cast_obs(env.reset(), H)
     init_humans = np.array([[h.px, h.py, h.vx, h.vy, h.gx, h.gy, h.radius, h.v_pref] for h in env.humans])
     init_robot = np.array(env.robot.get_full_state_list(), dtype=np.float64)
@@ -95,6 +95,7 @@ def trace(env_name, over, seed, rank, nenv, steps, tag):
         rets.append(reward)
         ep_len += 1
         code = info_code(info["info"])
+        rec["min_dist"].append(float(getattr(info["info"], "min_dist", 0.0)) if code == 4 else 0.0)
         if done:
             ep_ret = round(sum(rets), 6)
             rec["ep_return"].append(ep_ret)
@@ -147,11 +148,24 @@ def env_goldens():
           "pred_h10_rand_r1")
     trace("CrowdSimPredRealGST-v0", dict(NON_RAND, **{"sim.human_num": 20, "sim.predict_method": "inferred"}), 425, 0, 4,
           140, "predgst_h20_r0")
+    # nenv = 1 -> phase 'test' (rl/networks/envs.py:55-58): seeds 1000 + case, 'truth' roll-out every step, Danger decided by
+    # the humans' true future positions (min_dist recorded), CrowdSimPred's social reward on the true futures
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20}), 425, 0, 1, 260, "varnum_h20_test_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 5}), 425, 0, 1, 300, "varnum_h5_rand_test_r0")
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 20, "sim.predict_method": "const_vel"}), 425, 0, 1, 200,
+          "pred_h20_constvel_test_r0")
 
 
 if __name__ == "__main__":
     what = _ARGV or ["env"]
     if "env" in what:
+        env_goldens()
+    if "env-test" in what:  # only the test-phase traces (the train-phase fixtures stay byte-identical)
+        _all = trace
+
+        def trace(env_name, over, seed, rank, nenv, steps, tag):  # noqa: F811
+            if nenv == 1:
+                _all(env_name, over, seed, rank, nenv, steps, tag)
         env_goldens()
     if "policy" in what:
         import make_golden_policy
