@@ -55,6 +55,11 @@ struct EnvDev {
     uint32_t *nx_mt;    // [E][624]
     int32_t *nx_mt_pos; // [E]
     uint8_t *nx_ready;  // [E]
+    // test phase only (crowd_sim_var_num.py:386-388, :499-511): the humans' true future states rolled out with their own
+    // ORCA policies, the robot's visibility flags of the last observation, and Danger's min_dist of the last step
+    double *tr;       // [E][P+1][4][H] px,py,vx,vy; slice 0 unused (k = 1 reads the live state)
+    uint8_t *vis;     // [E][H]
+    double *min_dist; // [E]
 };
 
 enum { F_PX = 0, F_PY, F_VX, F_VY, F_GX, F_GY, F_RAD, F_VPREF };
@@ -334,6 +339,44 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
     }
 }
 
+// calc_human_future_traj(method='truth') (crowd_sim_var_num.py:152-206), one roll per launch: every human acts with its own
+// ORCA policy (act_joint_state -> ORCA.predict on its private simulator: frozen radii / neighbour distance) on the states
+// predicted by roll k-1 and is stepped by one_step_lookahead (agent.py:185-192).  The other humans' states are passed as
+// they are (no FOV / dummy substitution here).  Roll k needs all of roll k-1 of the same env -> one launch per roll.
+__global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
+{
+    const int lane = threadIdx.x & 63;
+    const int agent = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (agent >= s.E * s.H) return;
+    const int H = s.H;
+    const int e = agent / H, i = agent - e * H;
+    const double *hum = s.hum + (size_t)e * 8 * H;
+    double *trk = s.tr + ((size_t)e * (s.P + 1) + k) * 4 * H;
+    const double *src = k == 1 ? hum : trk - 4 * H; // F_PX..F_VY are fields 0..3: the live state has the same [4][H] layout
+    const bool isH = lane < H;
+    const int lj = isH ? lane : 0;
+    const double px = src[0 * H + lj], py = src[1 * H + lj], vx = src[2 * H + lj], vy = src[3 * H + lj];
+    const double rad = hum[F_RAD * H + lj];
+    const double spx = __shfl(px, i, 64), spy = __shfl(py, i, 64), svx = __shfl(vx, i, 64), svy = __shfl(vy, i, 64);
+    const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i];
+    const size_t ei = (size_t)e * H + i;
+    const float nd = s.sim_nd[ei], self_r = s.sim_self_radius[ei], self_ms = s.sim_self_maxspeed[ei]; // built by orca_kernel just before
+    const float seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + s.cfg.orca_safety_space);
+    const bool cand = isH && lane != i;
+    double gvx = sgx - spx, gvy = sgy - spy;
+    const double speed = sqrt(gvx * gvx + gvy * gvy);
+    if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
+    float ox, oy;
+    orca_wave(lane, H, cand, (float)px, (float)py, (float)vx, (float)vy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
+              (float)gvx, (float)gvy, nd, H - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
+    if (lane == 0) {
+        trk[0 * H + i] = spx + (double)ox * s.cfg.time_step;
+        trk[1 * H + i] = spy + (double)oy * s.cfg.time_step;
+        trk[2 * H + i] = (double)ox;
+        trk[3 * H + i] = (double)oy;
+    }
+}
+
 // stand-alone batched solve (cn_orca_solve)
 __global__ __launch_bounds__(256) void orca_solve_kernel(int B, int n_other, const float *self, const float *others, float nd,
                                                          int max_nb, float th, float dt, float *out)
@@ -532,6 +575,7 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool
     const bool vis = isH && !(dx == 0.0 && dy == 0.0) && (norm2(dx, dy) - c.robot_radius - h.rad <= c.sensor_range);
     const uint64_t vmask = __ballot(vis);
     const int num_visible = __popcll(vmask);
+    if (s.vis && isH) s.vis[(size_t)e * H + lane] = vis ? 1 : 0; // human_visibility, read by the next step's 'truth' blanking
     const double prev_vx = h.l2, prev_vy = h.l3;
     if (vis) { h.l0 = h.px; h.l1 = h.py; h.l2 = h.vx; h.l3 = h.vy; h.l4 = h.rad; }
     else if (reset) { h.l0 = 15.0; h.l1 = 15.0; h.l2 = 0.0; h.l3 = 0.0; h.l4 = 0.3; }
@@ -757,10 +801,34 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     const double global_time = (double)step_counter * c.time_step;
     double reward;
     int done, info;
+    // Danger condition: the discomfort circle (train, :496-498) or, in the test phase, an intrusion into the humans' TRUE
+    // future positions k = 1..P (:499-511; humans the robot did not see in its last observation are blanked to (15,15))
+    const bool test_phase = c.phase == CN_PHASE_TEST;
+    bool danger_cond = dmin < c.discomfort_dist;
+    double min_danger = 0.0, rf_truth = 0.0;
+    if (test_phase) {
+        const double *tre = s.tr + (size_t)e * (s.P + 1) * 4 * H;
+        const bool seen = isH && s.vis[(size_t)e * H + lane];
+        double best = INFINITY;
+        for (int k = 1; k <= s.P; ++k) {
+            if (isH) {
+                const double fx = (seen ? tre[(k * 4 + 0) * H + lane] : 15.0) - rb.px, fy = (seen ? tre[(k * 4 + 1) * H + lane] : 15.0) - rb.py;
+                const double d = sqrt(fx * fx + fy * fy);
+                if (d < c.robot_radius + c.human_radius) {
+                    best = fmin(best, d);
+                    const double pen = c.collision_penalty / (double)(1 << (k + 1));
+                    if (pen < rf_truth) rf_truth = pen;
+                }
+            }
+        }
+        best = wv_min(best);
+        danger_cond = best < INFINITY;
+        min_danger = danger_cond ? best : 0.0;
+    }
     if (global_time >= c.time_limit - 1.0) { reward = 0.0; done = 1; info = CN_INFO_TIMEOUT; }
     else if (collision) { reward = c.collision_penalty; done = 1; info = CN_INFO_COLLISION; }
     else if (reaching_goal) { reward = c.success_reward; done = 1; info = CN_INFO_REACHGOAL; }
-    else if (dmin < c.discomfort_dist) {
+    else if (danger_cond) {
         reward = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * c.time_step;
         done = 0; info = CN_INFO_DANGER;
     } else {
@@ -768,7 +836,11 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         rb.pot = -fabs(goal_dist);
         done = 0; info = CN_INFO_NOTHING;
     }
-    if (c.env_kind == CN_ENV_PRED) {
+    if (s.min_dist && lane == 0) s.min_dist[e] = info == CN_INFO_DANGER ? min_danger : 0.0; // Danger(min_dist)
+    if (c.env_kind == CN_ENV_PRED && test_phase) {
+        // test phase: self.human_future_traj was just overwritten by the 'truth' roll-out, so the social reward sees it too
+        reward = reward + wv_min(rf_truth);
+    } else if (c.env_kind == CN_ENV_PRED) {
         // social reward from the predictions stored by the previous observation (crowd_sim_pred.py:216-233)
         const double *ft = s.ftraj + (size_t)e * s.P * 2 * H;
         double rf = 0.0;
@@ -868,6 +940,11 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
     const int agents = env->d.E * env->d.H;
     hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
     CN_CHECK_LAUNCH();
+    if (env->d.cfg.phase == CN_PHASE_TEST)
+        for (int k = 1; k <= env->d.P; ++k) { // 'truth' roll-out for the next step's Danger decision
+            hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d, k);
+            CN_CHECK_LAUNCH();
+        }
     // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step)
     hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
     CN_CHECK_LAUNCH();
@@ -904,7 +981,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(cfg->human_num >= 1 && cfg->human_num <= CN_MAX_HUMANS, "cn_env_create: human_num must be in [1,%d]", CN_MAX_HUMANS);
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_PRED_GST, "cn_env_create: unknown env_kind %d", cfg->env_kind);
-    CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN, "cn_env_create: only phase=train is implemented on the device (test phase needs the 'truth' predictor)");
+    CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST,
+               "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
     CN_REQUIRE(cfg->time_step > 0 && std::fabs(5.0 / cfg->time_step - std::round(5.0 / cfg->time_step)) < 1e-9,
                "cn_env_create: time_step must divide 5 s");
@@ -925,6 +1003,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_seen = cfg->randomize_attributes ? carve(E * H * H * 4) : 0;
     const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
     const size_t o_nh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
+    const bool test_phase = cfg->phase == CN_PHASE_TEST;
+    const size_t o_tr = test_phase ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = test_phase ? carve(E * H) : 0, o_md = carve(E * 8);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -941,6 +1021,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
     d.nx_hum = (double *)(base + o_nh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
+    d.tr = test_phase ? (double *)(base + o_tr) : nullptr; d.vis = test_phase ? (uint8_t *)(base + o_vis) : nullptr;
+    d.min_dist = (double *)(base + o_md);
     b->reset_done = false;
     b->orca_ready = false;
     int prio_least = 0, prio_greatest = 0;
@@ -1017,6 +1099,13 @@ extern "C" int cn_env_get_human_actions(cn_env_batch *env, float *out, void *str
     const int n = env->d.E * env->d.H * 2;
     hipLaunchKernelGGL(export_hact_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, out);
     CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream)
+{
+    CN_REQUIRE(env && out, "cn_env_get_danger_min_dist: null argument");
+    CN_HIP(hipMemcpyAsync(out, env->d.min_dist, (size_t)env->d.E * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CN_OK;
 }
 

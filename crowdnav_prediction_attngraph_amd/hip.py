@@ -80,6 +80,13 @@ class HipEnvBatch:
             A.check(A.lib().cn_env_get_state(self._h, A.ptr(humans), A.ptr(robot), A.stream_ptr()), "cn_env_get_state")
         return humans, robot
 
+    def get_danger_min_dist(self):
+        """Danger.min_dist of the last step per env (float64 [E]); non-zero only in the test phase."""
+        out = torch.zeros(self.E, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_get_danger_min_dist(self._h, A.ptr(out), A.stream_ptr()), "cn_env_get_danger_min_dist")
+        return out
+
     def get_human_actions(self):
         out = torch.zeros(self.E, self.H, 2, device=self.device)
         with torch.cuda.device(self.device):

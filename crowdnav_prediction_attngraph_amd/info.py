@@ -33,8 +33,9 @@ class Nothing(object):
 _NOTHING, _TIMEOUT, _COLLISION, _REACHGOAL = Nothing(), Timeout(), Collision(), ReachGoal()
 
 
-def from_code(code):
-    """CN_INFO_* -> info object (train phase: Danger.min_dist is 0, crowd_sim_var_num.py:496-498)."""
+def from_code(code, min_dist=0):
+    """CN_INFO_* -> info object (train phase: Danger.min_dist is 0, crowd_sim_var_num.py:496-498; test phase: the distance
+    to the closest intruded future position, :499-511)."""
     if code == 0:
         return _NOTHING
     if code == 1:
@@ -44,5 +45,5 @@ def from_code(code):
     if code == 3:
         return _REACHGOAL
     if code == 4:
-        return Danger(0)
+        return Danger(min_dist)
     raise ValueError("unknown info code %r" % (code,))

@@ -61,7 +61,7 @@ typedef struct {
     int32_t random_goal_changing; /* humans.random_goal_changing */
     int32_t end_goal_changing;    /* humans.end_goal_changing */
     int32_t sort_humans;          /* args.sort_humans */
-    int32_t phase;                /* CN_PHASE_* (only TRAIN is implemented on the device in this round) */
+    int32_t phase;                /* CN_PHASE_TRAIN or CN_PHASE_TEST (test: seeds 1000 + case, 'truth' roll-out, future-zone Danger) */
     int32_t nenv;                 /* TOTAL number of envs across all GPUs: the case_counter stride (crowd_sim_var_num.py:348) */
     uint32_t val_size, test_size;
     double time_step, time_limit;
@@ -110,6 +110,11 @@ int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *str
 /* ORCA velocities of the humans for the CURRENT state (the ones the next cn_env_step will apply; they are computed
  * ahead of time on an internal side stream, overlapped with the caller's policy forward), [E,H,2] float32 */
 int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream);
+/* Danger(min_dist) of the last step (crowd_sim_var_num.py:499-533): in the test phase the smallest distance between the
+ * robot and an intruded TRUE future position of a visible human (humans rolled forward predict_steps times with their
+ * own ORCA policies, calc_human_future_traj('truth') :152-206); 0 for every other info and in the train phase.
+ * out [E] float64 (device). */
+int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream);
 
 /* Stand-alone batched ORCA solve (the rvo2 replacement): B independent agents, each with n_other neighbours.
  * self [B,8] = px,py,vx,vy,radius,max_speed,pref_vx,pref_vy ; others [B,n_other,5] = px,py,vx,vy,radius (float32);

@@ -39,6 +39,10 @@ CASES = {
     "pred_h20_constvel": dict(human_num=20, env_kind=1),
     "pred_h10_rand": dict(human_num=10, env_kind=1, randomize_attributes=1, random_goal_changing=1),
     "predgst_h20": dict(human_num=20, env_kind=2),
+    # test phase: seeds 1000 + case, 'truth' roll-out every step, Danger from the true future positions
+    "varnum_h20_test": dict(human_num=20, phase=2),
+    "varnum_h10_rand_test": dict(human_num=10, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "pred_h20_test": dict(human_num=20, env_kind=1, phase=2),
 }
 
 
@@ -68,8 +72,10 @@ def test_hip_env_matches_oracle_bit_exact(name):
         assert torch.equal(nd.view(-1), (done == 0).to(torch.float32)), "not_done mask t=%d" % t
         host = {k: obs[k].cpu().numpy() for k in keys}
         rew_h, done_h, info_h, epr_h, epl_h = rew.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), epr.cpu().numpy(), epl.cpu().numpy()
+        md_h = env.get_danger_min_dist().cpu().numpy()
         for i, oe in enumerate(oenvs):
             ob, r, d, inf = oe.step(act[i], autoreset=True)
+            assert md_h[i] == inf["min_dist"], "min_dist t=%d env=%d" % (t, i)
             assert bool(done_h[i]) == d, "done t=%d env=%d" % (t, i)
             assert int(info_h[i]) == inf["info"], "info t=%d env=%d" % (t, i)
             assert rew_h[i] == np.float32(r), "reward t=%d env=%d: %r vs %r" % (t, i, rew_h[i], r)
@@ -105,6 +111,8 @@ def test_hip_env_replays_reference_golden(path):
         assert bool(done.item()) == bool(z["done"][t]), "done @%d" % t
         assert int(info.item()) == int(z["info"][t]), "info @%d" % t
         assert abs(float(rew.item()) - float(z["reward"][t])) <= 1e-6, "reward @%d" % t
+        if "min_dist" in z.files:   # test-phase traces: Danger(min_dist) from the 'truth' roll-out
+            assert abs(float(env.get_danger_min_dist().item()) - float(z["min_dist"][t])) <= 1e-9, "min_dist @%d" % t
         if z["done"][t]:
             assert int(epl.item()) == int(z["ep_len"][t])
             assert abs(float(epr.item()) - float(z["ep_return"][t])) <= 2e-6
