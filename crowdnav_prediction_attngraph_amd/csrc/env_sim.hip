@@ -1102,6 +1102,16 @@ extern "C" int cn_env_get_human_actions(cn_env_batch *env, float *out, void *str
     return CN_OK;
 }
 
+extern "C" int cn_env_set_case_counters(cn_env_batch *env, const uint64_t *counters, void *stream)
+{
+    CN_REQUIRE(env && counters, "cn_env_set_case_counters: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // the side stream may be pre-generating episodes
+    CN_HIP(hipMemcpyAsync(env->d.case_counter, counters, (size_t)env->d.E * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    CN_HIP(hipMemsetAsync(env->d.nx_ready, 0, (size_t)env->d.E, st)); // staged episodes were generated for the old counters
+    return CN_OK;
+}
+
 extern "C" int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream)
 {
     CN_REQUIRE(env && out, "cn_env_get_danger_min_dist: null argument");

@@ -80,6 +80,14 @@ class HipEnvBatch:
             A.check(A.lib().cn_env_get_state(self._h, A.ptr(humans), A.ptr(robot), A.stream_ptr()), "cn_env_get_state")
         return humans, robot
 
+    def set_case_counters(self, counters):
+        """counters: int64/uint64 [E] tensor; the next reset of env e generates test/train case `counters[e]` (+ its seed)."""
+        c = torch.as_tensor(counters, dtype=torch.int64).to(self.device).contiguous()
+        if c.numel() != self.E or bool((c < 0).any()):
+            raise A.CnError("counters must be %d non-negative integers" % self.E)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_set_case_counters(self._h, A.ptr(c), A.stream_ptr()), "cn_env_set_case_counters")
+
     def get_danger_min_dist(self):
         """Danger.min_dist of the last step per env (float64 [E]); non-zero only in the test phase."""
         out = torch.zeros(self.E, dtype=torch.float64, device=self.device)

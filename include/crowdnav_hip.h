@@ -115,6 +115,10 @@ int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream);
  * own ORCA policies, calc_human_future_traj('truth') :152-206); 0 for every other info and in the train phase.
  * out [E] float64 (device). */
 int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream);
+/* Overwrite the per-env case counters (crowd_sim_var_num.py:316-318 `case_counter[phase] = test_case`, :337
+ * rand_seed = offset[phase] + case_counter + thisSeed): the NEXT reset of env e generates the scenario of that case.
+ * counters [E] uint64 (device).  Lets a batch replay chosen test cases (one per env) instead of consecutive ones. */
+int cn_env_set_case_counters(cn_env_batch *env, const uint64_t *counters, void *stream);
 
 /* Stand-alone batched ORCA solve (the rvo2 replacement): B independent agents, each with n_other neighbours.
  * self [B,8] = px,py,vx,vy,radius,max_speed,pref_vx,pref_vy ; others [B,n_other,5] = px,py,vx,vy,radius (float32);

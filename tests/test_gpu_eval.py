@@ -1,0 +1,37 @@
+"""-m gpu: deterministic evaluation (rl/evaluation.py protocol) in the test phase -- the reference-shaped sequential
+loop over ONE env and the batched form (every test case one env) must report the same metrics."""
+import logging
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("env_name,over", [("CrowdSimVarNum-v0", {}), ("CrowdSimPred-v0", {"sim.predict_method": "const_vel"})])
+def test_sequential_and_batched_evaluation_agree(env_name, over):
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.evaluation import evaluate, evaluate_batched
+    from crowdnav_prediction_attngraph_amd.policy import Policy
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    cfg = C.non_randomized(**dict({"sim.human_num": 10, "env.test_size": 16}, **over))
+    dev = torch.device("cuda", 0)
+    envs = make_vec_envs(env_name, 7, 1, 0.99, None, dev, True, config=cfg)          # 1 env -> phase 'test' (envs.py:55-58)
+    assert envs.cfg.phase == 2
+    torch.manual_seed(3)
+    pol = Policy(envs.observation_space.spaces, envs.action_space, base="selfAttn_merge_srnn",
+                 base_kwargs=dict(env_name=env_name, num_processes=1, num_mini_batch=1, seq_length=30)).to(dev)
+    with torch.no_grad():                      # make the untrained policy head for the goal-ish direction: varied outcomes
+        pol.dist.fc_mean.bias.copy_(torch.tensor([0.3, -0.2]))
+    log = logging.getLogger("eval-test")
+    n = 20                                     # > test_size / 2: the case index wraps and cases repeat, as in the reference
+    seq = evaluate(pol, envs, 1, dev, n, log, cfg, None)
+    bat = evaluate_batched(pol, env_name, cfg, 7, n, device=dev, logging=log)
+    assert seq["episodes"] == bat["episodes"] == n
+    for k in ("success_rate", "collision_rate", "timeout_rate", "collision_cases", "timeout_cases"):
+        assert seq[k] == bat[k], (k, seq[k], bat[k])
+    for k in ("nav_time", "path_length", "intrusion_ratio", "mean_reward"):
+        assert seq[k] == pytest.approx(bat[k], rel=1e-6, abs=1e-6), (k, seq[k], bat[k])
+    if seq["min_intrusion_dist"] == seq["min_intrusion_dist"]:
+        assert seq["min_intrusion_dist"] == pytest.approx(bat["min_intrusion_dist"], rel=1e-9)
+    assert seq["collision_rate"] + seq["timeout_rate"] + seq["success_rate"] == pytest.approx(1.0)

@@ -30,7 +30,13 @@ def test_vec_env_api_contract():
     with pytest.raises(NotImplementedError):
         make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"robot.visible": True}))
     with pytest.raises(NotImplementedError):
-        make_vec_envs("CrowdSimVarNum-v0", 425, 1, 0.99, None, torch.device("cuda"), False)   # num_processes=1 -> phase 'test'
+        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"sim.human_num_range": 2}))
+    one = make_vec_envs("CrowdSimVarNum-v0", 425, 1, 0.99, None, torch.device("cuda"), False)   # num_processes=1 -> phase 'test' (envs.py:55-58)
+    assert one.cfg.phase == 2
+    ob = one.reset()
+    ob, rew, done, infos = one.step(torch.zeros(1, 2))
+    assert ob["robot_node"].shape == (1, 1, 7) and isinstance(infos[0]["info"], (I.Nothing, I.Danger))
+    one.close()
 
 
 def test_policy_module_uses_hip_for_act_and_tracks_weight_updates():
