@@ -13,11 +13,20 @@ namespace {
 // fragment reads of 16 consecutive rows then hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int BK3 = 64;        // K tile of the split kernel: 4 MFMA k-steps (48 MFMAs per wavefront) between barriers
-constexpr int L3_STRIDE = 72;  // 64 bf16 + 8 pad = 144 B rows: 16-byte fragment reads of 16 consecutive rows are conflict-free
+// K tile = ONE MFMA k-step (16): 24.6 KB of LDS and <= 128 VGPRs per workgroup -> FOUR workgroups (16 wavefronts) per CU.
+// The kernel is a plain two-barrier loop whose phases (global loads in flight, convert + LDS stores, MFMA, C stores) do
+// not overlap inside one workgroup; what hides them is other workgroups in other phases, so occupancy beats tile depth:
+// measured on the q|k|v shapes (stand-alone, random operands)  BK 64 / 2 per CU: 180 us | 2348 us (M = 24.5 k | 368 k),
+// BK 32 / 3 per CU: 168 | 2025,  BK 16 / 4 per CU: 161 | 1888 (307 TFLOP/s algorithmic = 920 executed).
+#ifndef CN_BK3
+#define CN_BK3 16
+#endif
+constexpr int BK3 = CN_BK3;
+constexpr int L3_STRIDE = BK3 + 8;  // +8 bf16 pad: rows 48 B apart (BK3 = 16) -> 16 consecutive rows' 16-byte reads tile all 64 banks
+constexpr int G3_OCC = BK3 <= 16 ? 4 : (BK3 <= 32 ? 3 : 2); // workgroups per CU the register budget is compiled for
 
 template <int TBM, int BN, int ACT>
-__global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+__global__ __launch_bounds__(256, G3_OCC) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
                                                        const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                        const int *__restrict__ m_dev)
@@ -28,8 +37,11 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
     if (row_tile * TBM >= M) return;
     constexpr int MI = TBM / 64;             // 32-row MFMA blocks per wavefront (2 x 2 wavefronts: TBM/2 rows each)
     constexpr int NB = BN / 64;
-    constexpr int ALD = TBM * BK3 / 4 / 256;  // float4 loads of A per thread per K tile (8)
-    constexpr int WCH = BN * BK3 / 8 / 256;  // 16-byte chunks of each W array per thread per K tile (4)
+    constexpr int AQ = BK3 / 4, ARP = 256 / AQ;  // float4 per A row of the K tile, rows staged per pass
+    constexpr int ALD = TBM / ARP;               // float4 loads of A per thread per K tile
+    constexpr int WQ = BK3 / 8;                  // 16-byte chunks per W row of the K tile
+    constexpr int WCH = BN * WQ / 256;           // chunks of each W plane per thread per K tile
+    static_assert(WCH >= 1 && ALD >= 1, "tile too small for 256 staging threads");
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     __bf16 *Ah = reinterpret_cast<__bf16 *>(smem3);
     __bf16 *Al = Ah + TBM * L3_STRIDE;
@@ -38,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m_blk = row_tile * TBM, n_blk = col_tile * BN;
-    const int lrow = tid >> 4, lcol = (tid & 15) * 4; // A staging: 16 lanes cover one 256-byte row segment
+    const int lrow = tid / AQ, lcol = (tid % AQ) * 4; // A staging: AQ lanes cover one row segment of the K tile
 
     f32x16 acc[MI][NB];
 #pragma unroll
@@ -53,13 +65,13 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < ALD; ++p) {
-            const int r = m_blk + lrow + 16 * p;
+            const int r = m_blk + lrow + ARP * p;
             if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
             else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int p = 0; p < WCH; ++p) {
-            const int c = tid + 256 * p, r = n_blk + (c >> 3), col = (c & 7) * 8;
+            const int c = tid + 256 * p, r = n_blk + c / WQ, col = (c % WQ) * 8;
             pwh[p] = *reinterpret_cast<const bf16x8 *>(Whi + (size_t)r * K + k0 + col);
             pwl[p] = *reinterpret_cast<const bf16x8 *>(Wlo + (size_t)r * K + k0 + col);
         }
@@ -73,12 +85,12 @@ __global__ __launch_bounds__(256) void gemm3_nt_kernel(int M, int N, int K, cons
                 hi[q] = (__bf16)pa[p][q];
                 lo[q] = (__bf16)(pa[p][q] - (float)hi[q]);
             }
-            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + 16 * p) * L3_STRIDE + lcol]) = hi;
-            *reinterpret_cast<bf16x4 *>(&Al[(lrow + 16 * p) * L3_STRIDE + lcol]) = lo;
+            *reinterpret_cast<bf16x4 *>(&Ah[(lrow + ARP * p) * L3_STRIDE + lcol]) = hi;
+            *reinterpret_cast<bf16x4 *>(&Al[(lrow + ARP * p) * L3_STRIDE + lcol]) = lo;
         }
 #pragma unroll
         for (int p = 0; p < WCH; ++p) {
-            const int c = tid + 256 * p, r = c >> 3, col = (c & 7) * 8;
+            const int c = tid + 256 * p, r = c / WQ, col = (c % WQ) * 8;
             *reinterpret_cast<bf16x8 *>(&Wh[r * L3_STRIDE + col]) = pwh[p];
             *reinterpret_cast<bf16x8 *>(&Wl[r * L3_STRIDE + col]) = pwl[p];
         }
@@ -197,7 +209,7 @@ __global__ void split_bf16_t_kernel(int rows, int cols, const float *__restrict_
 // exactly the NT kernel's, so the MFMA section is shared.  The m range is cut into `gridDim.z` splits (partials summed
 // by reduce_partials_kernel in a fixed order: deterministic).  Blocks of k tile 0 also produce the column sums of dY
 // (the bias gradient) from the registers they stage anyway.
-__global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
+__global__ __launch_bounds__(256, G3_OCC) void gemm3_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
                                                        int rows_per_split, float *__restrict__ partials, float *__restrict__ db_part)
 {
     constexpr int BN = 128;
@@ -224,11 +236,12 @@ __global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float pa[4][8], pb[4][8];
+    constexpr int TG = BK3 / 16; // 8-row groups per thread per chunk (2 thread halves x TG groups x 8 rows = BK3 rows)
+    float pa[TG][8], pb[TG][8];
     const float *a_col = dY + n_blk + c, *b_col = X + k_blk + c;
     auto load_chunk = [&](int m0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < TG; ++p)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int m = m0 + (g0 + 2 * p) * 8 + u;
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void gemm3_tn_kernel(int M, int N, int K, cons
     float colsum = 0.0f;
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < TG; ++p) {
             bf16x8 ahi, alo, bhi, blo;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
