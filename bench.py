@@ -232,8 +232,9 @@ def main():
         "metric": "env-steps/sec (sim+policy fwd) at %d humans" % H, "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not split else "f32 (big GEMMs as bf16x3 split-precision MFMA, fp32 accumulate)", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %s, %d humans, %d parallel envs per GPU, HH+HR attention on, "
-                               "policy forward + ORCA sim step + auto-reset per step" % (args.env_name, H, E),
+        "config": {"workload": "%s%s, %d humans, %d parallel envs per GPU, HH+HR attention on, "
+                               "policy forward + ORCA sim step + auto-reset per step" % (
+                                   "BASELINE configs[1]: " if (args.env_name, H, E) == ("CrowdSimVarNum-v0", 20, 4096) else "", args.env_name, H, E),
                    "envs_per_gpu": E, "humans": H, "parallelism": "dp%d (envs sharded, no rollout collective)" % world,
                    "policy_init": "orthogonal, torch.manual_seed(425)", "sampled_actions": True},
         "roofline": {"bound": "mfma", "kernel": "%s: folded q|k|v projection, M=%d live rows of %d, N=1536 K=512" % (kname, M, E * H),
