@@ -628,7 +628,28 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     const int H = c->human_num;
     /* srnn.clip_action (srnn.py:17-34): float32 arithmetic on the raw action */
     float ax = action_in[0], ay = action_in[1];
-    {
+    if (c->robot_policy == ORC_ROBOT_ORCA) {
+        /* crowd_sim_var_num.py:371-375: robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the robot's
+         * BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path */
+        if (!e->rob_sim_valid) {
+            e->rob_sim_nd = (float)e->shared_neighbor_dist;
+            e->rob_sim_self_radius = (float)(c->robot_radius + 0.01 + c->orca_safety_space);
+            e->rob_sim_self_maxspeed = (float)c->robot_v_pref;
+            for (int j = 0; j < H; ++j) e->rob_sim_seen_radius[j] = (float)(e->last_human_states[j][4] + 0.01 + c->orca_safety_space);
+            e->rob_sim_valid = 1;
+        }
+        float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS];
+        for (int j = 0; j < H; ++j) {
+            opx[j] = (float)e->last_human_states[j][0]; opy[j] = (float)e->last_human_states[j][1];
+            ovx[j] = (float)e->last_human_states[j][2]; ovy[j] = (float)e->last_human_states[j][3];
+        }
+        double vx = e->rgx - e->rpx, vy = e->rgy - e->rpy;
+        const double speed = norm2(vx, vy);
+        if (speed > 1.0) { vx = vx / speed; vy = vy / speed; }
+        orc_orca_velocity((float)e->rpx, (float)e->rpy, (float)e->rvx, (float)e->rvy, e->rob_sim_self_radius, e->rob_sim_self_maxspeed,
+                          (float)vx, (float)vy, e->rob_sim_nd, H, (float)c->orca_time_horizon, (float)c->time_step, H, opx, opy, ovx, ovy,
+                          e->rob_sim_seen_radius, &ax, &ay, 0, 0);
+    } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c->robot_v_pref;
         if (act_norm > vp) { ax = ax / act_norm * vp; ay = ay / act_norm * vp; }
@@ -735,6 +756,8 @@ OrcEnv *orc_env_new(const OrcConfig *cfg, int64_t this_seed)
     return e;
 }
 void orc_env_free(OrcEnv *e) { free(e); }
+/* crowd_sim_var_num.py:316-318: `case_counter[phase] = test_case` */
+void orc_env_set_case_counter(OrcEnv *e, uint64_t value) { e->case_counter[e->cfg.phase] = value; }
 int orc_sizeof_env(void) { return (int)sizeof(OrcEnv); }
 int orc_sizeof_obs(void) { return (int)sizeof(OrcObs); }
 int orc_sizeof_config(void) { return (int)sizeof(OrcConfig); }

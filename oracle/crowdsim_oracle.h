@@ -48,6 +48,7 @@ extern "C" {
 
 enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
 enum { ORC_PHASE_TRAIN = 0, ORC_PHASE_VAL = 1, ORC_PHASE_TEST = 2 };
+enum { ORC_ROBOT_NETWORK = 0, ORC_ROBOT_ORCA = 1 };
 /* episode info codes, crowd_sim/envs/utils/info.py */
 enum { ORC_INFO_NOTHING = 0, ORC_INFO_TIMEOUT = 1, ORC_INFO_COLLISION = 2, ORC_INFO_REACHGOAL = 3, ORC_INFO_DANGER = 4 };
 
@@ -62,6 +63,7 @@ typedef struct {
     int32_t phase;                /* ORC_PHASE_* */
     int32_t nenv;                 /* env.nenv (case_counter stride), envs.py:54 */
     uint32_t val_size, test_size; /* config.env.val_size/test_size */
+    int32_t robot_policy;         /* ORC_ROBOT_* : config.robot.policy (the network's action, or ORCA on the robot's beliefs) */
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;
@@ -98,6 +100,9 @@ typedef struct OrcEnv {
     double shared_neighbor_dist;   /* config.orca.neighbor_dist (class attribute, agent.py:21-22) */
     /* robot belief */
     double last_human_states[ORC_MAX_HUMANS][5];
+    /* the robot's own rvo2 simulator when robot.policy == 'orca' (created once, lives across episodes: orca.py:80-89) */
+    int32_t rob_sim_valid;
+    float rob_sim_nd, rob_sim_self_radius, rob_sim_self_maxspeed, rob_sim_seen_radius[ORC_MAX_HUMANS];
     int32_t human_visibility[ORC_MAX_HUMANS];
     double future_traj[ORC_MAX_PRED + 1][ORC_MAX_HUMANS][2]; /* const_vel predictions (positions) */
     double potential;
@@ -150,6 +155,7 @@ int orc_obs_width(const OrcConfig *cfg);
 /* flat helpers for ctypes */
 OrcEnv *orc_env_new(const OrcConfig *cfg, int64_t this_seed);
 void orc_env_free(OrcEnv *env);
+void orc_env_set_case_counter(OrcEnv *env, uint64_t value);
 int orc_sizeof_env(void);
 int orc_sizeof_obs(void);
 int orc_sizeof_config(void);

@@ -31,7 +31,7 @@ class OrcConfig(C.Structure):
         ("human_num", C.c_int32), ("predict_steps", C.c_int32), ("env_kind", C.c_int32),
         ("randomize_attributes", C.c_int32), ("random_goal_changing", C.c_int32),
         ("end_goal_changing", C.c_int32), ("sort_humans", C.c_int32), ("phase", C.c_int32),
-        ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32),
+        ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32), ("robot_policy", C.c_int32),
         ("time_step", C.c_double), ("time_limit", C.c_double),
         ("success_reward", C.c_double), ("collision_penalty", C.c_double),
         ("discomfort_dist", C.c_double), ("discomfort_penalty_factor", C.c_double),
@@ -63,6 +63,7 @@ def lib():
         L.orc_env_new.restype = C.c_void_p
         L.orc_env_new.argtypes = [C.POINTER(OrcConfig), C.c_int64]
         L.orc_env_free.argtypes = [C.c_void_p]
+        L.orc_env_set_case_counter.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_env_reset.argtypes = [C.c_void_p, C.POINTER(OrcObs)]
         L.orc_env_step.restype = C.c_int
         L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(OrcObs), C.POINTER(C.c_double),
@@ -127,6 +128,9 @@ class OracleEnv:
             self._L.orc_env_free(self._h)
         except Exception:
             pass
+
+    def set_case_counter(self, value):
+        self._L.orc_env_set_case_counter(self._h, int(value))
 
     def reset(self):
         self._L.orc_env_reset(self._h, C.byref(self._obs))

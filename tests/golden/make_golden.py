@@ -154,6 +154,9 @@ def env_goldens():
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 5}), 425, 0, 1, 300, "varnum_h5_rand_test_r0")
     trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 20, "sim.predict_method": "const_vel"}), 425, 0, 1, 200,
           "pred_h20_constvel_test_r0")
+    # robot.policy = 'orca' (trained_models/ORCA_no_rand): the robot's action is ORCA on its beliefs, the passed action is ignored
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "robot.policy": "orca"}), 425, 0, 1, 400, "varnum_h20_orcarobot_test_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 10, "robot.policy": "orca"}), 425, 0, 1, 300, "varnum_h10_rand_orcarobot_test_r0")
 
 
 if __name__ == "__main__":

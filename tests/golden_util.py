@@ -31,4 +31,5 @@ def sim_kwargs(meta):
         sort_humans=int(bool(meta.get("sort_humans", True))),
         nenv=int(meta["nenv"]),
         phase=0 if meta["nenv"] > 1 else 2,
+        robot_policy=1 if over.get("robot.policy", "selfAttn_merge_srnn") == "orca" else 0,
     )
