@@ -25,7 +25,7 @@ class EnvConfig(C.Structure):
         ("human_num", C.c_int32), ("predict_steps", C.c_int32), ("env_kind", C.c_int32),
         ("randomize_attributes", C.c_int32), ("random_goal_changing", C.c_int32),
         ("end_goal_changing", C.c_int32), ("sort_humans", C.c_int32), ("phase", C.c_int32),
-        ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32),
+        ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32), ("robot_policy", C.c_int32),
         ("time_step", C.c_double), ("time_limit", C.c_double),
         ("success_reward", C.c_double), ("collision_penalty", C.c_double),
         ("discomfort_dist", C.c_double), ("discomfort_penalty_factor", C.c_double),

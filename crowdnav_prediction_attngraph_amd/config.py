@@ -63,6 +63,9 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         unsupported.append("FOV != 2*pi")
     if env_name == "CrowdSimPred-v0" and g("sim", "predict_method", "const_vel") != "const_vel":
         unsupported.append("sim.predict_method=%r (only const_vel)" % g("sim", "predict_method", None))
+    rp = g("robot", "policy", "selfAttn_merge_srnn")
+    if rp not in ("selfAttn_merge_srnn", "srnn", "orca"):
+        unsupported.append("robot.policy=%r (the network policies and 'orca' are implemented)" % rp)
     if phase not in ("train", "test"):
         unsupported.append("phase=%r (train.py / test.py only use 'train' and 'test')" % phase)
     if float(g("env", "time_step", 0.25)) != float(g("data", "pred_timestep", 0.25)):
@@ -75,7 +78,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
         sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
-        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
+        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy=1 if rp == "orca" else 0, val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
         time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),
         success_reward=float(g("reward", "success_reward", 10)), collision_penalty=float(g("reward", "collision_penalty", -20)),
         discomfort_dist=float(g("reward", "discomfort_dist", 0.25)),

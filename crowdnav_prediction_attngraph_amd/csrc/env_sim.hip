@@ -57,6 +57,10 @@ struct EnvDev {
     uint8_t *nx_ready;  // [E]
     // test phase only (crowd_sim_var_num.py:386-388, :499-511): the humans' true future states rolled out with their own
     // ORCA policies, the robot's visibility flags of the last observation, and Danger's min_dist of the last step
+    // robot.policy == 'orca': the robot's own rvo2 simulator, created at its first use and kept across episodes (orca.py:80-89)
+    uint8_t *rob_sim_valid; // [E]
+    float *rob_nd;          // [E]   neighbour distance frozen at creation
+    float *rob_seen;        // [E][H] believed radii (+0.01 + safety space) frozen at creation
     double *tr;       // [E][P+1][4][H] px,py,vx,vy; slice 0 unused (k = 1 reads the live state)
     uint8_t *vis;     // [E][H]
     double *min_dist; // [E]
@@ -785,7 +789,26 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
 
     // srnn.clip_action (crowd_nav/policy/srnn.py:17-34), float32 like the numpy action array
     float ax = actions[2 * e], ay = actions[2 * e + 1];
-    {
+    if (c.robot_policy == CN_ROBOT_ORCA) {
+        // crowd_sim_var_num.py:371-375: action = robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the
+        // robot's BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path
+        float nd, seen_r;
+        if (!s.rob_sim_valid[e]) {
+            nd = (float)shared_nd;
+            seen_r = (float)(h.l4 + 0.01 + c.orca_safety_space);
+            if (isH) s.rob_seen[(size_t)e * H + lane] = seen_r;
+            if (lane == 0) { s.rob_nd[e] = nd; s.rob_sim_valid[e] = 1; }
+        } else {
+            nd = s.rob_nd[e];
+            seen_r = s.rob_seen[(size_t)e * H + (isH ? lane : 0)];
+        }
+        double gvx = rb.gx - rb.px, gvy = rb.gy - rb.py;
+        const double speed = sqrt(gvx * gvx + gvy * gvy);
+        if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
+        orca_wave(lane, H, isH, (float)h.l0, (float)h.l1, (float)h.l2, (float)h.l3, seen_r, (float)rb.px, (float)rb.py, (float)rb.vx, (float)rb.vy,
+                  (float)(c.robot_radius + 0.01 + c.orca_safety_space), (float)c.robot_v_pref, (float)gvx, (float)gvy, nd, H,
+                  (float)c.orca_time_horizon, (float)c.time_step, ax, ay);
+    } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c.robot_v_pref;
         if (act_norm > vp) { ax = ax / act_norm * vp; ay = ay / act_norm * vp; }
@@ -984,6 +1007,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST,
                "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
+    CN_REQUIRE(cfg->robot_policy == CN_ROBOT_NETWORK || cfg->robot_policy == CN_ROBOT_ORCA, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
     CN_REQUIRE(cfg->time_step > 0 && std::fabs(5.0 / cfg->time_step - std::round(5.0 / cfg->time_step)) < 1e-9,
                "cn_env_create: time_step must divide 5 s");
     cn_env_batch *b = new (std::nothrow) cn_env_batch{};
@@ -1004,6 +1028,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
     const size_t o_nh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
     const bool test_phase = cfg->phase == CN_PHASE_TEST;
+    const bool rob_orca = cfg->robot_policy == CN_ROBOT_ORCA;
+    const size_t o_rsv = rob_orca ? carve(E) : 0, o_rnd = rob_orca ? carve(E * 4) : 0, o_rsn = rob_orca ? carve(E * H * 4) : 0;
     const size_t o_tr = test_phase ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = test_phase ? carve(E * H) : 0, o_md = carve(E * 8);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
@@ -1023,6 +1049,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
     d.tr = test_phase ? (double *)(base + o_tr) : nullptr; d.vis = test_phase ? (uint8_t *)(base + o_vis) : nullptr;
     d.min_dist = (double *)(base + o_md);
+    d.rob_sim_valid = rob_orca ? (uint8_t *)(base + o_rsv) : nullptr; d.rob_nd = rob_orca ? (float *)(base + o_rnd) : nullptr;
+    d.rob_seen = rob_orca ? (float *)(base + o_rsn) : nullptr;
     b->reset_done = false;
     b->orca_ready = false;
     int prio_least = 0, prio_greatest = 0;

@@ -44,9 +44,13 @@ def evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging,
         raise NotImplementedError("the reference evaluates with ONE env (test.py:136); use evaluate_batched for the parallel form")
     if visualize:
         raise NotImplementedError("rendering is out of scope of the accelerated path")
-    base = actor_critic.base
-    hxs = {"human_node_rnn": torch.zeros(1, 1, base.human_node_rnn_size, device=device),
-           "human_human_edge_rnn": torch.zeros(1, base.human_num + 1, base.human_human_edge_rnn_size, device=device)}
+    scripted = actor_critic is None          # robot.policy in ('orca', ...): the env drives the robot itself (test.py:152-153)
+    if scripted and int(eval_envs.cfg.robot_policy) == 0:
+        raise ValueError("actor_critic is None but the env was not configured with robot.policy = 'orca'")
+    if not scripted:
+        base = actor_critic.base
+        hxs = {"human_node_rnn": torch.zeros(1, 1, base.human_node_rnn_size, device=device),
+               "human_human_edge_rnn": torch.zeros(1, base.human_num + 1, base.human_human_edge_rnn_size, device=device)}
     masks = torch.zeros(1, 1, device=device)
     time_limit, time_step = float(eval_envs.cfg.time_limit), float(eval_envs.cfg.time_step)
     outcomes, steps, path_lens, too_closes, min_dists, ep_rewards = [], [], [], [], [], []
@@ -56,8 +60,11 @@ def evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging,
         last_pos = obs["robot_node"][0, 0, :2].cpu().numpy()
         while not done:
             n += 1
-            with torch.no_grad():
-                _, action, _, hxs = actor_critic.act(obs, hxs, masks, deterministic=True)
+            if scripted:
+                action = torch.zeros(1, 2, device=device)                       # rl/evaluation.py:73-74
+            else:
+                with torch.no_grad():
+                    _, action, _, hxs = actor_critic.act(obs, hxs, masks, deterministic=True)
             obs, rew, dones, infos = eval_envs.step(action)
             pos = obs["robot_node"][0, 0, :2].cpu().numpy()
             path_len += float(np.linalg.norm(pos - last_pos))
@@ -82,6 +89,12 @@ def evaluate_batched(actor_critic, env_name, config, seed, test_size, device=Non
     from .hip import HipEnvBatch
     device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     cfg = to_env_config(config, env_name, 1, "test")          # nenv = 1: case counters advance by one, as in the sequential run
+    scripted = actor_critic is None
+    if scripted and int(cfg.robot_policy) == 0:
+        raise ValueError("actor_critic is None but config.robot.policy is not 'orca'")
+    if int(cfg.robot_policy) == 1 and int(cfg.randomize_attributes):
+        raise NotImplementedError("an ORCA robot with randomised humans keeps ONE rvo2 simulator (radii / neighbour distance frozen in the "
+                                  "first episode) across the whole sequential run; use evaluate() for that configuration")
     case_size = int(cfg.test_size)
     case_of = [(2 * k) % case_size for k in range(test_size)]  # reset() + the vec-env's auto-reset: two resets per episode
     cases = sorted(set(case_of))
@@ -90,7 +103,8 @@ def evaluate_batched(actor_critic, env_name, config, seed, test_size, device=Non
     # env e draws seed offset + counter[e] + (seed + e): counter[e] = case - e  (cases are distinct and sorted, so case >= e)
     env.set_case_counters(torch.tensor([c - e for e, c in enumerate(cases)], dtype=torch.int64))
     obs = env.reset()
-    pol = actor_critic._hip_policy(E, device)
+    pol = None if scripted else actor_critic._hip_policy(E, device)
+    zero_action = torch.zeros(E, 2, device=device)
     H = env.H
     hx = [torch.zeros(E, 1, 128, device=device), torch.zeros(E, 1, 128, device=device)]
     masks = torch.zeros(E, 1, device=device)
@@ -104,10 +118,14 @@ def evaluate_batched(actor_critic, env_name, config, seed, test_size, device=Non
     md_steps = []                                              # (env, step, min_dist) of every Danger step of a first episode
     max_steps = int(round(float(cfg.time_limit) / float(cfg.time_step))) + 1
     for t in range(max_steps):
-        pobs = {k: obs[k] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
-        out = pol.act(pobs, hx[t & 1], masks, eps=None)          # deterministic: dist.mode() (model.py:66-67)
-        hx[(t + 1) & 1] = out["hxs"].view(E, 1, 128)
-        obs, rew, done, info, ep_ret, _ = env.step(out["action"])
+        if scripted:
+            action = zero_action
+        else:
+            pobs = {k: obs[k] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+            out = pol.act(pobs, hx[t & 1], masks, eps=None)      # deterministic: dist.mode() (model.py:66-67)
+            hx[(t + 1) & 1] = out["hxs"].view(E, 1, 128)
+            action = out["action"]
+        obs, rew, done, info, ep_ret, _ = env.step(action)
         pos = obs["robot_node"].view(E, 7)[:, :2]
         # the reference measures the path on the float32 observation tensors, episode-end jump to the auto-reset start included
         path_len += torch.where(active, torch.linalg.norm((pos - last_pos).float(), dim=1).double(), torch.zeros_like(path_len))

@@ -49,6 +49,7 @@ enum { CN_ENV_VARNUM = 0, CN_ENV_PRED = 1, CN_ENV_PRED_GST = 2 };   /* gym ids C
 enum { CN_PHASE_TRAIN = 0, CN_PHASE_VAL = 1, CN_PHASE_TEST = 2 };
 enum { CN_INFO_NOTHING = 0, CN_INFO_TIMEOUT = 1, CN_INFO_COLLISION = 2, CN_INFO_REACHGOAL = 3, CN_INFO_DANGER = 4 }; /* crowd_sim/envs/utils/info.py */
 
+enum { CN_ROBOT_NETWORK = 0, CN_ROBOT_ORCA = 1 };
 #define CN_MAX_HUMANS 64 /* one wavefront lane per human */
 #define CN_MAX_PRED 8
 
@@ -64,6 +65,8 @@ typedef struct {
     int32_t phase;                /* CN_PHASE_TRAIN or CN_PHASE_TEST (test: seeds 1000 + case, 'truth' roll-out, future-zone Danger) */
     int32_t nenv;                 /* TOTAL number of envs across all GPUs: the case_counter stride (crowd_sim_var_num.py:348) */
     uint32_t val_size, test_size;
+    int32_t robot_policy;         /* CN_ROBOT_NETWORK: cn_env_step's action drives the robot; CN_ROBOT_ORCA: robot.policy = 'orca'
+                                   * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored */
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;

@@ -21,9 +21,14 @@
  *       rvo2 (sybrenstuvel/Python-RVO2 wrapping RVO2 Library v2.0.2 -- NOT vendored in
  *       /root/reference, no version pinned in requirements.txt).  The ORCA arithmetic below is a
  *       restatement of the published RVO2 v2.0.2 algorithm (Agent::computeNeighbors /
- *       computeNewVelocity / linearProgram1-3, fp32, RVO_EPSILON=1e-5).  PARITY UNPINNED for this
- *       one function: the reference holds no test or golden vector for rvo2 output; it is anchored
- *       on the reference's call sites (orca.py:80-114) and defended by property tests.
+ *       computeNewVelocity / linearProgram1-3, fp32, RVO_EPSILON=1e-5), anchored on the reference's
+ *       call sites (orca.py:80-114).  The reference has no unit test of rvo2 output, but it ships one
+ *       end-to-end fixture produced WITH the real library: the evaluation log of its ORCA-driven robot
+ *       (trained_models/ORCA_no_rand/test/test_00000.pt.log: 500 seeded test episodes).  This oracle
+ *       reproduces that log exactly -- every one of the 146 collision and 8 timeout episode indices and
+ *       the six printed metrics (tests/test_reference_eval_log.py); in a chaotic crowd simulation a
+ *       single differing rounding in the linear programs would flip outcomes, so the ORCA arithmetic
+ *       is PINNED by that fixture (and additionally covered by property tests).
  *   - vec-env wrapper semantics: rl/networks/shmem_vec_env.py:136-142 (auto-reset on done),
  *       rl/networks/envs.py:49-58 (thisSeed = seed + rank, nenv, phase)
  *   - rollout math: rl/networks/storage.py:123-132 (GAE), rl/ppo/ppo.py:37-39 (advantage norm)

@@ -43,6 +43,9 @@ CASES = {
     "varnum_h20_test": dict(human_num=20, phase=2),
     "varnum_h10_rand_test": dict(human_num=10, phase=2, randomize_attributes=1, random_goal_changing=1),
     "pred_h20_test": dict(human_num=20, env_kind=1, phase=2),
+    # robot.policy = 'orca': the robot is driven by ORCA on its beliefs (the action argument is ignored)
+    "varnum_h20_orcarobot": dict(human_num=20, robot_policy=1),
+    "varnum_h10_rand_orcarobot_test": dict(human_num=10, robot_policy=1, phase=2, randomize_attributes=1, random_goal_changing=1),
 }
 
 

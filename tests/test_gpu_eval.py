@@ -35,3 +35,40 @@ def test_sequential_and_batched_evaluation_agree(env_name, over):
     if seq["min_intrusion_dist"] == seq["min_intrusion_dist"]:
         assert seq["min_intrusion_dist"] == pytest.approx(bat["min_intrusion_dist"], rel=1e-9)
     assert seq["collision_rate"] + seq["timeout_rate"] + seq["success_rate"] == pytest.approx(1.0)
+
+
+def test_device_evaluation_reproduces_the_shipped_orca_robot_log():
+    """The reference's own end-to-end fixture (trained_models/ORCA_no_rand/test/test_00000.pt.log, real Python-RVO2), replayed
+    through the reference-shaped `evaluate` on the HIP simulator: all 500 outcomes and the six logged metrics."""
+    import json
+    import os
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.evaluation import evaluate
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_eval_orca_robot_log.json")))
+    c = ref["config"]
+    cfg = C.Config(**{"sim.human_num": c["human_num"], "robot.policy": "orca", "env.randomize_attributes": True,
+                      "humans.random_goal_changing": True, "humans.end_goal_changing": True, "env.test_size": c["test_size"]})
+    dev = torch.device("cuda", 0)
+    envs = make_vec_envs(c["env_name"], c["seed"], 1, 0.99, None, dev, True, config=cfg)
+    m = evaluate(None, envs, 1, dev, c["test_size"], logging.getLogger("eval-test"), cfg, None)
+    assert m["collision_cases"] == ref["collision_cases"]
+    assert m["timeout_cases"] == ref["timeout_cases"]
+    for k in ("success_rate", "collision_rate", "timeout_rate", "nav_time", "path_length", "intrusion_ratio", "min_intrusion_dist"):
+        assert "%.2f" % m[k] == "%.2f" % ref[k], (k, m[k], ref[k])
+
+
+def test_batched_evaluation_with_orca_robot_matches_sequential():
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.evaluation import evaluate, evaluate_batched
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    cfg = C.non_randomized(**{"sim.human_num": 20, "robot.policy": "orca", "env.test_size": 40})
+    dev = torch.device("cuda", 0)
+    log = logging.getLogger("eval-test")
+    seq = evaluate(None, make_vec_envs("CrowdSimVarNum-v0", 425, 1, 0.99, None, dev, True, config=cfg), 1, dev, 30, log, cfg, None)
+    bat = evaluate_batched(None, "CrowdSimVarNum-v0", cfg, 425, 30, device=dev, logging=log)
+    for k in ("success_rate", "collision_rate", "timeout_rate", "collision_cases", "timeout_cases"):
+        assert seq[k] == bat[k], (k, seq[k], bat[k])
+    for k in ("nav_time", "path_length", "intrusion_ratio", "min_intrusion_dist"):
+        assert seq[k] == pytest.approx(bat[k], rel=1e-6), (k, seq[k], bat[k])
+    assert seq["success_rate"] > 0.3          # the ORCA robot does reach goals

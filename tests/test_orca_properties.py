@@ -1,5 +1,6 @@
-"""Property tests of the ORCA restatement (rvo2 itself is unavailable, so its arithmetic is 'parity unpinned':
-these properties + bit-exact agreement of the two independent implementations are the defence)."""
+"""Property tests of the ORCA restatement.  rvo2 itself is unavailable here; its arithmetic is pinned end to end by the
+reference's shipped ORCA-robot evaluation log (tests/test_reference_eval_log.py) -- these properties and the bit-exact
+agreement of the two independent implementations are the fine-grained complement."""
 import numpy as np
 import pytest
 
