@@ -308,6 +308,7 @@ void orc_config_default(OrcConfig *c)
     c->circle_radius = 6.0 * sqrt(2.0); c->arena_size = 6.0;
     c->human_radius = 0.3; c->human_v_pref = 1.0; c->robot_radius = 0.3; c->robot_v_pref = 1.0;
     c->sensor_range = 5.0; c->goal_change_chance = 0.5; c->end_goal_change_chance = 1.0;
+    c->sf_A = 2.0; c->sf_B = 1.0; c->sf_KI = 1.0;
     c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0;
     c->orca_time_horizon_obst = 5.0;
 }
@@ -628,7 +629,26 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     const int H = c->human_num;
     /* srnn.clip_action (srnn.py:17-34): float32 arithmetic on the raw action */
     float ax = action_in[0], ay = action_in[1];
-    if (c->robot_policy == ORC_ROBOT_ORCA) {
+    double axd = 0.0, ayd = 0.0; /* float64 action of the social-force robot */
+    if (c->robot_policy == ORC_ROBOT_SOCIAL_FORCE) {
+        /* SOCIAL_FORCE.predict (crowd_nav/policy/social_force.py:11-52) on the robot's beliefs, all in float64 */
+        const double dxg = e->rgx - e->rpx, dyg = e->rgy - e->rpy;
+        const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
+        const double desired_vx = (dxg / dist_to_goal) * c->robot_v_pref, desired_vy = (dyg / dist_to_goal) * c->robot_v_pref;
+        const double curr_dvx = c->sf_KI * (desired_vx - e->rvx), curr_dvy = c->sf_KI * (desired_vy - e->rvy);
+        double ivx = 0.0, ivy = 0.0;
+        for (int j = 0; j < H; ++j) {
+            const double dx = e->rpx - e->last_human_states[j][0], dy = e->rpy - e->last_human_states[j][1];
+            const double d = sqrt(dx * dx + dy * dy);
+            const double f = c->sf_A * exp((c->robot_radius + e->last_human_states[j][4] - d) / c->sf_B);
+            ivx += f * (dx / d);
+            ivy += f * (dy / d);
+        }
+        const double nvx = e->rvx + (curr_dvx + ivx) * c->time_step, nvy = e->rvy + (curr_dvy + ivy) * c->time_step;
+        const double act_norm = sqrt(nvx * nvx + nvy * nvy);
+        if (act_norm > c->robot_v_pref) { axd = nvx / act_norm * c->robot_v_pref; ayd = nvy / act_norm * c->robot_v_pref; }
+        else { axd = nvx; ayd = nvy; }
+    } else if (c->robot_policy == ORC_ROBOT_ORCA) {
         /* crowd_sim_var_num.py:371-375: robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the robot's
          * BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path */
         if (!e->rob_sim_valid) {
@@ -710,9 +730,14 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         reward = reward + rf;
     }
     /* apply actions, agent.py:170-183 (holonomic) */
-    e->rpx = e->rpx + (double)(ax * (float)c->time_step); /* float32 * python float stays float32 (NEP 50), exact for 0.25 */
-    e->rpy = e->rpy + (double)(ay * (float)c->time_step);
-    e->rvx = (double)ax; e->rvy = (double)ay;
+    if (c->robot_policy == ORC_ROBOT_SOCIAL_FORCE) {
+        e->rpx = e->rpx + axd * c->time_step; e->rpy = e->rpy + ayd * c->time_step;
+        e->rvx = axd; e->rvy = ayd;
+    } else {
+        e->rpx = e->rpx + (double)(ax * (float)c->time_step); /* float32 * python float stays float32 (NEP 50), exact for 0.25 */
+        e->rpy = e->rpy + (double)(ay * (float)c->time_step);
+        e->rvx = (double)ax; e->rvy = (double)ay;
+    }
     for (int i = 0; i < H; ++i) {
         OrcHuman *h = &e->humans[i];
         h->px = h->px + (double)hax[i] * c->time_step;

@@ -28,7 +28,8 @@
  *       reproduces that log exactly -- every one of the 146 collision and 8 timeout episode indices and
  *       the six printed metrics (tests/test_reference_eval_log.py); in a chaotic crowd simulation a
  *       single differing rounding in the linear programs would flip outcomes, so the ORCA arithmetic
- *       is PINNED by that fixture (and additionally covered by property tests).
+ *       is PINNED by that fixture; the second shipped log (trained_models/SF_no_rand, social-force
+ *       robot among non-randomised ORCA humans: 318 collisions, 12 timeouts) is reproduced exactly too.
  *   - vec-env wrapper semantics: rl/networks/shmem_vec_env.py:136-142 (auto-reset on done),
  *       rl/networks/envs.py:49-58 (thisSeed = seed + rank, nenv, phase)
  *   - rollout math: rl/networks/storage.py:123-132 (GAE), rl/ppo/ppo.py:37-39 (advantage norm)
@@ -53,7 +54,7 @@ extern "C" {
 
 enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
 enum { ORC_PHASE_TRAIN = 0, ORC_PHASE_VAL = 1, ORC_PHASE_TEST = 2 };
-enum { ORC_ROBOT_NETWORK = 0, ORC_ROBOT_ORCA = 1 };
+enum { ORC_ROBOT_NETWORK = 0, ORC_ROBOT_ORCA = 1, ORC_ROBOT_SOCIAL_FORCE = 2 };
 /* episode info codes, crowd_sim/envs/utils/info.py */
 enum { ORC_INFO_NOTHING = 0, ORC_INFO_TIMEOUT = 1, ORC_INFO_COLLISION = 2, ORC_INFO_REACHGOAL = 3, ORC_INFO_DANGER = 4 };
 
@@ -76,6 +77,7 @@ typedef struct {
     double robot_radius, robot_v_pref, sensor_range;
     double goal_change_chance, end_goal_change_chance;
     double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
+    double sf_A, sf_B, sf_KI;     /* config.sf.* (social-force robot, crowd_nav/policy/social_force.py) */
 } OrcConfig;
 
 typedef struct {

@@ -41,6 +41,7 @@ class OrcConfig(C.Structure):
         ("goal_change_chance", C.c_double), ("end_goal_change_chance", C.c_double),
         ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
+        ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
     ]
 
 

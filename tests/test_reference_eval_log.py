@@ -1,5 +1,7 @@
-"""The reference ships ONE end-to-end result produced with the real Python-RVO2: the evaluation log of its ORCA-driven robot
-(trained_models/ORCA_no_rand/test/test_00000.pt.log: 500 test episodes, per-episode outcome lists and six aggregate metrics).
+"""The reference ships two end-to-end results produced with the real Python-RVO2: the evaluation logs of its ORCA-driven robot
+(trained_models/ORCA_no_rand/test/test_00000.pt.log, randomised humans) and of its social-force robot
+(trained_models/SF_no_rand/test/test_00000.pt.log, the non-randomised humans of BASELINE configs[1]); each holds 500 test
+episodes with per-episode outcome lists and six aggregate metrics.
 Replaying test.py's protocol with the CPU oracle -- one env for the whole run (the robot's rvo2 simulator, with the radii and
 neighbour distance frozen at its creation, lives across episodes), `reset()` per episode on top of the vec-env auto-reset,
 robot action = ORCA on the robot's beliefs, Danger from the humans' true future positions -- must reproduce that log exactly.
@@ -40,10 +42,14 @@ def replay(cfg, seed, n_episodes):
     return out
 
 
-def test_oracle_reproduces_the_shipped_orca_robot_evaluation_log():
-    ref = json.load(open(os.path.join(HERE, "golden", "ref_eval_orca_robot_log.json")))
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("fixture,robot_policy", [("ref_eval_orca_robot_log.json", 1), ("ref_eval_sf_robot_log.json", 2)])
+def test_oracle_reproduces_the_shipped_evaluation_logs(fixture, robot_policy):
+    ref = json.load(open(os.path.join(HERE, "golden", fixture)))
     c = ref["config"]
-    cfg = O.default_config(human_num=c["human_num"], phase=2, robot_policy=1, nenv=1, randomize_attributes=c["randomize_attributes"],
+    cfg = O.default_config(human_num=c["human_num"], phase=2, robot_policy=robot_policy, nenv=1, randomize_attributes=c["randomize_attributes"],
                            random_goal_changing=c["random_goal_changing"], end_goal_changing=c["end_goal_changing"], test_size=c["test_size"])
     N = c["test_size"]
     out = replay(cfg, c["seed"], N)
@@ -53,6 +59,7 @@ def test_oracle_reproduces_the_shipped_orca_robot_evaluation_log():
     assert coll == ref["collision_cases"]
     assert tout == ref["timeout_cases"]
     assert len(succ) + len(coll) + len(tout) == N
+    assert len(coll) > 100 and len(tout) >= 8
     # the six aggregates, formatted like rl/evaluation.py:141-146
     got = dict(success_rate=len(succ) / N, collision_rate=len(coll) / N, timeout_rate=len(tout) / N,
                nav_time=np.mean([(out[k][1] - 1) * 0.25 for k in succ]), path_length=np.mean([o[2] for o in out]),
