@@ -22,6 +22,18 @@ __device__ __forceinline__ void xcd_tile(int &row_tile, int &col_tile)
     col_tile = q % nbx;
     row_tile = (q / nbx) * 8 + x;
 }
+// Variant for wide weight matrices: when the whole W (hi + lo planes) plus the A tiles in flight exceed one XCD's 4 MB L2
+// (q|k|v: 3.1 MB of W + 5 x 256 KB of A), the L2 thrashes and every A tile is fetched ~4x.  Here XCDs 0-3 take the left
+// half of the column tiles and XCDs 4-7 the right half (W working set per L2 halves), XCD x' of a half owns row tiles
+// x', x'+4, ...; an A tile is then fetched by two L2s instead of being re-fetched by one.  gridDim.x must be even.
+__device__ __forceinline__ void xcd_tile_split(int &row_tile, int &col_tile)
+{
+    const int nbx = gridDim.x, ch = nbx >> 1;
+    const int L = blockIdx.y * nbx + blockIdx.x;
+    const int x = L & 7, q = L >> 3;
+    col_tile = (x >> 2) * ch + q % ch;
+    row_tile = (q / ch) * 4 + (x & 3);
+}
 
 constexpr int BM = 128, BK = 32, LDS_STRIDE = 36; // 36 floats = 144 B rows: conflict-free ds_read_b128
 

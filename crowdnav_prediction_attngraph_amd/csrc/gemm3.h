@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_nt_kernel(int M, int N, int
 {
     if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
     int row_tile, col_tile;
-    xcd_tile(row_tile, col_tile);
+    if ((size_t)N * K > (size_t)512 * 1024 && !(gridDim.x & 1)) xcd_tile_split(row_tile, col_tile); // W planes > 2 MB: halve the per-L2 W set
+    else xcd_tile(row_tile, col_tile);
     if (row_tile * TBM >= M) return;
     constexpr int MI = TBM / 64;             // 32-row MFMA blocks per wavefront (2 x 2 wavefronts: TBM/2 rows each)
     constexpr int NB = BN / 64;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_nt_kernel(int M, int N, int
                     float v = acc[i][j][r] + b;
                     if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
                     if (ACT == ACT_TANH) v = tanhf(v);
-                    C[(size_t)row * ldc + col] = v;
+                    // streaming result (150 MB for q|k|v, far beyond any L2): non-temporal stores keep A / W resident in the L2
+                    __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
                 }
             }
         }
