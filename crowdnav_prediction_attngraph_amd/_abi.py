@@ -150,9 +150,9 @@ def lib():
         L.cn_embed0_fwd.argtypes = [i32, i32, vp, vp, vp, vp, vp]
         L.cn_embed0_bwd.argtypes = [i32, i32, vp, vp, vp, i32, vp, vp, vp]
         L.cn_split_bf16.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-        L.cn_linear_fwd.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp]
+        L.cn_linear_fwd.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp]
         L.cn_linear_wgrad_splits.argtypes = [i32, i32, i32]
-        L.cn_linear_wgrad.argtypes = [i32, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]
+        L.cn_linear_wgrad.argtypes = [i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         L.cn_gst_create.argtypes = [i32, i32, C.POINTER(vp)]
         L.cn_gst_destroy.argtypes = [vp]
         L.cn_gst_set_weights.argtypes = [vp, C.POINTER(GstWeights), vp]

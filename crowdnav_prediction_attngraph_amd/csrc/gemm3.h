@@ -25,9 +25,9 @@ constexpr int BK3 = CN_BK3;
 constexpr int L3_STRIDE = BK3 + 8;  // +8 bf16 pad: rows 48 B apart (BK3 = 16) -> 16 consecutive rows' 16-byte reads tile all 64 banks
 constexpr int G3_OCC = BK3 <= 16 ? 4 : (BK3 <= 32 ? 3 : 2); // workgroups per CU the register budget is compiled for
 
-template <int TBM, int BN, int ACT>
-__global__ __launch_bounds__(256, G3_OCC) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
-                                                       const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+template <int TBM, int BN, int ACT, bool GATE>
+__global__ __launch_bounds__(256, (GATE && G3_OCC > 2) ? G3_OCC - 1 : G3_OCC) void gemm3_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ Agate, const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
                                                        const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                        const int *__restrict__ m_dev)
 {
@@ -61,14 +61,21 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_nt_kernel(int M, int N, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    f32x4 pa[ALD];
+    f32x4 pa[ALD], pg[GATE ? ALD : 1];
     bf16x8 pwh[WCH], pwl[WCH];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < ALD; ++p) {
             const int r = m_blk + lrow + ARP * p;
-            if (r < M) pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
-            else pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < M) {
+                pa[p] = *reinterpret_cast<const f32x4 *>(A + (size_t)r * lda + k0 + lcol);
+                // backward through a ReLU: A = dY gated by the forward output (same shape / leading dimension).  Only the raw
+                // load is issued here; the select happens in store_tiles so that it does not wait for the prefetch
+                if (GATE) pg[p] = *reinterpret_cast<const f32x4 *>(Agate + (size_t)r * lda + k0 + lcol);
+            } else {
+                pa[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (GATE) pg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int p = 0; p < WCH; ++p) {
@@ -83,8 +90,9 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_nt_kernel(int M, int N, int
             bf16x4 hi, lo;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                hi[q] = (__bf16)pa[p][q];
-                lo[q] = (__bf16)(pa[p][q] - (float)hi[q]);
+                const float a = GATE ? (pg[GATE ? p : 0][q] > 0.0f ? pa[p][q] : 0.0f) : pa[p][q];
+                hi[q] = (__bf16)a;
+                lo[q] = (__bf16)(a - (float)hi[q]);
             }
             *reinterpret_cast<bf16x4 *>(&Ah[(lrow + ARP * p) * L3_STRIDE + lcol]) = hi;
             *reinterpret_cast<bf16x4 *>(&Al[(lrow + ARP * p) * L3_STRIDE + lcol]) = lo;
@@ -167,7 +175,7 @@ __global__ void split_bf16_kernel(size_t n, const float *__restrict__ w, __bf16 
 
 template <int TBM, int BN, int ACT>
 static int launch_gemm3_t(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
-                          hipStream_t st, const int *m_dev)
+                          hipStream_t st, const int *m_dev, const float *Agate = nullptr)
 {
     CN_REQUIRE(N % BN == 0 && K % BK3 == 0 && lda % 4 == 0, "gemm3: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
     if (M == 0) return CN_OK;
@@ -175,18 +183,20 @@ static int launch_gemm3_t(int M, int N, int K, const float *A, int lda, const __
     constexpr size_t lds = (size_t)(2 * TBM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB at 128 x 128: needs the opt-in above 64 KB
     static bool attr_set = false;
     if (!attr_set) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<TBM, BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<TBM, BN, ACT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<TBM, BN, ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm3_nt_kernel<TBM, BN, ACT>), grid, dim3(256), lds, st, M, N, K, A, lda, Whi, Wlo, bias, C, ldc, m_dev);
+    if (Agate) hipLaunchKernelGGL((gemm3_nt_kernel<TBM, BN, ACT, true>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, m_dev);
+    else hipLaunchKernelGGL((gemm3_nt_kernel<TBM, BN, ACT, false>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, m_dev);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
 template <int BN, int ACT>
 static int launch_gemm3(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
-                        hipStream_t st, const int *m_dev)
+                        hipStream_t st, const int *m_dev, const float *Agate = nullptr)
 {
-    return launch_gemm3_t<BM, BN, ACT>(M, N, K, A, lda, Whi, Wlo, bias, C, ldc, st, m_dev);
+    return launch_gemm3_t<BM, BN, ACT>(M, N, K, A, lda, Whi, Wlo, bias, C, ldc, st, m_dev, Agate);
 }
 
 // hi/lo split of W^T: w [rows, cols] row-major -> hi, lo [cols, rows].  Lets the NT kernel compute dX = dY * W
@@ -211,8 +221,10 @@ __global__ void split_bf16_t_kernel(int rows, int cols, const float *__restrict_
 // exactly the NT kernel's, so the MFMA section is shared.  The m range is cut into `gridDim.z` splits (partials summed
 // by reduce_partials_kernel in a fixed order: deterministic).  Blocks of k tile 0 also produce the column sums of dY
 // (the bias gradient) from the registers they stage anyway.
-__global__ __launch_bounds__(256, G3_OCC) void gemm3_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ X, int ldx,
-                                                       int rows_per_split, float *__restrict__ partials, float *__restrict__ db_part)
+template <bool GATE>
+__global__ __launch_bounds__(256, (GATE && G3_OCC > 2) ? G3_OCC - 1 : G3_OCC) void gemm3_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ Ygate,
+                                                       const float *__restrict__ X, int ldx, int rows_per_split, float *__restrict__ partials,
+                                                       float *__restrict__ db_part)
 {
     constexpr int BN = 128;
     constexpr int NB = BN / 64;
@@ -239,8 +251,9 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_tn_kernel(int M, int N, int
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     constexpr int TG = BK3 / 16; // 8-row groups per thread per chunk (2 thread halves x TG groups x 8 rows = BK3 rows)
-    float pa[TG][8], pb[TG][8];
+    float pa[TG][8], pb[TG][8], pg[GATE ? TG : 1][8];
     const float *a_col = dY + n_blk + c, *b_col = X + k_blk + c;
+    const float *g_col = GATE ? Ygate + n_blk + c : nullptr; // backward through a ReLU: dY gated by the forward output
     auto load_chunk = [&](int m0) {
 #pragma unroll
         for (int p = 0; p < TG; ++p)
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_tn_kernel(int M, int N, int
                 const int m = m0 + (g0 + 2 * p) * 8 + u;
                 const bool ok = m < m_end;
                 pa[p][u] = ok && n_ok ? a_col[(size_t)m * ldy] : 0.0f;
+                if (GATE) pg[p][u] = ok && n_ok ? g_col[(size_t)m * ldy] : 0.0f; // raw load; the select happens in store_chunk
                 pb[p][u] = ok ? b_col[(size_t)m * ldx] : 0.0f;
             }
     };
@@ -259,6 +273,7 @@ __global__ __launch_bounds__(256, G3_OCC) void gemm3_tn_kernel(int M, int N, int
             bf16x8 ahi, alo, bhi, blo;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
+                if (GATE) pa[p][u] = pg[GATE ? p : 0][u] > 0.0f ? pa[p][u] : 0.0f;
                 ahi[u] = (__bf16)pa[p][u];
                 alo[u] = (__bf16)(pa[p][u] - (float)ahi[u]);
                 bhi[u] = (__bf16)pb[p][u];

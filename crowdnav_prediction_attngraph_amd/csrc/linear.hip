@@ -145,16 +145,16 @@ extern "C" int cn_split_bf16(const float *w, int rows, int cols, int transpose, 
     return CN_OK;
 }
 
-extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act, float *Y,
-                             int ldy, void *stream)
+extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const float *relu_gate, const void *Whi, const void *Wlo, const float *bias,
+                             int act, float *Y, int ldy, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(X && Whi && Wlo && Y && M >= 0, "cn_linear_fwd: bad argument");
     CN_REQUIRE(act == 0 || act == 1, "cn_linear_fwd: act must be 0 (none) or 1 (relu)");
     CN_REQUIRE(ldx >= K && ldy >= N, "cn_linear_fwd: leading dimension smaller than the row length");
     hipStream_t st = (hipStream_t)stream;
-    if (act == 1) return launch_gemm3<128, ACT_RELU>(M, N, K, X, ldx, (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Y, ldy, st, nullptr);
-    return launch_gemm3<128, ACT_NONE>(M, N, K, X, ldx, (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Y, ldy, st, nullptr);
+    if (act == 1) return launch_gemm3<128, ACT_RELU>(M, N, K, X, ldx, (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Y, ldy, st, nullptr, relu_gate);
+    return launch_gemm3<128, ACT_NONE>(M, N, K, X, ldx, (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Y, ldy, st, nullptr, relu_gate);
 }
 
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
@@ -168,8 +168,8 @@ extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
     return (int)(s < 1 ? 1 : s);
 }
 
-extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, int splits, float *partials,
-                               float *db_partials, float *dW, float *db, void *stream)
+extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *relu_gate, const float *X, int ldx, int splits,
+                               float *partials, float *db_partials, float *dW, float *db, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(dY && X && partials && dW && M > 0 && splits >= 1, "cn_linear_wgrad: bad argument");
@@ -183,10 +183,12 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
     constexpr size_t lds = (size_t)(2 * BM + 2 * 128) * L3_STRIDE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm3_tn_kernel, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, X, ldx, rows, partials, db_partials);
+    if (relu_gate) hipLaunchKernelGGL(gemm3_tn_kernel<true>, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
+    else hipLaunchKernelGGL(gemm3_tn_kernel<false>, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
     CN_CHECK_LAUNCH();
     const size_t nk = (size_t)N * K;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, nk, used, partials, dW);

@@ -426,7 +426,7 @@ class WgradLinear(torch.autograd.Function):
         dbp = torch.empty(splits, N, device=x.device)
         dw = torch.empty(N, K, device=x.device)
         db = torch.empty(N, device=x.device)
-        A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
+        A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, None, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
                 "cn_linear_wgrad")
         return dx, dw, db
 
@@ -443,7 +443,7 @@ class HipLinear(torch.autograd.Function):
         y = torch.empty(M, N, device=x.device)
         if M:
             hi, lo = split_bf16(w.detach())
-            A.check(A.lib().cn_linear_fwd(M, N, K, A.ptr(x), K, A.ptr(hi), A.ptr(lo), A.ptr(b.detach().contiguous()), int(bool(relu)), A.ptr(y), N,
+            A.check(A.lib().cn_linear_fwd(M, N, K, A.ptr(x), K, None, A.ptr(hi), A.ptr(lo), A.ptr(b.detach().contiguous()), int(bool(relu)), A.ptr(y), N,
                                           A.stream_ptr()), "cn_linear_fwd")
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu = bool(relu)
@@ -454,23 +454,22 @@ class HipLinear(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         M, K = x.shape
         N = w.shape[0]
-        if ctx.relu:
-            dy = dy * (y > 0)
         dy = dy.contiguous()
+        gate = A.ptr(y) if ctx.relu else None          # ReLU backward is applied while dY is loaded (no masking pass)
         dx = dw = db = None
         if M == 0:
             return torch.zeros_like(x), torch.zeros_like(w), x.new_zeros(N), None
         if ctx.needs_input_grad[0]:
             hi_t, lo_t = split_bf16(w.detach(), transpose=True)              # [K,N]: dX = dY W as an NT product with W^T
             dx = torch.empty(M, K, device=x.device)
-            A.check(A.lib().cn_linear_fwd(M, K, N, A.ptr(dy), N, A.ptr(hi_t), A.ptr(lo_t), None, 0, A.ptr(dx), K, A.stream_ptr()), "cn_linear_fwd(dX)")
+            A.check(A.lib().cn_linear_fwd(M, K, N, A.ptr(dy), N, gate, A.ptr(hi_t), A.ptr(lo_t), None, 0, A.ptr(dx), K, A.stream_ptr()), "cn_linear_fwd(dX)")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             splits = A.lib().cn_linear_wgrad_splits(M, N, K)
             part = torch.empty(splits, N, K, device=x.device)
             dbp = torch.empty(splits, N, device=x.device)
             dw = torch.empty(N, K, device=x.device)
             db = torch.empty(N, device=x.device)
-            A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
+            A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, gate, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
                     "cn_linear_wgrad")
         return dx, dw, db, None
 

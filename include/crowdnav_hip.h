@@ -224,17 +224,19 @@ int cn_gru_cell_bwd(int N, const float *gates, const float *hm, const float *dh,
  * cn_split_bf16:   w [rows,cols] fp32 -> hi, lo (bf16) of w (transpose = 0) or of w^T [cols,rows] (transpose = 1).
  * cn_linear_fwd:   Y[M,N] = act(X[M,K] W^T + bias), W given as hi/lo [N,K]; act 0 = none, 1 = ReLU; bias may be NULL.
  *                  With the transposed split of W [N,K] passed as a [K,N] weight it computes dX = dY W (no bias).
- *                  N % 128 == 0, K % 64 == 0.
- * cn_linear_wgrad: dW[N,K] = dY[M,N]^T X[M,K] and (optional) db[N] = column sums of dY.  The M reduction is cut into
+ *                  relu_gate (optional, same shape and leading dimension as X): X is replaced by X * [relu_gate > 0] while it
+ *                  is loaded -- the backward of Linear+ReLU without a separate masking pass.  N % 128 == 0, K % 64 == 0.
+ * cn_linear_wgrad: dW[N,K] = dY[M,N]^T X[M,K] and (optional) db[N] = column sums of dY (dY gated by relu_gate > 0 when that
+ *                  pointer, shaped like dY, is given).  The M reduction is cut into
  *                  `splits` ranges whose partial products land in partials [splits,N,K] (db_partials [splits,N]) and are
  *                  summed in split order (deterministic).  N % 64 == 0, K % 128 == 0.
  * cn_linear_wgrad_splits: the split count the library would pick for (M,N,K); 0 if the shape is unsupported. */
 int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream);
-int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act,
-                  float *Y, int ldy, void *stream);
+int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const float *relu_gate, const void *Whi, const void *Wlo,
+                  const float *bias, int act, float *Y, int ldy, void *stream);
 int cn_linear_wgrad_splits(int M, int N, int K);
-int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, int splits, float *partials,
-                    float *db_partials, float *dW, float *db, void *stream);
+int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *relu_gate, const float *X, int ldx, int splits,
+                    float *partials, float *db_partials, float *dW, float *db, void *stream);
 
 /* ---- GST trajectory predictor + VecPretextNormalize (CrowdSimPredRealGST-v0, BASELINE configs[3]) ----
  * cn_gst_predict          <- gst_updated/scripts/wrapper/crowd_nav_interface_parallel.py:45-114 CrowdNavPredInterfaceMultiEnv.forward
