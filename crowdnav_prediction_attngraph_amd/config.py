@@ -53,8 +53,9 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     unsupported = []
     if g("sim", "human_num_range", 0) != 0:
         unsupported.append("sim.human_num_range != 0")
-    if g("robot", "visible", False):
-        unsupported.append("robot.visible=True")
+    rv = bool(g("robot", "visible", False))
+    if rv and (env_name != "CrowdSimVarNum-v0" or phase != "train" or int(g("sim", "human_num", 20)) > 63):
+        unsupported.append("robot.visible=True outside CrowdSimVarNum-v0 / phase train / human_num <= 63")
     if g("action_space", "kinematics", "holonomic") != "holonomic":
         unsupported.append("unicycle kinematics")
     if g("humans", "policy", "orca") != "orca":
@@ -78,7 +79,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
         sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
-        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy=1 if rp == "orca" else 0, val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
+        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy=1 if rp == "orca" else 0, robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
         time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),
         success_reward=float(g("reward", "success_reward", 10)), collision_penalty=float(g("reward", "collision_penalty", -20)),
         discomfort_dist=float(g("reward", "discomfort_dist", 0.25)),

@@ -325,18 +325,24 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
         nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
         seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + safety);
     }
-    // other humans as seen by i (human FOV = 2*pi: always the true state unless coincident -> dummy (7,7,0,0))
-    const bool cand = isH && lane != i;
-    const bool coincident = (px == spx) && (py == spy);
-    const float opx = coincident ? 7.0f : (float)px, opy = coincident ? 7.0f : (float)py;
-    const float ovx = coincident ? 0.0f : (float)vx, ovy = coincident ? 0.0f : (float)vy;
+    // other humans as seen by i (human FOV = 2*pi: always the true state unless coincident -> dummy (7,7,0,0)); with
+    // robot.visible the robot is appended as the last neighbour on lane H (crowd_sim.py:695-699), same visibility rule
+    const bool rv = s.cfg.robot_visible != 0;
+    const bool isR = rv && lane == H;
+    const double *rob = s.rob + (size_t)e * 8;
+    const double qx = isR ? rob[R_PX] : px, qy = isR ? rob[R_PY] : py, qvx = isR ? rob[R_VX] : vx, qvy = isR ? rob[R_VY] : vy;
+    if (isR) seen_r = (float)(s.cfg.robot_radius + 0.01 + safety); // fixed for the whole run
+    const bool cand = (isH && lane != i) || isR;
+    const bool coincident = (qx == spx) && (qy == spy);
+    const float opx = coincident ? 7.0f : (float)qx, opy = coincident ? 7.0f : (float)qy;
+    const float ovx = coincident ? 0.0f : (float)qvx, ovy = coincident ? 0.0f : (float)qvy;
     // preferred velocity: orca.py:97-100
     double gvx = sgx - spx, gvy = sgy - spy;
     const double speed = sqrt(gvx * gvx + gvy * gvy);
     if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
     float ox, oy;
-    orca_wave(lane, H, cand, opx, opy, ovx, ovy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
-              (float)gvx, (float)gvy, nd, H - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
+    orca_wave(lane, rv ? H + 1 : H, cand, opx, opy, ovx, ovy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
+              (float)gvx, (float)gvy, nd, rv ? H : H - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
     if (lane == 0) {
         s.hact[(size_t)e * 2 * H + i] = ox;
         s.hact[(size_t)e * 2 * H + H + i] = oy;
@@ -1008,6 +1014,9 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
                "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
     CN_REQUIRE(cfg->robot_policy == CN_ROBOT_NETWORK || cfg->robot_policy == CN_ROBOT_ORCA, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
+    CN_REQUIRE(!cfg->robot_visible || (cfg->env_kind == CN_ENV_VARNUM && cfg->phase == CN_PHASE_TRAIN && cfg->human_num <= CN_MAX_HUMANS - 1),
+               "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num <= %d (the reference rebuilds every private "
+               "simulator twice per step in the test phase and breaks in CrowdSimPred)", CN_MAX_HUMANS - 1);
     CN_REQUIRE(cfg->time_step > 0 && std::fabs(5.0 / cfg->time_step - std::round(5.0 / cfg->time_step)) < 1e-9,
                "cn_env_create: time_step must divide 5 s");
     cn_env_batch *b = new (std::nothrow) cn_env_batch{};

@@ -67,6 +67,9 @@ typedef struct {
     uint32_t val_size, test_size;
     int32_t robot_policy;         /* CN_ROBOT_NETWORK: cn_env_step's action drives the robot; CN_ROBOT_ORCA: robot.policy = 'orca'
                                    * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored */
+    int32_t robot_visible;        /* robot.visible: every human's ORCA sees the robot as one more neighbour (crowd_sim.py:695-699);
+                                   * CrowdSimVarNum-v0, train phase, human_num <= 63 */
+    int32_t reserved0;
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;

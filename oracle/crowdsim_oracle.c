@@ -531,12 +531,20 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
         orad[n] = e->sim_seen_radius[i][j];
         ++n;
     }
+    if (c->robot_visible) {
+        /* crowd_sim.py:695-699: the robot is appended as the last neighbour; FOV = 2*pi -> visible unless coincident, else the
+         * dummy robot parked at (7,7).  Its rvo2 radius was fixed when human i's simulator was created. */
+        if (e->rpx == me->px && e->rpy == me->py) { opx[n] = 7.0f; opy[n] = 7.0f; ovx[n] = 0.0f; ovy[n] = 0.0f; }
+        else { opx[n] = (float)e->rpx; opy[n] = (float)e->rpy; ovx[n] = (float)e->rvx; ovy[n] = (float)e->rvy; }
+        orad[n] = (float)(c->robot_radius + 0.01 + c->orca_safety_space);
+        ++n;
+    }
     /* :97-100 pref velocity: goal vector, normalised only when longer than 1 */
     double vx = me->gx - me->px, vy = me->gy - me->py;
     const double speed = norm2(vx, vy);
     if (speed > 1.0) { vx = vx / speed; vy = vy / speed; }
     orc_orca_velocity((float)me->px, (float)me->py, (float)me->vx, (float)me->vy, e->sim_self_radius[i],
-                      e->sim_self_maxspeed[i], (float)vx, (float)vy, e->sim_nd[i], H - 1,
+                      e->sim_self_maxspeed[i], (float)vx, (float)vy, e->sim_nd[i], n /* max_neighbors = len(human_states) */,
                       (float)c->orca_time_horizon, (float)c->time_step, n, opx, opy, ovx, ovy, orad, avx, avy, 0, 0);
 }
 

@@ -70,6 +70,8 @@ typedef struct {
     int32_t nenv;                 /* env.nenv (case_counter stride), envs.py:54 */
     uint32_t val_size, test_size; /* config.env.val_size/test_size */
     int32_t robot_policy;         /* ORC_ROBOT_* : config.robot.policy (the network's action, or ORCA on the robot's beliefs) */
+    int32_t robot_visible;        /* config.robot.visible: humans treat the robot as one more ORCA neighbour (crowd_sim.py:695-699) */
+    int32_t reserved0;
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;

@@ -157,11 +157,22 @@ def env_goldens():
     # robot.policy = 'orca' (trained_models/ORCA_no_rand): the robot's action is ORCA on its beliefs, the passed action is ignored
     trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "robot.policy": "orca"}), 425, 0, 1, 400, "varnum_h20_orcarobot_test_r0")
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 10, "robot.policy": "orca"}), 425, 0, 1, 300, "varnum_h10_rand_orcarobot_test_r0")
+    # robot.visible = True: every human's ORCA gets the robot as one more neighbour (crowd_sim.py:695-699)
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "robot.visible": True}), 425, 1, 4, 300, "varnum_h20_robotvisible_r1")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 7, "robot.visible": True}), 425, 2, 4, 320, "varnum_h7_rand_robotvisible_r2")
 
 
 if __name__ == "__main__":
     what = _ARGV or ["env"]
     if "env" in what:
+        env_goldens()
+    only = [w[5:] for w in what if w.startswith("only:")]
+    if only:                # python make_golden.py only:<substring of the tag>
+        _all2 = trace
+
+        def trace(env_name, over, seed, rank, nenv, steps, tag):  # noqa: F811
+            if any(o in tag for o in only):
+                _all2(env_name, over, seed, rank, nenv, steps, tag)
         env_goldens()
     if "env-test" in what:  # only the test-phase traces (the train-phase fixtures stay byte-identical)
         _all = trace

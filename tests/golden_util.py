@@ -32,4 +32,5 @@ def sim_kwargs(meta):
         nenv=int(meta["nenv"]),
         phase=0 if meta["nenv"] > 1 else 2,
         robot_policy=1 if over.get("robot.policy", "selfAttn_merge_srnn") == "orca" else 0,
+        robot_visible=int(bool(over.get("robot.visible", False))),
     )

@@ -46,6 +46,9 @@ CASES = {
     # robot.policy = 'orca': the robot is driven by ORCA on its beliefs (the action argument is ignored)
     "varnum_h20_orcarobot": dict(human_num=20, robot_policy=1),
     "varnum_h10_rand_orcarobot_test": dict(human_num=10, robot_policy=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    # robot.visible: the humans' ORCA sees the robot as one more neighbour
+    "varnum_h20_robotvisible": dict(human_num=20, robot_visible=1),
+    "varnum_h63_rand_robotvisible": dict(human_num=63, robot_visible=1, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
 }
 
 
