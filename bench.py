@@ -197,15 +197,18 @@ def main():
         if args.env_name == "CrowdSimPred-v0":
             over["sim.predict_method"] = "const_vel"
         tcfg = CFG.non_randomized(**over)
-        hist, _ = train(env_name=args.env_name, num_processes=E, num_steps=30, num_updates=3, seed=425, config=tcfg, log=None)
-        last = hist[-1]
-        tt = torch.tensor([last["rollout_s"], last["update_s"]], device="cuda" if (dist is None or args.dist_backend == "nccl") else "cpu", dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        r_s, u_s = float(tt[0]), float(tt[1])
-        ppo = {"samples_per_s": round(30 * E * world / (r_s + u_s), 1), "rollout_s": round(r_s, 5), "update_s": round(u_s, 5),
-               "config": "T=30 steps x %d envs per GPU, ppo_epoch 5, num_mini_batch 2, Adam; 3 updates run, the last one timed" % E,
-               "value_loss": round(last["value_loss"], 6)}
+        try:
+            hist, _ = train(env_name=args.env_name, num_processes=E, num_steps=30, num_updates=3, seed=425, config=tcfg, log=None)
+            last = hist[-1]
+            tt = torch.tensor([last["rollout_s"], last["update_s"]], device="cuda" if (dist is None or args.dist_backend == "nccl") else "cpu", dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            r_s, u_s = float(tt[0]), float(tt[1])
+            ppo = {"samples_per_s": round(30 * E * world / (r_s + u_s), 1), "rollout_s": round(r_s, 5), "update_s": round(u_s, 5),
+                   "config": "T=30 steps x %d envs per GPU, ppo_epoch 5, num_mini_batch 2, Adam; 3 updates run, the last one timed" % E,
+                   "value_loss": round(last["value_loss"], 6)}
+        except Exception as exc:   # the headline line is still printed; a failure here is the same on every rank
+            ppo = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
