@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (BASELINE configs[1]: 4096)")
     ap.add_argument("--humans", type=int, default=20)
     ap.add_argument("--env-name", default="CrowdSimVarNum-v0")
+    ap.add_argument("--randomized", action="store_true", help="randomize_attributes + random_goal_changing (BASELINE configs[4] stress shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -125,7 +126,8 @@ def main():
 
     E, H = args.envs, args.humans
     kind = A.ENV_KINDS[args.env_name]
-    cfg = A.default_env_config(human_num=H, env_kind=kind, nenv=E * world)
+    cfg = A.default_env_config(human_num=H, env_kind=kind, nenv=E * world, randomize_attributes=int(args.randomized),
+                               random_goal_changing=int(args.randomized))
     env = HipEnvBatch(cfg, E, 425, first_env_index=rank * E)
     D = env.D
     torch.manual_seed(425)
@@ -196,7 +198,7 @@ def main():
         over = {"sim.human_num": H}
         if args.env_name == "CrowdSimPred-v0":
             over["sim.predict_method"] = "const_vel"
-        tcfg = CFG.non_randomized(**over)
+        tcfg = CFG.Config(**dict(over, **{"humans.end_goal_changing": True})) if args.randomized else CFG.non_randomized(**over)
         try:
             hist, _ = train(env_name=args.env_name, num_processes=E, num_steps=30, num_updates=3, seed=425, config=tcfg, log=None)
             last = hist[-1]
@@ -237,7 +239,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not split else "f32 (big GEMMs as bf16x3 split-precision MFMA, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "%s%s, %d humans, %d parallel envs per GPU, HH+HR attention on, "
                                "policy forward + ORCA sim step + auto-reset per step" % (
-                                   "BASELINE configs[1]: " if (args.env_name, H, E) == ("CrowdSimVarNum-v0", 20, 4096) else "", args.env_name, H, E),
+                                   "BASELINE configs[1]: " if (args.env_name, H, E, args.randomized) == ("CrowdSimVarNum-v0", 20, 4096, False) else ("randomized humans, " if args.randomized else ""), args.env_name, H, E),
                    "envs_per_gpu": E, "humans": H, "parallelism": "dp%d (envs sharded, no rollout collective)" % world,
                    "policy_init": "orthogonal, torch.manual_seed(425)", "sampled_actions": True},
         "roofline": {"bound": "mfma", "kernel": "%s: folded q|k|v projection, M=%d live rows of %d, N=1536 K=512" % (kname, M, E * H),
