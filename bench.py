@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--humans", type=int, default=20)
     ap.add_argument("--env-name", default="CrowdSimVarNum-v0")
     ap.add_argument("--randomized", action="store_true", help="randomize_attributes + random_goal_changing (BASELINE configs[4] stress shape)")
+    ap.add_argument("--max-placement-attempts", type=int, default=0,
+                    help="bound of the reference's unbounded rejection sampling of human positions / goals (0 = library default 65536); dense "
+                         "randomised crowds (configs[4]) need a small bound or the batch waits for its unluckiest env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -127,7 +130,7 @@ def main():
     E, H = args.envs, args.humans
     kind = A.ENV_KINDS[args.env_name]
     cfg = A.default_env_config(human_num=H, env_kind=kind, nenv=E * world, randomize_attributes=int(args.randomized),
-                               random_goal_changing=int(args.randomized))
+                               random_goal_changing=int(args.randomized), max_placement_attempts=args.max_placement_attempts)
     env = HipEnvBatch(cfg, E, 425, first_env_index=rank * E)
     D = env.D
     torch.manual_seed(425)

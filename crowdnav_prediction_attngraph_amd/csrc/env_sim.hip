@@ -66,6 +66,10 @@ struct EnvDev {
     double *min_dist; // [E]
 };
 
+// The reference's rejection sampling of human positions / goals is unbounded; after this many attempts the last candidate is
+// accepted (same constant and rule in the oracle: oracle/crowdsim_oracle.h ORC_MAX_PLACEMENT_ATTEMPTS).
+constexpr int CN_MAX_PLACEMENT_ATTEMPTS = 1 << 16;
+
 enum { F_PX = 0, F_PY, F_VX, F_VY, F_GX, F_GY, F_RAD, F_VPREF };
 enum { R_PX = 0, R_PY, R_VX, R_VY, R_GX, R_GY, R_THETA, R_POT };
 
@@ -524,7 +528,7 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
         radius = rng_uniform(R, lane, 0.3, 0.5);     // agent.py:50
     }
     double px, py;
-    for (;;) {
+    for (int attempt = 0;; ++attempt) { // unbounded in the reference: see CN_MAX_PLACEMENT_ATTEMPTS
         const double angle = rng_double(R, lane) * M_PI * 2.0;
         const double px_noise = rng_uniform(R, lane, 0.0, 1.0) * 2.0;
         const double py_noise = rng_uniform(R, lane, 0.0, 1.0) * 2.0;
@@ -536,7 +540,7 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
         const bool coll_r = norm2(px - rb.px, py - rb.py) < md_r || norm2(px - rb.gx, py - rb.gy) < md_r;
         const double md = radius + h.rad + c.discomfort_dist;
         const bool coll_h = lane < n_existing && (norm2(px - h.px, py - h.py) < md || norm2(px - h.gx, py - h.gy) < md);
-        if (!(coll_r || wv_any(coll_h))) break;
+        if (!(coll_r || wv_any(coll_h)) || attempt >= (c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS)) break;
     }
     if (lane == slot) {
         h.px = px; h.py = py; h.gx = -px; h.gy = -py; h.vx = 0.0; h.vy = 0.0; h.rad = radius; h.vpref = vpref;
@@ -554,7 +558,7 @@ __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, 
         if (vp_i == 0.0) continue;
         if (rng_double(R, lane) <= c.goal_change_chance) {
             double gx, gy;
-            for (;;) {
+            for (int attempt = 0;; ++attempt) {
                 const double angle = rng_double(R, lane) * M_PI * 2.0;
                 const double gx_noise = (rng_double(R, lane) - 0.5) * vp_i;
                 const double gy_noise = (rng_double(R, lane) - 0.5) * vp_i;
@@ -566,7 +570,7 @@ __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, 
                 const bool coll_r = norm2(gx - rb.px, gy - rb.py) < md_r || norm2(gx - rb.gx, gy - rb.gy) < md_r;
                 const double md = rad_i + h.rad + c.discomfort_dist;
                 const bool coll_h = lane < H && lane != i && (norm2(gx - h.px, gy - h.py) < md || norm2(gx - h.gx, gy - h.gy) < md);
-                if (!(coll_r || wv_any(coll_h))) break;
+                if (!(coll_r || wv_any(coll_h)) || attempt >= (c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS)) break;
             }
             if (lane == i) { h.gx = gx; h.gy = gy; }
         }

@@ -69,7 +69,10 @@ typedef struct {
                                    * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored */
     int32_t robot_visible;        /* robot.visible: every human's ORCA sees the robot as one more neighbour (crowd_sim.py:695-699);
                                    * CrowdSimVarNum-v0, train phase, human_num <= 63 */
-    int32_t reserved0;
+    int32_t max_placement_attempts; /* bound of the reference's UNBOUNDED rejection sampling of human positions / goals
+                                   * (crowd_sim_var_num.py:116-146, crowd_sim.py:415-450): after this many attempts the last
+                                   * candidate is accepted; 0 = 65536.  Dense randomised crowds have seeds where the reference
+                                   * loop runs for minutes, and a batch waits for its slowest env. */
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;

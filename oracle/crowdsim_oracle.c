@@ -341,7 +341,7 @@ static void gen_circle_crossing_human(OrcEnv *e, int slot, int n_existing)
         h.radius = env_uniform(e, 0.3, 0.5);                  /* agent.py:50 */
     }
     double px, py;
-    for (;;) {
+    for (int attempt = 0;; ++attempt) { /* unbounded in the reference; see ORC_MAX_PLACEMENT_ATTEMPTS */
         const double angle = env_random(e) * M_PI * 2.0;
         const double px_noise = env_uniform(e, 0.0, 1.0) * 2.0;
         const double py_noise = env_uniform(e, 0.0, 1.0) * 2.0;
@@ -360,7 +360,7 @@ static void gen_circle_crossing_human(OrcEnv *e, int slot, int n_existing)
             const double min_dist = h.radius + a->radius + c->discomfort_dist;
             if (norm2(px - a->px, py - a->py) < min_dist || norm2(px - a->gx, py - a->gy) < min_dist) collide = 1;
         }
-        if (!collide) break;
+        if (!collide || attempt >= (c->max_placement_attempts > 0 ? c->max_placement_attempts : ORC_MAX_PLACEMENT_ATTEMPTS)) break;
     }
     h.px = px; h.py = py; h.gx = -px; h.gy = -py; h.vx = 0.0; h.vy = 0.0;
     e->humans[slot] = h;
@@ -604,7 +604,7 @@ static void update_human_goals_randomly(OrcEnv *e)
         if (h->v_pref == 0.0) continue;
         if (env_random(e) <= c->goal_change_chance) {
             double gx, gy;
-            for (;;) {
+            for (int attempt = 0;; ++attempt) {
                 const double angle = env_random(e) * M_PI * 2.0;
                 const double v_pref = h->v_pref == 0.0 ? 1.0 : h->v_pref;
                 const double gx_noise = (env_random(e) - 0.5) * v_pref;
@@ -624,7 +624,7 @@ static void update_human_goals_randomly(OrcEnv *e)
                     const double md = h->radius + a->radius + c->discomfort_dist;
                     if (norm2(gx - a->px, gy - a->py) < md || norm2(gx - a->gx, gy - a->gy) < md) collide = 1;
                 }
-                if (!collide) break;
+                if (!collide || attempt >= (c->max_placement_attempts > 0 ? c->max_placement_attempts : ORC_MAX_PLACEMENT_ATTEMPTS)) break;
             }
             h->gx = gx; h->gy = gy;
         }

@@ -50,6 +50,12 @@ extern "C" {
 #endif
 
 #define ORC_MAX_HUMANS 64
+/* The reference places humans / goals by rejection sampling without a bound (crowd_sim_var_num.py:116-146, crowd_sim.py:415-450).
+ * Dense randomised crowds (50 humans of radius up to 0.5 on the default circle) have seeds for which that loop runs for
+ * minutes (measured: 147 s for ONE step of env 3627 of the 50-human stress config) ; a batch of thousands of envs always
+ * contains one.  After `max_placement_attempts` (default below) attempts the last candidate is accepted: a deviation only where
+ * the reference would still be spinning after that many draws. */
+#define ORC_MAX_PLACEMENT_ATTEMPTS (1 << 16)
 #define ORC_MAX_PRED 8
 
 enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
@@ -71,7 +77,7 @@ typedef struct {
     uint32_t val_size, test_size; /* config.env.val_size/test_size */
     int32_t robot_policy;         /* ORC_ROBOT_* : config.robot.policy (the network's action, or ORCA on the robot's beliefs) */
     int32_t robot_visible;        /* config.robot.visible: humans treat the robot as one more ORCA neighbour (crowd_sim.py:695-699) */
-    int32_t reserved0;
+    int32_t max_placement_attempts; /* 0 = ORC_MAX_PLACEMENT_ATTEMPTS; bound of the reference's unbounded rejection loops (see below) */
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;
