@@ -28,7 +28,7 @@ def test_vec_env_api_contract():
     assert envs.talk2Env(None) == [True] * 16
     envs.close()
     with pytest.raises(NotImplementedError):
-        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"robot.visible": True}))
+        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"action_space.kinematics": "unicycle"}))
     with pytest.raises(NotImplementedError):
         make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"sim.human_num_range": 2}))
     one = make_vec_envs("CrowdSimVarNum-v0", 425, 1, 0.99, None, torch.device("cuda"), False)   # num_processes=1 -> phase 'test' (envs.py:55-58)
