@@ -10,7 +10,6 @@ Both return the metrics as a dict (the reference only logs them).
 import numpy as np
 import torch
 
-from . import _abi as A
 from . import info as I
 from .config import to_env_config
 
