@@ -88,6 +88,151 @@ __global__ __launch_bounds__(128) void embed0_bwd_kernel(int R, int D, const flo
     p[D] = acc[16];
 }
 
+
+// ---- whole GRU sequence in one launch (forward) / one launch (backward) ---------------------------------------------------
+// The update runs the human-node GRU over T = 30 steps with only N x 128 of state: as separate launches (a BLAS product and
+// a pointwise kernel per step and direction) it is launch- and latency-bound.  Here a workgroup owns 32 rows (envs) for
+// the whole sequence and W_hh never leaves the register file:
+//   * forward: wavefront w owns hidden units 32w .. 32w+31, i.e. the three gate columns {u, 128+u, 256+u}; its 96 x 128
+//     slice of W_hh is loaded once as 48 float4 fragments per lane (192 VGPRs).  Per step the masked state hm (32 x 128,
+//     LDS, double buffered) is the A operand of 192 exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32, K order remapped so that one
+//     16-byte LDS read feeds four k-steps); the accumulators of the r, z, n gates of one (row, unit) sit in the same lane and
+//     register index, so the cell's pointwise part needs no exchange at all; one barrier per step.
+//   * backward (reverse time): the same wavefront computes d(gates) for its units from the saved (r, z, n, gh_n), publishes
+//     d(gh) [32 x 384] in LDS, and multiplies it with its 384 x 32 slice of W_hh (again 192 resident VGPRs) to get d(hm);
+//     the carried gradient stays in registers in the accumulator layout.  d(W_hh) is one product over all T*N rows afterwards.
+constexpr int GR = 32, GHS = 132, GDS = 388; // rows per workgroup; LDS row strides (floats): 16-byte reads of 16 rows tile all banks
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const float *__restrict__ gi, const float *__restrict__ h0,
+                                                          const float *__restrict__ m, const float *__restrict__ Whh, const float *__restrict__ bhh,
+                                                          float *__restrict__ hs, float *__restrict__ hms, float *__restrict__ gates)
+{
+    __shared__ __attribute__((aligned(16))) float hm[2][GR * GHS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.x * GR, u = 32 * wave + l31;
+    f32x4 wf[3][16];
+    float bias[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float *wr = Whh + (size_t)(j * 128 + u) * 128 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) wf[j][g] = *reinterpret_cast<const f32x4 *>(wr + 8 * g);
+        bias[j] = bhh[j * 128 + u];
+    }
+    for (int i = tid; i < GR * 128; i += 256) {
+        const int r = i >> 7, c = i & 127, row = row0 + r;
+        const float v = row < N ? h0[(size_t)row * 128 + c] * m[row] : 0.0f;
+        hm[0][r * GHS + c] = v;
+        if (row < N) hms[(size_t)row * 128 + c] = v;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        f32x16 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(&hm[cur][l31 * GHS + 8 * g + 4 * half]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wf[j][g][s], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + rl;
+            float next = 0.0f;
+            if (row < N) {
+                const size_t tr = (size_t)t * N + row;
+                const float *gip = gi + tr * 384;
+                const float hn = acc[2][r] + bias[2];
+                const float rg = sigmoidf_(gip[u] + acc[0][r] + bias[0]);
+                const float zg = sigmoidf_(gip[128 + u] + acc[1][r] + bias[1]);
+                const float ng = tanhf(gip[256 + u] + rg * hn);
+                const float hnew = (1.0f - zg) * ng + zg * hm[cur][rl * GHS + u];
+                hs[tr * 128 + u] = hnew;
+                float *gp = gates + tr * 512;
+                gp[u] = rg; gp[128 + u] = zg; gp[256 + u] = ng; gp[384 + u] = hn;
+                if (t + 1 < T) {
+                    next = hnew * m[(size_t)(t + 1) * N + row];
+                    hms[(tr + N) * 128 + u] = next;
+                }
+            }
+            if (t + 1 < T) hm[cur ^ 1][rl * GHS + u] = next;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const float *__restrict__ gates, const float *__restrict__ hms,
+                                                          const float *__restrict__ m, const float *__restrict__ Whh, const float *__restrict__ d_hs,
+                                                          float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh0)
+{
+    __shared__ __attribute__((aligned(16))) float dg[GR * GDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.x * GR, u = 32 * wave + l31;
+    // d(hm)[row][n] = sum_c d(gh)[row][c] * W_hh[c][n]: this lane's column n = u, k runs over the 384 gate columns
+    f32x4 wf[48];
+#pragma unroll
+    for (int g = 0; g < 48; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wf[g][s] = Whh[(size_t)(8 * g + 4 * half + s) * 128 + u];
+    f32x16 carry;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) carry[r] = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        float direct[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + rl;
+            float dr = 0.0f, dz = 0.0f, dn = 0.0f;
+            direct[r] = 0.0f;
+            if (row < N) {
+                const size_t tr = (size_t)t * N + row;
+                const float *gp = gates + tr * 512;
+                const float rg = gp[u], zg = gp[128 + u], ng = gp[256 + u], hn = gp[384 + u];
+                const float h = hms[tr * 128 + u];
+                const float d = d_hs[tr * 128 + u] + carry[r];
+                const float din = d * (1.0f - zg) * (1.0f - ng * ng);
+                dr = din * hn * rg * (1.0f - rg);
+                dz = d * (h - ng) * zg * (1.0f - zg);
+                dn = din * rg;
+                float *a = dgi + tr * 384, *b = dgh + tr * 384;
+                a[u] = dr; a[128 + u] = dz; a[256 + u] = din;
+                b[u] = dr; b[128 + u] = dz; b[256 + u] = dn;
+                direct[r] = d * zg;
+            }
+            dg[rl * GDS + u] = dr; dg[rl * GDS + 128 + u] = dz; dg[rl * GDS + 256 + u] = dn;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 48; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(&dg[l31 * GDS + 8 * g + 4 * half]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wf[g][s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            carry[r] = row < N ? (direct[r] + acc[r]) * m[(size_t)t * N + row] : 0.0f;
+        }
+        __syncthreads(); // the next (earlier) step overwrites dg
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < N) dh0[(size_t)row * 128 + u] = carry[r];
+    }
+}
+
 } // namespace
 
 extern "C" int cn_embed0_fwd(int R, int D, const float *x, const float *W, const float *b, float *y, void *stream)
@@ -110,6 +255,26 @@ extern "C" int cn_embed0_bwd(int R, int D, const float *x, const float *y, const
     CN_CHECK_LAUNCH();
     const size_t n = (size_t)128 * (D + 1);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, blocks, partials, dWb);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_gru_seq_fwd(int T, int N, const float *gi, const float *h0, const float *masks, const float *w_hh, const float *b_hh, float *hs,
+                              float *hms, float *gates, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(T >= 1 && N >= 1 && gi && h0 && masks && w_hh && b_hh && hs && hms && gates, "cn_gru_seq_fwd: bad argument");
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3((N + GR - 1) / GR), dim3(256), 0, (hipStream_t)stream, T, N, gi, h0, masks, w_hh, b_hh, hs, hms, gates);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_gru_seq_bwd(int T, int N, const float *gates, const float *hms, const float *masks, const float *w_hh, const float *d_hs, float *dgi,
+                              float *dgh, float *dh0, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(T >= 1 && N >= 1 && gates && hms && masks && w_hh && d_hs && dgi && dgh && dh0, "cn_gru_seq_bwd: bad argument");
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((N + GR - 1) / GR), dim3(256), 0, (hipStream_t)stream, T, N, gates, hms, masks, w_hh, d_hs, dgi, dgh, dh0);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -315,45 +315,35 @@ class HRAttention(torch.autograd.Function):
 class GRUSequence(torch.autograd.Function):
     """The human-node GRU over a [T,N] rollout slice with the done mask applied to h before every step (the reference's
     split-at-done trick, rl/networks/srnn_model.py:52-104, is arithmetically this).  gi [T,N,384] = x W_ih^T + b_ih,
-    h0 [N,128], m [T,N,1] -> hs [T,N,128].  Per step: one rocBLAS product for the hidden-side gates and ONE pointwise
-    kernel (cn_gru_cell_fwd / cn_gru_cell_bwd) instead of ~20 elementwise launches; the weight gradient of W_hh is one
+    h0 [N,128], m [T,N,1] -> hs [T,N,128].  ONE launch for the whole forward sequence and one for the backward
+    (cn_gru_seq_fwd / cn_gru_seq_bwd: W_hh resident in registers, exact-fp32 MFMA); the weight gradient of W_hh is one
     product over all T*N rows at the end."""
 
     @staticmethod
     def forward(ctx, gi, h0, m, w_hh, b_hh):
         T, N = gi.shape[0], gi.shape[1]
-        gi = gi.contiguous()
+        gi, h0, m = gi.contiguous(), h0.contiguous(), m.contiguous()
+        w, b = w_hh.detach().contiguous(), b_hh.detach().contiguous()
         hs = torch.empty(T, N, 128, device=gi.device)
         hms = torch.empty(T, N, 128, device=gi.device)
         gates = torch.empty(T, N, 512, device=gi.device)
-        L, st = A.lib(), A.stream_ptr()
-        h = h0
-        w_t = w_hh.detach().t()
-        for t in range(T):
-            torch.mul(h, m[t], out=hms[t])
-            gh = torch.addmm(b_hh.detach(), hms[t], w_t)
-            A.check(L.cn_gru_cell_fwd(N, A.ptr(gi[t]), A.ptr(gh), A.ptr(hms[t]), A.ptr(hs[t]), A.ptr(gates[t]), st), "cn_gru_cell_fwd")
-            h = hs[t]
-        ctx.save_for_backward(hms, gates, m, w_hh)
+        A.check(A.lib().cn_gru_seq_fwd(T, N, A.ptr(gi), A.ptr(h0), A.ptr(m), A.ptr(w), A.ptr(b), A.ptr(hs), A.ptr(hms), A.ptr(gates), A.stream_ptr()),
+                "cn_gru_seq_fwd")
+        ctx.save_for_backward(hms, gates, m, w)
         return hs
 
     @staticmethod
     def backward(ctx, d_hs):
-        hms, gates, m, w_hh = ctx.saved_tensors
+        hms, gates, m, w = ctx.saved_tensors
         T, N = hms.shape[0], hms.shape[1]
         d_hs = d_hs.contiguous()
         dgi = torch.empty(T, N, 384, device=hms.device)
         dgh = torch.empty(T, N, 384, device=hms.device)
-        dhm = torch.empty(N, 128, device=hms.device)
-        L, st = A.lib(), A.stream_ptr()
-        w = w_hh.detach()
-        dh = None
-        for t in range(T - 1, -1, -1):
-            d = d_hs[t] if dh is None else d_hs[t] + dh
-            A.check(L.cn_gru_cell_bwd(N, A.ptr(gates[t]), A.ptr(hms[t]), A.ptr(d), A.ptr(dgi[t]), A.ptr(dgh[t]), A.ptr(dhm), st), "cn_gru_cell_bwd")
-            dh = torch.addmm(dhm, dgh[t], w) * m[t]
+        dh0 = torch.empty(N, 128, device=hms.device)
+        A.check(A.lib().cn_gru_seq_bwd(T, N, A.ptr(gates), A.ptr(hms), A.ptr(m), A.ptr(w), A.ptr(d_hs), A.ptr(dgi), A.ptr(dgh), A.ptr(dh0), A.stream_ptr()),
+                "cn_gru_seq_bwd")
         dgh2 = dgh.view(T * N, 384)
-        return dgi, dh, None, dgh2.t() @ hms.view(T * N, 128), dgh2.sum(0)
+        return dgi, dh0, None, dgh2.t() @ hms.view(T * N, 128), dgh2.sum(0)
 
 
 def split_bf16(w, transpose=False):

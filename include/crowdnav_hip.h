@@ -222,6 +222,14 @@ int cn_embed0_bwd(int R, int D, const float *x, const float *y, const float *dy,
 int cn_gru_cell_fwd(int N, const float *gi, const float *gh, const float *hm, float *h_out, float *gates, void *stream);
 int cn_gru_cell_bwd(int N, const float *gates, const float *hm, const float *dh, float *dgi, float *dgh, float *dhm,
                     void *stream);
+/* The whole sequence in one launch per direction (W_hh resident in registers, one workgroup per 32 rows):
+ * gi [T,N,384] = x W_ih^T + b_ih, h0 [N,128], masks [T,N] -> hs [T,N,128]; hms [T,N,128] (masked previous states) and
+ * gates [T,N,512] are kept for the backward.  bwd: d_hs [T,N,128] -> dgi [T,N,384], dgh [T,N,384] (the caller forms
+ * d(W_hh) = dgh^T hms and d(b_hh) = column sums of dgh) and dh0 [N,128]. */
+int cn_gru_seq_fwd(int T, int N, const float *gi, const float *h0, const float *masks, const float *w_hh, const float *b_hh,
+                   float *hs, float *hms, float *gates, void *stream);
+int cn_gru_seq_bwd(int T, int N, const float *gates, const float *hms, const float *masks, const float *w_hh,
+                   const float *d_hs, float *dgi, float *dgh, float *dh0, void *stream);
 
 /* ---- large Linear layers of the PPO update (training path), split-precision bf16x3 MFMA like the rollout forward ----
  * Replace torch.nn.Linear forward/backward of embedding_layer.2, the folded (q|k|v)_linear∘in_proj and the folded

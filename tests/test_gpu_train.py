@@ -226,3 +226,38 @@ def test_hr_attention_forward_backward_matches_dense_torch():
     for got, want, what in ((hr.detach(), ref.detach(), "hr"), (tg.grad, tr.grad, "d_t"), (wg.grad, wr.grad, "d_Ws"), (og.grad, orr.grad, "d_o")):
         err = float((got.cpu().double() - want).abs().max())
         assert err <= 2e-5 * max(float(want.abs().max()), 1.0), (what, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,N", [(5, 6), (30, 70), (7, 32), (3, 129)])
+def test_gru_sequence_kernels_match_torch_autograd(T, N):
+    """cn_gru_seq_fwd / cn_gru_seq_bwd (one launch per direction, W_hh in registers) against the step-by-step torch graph of
+    AttnGraphBase._gru_cell in fp64: states and every gradient (gi, h0, W_hh, b_hh), with done masks in the sequence."""
+    from crowdnav_prediction_attngraph_amd import hip
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    gi = torch.randn(T, N, 384, generator=g)
+    h0 = torch.randn(N, 128, generator=g)
+    m = (torch.rand(T, N, 1, generator=g) > 0.25).float()
+    w = torch.randn(384, 128, generator=g) / 128 ** 0.5
+    b = torch.randn(384, generator=g) * 0.1
+    d_hs = torch.randn(T, N, 128, generator=g)
+    gi_g, h0_g, w_g, b_g = (x.cuda().requires_grad_() for x in (gi, h0, w, b))
+    hs = hip.GRUSequence.apply(gi_g, h0_g, m.cuda(), w_g, b_g)
+    hs.backward(d_hs.cuda())
+    gi_r, h0_r, w_r, b_r = (x.double().requires_grad_() for x in (gi, h0, w, b))
+    h, out = h0_r, []
+    for t in range(T):
+        hm = h * m[t].double()
+        gh = torch.nn.functional.linear(hm, w_r, b_r)
+        i_r, i_z, i_n = gi_r[t].chunk(3, -1)
+        h_r, h_z, h_n = gh.chunk(3, -1)
+        r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        h = (1.0 - z) * n + z * hm
+        out.append(h)
+    ref = torch.stack(out, 0)
+    ref.backward(d_hs.double())
+    for got, want, what in ((hs.detach(), ref.detach(), "hs"), (gi_g.grad, gi_r.grad, "d_gi"), (h0_g.grad, h0_r.grad, "d_h0"),
+                            (w_g.grad, w_r.grad, "d_Whh"), (b_g.grad, b_r.grad, "d_bhh")):
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 2e-5 * max(float(want.abs().max()), 1.0), (what, err, float(want.abs().max()))
