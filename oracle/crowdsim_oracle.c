@@ -548,6 +548,43 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
                       (float)c->orca_time_horizon, (float)c->time_step, n, opx, opy, ovx, ovy, orad, avx, avy, 0, 0);
 }
 
+/* SOCIAL_FORCE.predict for human i (crowd_nav/policy/social_force.py:11-52; humans.policy = 'social_force'), float64 throughout.
+ * The other agents are the ones get_human_actions passes: every other human (true state unless coincident -> the dummy at (7,7)),
+ * then the robot when robot.visible.  This path never touches rvo2: traces of it are the reference's own arithmetic end to end. */
+static void human_sf_action(const OrcEnv *e, int i, double *avx, double *avy)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = c->human_num;
+    const OrcHuman *me = &e->humans[i];
+    const double dxg = me->gx - me->px, dyg = me->gy - me->py;
+    const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
+    const double desired_vx = (dxg / dist_to_goal) * me->v_pref, desired_vy = (dyg / dist_to_goal) * me->v_pref;
+    const double curr_dvx = c->sf_KI * (desired_vx - me->vx), curr_dvy = c->sf_KI * (desired_vy - me->vy);
+    double ivx = 0.0, ivy = 0.0;
+    for (int j = 0; j <= H; ++j) {
+        double ox, oy, orad;
+        if (j == i) continue;
+        if (j < H) {
+            const OrcHuman *o = &e->humans[j];
+            if (o->px == me->px && o->py == me->py) { ox = 7.0; oy = 7.0; orad = c->human_radius; } /* dummy_human: config radius */
+            else { ox = o->px; oy = o->py; orad = o->radius; }
+        } else {
+            if (!c->robot_visible) continue;
+            if (e->rpx == me->px && e->rpy == me->py) { ox = 7.0; oy = 7.0; } else { ox = e->rpx; oy = e->rpy; }
+            orad = c->robot_radius;
+        }
+        const double dx = me->px - ox, dy = me->py - oy;
+        const double d = sqrt(dx * dx + dy * dy);
+        const double f = c->sf_A * exp((me->radius + orad - d) / c->sf_B);
+        ivx += f * (dx / d);
+        ivy += f * (dy / d);
+    }
+    const double nvx = me->vx + (curr_dvx + ivx) * c->time_step, nvy = me->vy + (curr_dvy + ivy) * c->time_step;
+    const double act_norm = sqrt(nvx * nvx + nvy * nvy);
+    if (act_norm > me->v_pref) { *avx = nvx / act_norm * me->v_pref; *avy = nvy / act_norm * me->v_pref; }
+    else { *avx = nvx; *avy = nvy; }
+}
+
 /* calc_human_future_traj(method='truth'), crowd_sim_var_num.py:152-227 (test phase, :386-388): roll every human forward
  * predict_steps times with its own ORCA policy on the states predicted by the previous roll (act_joint_state ->
  * ORCA.predict on the human's private simulator, so the frozen radii / neighbour distance of human_orca_action apply;
@@ -684,8 +721,15 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     }
     /* get_human_actions, crowd_sim.py:680-703 */
     float hax[ORC_MAX_HUMANS], hay[ORC_MAX_HUMANS];
+    double haxd[ORC_MAX_HUMANS], hayd[ORC_MAX_HUMANS]; /* the actions as Python floats (ORCA: widened float32) */
     for (int i = 0; i < H; ++i) {
-        human_orca_action(e, i, &hax[i], &hay[i]);
+        if (c->humans_policy == ORC_HUMANS_SOCIAL_FORCE) {
+            human_sf_action(e, i, &haxd[i], &hayd[i]);
+            hax[i] = (float)haxd[i]; hay[i] = (float)hayd[i];
+        } else {
+            human_orca_action(e, i, &hax[i], &hay[i]);
+            haxd[i] = (double)hax[i]; hayd[i] = (double)hay[i];
+        }
         e->last_human_actions[i][0] = hax[i]; e->last_human_actions[i][1] = hay[i];
     }
     /* test phase (:386-388): the true future positions decide the Danger flag (and, for CrowdSimPred, the social reward) */
@@ -748,9 +792,9 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     }
     for (int i = 0; i < H; ++i) {
         OrcHuman *h = &e->humans[i];
-        h->px = h->px + (double)hax[i] * c->time_step;
-        h->py = h->py + (double)hay[i] * c->time_step;
-        h->vx = (double)hax[i]; h->vy = (double)hay[i];
+        h->px = h->px + haxd[i] * c->time_step;
+        h->py = h->py + hayd[i] * c->time_step;
+        h->vx = haxd[i]; h->vy = hayd[i];
     }
     e->step_counter += 1;
     write_obs(e, obs, 0);

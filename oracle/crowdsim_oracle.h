@@ -61,6 +61,7 @@ extern "C" {
 enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
 enum { ORC_PHASE_TRAIN = 0, ORC_PHASE_VAL = 1, ORC_PHASE_TEST = 2 };
 enum { ORC_ROBOT_NETWORK = 0, ORC_ROBOT_ORCA = 1, ORC_ROBOT_SOCIAL_FORCE = 2 };
+enum { ORC_HUMANS_ORCA = 0, ORC_HUMANS_SOCIAL_FORCE = 1 };
 /* episode info codes, crowd_sim/envs/utils/info.py */
 enum { ORC_INFO_NOTHING = 0, ORC_INFO_TIMEOUT = 1, ORC_INFO_COLLISION = 2, ORC_INFO_REACHGOAL = 3, ORC_INFO_DANGER = 4 };
 
@@ -85,7 +86,9 @@ typedef struct {
     double robot_radius, robot_v_pref, sensor_range;
     double goal_change_chance, end_goal_change_chance;
     double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
-    double sf_A, sf_B, sf_KI;     /* config.sf.* (social-force robot, crowd_nav/policy/social_force.py) */
+    double sf_A, sf_B, sf_KI;     /* config.sf.* (social-force robot / humans, crowd_nav/policy/social_force.py) */
+    int32_t humans_policy;        /* ORC_HUMANS_ORCA (default) or ORC_HUMANS_SOCIAL_FORCE (config.humans.policy; oracle only) */
+    int32_t reserved1;
 } OrcConfig;
 
 typedef struct {

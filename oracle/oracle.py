@@ -43,6 +43,7 @@ class OrcConfig(C.Structure):
         ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
         ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
+        ("humans_policy", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 

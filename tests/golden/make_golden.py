@@ -157,6 +157,10 @@ def env_goldens():
     # robot.policy = 'orca' (trained_models/ORCA_no_rand): the robot's action is ORCA on its beliefs, the passed action is ignored
     trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "robot.policy": "orca"}), 425, 0, 1, 400, "varnum_h20_orcarobot_test_r0")
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 10, "robot.policy": "orca"}), 425, 0, 1, 300, "varnum_h10_rand_orcarobot_test_r0")
+    # humans.policy = 'social_force': no rvo2 anywhere -> these traces are the reference's own arithmetic end to end (oracle only)
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "humans.policy": "social_force"}), 425, 0, 4, 300, "varnum_h20_sfhumans_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 10, "humans.policy": "social_force", "robot.visible": True}), 425, 1, 4, 300,
+          "varnum_h10_rand_sfhumans_robotvisible_r1")
     # robot.visible = True: every human's ORCA gets the robot as one more neighbour (crowd_sim.py:695-699)
     trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "robot.visible": True}), 425, 1, 4, 300, "varnum_h20_robotvisible_r1")
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 7, "robot.visible": True}), 425, 2, 4, 320, "varnum_h7_rand_robotvisible_r2")

@@ -9,8 +9,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_KIND = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
 
 
-def env_fixtures():
-    return sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+def env_fixtures(device=False):
+    """All env traces; device=True leaves out the ones that exercise oracle-only settings (social-force humans)."""
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
+    return [p for p in paths if not (device and "sfhumans" in os.path.basename(p))]
 
 
 def load(path):
@@ -19,10 +21,14 @@ def load(path):
     return z, meta
 
 
-def sim_kwargs(meta):
-    """Reference config overrides -> the flat keyword set both the oracle and the HIP env understand."""
+def sim_kwargs(meta, oracle=False):
+    """Reference config overrides -> the flat keyword set both the oracle and the HIP env understand (oracle=True adds the
+    settings only the oracle implements)."""
     over = meta["over"]
-    return dict(
+    extra = {}
+    if oracle and over.get("humans.policy", "orca") == "social_force":
+        extra["humans_policy"] = 1
+    return dict(extra,
         human_num=int(over.get("sim.human_num", 20)),
         env_kind=ENV_KIND[meta["env_name"]],
         randomize_attributes=int(bool(over.get("env.randomize_attributes", True))),

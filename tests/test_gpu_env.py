@@ -99,7 +99,7 @@ def test_hip_env_matches_oracle_bit_exact(name):
     env.close()
 
 
-@pytest.mark.parametrize("path", G.env_fixtures(), ids=lambda p: p.split("env_")[-1][:-4])
+@pytest.mark.parametrize("path", G.env_fixtures(device=True), ids=lambda p: p.split("env_")[-1][:-4])
 def test_hip_env_replays_reference_golden(path):
     """The reference's own traces (tests/golden) replayed on the GPU: flags exact, float32 obs <= 1e-6."""
     from crowdnav_prediction_attngraph_amd import _abi as A

@@ -28,7 +28,7 @@ def test_sincos_accuracy():
 @pytest.mark.parametrize("path", G.env_fixtures(), ids=lambda p: p.split("env_")[-1][:-4])
 def test_env_trace_matches_reference(path):
     z, meta = G.load(path)
-    cfg = O.default_config(**G.sim_kwargs(meta))
+    cfg = O.default_config(**G.sim_kwargs(meta, oracle=True))
     env = O.OracleEnv(cfg, meta["seed"] + meta["rank"])
     ob = env.reset()
     for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num"):
