@@ -10,8 +10,12 @@
 //   robot_embed   [E,9]   -> [E,256]  ReLU ; gemm -> [E,256]    robot_linear, u = spatial_edge_layer^T temporal_edge_layer(.)
 //   hr_attention  per env: scores u . out_sp_j, masked softmax over humans, weighted sum of [H,256]
 //   gemms + gru_pointwise + gemms(tanh) + gauss_head            EndRNN, actor/critic, DiagGaussian
-// The dense contractions run on the matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32, 155 TF peak): the
-// reference computes in fp32 and the parity bar is 1e-4, which bf16 inputs cannot hold at K = 512.
+// The reference computes in fp32 and the parity bar is 1e-4, which plain bf16 inputs cannot hold at K = 512.  The three
+// large products (embedding_layer.2, q|k|v, out_proj∘spatial_linear) therefore run as bf16x3 split-precision MFMA
+// (gemm3.h: hi/lo bf16 pairs, three v_mfma_f32_32x32x16_bf16 per term, fp32 accumulate, ~2e-5 from fp32; default) or as
+// exact fp32 MFMA (cn_policy_set_gemm_mode(p, 0)); every other product is exact fp32 on v_mfma_f32_32x32x2_f32 (gemm.h).
+// The rows of the human-human block are the compacted "live" (env, human) rows only, the robot-node launches run on a side
+// stream beside that block.
 // The two affine pairs without a nonlinearity in between are folded once per weight snapshot (fp64 accumulation),
 // which removes 4 of the 9 [M,512]x[512,512] products (83.65 -> 52.2 MFLOP per env-step at H = 20).
 #include "common.h"
