@@ -19,6 +19,13 @@
  *   cn_gae                     <- rl/networks/storage.py:123-132 RolloutStorage.compute_returns (use_gae branch)
  *   cn_adv_stats / cn_adv_normalize <- rl/ppo/ppo.py:37-39 advantage normalisation (split so that N GPUs can
  *                                 all-reduce the three partial sums in between)
+ *   cn_linear_* / cn_hh_attention_* / cn_hr_attention_* / cn_gru_* / cn_embed0_*
+ *                              <- the operators of Policy.evaluate_actions (rl/networks/model.py:82-90) as autograd runs
+ *                                 them forward and backward inside PPO.update (rl/ppo/ppo.py:60-95)
+ *   cn_env_get_danger_min_dist / cn_env_set_case_counters
+ *                              <- test phase: Danger(min_dist) (crowd_sim_var_num.py:499-533) and the per-case seeding that
+ *                                 rl/evaluation.py's protocol relies on (crowd_sim_var_num.py:316-318,337)
+ *   cn_gst_*                   <- gst_updated wrapper + VecPretextNormalize (CrowdSimPredRealGST-v0)
  *
  * Conventions: every function returns 0 on success and a negative cn_status otherwise (no C++ exception crosses the
  * ABI); cn_last_error() returns a thread-local message.  All tensor arguments are raw DEVICE pointers owned by the
