@@ -63,6 +63,21 @@ static double env_random(OrcEnv *e)
 }
 static double env_uniform(OrcEnv *e, double lo, double hi) { return lo + (hi - lo) * env_random(e); }
 
+/* legacy RandomState.randint(low, high) for the default int64 dtype: numpy/random/_bounded_integers (_rand_int64 ->
+ * random_bounded_uint64_fill with use_masked = 1): no draw when the range is a single value, else 32-bit words masked to the
+ * next power of two minus one and rejected while above the range (ranges here are far below 2^32). */
+int64_t orc_mt_randint(OrcMT *mt, int64_t low, int64_t high, uint64_t *words)
+{
+    const uint64_t rng = (uint64_t)(high - 1 - low);
+    if (rng == 0) return low;
+    uint64_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+    uint32_t v;
+    do { v = orc_mt_next(mt) & (uint32_t)mask; if (words) *words += 1; } while (v > rng);
+    return low + (int64_t)v;
+}
+static int env_randint(OrcEnv *e, int low, int high) { return (int)orc_mt_randint(&e->rng, low, high, &e->rng_draws); }
+
 /* ------------------------------------------------------------------------------------------------
  * deterministic sin/cos for x in [0, 2*pi]: Cody-Waite reduction by pi/2 + the classic minimax
  * kernels.  Plain +,-,* only (no FMA) so the HIP twin is bit-identical.  <= ~1 ulp.
@@ -352,7 +367,8 @@ static void gen_circle_crossing_human(OrcEnv *e, int slot, int n_existing)
         int collide = 0;
         /* [self.robot] + self.humans */
         {
-            const double min_dist = h.radius + c->robot_radius + c->discomfort_dist;
+            /* :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal */
+            const double min_dist = c->kinematics == ORC_KIN_UNICYCLE ? c->circle_radius / 2.0 : h.radius + c->robot_radius + c->discomfort_dist;
             if (norm2(px - e->rpx, py - e->rpy) < min_dist || norm2(px - e->rgx, py - e->rgy) < min_dist) collide = 1;
         }
         for (int j = 0; j < n_existing && !collide; ++j) {
@@ -380,12 +396,18 @@ static int robot_sees(const OrcEnv *e, const OrcHuman *h)
 static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = c->human_num, D = orc_obs_width(c), P = c->predict_steps;
+    /* H humans exist right now; the observation always has HM = human_num + human_num_range rows (:249, crowd_sim_pred.py:78) */
+    const int H = e->n_humans, HM = c->human_num + c->human_num_range, D = orc_obs_width(c), P = c->predict_steps;
     /* get_num_human_in_fov, crowd_sim.py:558-572 */
     int num_visible = 0;
+    for (int i = 0; i < HM; ++i) e->human_visibility[i] = 0;
     for (int i = 0; i < H; ++i) {
         e->human_visibility[i] = robot_sees(e, &e->humans[i]);
         num_visible += e->human_visibility[i];
+    }
+    if (c->env_kind != ORC_ENV_PRED) { /* :275 -- CrowdSimPred's own generate_ob never refreshes the list (stays [] from reset) */
+        e->observed_count = num_visible; e->observed_max = -1;
+        for (int i = 0; i < H; ++i) if (e->human_visibility[i]) e->observed_max = i;
     }
     /* robot_node = get_full_state_list_noV (agent.py:105): px, py, r, gx, gy, v_pref, theta */
     obs->robot_node[0] = (float)e->rpx; obs->robot_node[1] = (float)e->rpy; obs->robot_node[2] = (float)c->robot_radius;
@@ -409,7 +431,7 @@ static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
     obs->temporal_edges[0] = (float)e->rvx; obs->temporal_edges[1] = (float)e->rvy;
 
     double edges[ORC_MAX_HUMANS][2 * (ORC_MAX_PRED + 1)];
-    for (int i = 0; i < H; ++i)
+    for (int i = 0; i < HM; ++i)
         for (int d = 0; d < D; ++d) edges[i][d] = INFINITY;
     if (c->env_kind == ORC_ENV_VARNUM) {
         /* crowd_sim_var_num.py:249-256 */
@@ -446,19 +468,19 @@ static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
     }
     /* sorted(..., key=norm of first two) is stable; all-inf rows keep index order and end last */
     int order[ORC_MAX_HUMANS];
-    for (int i = 0; i < H; ++i) order[i] = i;
+    for (int i = 0; i < HM; ++i) order[i] = i;
     /* PredRealGST never sorts in the env (crowd_sim_pred_real_gst.py:80: sort=False; the wrapper sorts later) */
     const int do_sort = c->sort_humans && c->env_kind != ORC_ENV_PRED_GST;
     if (do_sort) {
         double key[ORC_MAX_HUMANS];
-        for (int i = 0; i < H; ++i) key[i] = sqrt(edges[i][0] * edges[i][0] + edges[i][1] * edges[i][1]);
-        for (int i = 1; i < H; ++i) { /* stable insertion sort */
+        for (int i = 0; i < HM; ++i) key[i] = sqrt(edges[i][0] * edges[i][0] + edges[i][1] * edges[i][1]);
+        for (int i = 1; i < HM; ++i) { /* stable insertion sort */
             int oi = order[i]; double ki = key[oi]; int j = i - 1;
             while (j >= 0 && key[order[j]] > ki) { order[j + 1] = order[j]; --j; }
             order[j + 1] = oi;
         }
     }
-    for (int r = 0; r < H; ++r)
+    for (int r = 0; r < HM; ++r)
         for (int d = 0; d < D; ++d) {
             double v = edges[order[r]][d];
             if (isinf(v)) v = 15.0;
@@ -483,18 +505,37 @@ void orc_env_reset(OrcEnv *e, OrcObs *obs)
     orc_mt_seed(&e->rng, (uint32_t)seed);
     e->rng_draws = 0;
     e->step_counter = 0;
-    /* generate_robot_humans, holonomic branch :97-104 */
     double px, py, gx, gy;
-    for (;;) {
-        px = env_uniform(e, -c->arena_size, c->arena_size);
-        py = env_uniform(e, -c->arena_size, c->arena_size);
-        gx = env_uniform(e, -c->arena_size, c->arena_size);
-        gy = env_uniform(e, -c->arena_size, c->arena_size);
-        if (norm2(px - gx, py - gy) >= 8.0) break;
+    e->observed_count = 0; e->observed_max = -1; /* :327 */
+    if (c->kinematics == ORC_KIN_UNICYCLE) {
+        /* generate_robot_humans, sim2real branch :78-91: start on the arena circle, goal >= 4 m away, random heading,
+         * 1 .. human_num + human_num_range humans */
+        const double angle = env_uniform(e, 0.0, M_PI * 2.0);
+        double s, co;
+        orc_sincos(angle, &s, &co);
+        px = c->arena_size * co; py = c->arena_size * s;
+        for (;;) {
+            gx = env_uniform(e, -c->arena_size, c->arena_size);
+            gy = env_uniform(e, -c->arena_size, c->arena_size);
+            if (norm2(px - gx, py - gy) >= 4.0) break;
+        }
+        e->rtheta = env_uniform(e, 0.0, 2.0 * M_PI);
+        e->n_humans = env_randint(e, 1, c->human_num + c->human_num_range + 1);
+    } else {
+        /* holonomic branch :97-104 */
+        for (;;) {
+            px = env_uniform(e, -c->arena_size, c->arena_size);
+            py = env_uniform(e, -c->arena_size, c->arena_size);
+            gx = env_uniform(e, -c->arena_size, c->arena_size);
+            gy = env_uniform(e, -c->arena_size, c->arena_size);
+            if (norm2(px - gx, py - gy) >= 8.0) break;
+        }
+        e->rtheta = M_PI / 2.0;
+        /* randint(H - range, H + range + 1): consumes no draw when human_num_range == 0 */
+        e->n_humans = env_randint(e, c->human_num - c->human_num_range, c->human_num + c->human_num_range + 1);
     }
-    e->rpx = px; e->rpy = py; e->rgx = gx; e->rgy = gy; e->rvx = 0.0; e->rvy = 0.0; e->rtheta = M_PI / 2.0;
-    /* randint(H, H+1) consumes no draw (human_num_range == 0) */
-    for (int i = 0; i < c->human_num; ++i) gen_circle_crossing_human(e, i, i);
+    e->rpx = px; e->rpy = py; e->rgx = gx; e->rgy = gy; e->rvx = 0.0; e->rvy = 0.0;
+    for (int i = 0; i < e->n_humans; ++i) gen_circle_crossing_human(e, i, i);
     memset(e->last_human_states, 0, sizeof(e->last_human_states)); /* :108 */
     const uint64_t case_size[3] = {4294967295ull - 2000ull, c->val_size, c->test_size};
     e->case_counter[ph] = (e->case_counter[ph] + (uint64_t)c->nenv) % case_size[ph];
@@ -507,9 +548,12 @@ void orc_env_reset(OrcEnv *e, OrcObs *obs)
 static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = c->human_num;
+    const int H = e->n_humans;
     const OrcHuman *me = &e->humans[i];
+    const int n_agents = H + (c->robot_visible ? 1 : 0); /* self + the others (+ the robot) */
+    if (e->sim_valid[i] && e->sim_n[i] != n_agents) e->sim_valid[i] = 0; /* :80-82 crowd size changed -> new simulator */
     if (!e->sim_valid[i]) { /* :83-89 */
+        e->sim_n[i] = n_agents;
         e->sim_nd[i] = (float)e->shared_neighbor_dist;
         e->sim_self_radius[i] = (float)(me->radius + 0.01 + c->orca_safety_space);
         e->sim_self_maxspeed[i] = (float)me->v_pref;
@@ -554,7 +598,7 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
 static void human_sf_action(const OrcEnv *e, int i, double *avx, double *avy)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = c->human_num;
+    const int H = e->n_humans;
     const OrcHuman *me = &e->humans[i];
     const double dxg = me->gx - me->px, dyg = me->gy - me->py;
     const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
@@ -593,7 +637,7 @@ static void human_sf_action(const OrcEnv *e, int i, double *avx, double *avy)
 static void truth_future_traj(OrcEnv *e)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = c->human_num, P = c->predict_steps;
+    const int H = e->n_humans, P = c->predict_steps;
     double cur[ORC_MAX_HUMANS][4], nxt[ORC_MAX_HUMANS][4];
     for (int i = 0; i < H; ++i) {
         cur[i][0] = e->humans[i].px; cur[i][1] = e->humans[i].py; cur[i][2] = e->humans[i].vx; cur[i][3] = e->humans[i].vy;
@@ -631,15 +675,17 @@ static void truth_future_traj(OrcEnv *e)
             for (int k = 0; k <= P; ++k) { e->future_traj[k][i][0] = 15.0; e->future_traj[k][i][1] = 15.0; }
 }
 
-/* crowd_sim.py:415-450 */
-static void update_human_goals_randomly(OrcEnv *e)
+/* crowd_sim.py:415-450 (every human, goal_change_chance) and :453-485 (update_human_goal: one human, end_goal_change_chance;
+ * `only` >= 0 selects it) */
+static void update_human_goals_randomly(OrcEnv *e, int only)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = c->human_num;
+    const int H = e->n_humans;
     for (int i = 0; i < H; ++i) {
         OrcHuman *h = &e->humans[i];
-        if (h->v_pref == 0.0) continue;
-        if (env_random(e) <= c->goal_change_chance) {
+        if (only >= 0 && i != only) continue;
+        if (only < 0 && h->v_pref == 0.0) continue;
+        if (env_random(e) <= (only >= 0 ? c->end_goal_change_chance : c->goal_change_chance)) {
             double gx, gy;
             for (int attempt = 0;; ++attempt) {
                 const double angle = env_random(e) * M_PI * 2.0;
@@ -671,10 +717,11 @@ static void update_human_goals_randomly(OrcEnv *e)
 int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *reward_out, int *info_out, double *danger_min_dist)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = c->human_num;
+    const int H = e->n_humans;
     /* srnn.clip_action (srnn.py:17-34): float32 arithmetic on the raw action */
     float ax = action_in[0], ay = action_in[1];
     double axd = 0.0, ayd = 0.0; /* float64 action of the social-force robot */
+    double uni_v = 0.0, uni_r = 0.0; /* ActionRot(v, r) of the unicycle robot */
     if (c->robot_policy == ORC_ROBOT_SOCIAL_FORCE) {
         /* SOCIAL_FORCE.predict (crowd_nav/policy/social_force.py:11-52) on the robot's beliefs, all in float64 */
         const double dxg = e->rgx - e->rpx, dyg = e->rgy - e->rpy;
@@ -696,7 +743,9 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     } else if (c->robot_policy == ORC_ROBOT_ORCA) {
         /* crowd_sim_var_num.py:371-375: robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the robot's
          * BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path */
+        if (e->rob_sim_valid && e->rob_sim_n != H + 1) e->rob_sim_valid = 0; /* orca.py:80-82 */
         if (!e->rob_sim_valid) {
+            e->rob_sim_n = H + 1;
             e->rob_sim_nd = (float)e->shared_neighbor_dist;
             e->rob_sim_self_radius = (float)(c->robot_radius + 0.01 + c->orca_safety_space);
             e->rob_sim_self_maxspeed = (float)c->robot_v_pref;
@@ -714,6 +763,14 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         orc_orca_velocity((float)e->rpx, (float)e->rpy, (float)e->rvx, (float)e->rvy, e->rob_sim_self_radius, e->rob_sim_self_maxspeed,
                           (float)vx, (float)vy, e->rob_sim_nd, H, (float)c->orca_time_horizon, (float)c->time_step, H, opx, opy, ovx, ovy,
                           e->rob_sim_seen_radius, &ax, &ay, 0, 0);
+    } else if (c->kinematics == ORC_KIN_UNICYCLE) {
+        /* srnn.py:36-43: (change of v, change of theta) clipped in float32; crowd_sim_var_num.py:379-381: the commanded speed is
+         * the running sum self.desiredVelocity[0], clipped to +-v_pref.  With the numpy the reference pins (1.20.3) a float32
+         * scalar combined with a Python float gives float64, so everything after the clip runs in float64. */
+        const float dv = fminf(fmaxf(ax, (float)-0.1), (float)0.087);
+        ay = fminf(fmaxf(ay, (float)-0.06), (float)0.06);
+        e->desired_v = fmin(fmax(e->desired_v + (double)dv, -c->robot_v_pref), c->robot_v_pref);
+        uni_v = e->desired_v; uni_r = (double)ay;
     } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c->robot_v_pref;
@@ -743,7 +800,8 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         if (closest < 0.0) { collision = 1; break; }
         else if (closest < dmin) dmin = closest;
     }
-    const int reaching_goal = norm2(e->rpx - e->rgx, e->rpy - e->rgy) < c->robot_radius;
+    /* :487-492 */
+    const int reaching_goal = norm2(e->rpx - e->rgx, e->rpy - e->rgy) < (c->kinematics == ORC_KIN_UNICYCLE ? 0.6 : c->robot_radius);
     const double global_time = (double)e->step_counter * c->time_step;
     double reward; int done, info; double mind = 0.0;
     int danger_cond = dmin < c->discomfort_dist; /* :496-498 */
@@ -764,7 +822,7 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         done = 0; info = ORC_INFO_DANGER;
     } else {
         const double potential_cur = norm2(e->rpx - e->rgx, e->rpy - e->rgy);
-        reward = 2.0 * (-fabs(potential_cur) - e->potential);
+        reward = (c->kinematics == ORC_KIN_UNICYCLE ? 3.0 : 2.0) * (-fabs(potential_cur) - e->potential); /* :536-542 pot_factor */
         e->potential = -fabs(potential_cur);
         done = 0; info = ORC_INFO_NOTHING;
     }
@@ -781,8 +839,29 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         }
         reward = reward + rf;
     }
-    /* apply actions, agent.py:170-183 (holonomic) */
-    if (c->robot_policy == ORC_ROBOT_SOCIAL_FORCE) {
+    if (c->kinematics == ORC_KIN_UNICYCLE) {
+        /* :548-559 rotation penalty and reversing penalty, added to every outcome */
+        const double r_spin = -4.5 * (uni_r * uni_r);
+        const double r_back = uni_v < 0.0 ? -2.0 * fabs(uni_v) : 0.0;
+        reward = reward + r_spin + r_back;
+    }
+    /* apply actions, agent.py:143-183 */
+    if (c->kinematics == ORC_KIN_UNICYCLE) {
+        /* differential drive :148-165.  A rotation below 1e-4 sets R = 0, i.e. the robot does not translate on that step
+         * (the reference's formula, restated as it is). */
+        double R = 0.0;
+        if (!(fabs(uni_r) < 0.0001)) { const double w = uni_r / c->time_step; R = uni_v / w; }
+        double s0, c0, s1, c1;
+        orc_sincos(e->rtheta, &s0, &c0);
+        orc_sincos(e->rtheta + uni_r, &s1, &c1);
+        e->rpx = e->rpx - R * s0 + R * s1;
+        e->rpy = e->rpy + R * c0 - R * c1;
+        double th = fmod(e->rtheta + uni_r, 2.0 * M_PI); /* Python / numpy %: the result takes the divisor's sign */
+        if (th != 0.0 && th < 0.0) th += 2.0 * M_PI;
+        e->rtheta = th;
+        orc_sincos(th, &s0, &c0);
+        e->rvx = uni_v * c0; e->rvy = uni_v * s0;
+    } else if (c->robot_policy == ORC_ROBOT_SOCIAL_FORCE) {
         e->rpx = e->rpx + axd * c->time_step; e->rpy = e->rpy + ayd * c->time_step;
         e->rvx = axd; e->rvy = ayd;
     } else {
@@ -797,14 +876,44 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         h->vx = haxd[i]; h->vy = hayd[i];
     }
     e->step_counter += 1;
+    const int every_5s = (e->step_counter % (int)llround(5.0 / c->time_step)) == 0; /* self.global_time % 5 == 0 */
+    if (c->human_num_range > 0 && every_5s) {
+        /* crowd_sim_var_num.py:404-437 / crowd_sim_pred.py:165-190 (CrowdSimPredRealGST steps through CrowdSimPred.step):
+         * humans leave from the END of the list, and only ones the robot was not looking at; new ones are appended */
+        const int HM = c->human_num + c->human_num_range;
+        if (env_random(e) < 0.5) {
+            int max_remove;
+            if (c->env_kind == ORC_ENV_VARNUM) {
+                max_remove = e->n_humans - (c->human_num - c->human_num_range);
+                if (e->observed_count > 0 && (e->n_humans - 1) - e->observed_max < max_remove) max_remove = (e->n_humans - 1) - e->observed_max;
+            } else {
+                max_remove = e->observed_count == 0 ? e->n_humans - 1 : (e->n_humans - 1) - e->observed_max;
+                if (c->human_num_range < max_remove) max_remove = c->human_num_range;
+            }
+            e->n_humans -= env_randint(e, 0, max_remove + 1);
+        } else {
+            const int add_num = env_randint(e, 0, c->human_num_range + 1);
+            const int first = e->n_humans;
+            for (int i = first; i < first + add_num && i < HM; ++i) {
+                gen_circle_crossing_human(e, i, i);
+                double *ls = e->last_human_states[i];
+                ls[0] = 15.0; ls[1] = 15.0; ls[2] = 0.0; ls[3] = 0.0; ls[4] = 0.3;
+                e->n_humans = i + 1;
+            }
+        }
+    }
     write_obs(e, obs, 0);
     /* :446-448 random goal changing every 5 s of sim time */
-    if (c->random_goal_changing && (e->step_counter % (int)llround(5.0 / c->time_step)) == 0) update_human_goals_randomly(e);
-    /* :451-456 respawn humans that reached their goal */
+    if (c->random_goal_changing && every_5s) update_human_goals_randomly(e, -1);
+    /* :451-456 humans that reached their goal: respawned (holonomic robot) or given a new goal (unicycle robot) */
     if (c->end_goal_changing) {
-        for (int i = 0; i < H; ++i) {
+        const int n = e->n_humans;
+        for (int i = 0; i < n; ++i) {
             const OrcHuman *h = &e->humans[i];
-            if (norm2(h->gx - h->px, h->gy - h->py) < h->radius) gen_circle_crossing_human(e, i, H);
+            if (norm2(h->gx - h->px, h->gy - h->py) < h->radius) {
+                if (c->kinematics == ORC_KIN_UNICYCLE) update_human_goals_randomly(e, i);
+                else gen_circle_crossing_human(e, i, n);
+            }
         }
     }
     e->ep_return += reward; e->ep_len += 1;
@@ -835,6 +944,7 @@ OrcEnv *orc_env_new(const OrcConfig *cfg, int64_t this_seed)
 void orc_env_free(OrcEnv *e) { free(e); }
 /* crowd_sim_var_num.py:316-318: `case_counter[phase] = test_case` */
 void orc_env_set_case_counter(OrcEnv *e, uint64_t value) { e->case_counter[e->cfg.phase] = value; }
+int orc_env_human_count(const OrcEnv *e) { return e->n_humans; }
 int orc_sizeof_env(void) { return (int)sizeof(OrcEnv); }
 int orc_sizeof_obs(void) { return (int)sizeof(OrcObs); }
 int orc_sizeof_config(void) { return (int)sizeof(OrcConfig); }
@@ -846,7 +956,7 @@ void orc_env_batch_step(OrcEnv **envs, int n, const float *actions, float *robot
     for (int i = 0; i < n; ++i) {
         OrcObs obs;
         double r; int info;
-        const int H = envs[i]->cfg.human_num, D = orc_obs_width(&envs[i]->cfg);
+        const int H = envs[i]->cfg.human_num + envs[i]->cfg.human_num_range, D = orc_obs_width(&envs[i]->cfg);
         const int done = orc_env_step_autoreset(envs[i], actions + 2 * i, &obs, &r, &info, 0, 0, 0);
         memcpy(robot_node + 7 * i, obs.robot_node, 7 * sizeof(float));
         memcpy(temporal_edges + 2 * i, obs.temporal_edges, 2 * sizeof(float));

@@ -30,6 +30,14 @@
  *       single differing rounding in the linear programs would flip outcomes, so the ORCA arithmetic
  *       is PINNED by that fixture; the second shipped log (trained_models/SF_no_rand, social-force
  *       robot among non-randomised ORCA humans: 318 collisions, 12 timeouts) is reproduced exactly too.
+ *   - varying crowd size (config.sim.human_num_range > 0): crowd_sim_var_num.py:103-104 (size drawn at reset), :404-437 and
+ *       crowd_sim_pred.py:165-190 (humans leave / arrive every 5 s; legacy RandomState.randint restated as orc_mt_randint),
+ *       orca.py:80-82 (a simulator is rebuilt when the agent count changes); observations keep human_num + range rows
+ *   - unicycle robot (config.action_space.kinematics, CrowdSimVarNum-v0): crowd_sim_var_num.py:78-91 (start on the arena
+ *       circle, random heading, 1..max humans), :133-134 (placement distance), srnn.py:36-43 (clip), :379-381 (speed = running
+ *       sum), agent.py:148-183 (differential drive), :487-490 (goal radius 0.6), :536-559 (potential factor 3, spin / reverse
+ *       penalties), :451-456 + crowd_sim.py:453-485 (humans get a new goal instead of respawning).  Arithmetic follows the
+ *       numpy the reference pins (1.20.3): float32 scalar (+) Python scalar -> float64.
  *   - vec-env wrapper semantics: rl/networks/shmem_vec_env.py:136-142 (auto-reset on done),
  *       rl/networks/envs.py:49-58 (thisSeed = seed + rank, nenv, phase)
  *   - rollout math: rl/networks/storage.py:123-132 (GAE), rl/ppo/ppo.py:37-39 (advantage norm)
@@ -62,11 +70,12 @@ enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
 enum { ORC_PHASE_TRAIN = 0, ORC_PHASE_VAL = 1, ORC_PHASE_TEST = 2 };
 enum { ORC_ROBOT_NETWORK = 0, ORC_ROBOT_ORCA = 1, ORC_ROBOT_SOCIAL_FORCE = 2 };
 enum { ORC_HUMANS_ORCA = 0, ORC_HUMANS_SOCIAL_FORCE = 1 };
+enum { ORC_KIN_HOLONOMIC = 0, ORC_KIN_UNICYCLE = 1 };
 /* episode info codes, crowd_sim/envs/utils/info.py */
 enum { ORC_INFO_NOTHING = 0, ORC_INFO_TIMEOUT = 1, ORC_INFO_COLLISION = 2, ORC_INFO_REACHGOAL = 3, ORC_INFO_DANGER = 4 };
 
 typedef struct {
-    int32_t human_num;            /* config.sim.human_num (human_num_range must be 0) */
+    int32_t human_num;            /* config.sim.human_num (observations have human_num + human_num_range rows) */
     int32_t predict_steps;        /* config.sim.predict_steps */
     int32_t env_kind;             /* ORC_ENV_* */
     int32_t randomize_attributes; /* config.env.randomize_attributes */
@@ -88,6 +97,11 @@ typedef struct {
     double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
     double sf_A, sf_B, sf_KI;     /* config.sf.* (social-force robot / humans, crowd_nav/policy/social_force.py) */
     int32_t humans_policy;        /* ORC_HUMANS_ORCA (default) or ORC_HUMANS_SOCIAL_FORCE (config.humans.policy; oracle only) */
+    int32_t human_num_range;      /* config.sim.human_num_range: the crowd size varies in [human_num - range, human_num + range]
+                                     (drawn at reset, humans removed / added every 5 s: crowd_sim_var_num.py:103-104,404-437,
+                                     crowd_sim_pred.py:165-190); oracle only so far */
+    int32_t kinematics;           /* ORC_KIN_HOLONOMIC (default) or ORC_KIN_UNICYCLE (config.action_space.kinematics; CrowdSimVarNum-v0
+                                     only: CrowdSimPred.step adds the Turtlebot wheel model with Gaussian noise); oracle only so far */
     int32_t reserved1;
 } OrcConfig;
 
@@ -109,8 +123,12 @@ typedef struct OrcEnv {
     /* robot */
     double rpx, rpy, rvx, rvy, rgx, rgy, rtheta;
     OrcHuman humans[ORC_MAX_HUMANS];
+    int32_t n_humans;              /* len(self.humans): == cfg.human_num unless human_num_range > 0 or the robot is a unicycle */
+    int32_t observed_count, observed_max; /* self.observed_human_ids of the last generate_ob (crowd_sim_var_num.py:275) */
+    double desired_v;              /* self.desiredVelocity[0] (crowd_sim.py:82: set once at construction, never reset) */
     /* per-observer ORCA simulator state (orca.py:80-89: sim built lazily, radii frozen at addAgent) */
     int32_t sim_valid[ORC_MAX_HUMANS];
+    int32_t sim_n[ORC_MAX_HUMANS];      /* getNumAgents() of that simulator: a different crowd size rebuilds it (orca.py:80-82) */
     float sim_nd[ORC_MAX_HUMANS];       /* neighborDist of human i's private simulator */
     float sim_self_radius[ORC_MAX_HUMANS];
     float sim_self_maxspeed[ORC_MAX_HUMANS];
@@ -119,7 +137,7 @@ typedef struct OrcEnv {
     /* robot belief */
     double last_human_states[ORC_MAX_HUMANS][5];
     /* the robot's own rvo2 simulator when robot.policy == 'orca' (created once, lives across episodes: orca.py:80-89) */
-    int32_t rob_sim_valid;
+    int32_t rob_sim_valid, rob_sim_n;
     float rob_sim_nd, rob_sim_self_radius, rob_sim_self_maxspeed, rob_sim_seen_radius[ORC_MAX_HUMANS];
     int32_t human_visibility[ORC_MAX_HUMANS];
     double future_traj[ORC_MAX_PRED + 1][ORC_MAX_HUMANS][2]; /* const_vel predictions (positions) */
@@ -174,6 +192,8 @@ int orc_obs_width(const OrcConfig *cfg);
 OrcEnv *orc_env_new(const OrcConfig *cfg, int64_t this_seed);
 void orc_env_free(OrcEnv *env);
 void orc_env_set_case_counter(OrcEnv *env, uint64_t value);
+int orc_env_human_count(const OrcEnv *env);   /* len(self.humans) right now */
+int64_t orc_mt_randint(OrcMT *mt, int64_t low, int64_t high, uint64_t *words); /* legacy RandomState.randint(low, high) */
 int orc_sizeof_env(void);
 int orc_sizeof_obs(void);
 int orc_sizeof_config(void);

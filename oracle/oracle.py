@@ -43,7 +43,7 @@ class OrcConfig(C.Structure):
         ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
         ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
-        ("humans_policy", C.c_int32), ("reserved1", C.c_int32),
+        ("humans_policy", C.c_int32), ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -75,6 +75,9 @@ def lib():
         L.orc_env_step_autoreset.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(OrcObs), C.POINTER(C.c_double),
                                              C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_config_default.argtypes = [C.POINTER(OrcConfig)]
+        L.orc_env_human_count.argtypes = [C.c_void_p]
+        L.orc_mt_randint.restype = C.c_int64
+        L.orc_mt_randint.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.orc_mt_seed.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_mt_double.restype = C.c_double
         L.orc_mt_double.argtypes = [C.c_void_p]
@@ -99,6 +102,12 @@ def default_config(**over):
         if not hasattr(cfg, k):
             raise AttributeError(k)
         setattr(cfg, k, v)
+    if cfg.human_num + cfg.human_num_range > MAX_HUMANS or cfg.human_num_range >= max(cfg.human_num, 1):
+        raise ValueError("human_num + human_num_range must be <= %d and human_num > human_num_range (crowd_sim.py:158)" % MAX_HUMANS)
+    if cfg.kinematics == 1 and cfg.env_kind != ENV_VARNUM:
+        raise NotImplementedError("unicycle robot: CrowdSimVarNum-v0 only (CrowdSimPred.step adds the noisy wheel model)")
+    if cfg.kinematics == 1 and cfg.robot_policy != 0:
+        raise NotImplementedError("unicycle robot: the ORCA / social-force robot policies return ActionXY (holonomic only)")
     return cfg
 
 
@@ -107,7 +116,7 @@ def obs_width(cfg):
 
 
 def _obs_to_dict(o, cfg):
-    H, D = cfg.human_num, obs_width(cfg)
+    H, D = cfg.human_num + cfg.human_num_range, obs_width(cfg)   # rows = the largest crowd the config allows
     return {
         "robot_node": np.array(o.robot_node, dtype=np.float32).reshape(1, 7),
         "temporal_edges": np.array(o.temporal_edges, dtype=np.float32).reshape(1, 2),
@@ -134,6 +143,11 @@ class OracleEnv:
 
     def set_case_counter(self, value):
         self._L.orc_env_set_case_counter(self._h, int(value))
+
+    @property
+    def human_count(self):
+        """len(env.humans) right now (varies when human_num_range > 0 or the robot is a unicycle)."""
+        return self._L.orc_env_human_count(self._h)
 
     def reset(self):
         self._L.orc_env_reset(self._h, C.byref(self._obs))
@@ -187,6 +201,9 @@ class MT:
 
     def random(self):
         return lib().orc_mt_double(self._buf)
+
+    def randint(self, low, high):
+        return lib().orc_mt_randint(self._buf, low, high, None)
 
 
 def sincos(x):

@@ -56,8 +56,40 @@ def cast_obs(ob, H):
     return out
 
 
+def widen_unicycle_actions(env):
+    """numpy promotion shim for the unicycle path.  The reference pins numpy 1.20.3, where a float32 scalar combined with a
+    Python float / int gives float64 (`self.desiredVelocity[0] + action.v`, `self.theta + action.r`, `action.r ** 2`, ...), so
+    everything after srnn.clip_action runs in float64.  This container only has numpy 2 (NEP 50: the same expressions stay
+    float32).  The reference's own clip_action still does the clipping (float32, identical under both numpys); its two results are
+    re-typed as np.float64 -- same values -- which makes every later expression promote exactly as under 1.20.3."""
+    from crowd_sim.envs.utils.action import ActionRot
+    inner = env.robot.policy.clip_action
+
+    def clip_action(raw_action, v_pref):
+        a = inner(raw_action, v_pref)
+        return ActionRot(np.float64(a.v), np.float64(a.r))
+    env.robot.policy.clip_action = clip_action
+
+
+def unicycle_action_for(env, t, ep, rank):
+    """(change of speed, change of heading) script: steer at the goal with gains that exercise both clips, some exact zeros
+    (the R = 0 branch of the differential drive), a reversing phase at the start of some episodes."""
+    err = np.arctan2(env.robot.gy - env.robot.py, env.robot.gx - env.robot.px) - env.robot.theta
+    err = (err + np.pi) % (2 * np.pi) - np.pi
+    mode = (ep + rank) % 3
+    if mode == 0:
+        a = np.array([0.2, 0.9 * err])
+    elif mode == 1:
+        a = np.array([-0.15 if t % 50 < 8 else 0.05 + 0.04 * np.sin(0.3 * t), 0.05 * err + 0.02 * np.sin(0.21 * t)])
+    else:
+        a = np.array([0.03, 0.0 if t % 7 == 0 else 0.3 * err])
+    return a.astype(np.float32)
+
+
 def action_for(env, t, ep, rank):
     """Deterministic action script (never touches the global numpy RNG the env uses)."""
+    if env.robot.kinematics == "unicycle":
+        return unicycle_action_for(env, t, ep, rank)
     gx, gy = env.robot.gx - env.robot.px, env.robot.gy - env.robot.py
     n = max(np.hypot(gx, gy), 1e-9)
     mode = (ep + rank) % 4
@@ -76,10 +108,18 @@ def trace(env_name, over, seed, rank, nenv, steps, tag):
     cfg = R.make_config(**over)
     cfg.args.env_name = env_name
     env = make_env(env_name, cfg, seed, rank, nenv)
-    H = cfg.sim.human_num
+    if cfg.action_space.kinematics == "unicycle":
+        widen_unicycle_actions(env)
+    H = cfg.sim.human_num + cfg.sim.human_num_range   # rows of every observation; len(env.humans) may be smaller
+
+    def padded(rows, width):
+        out = np.full((H, width), np.nan)
+        if len(rows):
+            out[:len(rows)] = np.asarray(rows, dtype=np.float64)
+        return out
     rec = {k: [] for k in ("actions", "reward", "done", "info", "ep_return", "ep_len", "robot_state", "human_state",
                            "robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks",
-                           "human_action", "min_dist")}
+                           "human_action", "min_dist", "human_count")}
     ob0 = cast_obs(env.reset(), H)
     init_humans = np.array([[h.px, h.py, h.vx, h.vy, h.gx, h.gy, h.radius, h.v_pref] for h in env.humans])
     init_robot = np.array(env.robot.get_full_state_list(), dtype=np.float64)
@@ -91,7 +131,7 @@ def trace(env_name, over, seed, rank, nenv, steps, tag):
         pre = np.array([[h.px, h.py] for h in env.humans])
         ob, reward, done, info = env.step(a.copy())
         # human actions = displacement / dt is lossy; read velocities of humans that were not respawned instead
-        rec["human_action"].append(np.array([[h.vx, h.vy] for h in env.humans], dtype=np.float64))
+        rec["human_action"].append(padded([[h.vx, h.vy] for h in env.humans], 2))
         rets.append(reward)
         ep_len += 1
         code = info_code(info["info"])
@@ -113,7 +153,8 @@ def trace(env_name, over, seed, rank, nenv, steps, tag):
         rec["done"].append(bool(done))
         rec["info"].append(code)
         rec["robot_state"].append(np.array(env.robot.get_full_state_list(), dtype=np.float64))
-        rec["human_state"].append(np.array([[h.px, h.py, h.gx, h.gy, h.radius, h.v_pref] for h in env.humans]))
+        rec["human_state"].append(padded([[h.px, h.py, h.gx, h.gy, h.radius, h.v_pref] for h in env.humans], 6))
+        rec["human_count"].append(len(env.humans))
     out = {k: np.array(v) for k, v in rec.items()}
     out["reward64"] = np.array([float(x) for x in rec["reward"]])
     for k, v in ob0.items():
@@ -164,7 +205,20 @@ def env_goldens():
     # robot.visible = True: every human's ORCA gets the robot as one more neighbour (crowd_sim.py:695-699)
     trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 20, "robot.visible": True}), 425, 1, 4, 300, "varnum_h20_robotvisible_r1")
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 7, "robot.visible": True}), 425, 2, 4, 320, "varnum_h7_rand_robotvisible_r2")
-
+    # sim.human_num_range > 0: the crowd size is drawn at reset and humans leave / arrive every 5 s (oracle only so far)
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 5, "sim.human_num_range": 2}), 425, 0, 4, 600, "varnum_h5_range2_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 20, "sim.human_num_range": 5}), 425, 1, 4, 400, "varnum_h20_rand_range5_r1")
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 10, "sim.human_num_range": 3, "sim.predict_method": "const_vel"}), 425, 0, 4,
+          300, "pred_h10_range3_r0")
+    trace("CrowdSimPredRealGST-v0", dict(RAND, **{"sim.human_num": 12, "sim.human_num_range": 4, "sim.predict_method": "inferred"}), 425, 2, 4,
+          240, "predgst_h12_rand_range4_r2")
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 15, "sim.human_num_range": 5}), 425, 0, 1, 300, "varnum_h15_range5_test_r0")
+    # action_space.kinematics = 'unicycle' (CrowdSimVarNum-v0; oracle only so far).  The reset draws 1 .. human_num + range humans
+    # and the step asserts human_num - range <= len(humans) (:439), so the reference only runs with range = human_num - 1.
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 3, "sim.human_num_range": 2, "action_space.kinematics": "unicycle"}),
+          425, 0, 4, 700, "varnum_h3_unicycle_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 6, "sim.human_num_range": 5, "action_space.kinematics": "unicycle"}),
+          425, 1, 4, 500, "varnum_h6_rand_unicycle_r1")
 
 if __name__ == "__main__":
     what = _ARGV or ["env"]

@@ -45,6 +45,8 @@ def test_env_trace_matches_reference(path):
         assert np.float32(r) == pytest.approx(z["reward"][t], abs=1e-6), "reward @%d" % t
         if "min_dist" in z.files:  # test-phase traces: Danger(min_dist) from the humans' true future positions
             assert info["min_dist"] == pytest.approx(float(z["min_dist"][t]), abs=1e-9), "min_dist @%d" % t
+        if "human_count" in z.files:  # crowd size after this step (after the auto-reset when the episode ended)
+            assert env.human_count == int(z["human_count"][t]), "human_count @%d" % t
         if done:
             assert info["episode"]["l"] == int(z["ep_len"][t])
             assert info["episode"]["r"] == pytest.approx(float(z["ep_return"][t]), abs=2e-6)
