@@ -393,6 +393,8 @@ static int robot_sees(const OrcEnv *e, const OrcHuman *h)
     return dist <= e->cfg.sensor_range;
 }
 
+static void truth_future_traj(OrcEnv *e);
+
 static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
 {
     const OrcConfig *c = &e->cfg;
@@ -444,7 +446,9 @@ static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
         /* calc_human_future_traj('const_vel'), crowd_sim_var_num.py:166-226 + crowd_sim_pred.py:80-86.
          * PredRealGST (crowd_sim_pred_real_gst.py:78-93) fills the future slots with the current
          * relative position (np.tile), the wrapper overwrites them later. */
-        for (int k = 0; k <= P; ++k)
+        /* predict_method 'truth' (crowd_sim_pred.py:81 with config.sim.predict_method): the humans' own ORCA rolled forward */
+        if (c->predict_truth) truth_future_traj(e);
+        for (int k = 0; k <= P && !c->predict_truth; ++k)
             for (int i = 0; i < H; ++i) {
                 if (e->human_visibility[i]) {
                     const double t = (double)k * c->time_step * 1.0;
@@ -544,13 +548,12 @@ void orc_env_reset(OrcEnv *e, OrcObs *obs)
     write_obs(e, obs, 1);
 }
 
-/* ORCA.predict for human i, orca.py:64-117 */
-static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
+/* human i's private rvo2 simulator, orca.py:80-89: rebuilt when the agent count differs, parameters frozen at creation */
+static void ensure_human_sim(OrcEnv *e, int i, int n_agents)
 {
     const OrcConfig *c = &e->cfg;
     const int H = e->n_humans;
     const OrcHuman *me = &e->humans[i];
-    const int n_agents = H + (c->robot_visible ? 1 : 0); /* self + the others (+ the robot) */
     if (e->sim_valid[i] && e->sim_n[i] != n_agents) e->sim_valid[i] = 0; /* :80-82 crowd size changed -> new simulator */
     if (!e->sim_valid[i]) { /* :83-89 */
         e->sim_n[i] = n_agents;
@@ -561,6 +564,15 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
             if (j != i) e->sim_seen_radius[i][j] = (float)(e->humans[j].radius + 0.01 + c->orca_safety_space);
         e->sim_valid[i] = 1;
     }
+}
+
+/* ORCA.predict for human i, orca.py:64-117 */
+static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
+{
+    const OrcConfig *c = &e->cfg;
+    const int H = e->n_humans;
+    const OrcHuman *me = &e->humans[i];
+    ensure_human_sim(e, i, H + (c->robot_visible ? 1 : 0)); /* self + the others (+ the robot) */
     float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
     int n = 0;
     for (int j = 0; j < H; ++j) {
@@ -648,6 +660,7 @@ static void truth_future_traj(OrcEnv *e)
             const OrcHuman *me = &e->humans[i];
             float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
             int n = 0;
+            ensure_human_sim(e, i, H); /* only new at reset (predict_method 'truth'): act_joint_state builds it like ORCA.predict */
             for (int j = 0; j < H; ++j) {
                 if (j == i) continue;
                 opx[n] = (float)cur[j][0]; opy[n] = (float)cur[j][1]; ovx[n] = (float)cur[j][2]; ovy[n] = (float)cur[j][3];

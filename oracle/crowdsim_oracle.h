@@ -38,6 +38,7 @@
  *       sum), agent.py:148-183 (differential drive), :487-490 (goal radius 0.6), :536-559 (potential factor 3, spin / reverse
  *       penalties), :451-456 + crowd_sim.py:453-485 (humans get a new goal instead of respawning).  Arithmetic follows the
  *       numpy the reference pins (1.20.3): float32 scalar (+) Python scalar -> float64.
+ *   - predict_method 'truth' as CrowdSimPred-v0's observation predictor: crowd_sim_pred.py:81 -> crowd_sim_var_num.py:152-227
  *   - vec-env wrapper semantics: rl/networks/shmem_vec_env.py:136-142 (auto-reset on done),
  *       rl/networks/envs.py:49-58 (thisSeed = seed + rank, nenv, phase)
  *   - rollout math: rl/networks/storage.py:123-132 (GAE), rl/ppo/ppo.py:37-39 (advantage norm)
@@ -102,7 +103,8 @@ typedef struct {
                                      crowd_sim_pred.py:165-190); oracle only so far */
     int32_t kinematics;           /* ORC_KIN_HOLONOMIC (default) or ORC_KIN_UNICYCLE (config.action_space.kinematics; CrowdSimVarNum-v0
                                      only: CrowdSimPred.step adds the Turtlebot wheel model with Gaussian noise); oracle only so far */
-    int32_t reserved1;
+    int32_t predict_truth;        /* CrowdSimPred-v0 only: config.sim.predict_method == 'truth' -- the observation carries the humans' true
+                                     future positions (their own ORCA rolled forward) instead of the constant-velocity ones; oracle only so far */
 } OrcConfig;
 
 typedef struct {

@@ -43,7 +43,7 @@ class OrcConfig(C.Structure):
         ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
         ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
-        ("humans_policy", C.c_int32), ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("reserved1", C.c_int32),
+        ("humans_policy", C.c_int32), ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("predict_truth", C.c_int32),
     ]
 
 
@@ -104,6 +104,8 @@ def default_config(**over):
         setattr(cfg, k, v)
     if cfg.human_num + cfg.human_num_range > MAX_HUMANS or cfg.human_num_range >= max(cfg.human_num, 1):
         raise ValueError("human_num + human_num_range must be <= %d and human_num > human_num_range (crowd_sim.py:158)" % MAX_HUMANS)
+    if cfg.predict_truth and (cfg.env_kind != ENV_PRED or cfg.robot_visible or cfg.humans_policy != 0):
+        raise NotImplementedError("predict_method='truth': CrowdSimPred-v0 with ORCA humans and an invisible robot")
     if cfg.kinematics == 1 and cfg.env_kind != ENV_VARNUM:
         raise NotImplementedError("unicycle robot: CrowdSimVarNum-v0 only (CrowdSimPred.step adds the noisy wheel model)")
     if cfg.kinematics == 1 and cfg.robot_policy != 0:

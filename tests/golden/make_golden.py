@@ -213,6 +213,11 @@ def env_goldens():
     trace("CrowdSimPredRealGST-v0", dict(RAND, **{"sim.human_num": 12, "sim.human_num_range": 4, "sim.predict_method": "inferred"}), 425, 2, 4,
           240, "predgst_h12_rand_range4_r2")
     trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 15, "sim.human_num_range": 5}), 425, 0, 1, 300, "varnum_h15_range5_test_r0")
+    # sim.predict_method = 'truth' as the OBSERVATION predictor of CrowdSimPred-v0 (oracle only so far)
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 20, "sim.predict_method": "truth"}), 425, 1, 4, 260, "pred_h20_truthobs_r1")
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 8, "sim.human_num_range": 2, "sim.predict_method": "truth"}), 425, 0, 4, 300,
+          "pred_h8_rand_range2_truthobs_r0")
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 10, "sim.predict_method": "truth"}), 425, 0, 1, 200, "pred_h10_rand_truthobs_test_r0")
     # action_space.kinematics = 'unicycle' (CrowdSimVarNum-v0; oracle only so far).  The reset draws 1 .. human_num + range humans
     # and the step asserts human_num - range <= len(humans) (:439), so the reference only runs with range = human_num - 1.
     trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 3, "sim.human_num_range": 2, "action_space.kinematics": "unicycle"}),
