@@ -18,8 +18,19 @@ def test_mt19937_matches_numpy_legacy_stream():
         assert ref == [m.random() for _ in range(1500)]
 
 
+def test_randint_matches_numpy_legacy_stream():
+    """RandomState.randint (crowd size draws, crowd_sim_var_num.py:103,423): masked rejection on 32-bit words, no draw for a
+    single-value range -- values AND stream position must agree."""
+    for seed in (1, 425):
+        np.random.seed(seed)
+        m = O.MT(seed)
+        for lo, hi in [(0, 1), (0, 2), (0, 3), (3, 8), (15, 26), (1, 21), (0, 6), (0, 1000), (5, 6)] * 40:
+            assert np.random.randint(lo, hi) == m.randint(lo, hi)
+            assert np.random.random() == m.random()
+
+
 def test_sincos_accuracy():
-    xs = np.linspace(0.0, 2 * np.pi, 20001)
+    xs = np.linspace(-0.07, 2 * np.pi + 0.07, 20001)  # the unicycle heading + one clipped rotation leaves [0, 2 pi) by <= 0.06
     got = np.array([O.sincos(x) for x in xs])
     assert np.max(np.abs(got[:, 0] - np.sin(xs))) <= 2.3e-16
     assert np.max(np.abs(got[:, 1] - np.cos(xs))) <= 2.3e-16
