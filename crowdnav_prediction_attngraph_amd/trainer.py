@@ -89,6 +89,9 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
     envs = make_vec_envs(env_name, seed, num_processes, gamma, None, device, False, config=config, phase="train")
     base_kwargs = dict(env_name=env_name, num_processes=num_processes, num_mini_batch=num_mini_batch, seq_length=num_steps)
     actor_critic = Policy(envs.observation_space.spaces, envs.action_space, base_kwargs=base_kwargs, base="selfAttn_merge_srnn").to(device)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # identical weights on every rank (seeded above), but each env shard explores with its own action noise
+        torch.cuda.manual_seed(seed + 1000003 * torch.distributed.get_rank())
     rollouts = RolloutStorage(num_steps, num_processes, envs.observation_space.spaces, envs.action_space, 128, 256)
     rollouts.to(device)
     agent = PPO(actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, entropy_coef, lr=lr, eps=eps, max_grad_norm=max_grad_norm)
