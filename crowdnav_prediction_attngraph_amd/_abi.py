@@ -26,7 +26,7 @@ class EnvConfig(C.Structure):
         ("randomize_attributes", C.c_int32), ("random_goal_changing", C.c_int32),
         ("end_goal_changing", C.c_int32), ("sort_humans", C.c_int32), ("phase", C.c_int32),
         ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32), ("robot_policy", C.c_int32),
-        ("robot_visible", C.c_int32), ("max_placement_attempts", C.c_int32),
+        ("robot_visible", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32), ("max_placement_attempts", C.c_int32),
         ("time_step", C.c_double), ("time_limit", C.c_double),
         ("success_reward", C.c_double), ("collision_penalty", C.c_double),
         ("discomfort_dist", C.c_double), ("discomfort_penalty_factor", C.c_double),
@@ -101,11 +101,12 @@ class PolicyWeights(C.Structure):
 # every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
-    "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_set_case_counters", "cn_orca_solve",
+    "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
+    "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
 ]
 
 _lib = None
@@ -132,6 +133,10 @@ def lib():
         L.cn_env_get_danger_min_dist.argtypes = [vp, vp, vp]
         L.cn_env_set_case_counters.argtypes = [vp, vp, vp]
         L.cn_env_get_human_actions.argtypes = [vp, vp, vp]
+        L.cn_env_snapshot_bytes.argtypes = [vp]
+        L.cn_env_snapshot_bytes.restype = i64
+        L.cn_env_save.argtypes = [vp, vp, vp]
+        L.cn_env_load.argtypes = [vp, vp, vp]
         L.cn_orca_solve.argtypes = [i32, i32, vp, vp, f32, i32, f32, f32, vp, vp]
         L.cn_policy_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
         L.cn_policy_destroy.argtypes = [vp]
@@ -165,6 +170,11 @@ def lib():
         L.cn_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp]
         L.cn_adv_stats.argtypes = [i64, vp, vp, vp, vp]
         L.cn_adv_normalize.argtypes = [i64, vp, vp, vp, vp, vp]
+        L.cn_ppo_loss_workspace_doubles.argtypes = []
+        L.cn_adam_workspace_doubles.argtypes = []
+        L.cn_ppo_loss_fwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp]
+        L.cn_ppo_loss_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp]
+        L.cn_adam_clip_step.argtypes = [i64, vp, vp, vp, vp, f64, f64, f64, f64, f64, f64, i64, vp, vp, vp]
         _lib = L
     return _lib
 

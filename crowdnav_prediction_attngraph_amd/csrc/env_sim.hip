@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstring>
 #include <new>
 
 namespace {
@@ -904,11 +905,13 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         ep_ret_out[e] = ep_ret; ep_len_out[e] = ep_cnt;
         if (not_done_out) not_done_out[e] = done ? 0.0f : 1.0f; // the `masks` tensor of train.py:185-186
     }
-    if (done) {
+    if (done && c.auto_reset) {
         // vec-env auto-reset: the terminal observation is replaced by the first observation of the next episode.
         // (The terminal step's own goal-change / respawn draws happen before np.random.seed and cannot be observed.)
         do_reset(s, R, e, lane, rb, h, shared_nd, ob);
     } else {
+        // (auto_reset == 0, the single-env gym object: a terminal step is an ordinary step -- terminal observation, goal
+        // changes and respawns included, crowd_sim_var_num.py:430-458 -- and the caller resets explicitly)
         write_obs(s, e, lane, false, rb, h, ob);
         // crowd_sim_var_num.py:446-448: every 5 s of simulated time
         const int period = (int)(5.0 / c.time_step + 0.5);
@@ -959,6 +962,7 @@ struct cn_env_batch {
     EnvDev d;
     bool reset_done;
     void *blob;
+    size_t blob_bytes;
     // ORCA of step t+1 only needs the simulator state left by step t, not the robot's next action: it is launched on a
     // side stream as soon as step t (or a reset) is enqueued and overlaps the caller's policy forward.
     hipStream_t side;
@@ -992,7 +996,7 @@ extern "C" void cn_env_config_default(cn_env_config *c)
     *c = cn_env_config{};
     c->human_num = 20; c->predict_steps = 5; c->env_kind = CN_ENV_VARNUM;
     c->randomize_attributes = 0; c->random_goal_changing = 0; c->end_goal_changing = 1; c->sort_humans = 1;
-    c->phase = CN_PHASE_TRAIN; c->nenv = 1; c->val_size = 100; c->test_size = 500;
+    c->phase = CN_PHASE_TRAIN; c->nenv = 1; c->val_size = 100; c->test_size = 500; c->auto_reset = 1;
     c->time_step = 0.25; c->time_limit = 50.0;
     c->success_reward = 10.0; c->collision_penalty = -20.0; c->discomfort_dist = 0.25; c->discomfort_penalty_factor = 10.0;
     c->circle_radius = 6.0 * std::sqrt(2.0); c->arena_size = 6.0;
@@ -1050,6 +1054,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     herr = hipMemset(base, 0, off);
     if (herr != hipSuccess) { (void)hipFree(base); delete b; cn_set_error("cn_env_create: hipMemset failed: %s", hipGetErrorString(herr)); return CN_ERR_HIP; }
     b->blob = base;
+    b->blob_bytes = off;
     d.hum = (double *)(base + o_hum); d.rob = (double *)(base + o_rob); d.lhs = (double *)(base + o_lhs);
     d.ftraj = cfg->env_kind == CN_ENV_PRED ? (double *)(base + o_ft) : nullptr;
     d.step_counter = (int32_t *)(base + o_sc); d.case_counter = (uint64_t *)(base + o_cc);
@@ -1150,6 +1155,59 @@ extern "C" int cn_env_set_case_counters(cn_env_batch *env, const uint64_t *count
     if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // the side stream may be pre-generating episodes
     CN_HIP(hipMemcpyAsync(env->d.case_counter, counters, (size_t)env->d.E * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     CN_HIP(hipMemsetAsync(env->d.nx_ready, 0, (size_t)env->d.E, st)); // staged episodes were generated for the old counters
+    return CN_OK;
+}
+
+// ---- checkpointing (train.py:213-219 only saves the policy; a bit-exact --resume also needs the simulator) ----------
+// The whole persistent state of a batch is ONE device blob (agent records, beliefs, counters, private ORCA simulators, the
+// numpy MT19937 streams, the staged next episodes, the prefetched ORCA velocities): a snapshot is that blob behind a small
+// header that pins the layout it was taken from.
+struct SnapHeader {
+    uint64_t magic, blob_bytes;
+    int32_t E, H, D, P;
+    int64_t seed_base;
+    cn_env_config cfg;
+    int32_t reset_done, pad;
+};
+constexpr uint64_t SNAP_MAGIC = 0x434e454e56303032ull; // "CNENV002"
+
+extern "C" int64_t cn_env_snapshot_bytes(const cn_env_batch *env)
+{
+    return env ? (int64_t)(sizeof(SnapHeader) + env->blob_bytes) : 0;
+}
+
+extern "C" int cn_env_save(cn_env_batch *env, void *dst, void *stream)
+{
+    CN_REQUIRE(env && dst, "cn_env_save: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // the side stream owns hact / sim_* / nx_* until then
+    SnapHeader h{};
+    h.magic = SNAP_MAGIC; h.blob_bytes = env->blob_bytes; h.E = env->d.E; h.H = env->d.H; h.D = env->d.D; h.P = env->d.P;
+    h.seed_base = env->d.seed_base; h.cfg = env->d.cfg; h.reset_done = env->reset_done ? 1 : 0;
+    CN_HIP(hipMemcpyAsync(dst, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    CN_HIP(hipMemcpyAsync((char *)dst + sizeof(h), env->blob, env->blob_bytes, hipMemcpyDeviceToDevice, st));
+    CN_HIP(hipStreamSynchronize(st)); // `h` lives on this stack frame
+    return CN_OK;
+}
+
+extern "C" int cn_env_load(cn_env_batch *env, const void *src, void *stream)
+{
+    CN_REQUIRE(env && src, "cn_env_load: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    SnapHeader h{};
+    CN_HIP(hipMemcpyAsync(&h, src, sizeof(h), hipMemcpyDeviceToHost, st));
+    CN_HIP(hipStreamSynchronize(st));
+    CN_REQUIRE(h.magic == SNAP_MAGIC, "cn_env_load: not a cn_env snapshot (bad magic)");
+    CN_REQUIRE(h.blob_bytes == env->blob_bytes && h.E == env->d.E && h.H == env->d.H && h.D == env->d.D && h.P == env->d.P &&
+                   h.seed_base == env->d.seed_base && std::memcmp(&h.cfg, &env->d.cfg, sizeof(cn_env_config)) == 0,
+               "cn_env_load: the snapshot was taken from a batch with a different shape, seed, shard or configuration "
+               "(E=%d H=%d seed_base=%lld vs E=%d H=%d seed_base=%lld)", h.E, h.H, (long long)h.seed_base, env->d.E, env->d.H, (long long)env->d.seed_base);
+    CN_HIP(hipStreamSynchronize(env->side)); // nothing of ours may still be writing the blob
+    CN_HIP(hipMemcpyAsync(env->blob, (const char *)src + sizeof(h), env->blob_bytes, hipMemcpyDeviceToDevice, st));
+    env->reset_done = h.reset_done != 0;
+    // the snapshot holds the prefetched velocities of its state, but the event that orders them is gone: recompute on demand
+    // (orca_kernel / env_pregen_kernel are pure functions of the restored state, so the continuation is bit-identical)
+    env->orca_ready = false;
     return CN_OK;
 }
 

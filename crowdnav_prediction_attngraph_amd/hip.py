@@ -88,6 +88,24 @@ class HipEnvBatch:
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_env_set_case_counters(self._h, A.ptr(c), A.stream_ptr()), "cn_env_set_case_counters")
 
+    def state_dict(self):
+        """Snapshot of the whole simulator state (cn_env_save) as one uint8 CPU tensor -- torch.save()-able next to the policy."""
+        n = int(A.lib().cn_env_snapshot_bytes(self._h))
+        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_save(self._h, A.ptr(buf), A.stream_ptr()), "cn_env_save")
+        return buf.cpu()
+
+    def load_state_dict(self, snap):
+        """Restore a snapshot taken from a batch of the same configuration / shape / seed / shard (cn_env_load)."""
+        n = int(A.lib().cn_env_snapshot_bytes(self._h))
+        snap = torch.as_tensor(snap, dtype=torch.uint8)
+        if snap.numel() != n:
+            raise A.CnError("snapshot has %d bytes, this batch needs %d (different env count / humans / config?)" % (snap.numel(), n))
+        buf = snap.to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_load(self._h, A.ptr(buf), A.stream_ptr()), "cn_env_load")
+
     def get_danger_min_dist(self):
         """Danger.min_dist of the last step per env (float64 [E]); non-zero only in the test phase."""
         out = torch.zeros(self.E, dtype=torch.float64, device=self.device)
@@ -462,6 +480,44 @@ class HipLinear(torch.autograd.Function):
             A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, gate, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
                     "cn_linear_wgrad")
         return dx, dw, db, None
+
+
+class PPOLoss(torch.autograd.Function):
+    """(value_loss, action_loss) of rl/ppo/ppo.py:66-84 as one tensor [2]: forward = cn_ppo_loss_fwd, backward =
+    cn_ppo_loss_bwd (gradients w.r.t. `values` and `logp` only -- everything else is rollout data)."""
+
+    @staticmethod
+    def forward(ctx, values, logp, old_logp, adv, value_preds, returns, clip_param, use_clipped_value_loss):
+        ts = [t.reshape(-1).contiguous() for t in (values, logp, old_logp, adv, value_preds, returns)]
+        n = ts[0].numel()
+        if any(t.numel() != n or t.dtype != torch.float32 for t in ts):
+            raise A.CnError("PPOLoss: all inputs must be float32 tensors of the same number of elements")
+        ws = torch.empty(A.lib().cn_ppo_loss_workspace_doubles(), dtype=torch.float64, device=ts[0].device)
+        losses = torch.empty(2, device=ts[0].device)
+        A.check(A.lib().cn_ppo_loss_fwd(n, *[A.ptr(t) for t in ts], float(clip_param), int(bool(use_clipped_value_loss)), A.ptr(ws), A.ptr(losses),
+                                        A.stream_ptr()), "cn_ppo_loss_fwd")
+        ctx.save_for_backward(*ts)
+        ctx.meta = (n, float(clip_param), int(bool(use_clipped_value_loss)), values.shape, logp.shape)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        n, clip, ucv, vshape, lshape = ctx.meta
+        dv, dlp = torch.empty(n, device=g.device), torch.empty(n, device=g.device)
+        A.check(A.lib().cn_ppo_loss_bwd(n, *[A.ptr(t) for t in ts], clip, ucv, A.ptr(g.contiguous()), A.ptr(dv), A.ptr(dlp), A.stream_ptr()),
+                "cn_ppo_loss_bwd")
+        return dv.view(vshape), dlp.view(lshape), None, None, None, None, None, None
+
+
+def adam_clip_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, max_grad_norm, grad_scale=1.0, workspace=None, norm_out=None):
+    """nn.utils.clip_grad_norm_ + torch.optim.Adam.step over one flat fp32 bucket (cn_adam_clip_step), in place."""
+    n = param.numel()
+    if workspace is None:
+        workspace = torch.empty(A.lib().cn_adam_workspace_doubles(), dtype=torch.float64, device=param.device)
+    A.check(A.lib().cn_adam_clip_step(n, A.ptr(param), A.ptr(grad), A.ptr(exp_avg), A.ptr(exp_avg_sq), float(grad_scale),
+                                      float(max_grad_norm if max_grad_norm is not None else 0.0), float(lr), float(betas[0]), float(betas[1]),
+                                      float(eps), int(step), A.ptr(workspace), A.ptr(norm_out), A.stream_ptr()), "cn_adam_clip_step")
 
 
 def gae(rewards, values, masks, gamma, lam, returns):

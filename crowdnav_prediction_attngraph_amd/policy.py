@@ -322,6 +322,11 @@ class Policy(nn.Module):
             self._hip_version = ver
         return self._hip
 
+    def weights_changed(self):
+        """Tell the rollout path that parameter storage was written through raw pointers (the fused Adam kernel): the next
+        act / get_value re-snapshots the weights (cn_policy_set_weights)."""
+        self._hip_version = None
+
     def _edge_zeros(self, E, device):
         key = (E, str(device))
         if key not in self._zero_edge:

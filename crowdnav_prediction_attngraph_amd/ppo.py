@@ -34,21 +34,64 @@ class PPO():
         self.use_clipped_value_loss = use_clipped_value_loss
         self.optimizer = optim.Adam(actor_critic.parameters(), lr=lr, eps=eps)
         self._flat = None
+        self._step = 0
 
-    # one flat gradient bucket; p.grad are views into it, so the all-reduce needs no packing copies
-    def _bind_flat_grads(self):
-        params = [p for p in self.actor_critic.parameters() if p.requires_grad]
-        if self._flat is not None and self._flat.device == params[0].device and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
-                                                                                   for p, v in zip(params, self._views)):
+    # ---- flat buckets (GPU path) -------------------------------------------------------------------------------------
+    # ONE fp32 buffer each for the parameters, their gradients and the two Adam moments; every p.data / p.grad /
+    # optimizer.state[p]['exp_avg'|'exp_avg_sq'] is a view into them.  The gradient all-reduce then needs no packing and the
+    # clip + Adam step is a single pair of launches (cn_adam_clip_step).  `self.optimizer` stays the owner of the optimiser
+    # state: its state_dict() / load_state_dict() / param_groups (learning-rate schedule of train.py:148-152) keep working.
+    def _params(self):
+        return [p for p in self.actor_critic.parameters() if p.requires_grad]
+
+    def _bound(self, params):
+        if self._flat is None or self._flat["p"].device != params[0].device or len(params) != len(self._flat["views"]):
+            return False
+        st = self.optimizer.state
+        for p, (pv, gv, mv, vv) in zip(params, self._flat["views"]):
+            if p.data_ptr() != pv.data_ptr() or p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                return False
+            s = st.get(p)
+            if not s or s["exp_avg"].data_ptr() != mv.data_ptr() or s["exp_avg_sq"].data_ptr() != vv.data_ptr():
+                return False
+        return True
+
+    def _bind_flat(self):
+        params = self._params()
+        if self._bound(params):
             return
+        dev = params[0].device
         n = sum(p.numel() for p in params)
-        self._flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
-        self._views, off = [], 0
+        # 16-byte aligned starts for every parameter would waste nothing useful here: the kernels index the bucket as a whole
+        flat = {k: torch.zeros(n, dtype=torch.float32, device=dev) for k in ("p", "g", "m", "v")}
+        views, off, step = [], 0, 0
         for p in params:
-            v = self._flat[off:off + p.numel()].view_as(p)
-            p.grad = v
-            self._views.append(v)
-            off += p.numel()
+            k = p.numel()
+            pv, gv, mv, vv = (flat[key][off:off + k].view_as(p) for key in ("p", "g", "m", "v"))
+            pv.copy_(p.data)
+            s = self.optimizer.state.get(p)
+            if s:                                  # state restored by optimizer.load_state_dict() or left by the CPU path
+                mv.copy_(s["exp_avg"]); vv.copy_(s["exp_avg_sq"])
+                step = max(step, int(float(s["step"])))
+            p.data = pv
+            p.grad = gv
+            self.optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": mv, "exp_avg_sq": vv}
+            views.append((pv, gv, mv, vv))
+            off += k
+        flat["views"] = views
+        flat["ws"] = torch.empty(hip.A.lib().cn_adam_workspace_doubles(), dtype=torch.float64, device=dev)
+        self._flat = flat
+        self._step = step
+        self._weights_changed()
+
+    def _weights_changed(self):
+        f = getattr(self.actor_critic, "weights_changed", None)
+        if f is not None:
+            f()        # the rollout-side weight snapshot (cn_policy_set_weights) must be refreshed: raw-pointer writes bump no version
+
+    def _sync_optimizer_state(self):
+        for s in self.optimizer.state.values():
+            s["step"].fill_(float(self._step))
 
     def _advantages(self, rollouts):
         ret, val = rollouts.returns, rollouts.value_preds
@@ -72,38 +115,77 @@ class PPO():
             return (adv - mean.float()) / (std.float() + 1e-5)
         return (adv - adv.mean()) / (adv.std() + 1e-5)
 
+    def _losses(self, values, action_log_probs, old_logp, adv_targ, value_preds, returns):
+        """(value_loss, action_loss) of ppo.py:66-84.  GPU tensors: one fused HIP kernel each way (cn_ppo_loss_fwd/bwd)."""
+        if values.is_cuda:
+            losses = hip.PPOLoss.apply(values, action_log_probs, old_logp, adv_targ, value_preds, returns, self.clip_param,
+                                       self.use_clipped_value_loss)
+            return losses[0], losses[1]
+        ratio = torch.exp(action_log_probs - old_logp)
+        surr1 = ratio * adv_targ
+        surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
+        action_loss = -torch.min(surr1, surr2).mean()
+        if self.use_clipped_value_loss:
+            value_pred_clipped = value_preds + (values - value_preds).clamp(-self.clip_param, self.clip_param)
+            value_losses = (values - returns).pow(2)
+            value_losses_clipped = (value_pred_clipped - returns).pow(2)
+            value_loss = 0.5 * torch.max(value_losses, value_losses_clipped).mean()
+        else:
+            value_loss = 0.5 * (returns - values).pow(2).mean()
+        return value_loss, action_loss
+
     def update(self, rollouts):
         advantages = self._advantages(rollouts)
         dev = rollouts.rewards.device
         sums = torch.zeros(3, device=dev)
         d = _dist()
-        self._bind_flat_grads()
+        on_gpu = dev.type == "cuda"
+        if on_gpu:
+            self._bind_flat()
+        num_steps = 0
         for e in range(self.ppo_epoch):
             if not self.actor_critic.is_recurrent:
                 raise NotImplementedError("feed-forward policies are out of scope")
             for sample in rollouts.recurrent_generator(advantages, self.num_mini_batch):
                 obs_batch, hxs_batch, actions_batch, value_preds_batch, return_batch, masks_batch, old_logp_batch, adv_targ = sample
                 values, action_log_probs, dist_entropy, _ = self.actor_critic.evaluate_actions(obs_batch, hxs_batch, masks_batch, actions_batch)
-                ratio = torch.exp(action_log_probs - old_logp_batch)
-                surr1 = ratio * adv_targ
-                surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
-                action_loss = -torch.min(surr1, surr2).mean()
-                if self.use_clipped_value_loss:
-                    value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param, self.clip_param)
-                    value_losses = (values - return_batch).pow(2)
-                    value_losses_clipped = (value_pred_clipped - return_batch).pow(2)
-                    value_loss = 0.5 * torch.max(value_losses, value_losses_clipped).mean()
-                else:
-                    value_loss = 0.5 * (return_batch - values).pow(2).mean()
-                self._flat.zero_()
+                value_loss, action_loss = self._losses(values, action_log_probs, old_logp_batch, adv_targ, value_preds_batch, return_batch)
                 total_loss = value_loss * self.value_loss_coef + action_loss - dist_entropy * self.entropy_coef
-                total_loss.backward()
-                if d is not None:
-                    d.all_reduce(self._flat)
-                    self._flat.div_(d.get_world_size())
-                nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
-                self.optimizer.step()
+                if on_gpu:
+                    flat = self._flat
+                    flat["g"].zero_()                         # optimizer.zero_grad(): the views stay bound
+                    total_loss.backward()
+                    for p, (_, gv, _, _) in zip(self._params(), flat["views"]):
+                        if p.grad is not gv and p.grad.data_ptr() != gv.data_ptr():
+                            gv.copy_(p.grad)                  # something replaced .grad instead of accumulating into the bucket
+                            p.grad = gv
+                    scale = 1.0
+                    if d is not None:
+                        d.all_reduce(flat["g"])               # ONE collective per optimiser step (RCCL over xGMI)
+                        scale = 1.0 / d.get_world_size()
+                    g = self.optimizer.param_groups[0]
+                    self._step += 1
+                    hip.adam_clip_step(flat["p"], flat["g"], flat["m"], flat["v"], self._step, g["lr"], g["betas"], g["eps"],
+                                       self.max_grad_norm, grad_scale=scale, workspace=flat["ws"])
+                    self._weights_changed()
+                else:
+                    self.optimizer.zero_grad()
+                    total_loss.backward()
+                    if d is not None:                          # CPU tensors (gloo tests): pack, one all-reduce, unpack
+                        ps = [p for p in self._params() if p.grad is not None]
+                        bucket = torch.cat([p.grad.reshape(-1) for p in ps])
+                        d.all_reduce(bucket)
+                        bucket /= d.get_world_size()
+                        off = 0
+                        for p in ps:
+                            p.grad.copy_(bucket[off:off + p.numel()].view_as(p))
+                            off += p.numel()
+                    nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+                    self.optimizer.step()
                 sums += torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
+                num_steps += 1
+        if on_gpu:
+            self._sync_optimizer_state()
         num_updates = self.ppo_epoch * self.num_mini_batch
         if d is not None:
             d.all_reduce(sums)

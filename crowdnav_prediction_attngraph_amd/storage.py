@@ -102,6 +102,9 @@ class RolloutStorage(object):
         assert num_processes >= num_mini_batch, (
             "PPO requires the number of processes ({}) to be greater than or equal to the number of PPO mini batches ({}).".format(
                 num_processes, num_mini_batch))
+        if num_processes % num_mini_batch != 0:
+            # the reference's per-env loop indexes perm[start + offset] and raises IndexError here (storage.py:198-203)
+            raise IndexError("num_processes ({}) must be divisible by num_mini_batch ({})".format(num_processes, num_mini_batch))
         npb = num_processes // num_mini_batch
         perm = torch.randperm(num_processes)
         T = self.num_steps

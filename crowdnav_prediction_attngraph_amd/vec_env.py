@@ -139,9 +139,7 @@ def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_e
         raise NotImplementedError("rendering (ax=...) is out of scope of the accelerated path")
     if num_frame_stack is not None:
         raise NotImplementedError("frame stacking applies to image observations only")
-    if test_case is not None and test_case >= 0:
-        # envs.py:62-63 pins EVERY reset (auto-resets included) to one test case; the device simulator keeps running counters.
-        # Replaying chosen cases is what evaluation.evaluate_batched / HipEnvBatch.set_case_counters are for.
-        raise NotImplementedError("test_case >= 0 (replay one fixed test case at every reset) is not implemented; "
-                                  "use HipEnvBatch.set_case_counters / evaluation.evaluate_batched")
+    # test_case: rl/networks/envs.py:60-63 only forwards it to the env inside `if ax:` (rendering), so without an axis the
+    # reference ignores the argument -- same here.  Replaying chosen cases: HipEnvBatch.set_case_counters /
+    # evaluation.evaluate_batched, or the single-env objects of gym_env (env.test_case = k).
     return BatchedCrowdSim(env_name, seed, num_processes, device, config=config, phase=phase, pretext_wrapper=pretext_wrapper, predictor=predictor)

@@ -1,5 +1,7 @@
-"""Registers the three accelerated gym ids (crowd_sim/__init__.py:8-26 in the reference).  gym itself is not needed:
-the ids are resolved by crowdnav_prediction_attngraph_amd.vec_env.make_vec_envs."""
-from crowdnav_prediction_attngraph_amd._abi import ENV_KINDS as registry  # noqa: F401
+"""`import crowd_sim` of the reference (crowd_sim/__init__.py:8-26 registers the gym ids): here the three accelerated ids map
+to single-env objects that are E = 1 views over the device simulator (crowdnav_prediction_attngraph_amd.gym_env).  gym itself
+is not needed; `crowd_sim.make(id)` / `crowd_sim.registry` stand in for gym.make / gym's registry."""
+from crowdnav_prediction_attngraph_amd.gym_env import (CrowdSimPred, CrowdSimPredRealGST, CrowdSimVarNum, make,  # noqa: F401
+                                                       registry)
 
-__all__ = ["registry"]
+__all__ = ["registry", "make", "CrowdSimVarNum", "CrowdSimPred", "CrowdSimPredRealGST"]

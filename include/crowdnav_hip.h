@@ -19,16 +19,21 @@
  *   cn_gae                     <- rl/networks/storage.py:123-132 RolloutStorage.compute_returns (use_gae branch)
  *   cn_adv_stats / cn_adv_normalize <- rl/ppo/ppo.py:37-39 advantage normalisation (split so that N GPUs can
  *                                 all-reduce the three partial sums in between)
+ *   cn_ppo_loss_fwd / cn_ppo_loss_bwd <- rl/ppo/ppo.py:66-84 clipped surrogate + clipped value loss (and their gradients)
+ *   cn_adam_clip_step          <- rl/ppo/ppo.py:86-93 nn.utils.clip_grad_norm_ + torch.optim.Adam.step (ppo.py:32) over one flat bucket
  *   cn_linear_* / cn_hh_attention_* / cn_hr_attention_* / cn_gru_* / cn_embed0_*
  *                              <- the operators of Policy.evaluate_actions (rl/networks/model.py:82-90) as autograd runs
  *                                 them forward and backward inside PPO.update (rl/ppo/ppo.py:60-95)
  *   cn_env_get_danger_min_dist / cn_env_set_case_counters
  *                              <- test phase: Danger(min_dist) (crowd_sim_var_num.py:499-533) and the per-case seeding that
  *                                 rl/evaluation.py's protocol relies on (crowd_sim_var_num.py:316-318,337)
+ *   cn_env_snapshot_bytes / cn_env_save / cn_env_load
+ *                              <- (new) simulator state for a bit-exact --resume (train.py:105-108 restores the policy only)
  *   cn_gst_*                   <- gst_updated wrapper + VecPretextNormalize (CrowdSimPredRealGST-v0)
  *
  * Conventions: every function returns 0 on success and a negative cn_status otherwise (no C++ exception crosses the
- * ABI); cn_last_error() returns a thread-local message.  All tensor arguments are raw DEVICE pointers owned by the
+ * ABI); cn_last_error() returns a thread-local message (the buffer is `thread_local`: concurrent callers on different
+ * threads never see each other's text).  All tensor arguments are raw DEVICE pointers owned by the
  * caller (PyTorch allocates them); the library owns only the opaque handles (persistent per-env simulator state incl.
  * the numpy-compatible MT19937 streams, and the policy workspace / folded weights).  `stream` is a hipStream_t passed
  * as void*; all work is enqueued on it and nothing synchronises with the host.  A handle is re-entrant across handles,
@@ -76,6 +81,10 @@ typedef struct {
                                    * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored */
     int32_t robot_visible;        /* robot.visible: every human's ORCA sees the robot as one more neighbour (crowd_sim.py:695-699);
                                    * CrowdSimVarNum-v0, train phase, human_num <= 63 */
+    int32_t auto_reset;           /* 1 (default): vec-env semantics, a finished env is reset inside cn_env_step and `obs` holds the
+                                   * reset observation (shmem_vec_env.py:139-142); 0: single gym env semantics
+                                   * (crowd_sim_var_num.py:366-460 alone): the terminal observation is returned, cn_env_reset restarts */
+    int32_t reserved0;            /* keep 0 */
     int32_t max_placement_attempts; /* bound of the reference's UNBOUNDED rejection sampling of human positions / goals
                                    * (crowd_sim_var_num.py:116-146, crowd_sim.py:415-450): after this many attempts the last
                                    * candidate is accepted; 0 = 65536.  Dense randomised crowds have seeds where the reference
@@ -135,6 +144,14 @@ int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream);
  * rand_seed = offset[phase] + case_counter + thisSeed): the NEXT reset of env e generates the scenario of that case.
  * counters [E] uint64 (device).  Lets a batch replay chosen test cases (one per env) instead of consecutive ones. */
 int cn_env_set_case_counters(cn_env_batch *env, const uint64_t *counters, void *stream);
+
+/* Checkpointing of the simulator (the reference saves only the policy, train.py:213-219; resuming a run bit-exactly also needs
+ * the env state: agent records, beliefs, case counters, private ORCA simulators, the numpy MT19937 streams).  A snapshot is an
+ * opaque DEVICE buffer of cn_env_snapshot_bytes() bytes; cn_env_load only accepts a snapshot taken from a batch with the same
+ * configuration, shape, seed and shard (first_env_index).  Both synchronise `stream` (they are not on the hot path). */
+int64_t cn_env_snapshot_bytes(const cn_env_batch *env);
+int cn_env_save(cn_env_batch *env, void *dst, void *stream);
+int cn_env_load(cn_env_batch *env, const void *src, void *stream);
 
 /* Stand-alone batched ORCA solve (the rvo2 replacement): B independent agents, each with n_other neighbours.
  * self [B,8] = px,py,vx,vy,radius,max_speed,pref_vx,pref_vy ; others [B,n_other,5] = px,py,vx,vy,radius (float32);
@@ -299,6 +316,34 @@ int cn_gae(int T, int N, const float *rewards, const float *values, const float 
 int cn_adv_stats(int64_t n, const float *returns, const float *values, double *stats, void *stream);
 /* adv = ((returns - values) - mean) / (std_unbiased + 1e-5) with mean/std derived from stats (possibly all-reduced) */
 int cn_adv_normalize(int64_t n, const float *returns, const float *values, const double *stats, float *adv, void *stream);
+
+/* ---- PPO losses (rl/ppo/ppo.py:66-84) ----
+ * values, logp (new policy), old_logp, adv (normalised advantages), value_preds, returns: [n] float32 (the [T*N,1] minibatch
+ * tensors of recurrent_generator).  fwd: losses[0] = value_loss = 0.5 * mean(max((v - R)^2, (vp + clamp(v - vp, +-clip) - R)^2))
+ * (or 0.5 * mean((R - v)^2) when use_clipped_value_loss == 0), losses[1] = action_loss = -mean(min(ratio * A,
+ * clamp(ratio, 1 - clip, 1 + clip) * A)), ratio = exp(logp - old_logp).  workspace: cn_ppo_loss_workspace_doubles() float64.
+ * bwd: d_values[n], d_logp[n] = gradients of g_losses[0] * value_loss + g_losses[1] * action_loss (g_losses: 2 floats on the
+ * DEVICE, the upstream gradients autograd hands in -- value_loss_coef and 1 in ppo.py:86); torch's tie rules for min / max /
+ * clamp.  The entropy term of ppo.py:86 depends on dist.logstd only and stays in the host mirror. */
+int cn_ppo_loss_workspace_doubles(void);
+int cn_ppo_loss_fwd(int64_t n, const float *values, const float *logp, const float *old_logp, const float *adv,
+                    const float *value_preds, const float *returns, float clip_param, int use_clipped_value_loss,
+                    double *workspace, float *losses, void *stream);
+int cn_ppo_loss_bwd(int64_t n, const float *values, const float *logp, const float *old_logp, const float *adv,
+                    const float *value_preds, const float *returns, float clip_param, int use_clipped_value_loss,
+                    const float *g_losses, float *d_values, float *d_logp, void *stream);
+
+/* ---- gradient-norm clip + Adam over one flat bucket (rl/ppo/ppo.py:88-90, optimiser of ppo.py:32) ----
+ * param, grad, exp_avg, exp_avg_sq: [n] float32, the concatenation of all parameters / their gradients / Adam moments in
+ * Module.parameters() order (the host mirror makes every p.data / p.grad / optimizer.state[p] a view into these).
+ * grad <- grad * grad_scale (1 / world_size after a sum all-reduce, else 1); total_norm = ||grad||_2;
+ * grad <- grad * min(1, max_grad_norm / (total_norm + 1e-6)) (skipped when max_grad_norm <= 0); then torch.optim.Adam's
+ * update for step number `step` (1-based), no weight decay / amsgrad.  workspace: cn_adam_workspace_doubles() float64;
+ * grad_norm_out (optional, 1 float, device) receives total_norm.  Two launches, no host synchronisation. */
+int cn_adam_workspace_doubles(void);
+int cn_adam_clip_step(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double grad_scale,
+                      double max_grad_norm, double lr, double beta1, double beta2, double eps, int64_t step, double *workspace,
+                      float *grad_norm_out, void *stream);
 
 #ifdef __cplusplus
 }

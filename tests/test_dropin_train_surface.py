@@ -1,0 +1,136 @@
+"""Build-container only (skipped where /root/reference is absent, e.g. on the GPU box): the reference's own train.py / test.py
+against dropin/.
+
+1. Static: every `import` / `from ... import name` of the two scripts resolves with dropin/ first on sys.path, and every
+   attribute the scripts read off the objects the shims hand out exists on the mirrors.
+2. Dynamic: the reference's train.py is EXECUTED, unmodified, for one PPO update with `--no-cuda`; the only substitution is the
+   simulator behind `make_vec_envs` (the C oracle on CPU instead of the device batch, tests/oracle_vec_env.py) -- Policy,
+   RolloutStorage, PPO, arguments, Config and the crowd_sim registry are the shims' real objects.  It must write the
+   checkpoint train.py:213-219 writes, loadable by the mirror.
+The reference file itself never ships: nothing here copies it, the test only runs it where it lies."""
+import ast
+import importlib
+import os
+import runpy
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "dropin")
+REF = "/root/reference"
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train.py")), reason="needs the reference checkout (build container only)")
+
+THIRD_PARTY = {"os", "shutil", "time", "collections", "numpy", "torch", "pandas", "matplotlib", "logging", "argparse", "sys", "importlib"}
+
+
+@pytest.fixture()
+def dropin_path():
+    saved, mods = list(sys.path), set(sys.modules)
+    sys.path.insert(0, DROPIN)
+    yield
+    sys.path[:] = saved
+    for m in set(sys.modules) - mods:
+        if m.split(".")[0] in ("rl", "crowd_sim", "crowd_nav", "arguments"):
+            del sys.modules[m]
+
+
+@pytest.mark.parametrize("script", ["train.py", "test.py"])
+def test_every_import_of_the_reference_scripts_resolves_against_dropin(script, dropin_path):
+    tree = ast.parse(open(os.path.join(REF, script)).read())
+    checked = 0
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] not in THIRD_PARTY:
+            mod = importlib.import_module(node.module)
+            assert os.path.abspath(mod.__file__).startswith(DROPIN), "%s resolved outside dropin/: %s" % (node.module, mod.__file__)
+            for alias in node.names:
+                if alias.name == "*":
+                    assert getattr(mod, "__all__", None), "%s: `import *` needs __all__" % node.module
+                    for n in mod.__all__:
+                        assert hasattr(mod, n)
+                else:
+                    assert hasattr(mod, alias.name) or importlib.import_module(node.module + "." + alias.name), (node.module, alias.name)
+                checked += 1
+    assert checked >= 6
+
+
+def _attr_chains(tree, roots):
+    """dotted attribute reads `root.a.b` for the given root variable names"""
+    out = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Attribute):
+            parts, cur = [node.attr], node.value
+            while isinstance(cur, ast.Attribute):
+                parts.append(cur.attr)
+                cur = cur.value
+            if isinstance(cur, ast.Name) and cur.id in roots:
+                out.add((cur.id,) + tuple(reversed(parts)))
+    return out
+
+
+def test_attribute_surface_of_train_py_exists_on_the_mirrors(dropin_path):
+    """envs.* / actor_critic.* / rollouts.* / agent.* / algo_args.* / config.* as train.py reads them (:85-135,148,162-210)."""
+    from arguments import get_args
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from crowdnav_prediction_attngraph_amd.ppo import PPO
+    from crowdnav_prediction_attngraph_amd.storage import RolloutStorage
+    from tests.oracle_vec_env import OracleVecEnv
+    from crowdnav_prediction_attngraph_amd.vec_env import BatchedCrowdSim
+    old = sys.argv
+    sys.argv = ["train.py", "--no-cuda", "--env-name", "CrowdSimVarNum-v0"]
+    try:
+        args = get_args()
+        from crowd_nav.configs.config import Config
+        config = Config()
+    finally:
+        sys.argv = old
+    ob_space, act_space = make_spaces(20, 2)
+    pol = Policy(ob_space.spaces, act_space, base_kwargs=args, base=config.robot.policy)
+    ro = RolloutStorage(args.num_steps, args.num_processes, ob_space.spaces, act_space, args.human_node_rnn_size, args.human_human_edge_rnn_size)
+    agent = PPO(pol, args.clip_param, args.ppo_epoch, args.num_mini_batch, args.value_loss_coef, args.entropy_coef, lr=args.lr, eps=args.eps,
+                max_grad_norm=args.max_grad_norm)
+    objs = {"actor_critic": pol, "rollouts": ro, "agent": agent, "algo_args": args, "config": config, "env_config": config}
+    tree = ast.parse(open(os.path.join(REF, "train.py")).read())
+    chains = _attr_chains(tree, set(objs) | {"envs"})
+    assert len(chains) > 40
+    for chain in sorted(chains):
+        if chain[0] == "envs":
+            for cls in (BatchedCrowdSim, OracleVecEnv):      # the product's vec-env and the test stand-in expose the same surface
+                assert hasattr(cls, chain[1]) or chain[1] in ("observation_space", "action_space"), chain
+            continue
+        if chain[:2] == ("agent", "optimizer") and chain[2:] == ("lr",):
+            continue                                           # only read when algo == 'acktr' (train.py:150)
+        cur = objs[chain[0]]
+        for a in chain[1:]:
+            assert hasattr(cur, a), "train.py reads %s but %r has no attribute %r" % (".".join(chain), type(cur).__name__, a)
+            cur = getattr(cur, a)
+            if callable(cur) and not isinstance(cur, torch.nn.Module):
+                break
+
+
+def test_reference_train_py_runs_unchanged_for_one_update(dropin_path, tmp_path, monkeypatch):
+    import rl.networks.envs as shim_envs
+    from tests import oracle_vec_env
+    monkeypatch.setattr(shim_envs, "make_vec_envs", oracle_vec_env.make_vec_envs)   # the ONLY substitution: simulator -> CPU oracle
+    out = tmp_path / "run"
+    monkeypatch.chdir(DROPIN)              # train.py copies crowd_nav/configs/config.py and arguments.py relative to the cwd
+    monkeypatch.setattr(sys, "argv", ["train.py", "--no-cuda", "--env-name", "CrowdSimVarNum-v0", "--num-processes", "2", "--num-mini-batch", "1",
+                                      "--num-steps", "5", "--num-env-steps", "10", "--output_dir", str(out), "--ppo-epoch", "2", "--seed", "7"])
+    nthreads = torch.get_num_threads()
+    try:
+        runpy.run_path(os.path.join(REF, "train.py"), run_name="__main__")
+    finally:
+        torch.set_num_threads(nthreads)    # train.py:61 sets 1
+    ckpt = out / "checkpoints" / "00000.pt"
+    assert ckpt.is_file() and (out / "configs" / "config.py").is_file() and (out / "arguments.py").is_file()
+    sd = torch.load(str(ckpt))
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    ob_space, act_space = make_spaces(20, 2)
+    torch.manual_seed(7)
+    fresh = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=2, num_mini_batch=1, seq_length=30))
+    assert list(sd) == list(fresh.state_dict())
+    moved = sum(int(not torch.equal(sd[k], v)) for k, v in fresh.state_dict().items())
+    assert moved > 30, "one PPO update must have changed (almost) every parameter tensor; changed: %d" % moved
+    fresh.load_state_dict(sd)

@@ -1,0 +1,184 @@
+"""-m gpu: the drop-in boundary beyond the vec-env -- single-env gym objects behind `import crowd_sim`, the simulator
+checkpoint (cn_env_save / cn_env_load) and a reference-shaped train.py loop through the dropin/ module names."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "dropin")
+KEYS = ["robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks"]
+
+
+def _dropin():
+    if DROPIN not in sys.path:
+        sys.path.insert(0, DROPIN)
+
+
+def _walk(rn, t):
+    g = rn[3:5] - rn[0:2]
+    n = max(float(np.linalg.norm(g)), 1e-9)
+    return (1.3 * g / n + 0.2 * np.array([np.sin(0.3 * t), np.cos(0.2 * t)])).astype(np.float32)
+
+
+@pytest.mark.parametrize("env_id,kind,rand", [("CrowdSimVarNum-v0", 0, False), ("CrowdSimPred-v0", 1, True)])
+def test_single_env_gym_object_matches_oracle_without_autoreset(env_id, kind, rand):
+    """`import crowd_sim` -> make(id) -> configure / thisSeed / nenv / phase / reset / step like make_env (envs.py:36-94): a single
+    gym env does not reset itself, returns the terminal observation, and `test_case` pins the scenario of the next reset."""
+    _dropin()
+    import crowd_sim
+    from crowd_sim.envs import CrowdSimVarNum  # noqa: F401  (the registry's entry points resolve)
+    from crowdnav_prediction_attngraph_amd import config as C, info as I
+    from oracle import oracle as O
+    H = 7
+    cfg = C.Config(**{"sim.human_num": H, "env.randomize_attributes": rand, "humans.random_goal_changing": rand,
+                      "sim.predict_method": "const_vel" if kind == 1 else "none"})
+    env = crowd_sim.make(env_id)
+    env.configure(cfg)
+    env.thisSeed, env.nenv, env.phase = 425 + 2, 4, "train"
+    env.seed(425 + 2)
+    assert list(env.observation_space.spaces) == sorted(env.observation_space.spaces) and env.action_space.shape == (2,)
+    ocfg = O.default_config(human_num=H, env_kind=kind, nenv=4, randomize_attributes=int(rand), random_goal_changing=int(rand))
+    oe = O.OracleEnv(ocfg, 425 + 2)
+    keys = [k for k in KEYS if k in env.observation_space.spaces]
+    episodes = 0
+    for rep in range(3):
+        if rep == 2:                       # crowd_sim_var_num.py:316-318: case_counter[phase] = test_case
+            env.test_case = 11
+            oe.set_case_counter(11)
+        ob, oob = env.reset(), oe.reset()
+        for k in keys:
+            np.testing.assert_array_equal(ob[k].reshape(oob[k].shape), oob[k], err_msg="reset %s" % k)
+        for t in range(220):
+            a = _walk(ob["robot_node"].reshape(7).astype(np.float64), t)
+            ob, r, d, inf = env.step(a)
+            oob, orr, od, oinf = oe.step(a, autoreset=False)
+            assert isinstance(r, float) and isinstance(d, bool) and np.float32(r) == np.float32(orr) and d == od
+            assert type(inf["info"]) is type(I.from_code(oinf["info"]))
+            for k in keys:     # at d == True this is the TERMINAL observation, not a reset one
+                np.testing.assert_array_equal(ob[k].reshape(oob[k].shape), oob[k], err_msg="%s t=%d rep=%d" % (k, t, rep))
+            if d:
+                episodes += 1
+                break
+    assert episodes == 3
+    assert env.talk2Env(np.zeros((H, 10))) is True
+    env.close()
+    with pytest.raises(NotImplementedError):
+        crowd_sim.make("CrowdSimVarNumCollect-v0")
+
+
+def test_env_snapshot_resume_is_bit_exact():
+    """cn_env_save -> fresh batch -> cn_env_load continues exactly like the uninterrupted batch (observations, rewards, dones,
+    episode statistics; randomised humans, goal changes, respawns and auto-resets all draw from the restored MT19937 streams)."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch
+    E, seed = 64, 425
+    kw = dict(human_num=12, randomize_attributes=1, random_goal_changing=1, env_kind=1, nenv=E)
+    env = HipEnvBatch(A.default_env_config(**kw), E, seed, first_env_index=128)
+    obs = env.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = 0.8 * torch.randn(150, E, 2, device="cuda", generator=g)
+    for t in range(60):
+        obs, *_ = env.step(acts[t])
+    snap = env.state_dict()
+    assert snap.dtype == torch.uint8 and not snap.is_cuda
+
+    def run(e, t0):
+        out = []
+        for t in range(t0, 150):
+            o, r, d, i, er, el = e.step(acts[t])
+            out.append([o[k].clone() for k in KEYS] + [r.clone(), d.clone(), i.clone(), (er * d).clone(), (el * d).clone()])
+        return out
+    want = run(env, 60)
+    assert sum(int(x[-4].sum()) for x in want) > E // 2       # episodes ended (and restarted) after the snapshot
+    env2 = HipEnvBatch(A.default_env_config(**kw), E, seed, first_env_index=128)
+    env2.load_state_dict(snap)
+    got = run(env2, 60)
+    for t, (a, b) in enumerate(zip(want, got)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), "step %d after the snapshot" % (60 + t)
+    # a snapshot only fits the batch it came from
+    other = HipEnvBatch(A.default_env_config(**dict(kw, human_num=13)), E, seed, first_env_index=128)
+    with pytest.raises(A.CnError):
+        other.load_state_dict(snap)
+    shard = HipEnvBatch(A.default_env_config(**kw), E, seed, first_env_index=0)
+    with pytest.raises(A.CnError):
+        shard.load_state_dict(snap)
+    for e in (env, env2, other, shard):
+        e.close()
+
+
+def test_reference_shaped_train_loop_through_dropin_names(tmp_path):
+    """The statement sequence of the reference's train.py (imports :11-20, construction :85-126, rollout :152-189, update :191-210,
+    checkpoint :213-219) with the modules resolved from dropin/ -- the reference script itself cannot travel to this box; the
+    build-container test tests/test_dropin_train_surface.py runs the real file against the same names."""
+    _dropin()
+    old_argv = sys.argv
+    sys.argv = ["train.py", "--env-name", "CrowdSimVarNum-v0", "--num-processes", "8", "--num-mini-batch", "2", "--num-steps", "6",
+                "--output_dir", str(tmp_path)]
+    try:
+        from collections import deque
+
+        import torch.nn as nn
+        from arguments import get_args
+        from crowd_nav.configs.config import Config
+        from crowd_sim import registry  # noqa: F401   (`from crowd_sim import *`)
+        from rl import ppo
+        from rl.networks import network_utils
+        from rl.networks.envs import make_vec_envs
+        from rl.networks.model import Policy
+        from rl.networks.storage import RolloutStorage
+        algo_args = get_args()
+        env_config = config = Config()
+        torch.manual_seed(algo_args.seed)
+        device = torch.device("cuda" if algo_args.cuda else "cpu")
+        envs = make_vec_envs(algo_args.env_name, algo_args.seed, algo_args.num_processes, algo_args.gamma, None, device, False,
+                             config=env_config, ax=None, pretext_wrapper=config.env.use_wrapper)
+        actor_critic = Policy(envs.observation_space.spaces, envs.action_space, base_kwargs=algo_args, base=config.robot.policy)
+        rollouts = RolloutStorage(algo_args.num_steps, algo_args.num_processes, envs.observation_space.spaces, envs.action_space,
+                                  algo_args.human_node_rnn_size, algo_args.human_human_edge_rnn_size)
+        nn.DataParallel(actor_critic).to(device)
+        agent = ppo.PPO(actor_critic, algo_args.clip_param, algo_args.ppo_epoch, algo_args.num_mini_batch, algo_args.value_loss_coef,
+                        algo_args.entropy_coef, lr=algo_args.lr, eps=algo_args.eps, max_grad_norm=algo_args.max_grad_norm)
+        obs = envs.reset()
+        for key in obs:
+            rollouts.obs[key][0].copy_(obs[key])
+        rollouts.to(device)
+        episode_rewards = deque(maxlen=100)
+        before = {k: v.clone() for k, v in actor_critic.state_dict().items()}
+        for j in range(2):
+            network_utils.update_linear_schedule(agent.optimizer, j, 2, algo_args.lr)
+            for step in range(algo_args.num_steps):
+                with torch.no_grad():
+                    rollouts_obs = {key: rollouts.obs[key][step] for key in rollouts.obs}
+                    rollouts_hidden_s = {key: rollouts.recurrent_hidden_states[key][step] for key in rollouts.recurrent_hidden_states}
+                    value, action, action_log_prob, recurrent_hidden_states = actor_critic.act(rollouts_obs, rollouts_hidden_s, rollouts.masks[step])
+                obs, reward, done, infos = envs.step(action)
+                for info in infos:
+                    if "episode" in info.keys():
+                        episode_rewards.append(info["episode"]["r"])
+                masks = torch.FloatTensor([[0.0] if done_ else [1.0] for done_ in done])
+                bad_masks = torch.FloatTensor([[0.0] if "bad_transition" in info.keys() else [1.0] for info in infos])
+                rollouts.insert(obs, recurrent_hidden_states, action, action_log_prob, value, reward, masks, bad_masks)
+            with torch.no_grad():
+                rollouts_obs = {key: rollouts.obs[key][-1] for key in rollouts.obs}
+                rollouts_hidden_s = {key: rollouts.recurrent_hidden_states[key][-1] for key in rollouts.recurrent_hidden_states}
+                next_value = actor_critic.get_value(rollouts_obs, rollouts_hidden_s, rollouts.masks[-1]).detach()
+            rollouts.compute_returns(next_value, algo_args.use_gae, algo_args.gamma, algo_args.gae_lambda, algo_args.use_proper_time_limits)
+            value_loss, action_loss, dist_entropy = agent.update(rollouts)
+            rollouts.after_update()
+            assert all(np.isfinite(x) for x in (value_loss, action_loss, dist_entropy))
+        save_path = os.path.join(algo_args.output_dir, "checkpoints")
+        os.makedirs(save_path, exist_ok=True)
+        torch.save(actor_critic.state_dict(), os.path.join(save_path, "%.5i" % 1 + ".pt"))
+        sd = torch.load(os.path.join(save_path, "00001.pt"))
+        assert list(sd) == list(before) and any(not torch.equal(sd[k].cpu(), before[k].cpu()) for k in sd)     # weights moved
+        assert agent.optimizer.param_groups[0]["lr"] == pytest.approx(algo_args.lr * 0.5)                      # j = 1 of 2
+        actor_critic.load_state_dict(sd)          # train.py:105-108 --resume path
+        envs.close()
+    finally:
+        sys.argv = old_argv
