@@ -51,7 +51,18 @@ def synth_traj(E, H, seed):
     return traj, mask.astype(np.float32)
 
 
-def build_predictor(E):
+REAL_CKPT = ("/root/reference/gst_updated/results/100-gumbel_social_transformer-faster_lstm-lr_0.001-init_temp_0.5-edge_head_0-ebd_64-snl_1-snh_8-"
+             "seed_1000_rand/sj/checkpoint/epoch_100.pt")
+
+
+def real_state_dict():
+    """The shipped predictor weights (config.pred.model_dir of the reference, 67 269 parameters) as numpy arrays."""
+    from crowdnav_prediction_attngraph_amd.gst import GSTPredictor
+    m = GSTPredictor.from_checkpoint(REAL_CKPT, "cpu")      # weights_only load with the numpy allow-list (no pickle code runs)
+    return {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+
+
+def build_predictor(E, real=False):
     import torch
     from gst_updated.scripts.wrapper.crowd_nav_interface_parallel import CrowdNavPredInterfaceMultiEnv
     from gst_updated.src.gumbel_social_transformer.st_model import st_model
@@ -59,7 +70,7 @@ def build_predictor(E):
     torch.manual_seed(0)
     model = st_model(args, device="cpu")
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = gst_formula_state_dict(shapes)
+    sd = real_state_dict() if real else gst_formula_state_dict(shapes)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.eval()
     pred = CrowdNavPredInterfaceMultiEnv.__new__(CrowdNavPredInterfaceMultiEnv)
@@ -70,7 +81,29 @@ def build_predictor(E):
     return pred, shapes
 
 
+def main_real():
+    """Second fixture: the SHIPPED weights (stored in the fixture, 270 KB) and the reference predictor's outputs on three input
+    sets -- pins the kernels / oracle at the weight magnitudes of the real model, not only at formula weights."""
+    R.install()
+    import torch
+    E, H = 4, 20
+    pred, shapes = build_predictor(E, real=True)
+    out = {"w/" + k: v for k, v in real_state_dict().items()}
+    for case, seed in (("a", 11), ("b", 12), ("c", 13)):
+        traj, mask = synth_traj(E, H, seed)
+        with torch.no_grad():
+            o_traj, o_mask = pred.forward(input_traj=torch.from_numpy(traj), input_binary_mask=torch.from_numpy(mask))
+        out["in_traj_" + case], out["in_mask_" + case] = traj, mask
+        out["out_traj_" + case], out["out_mask_" + case] = o_traj.numpy(), o_mask.numpy()
+    out["meta"] = np.array(json.dumps(dict(E=E, H=H, args=GST_ARGS, shapes={k: list(v) for k, v in shapes.items()}, source=REAL_CKPT)))
+    path = os.path.join(HERE, "gst_real_e4_h20.npz")
+    np.savez_compressed(path, **out)
+    print("gst real-weights golden -> %s (%.0f KB); out_traj_a[0,0,0]=%s" % (os.path.basename(path), os.path.getsize(path) / 1024, out["out_traj_a"][0, 0, 0]))
+
+
 def main():
+    if "--real" in sys.argv:
+        return main_real()
     R.install()
     import torch
     E, H = 4, 20

@@ -59,7 +59,7 @@ def test_policy_act_matches_reference_golden(path, mode):
     eps = ((z["fixed_action"] - mean) / std).astype(np.float32)
     out2 = pol.act(obs, hxs, masks, eps=torch.from_numpy(eps).cuda())
     np.testing.assert_allclose(out2["action"].cpu().numpy(), z["fixed_action"], atol=TOL)
-    np.testing.assert_allclose(out2["logp"].cpu().numpy(), z["logp_fixed"], atol=2e-4)
+    np.testing.assert_allclose(out2["logp"].cpu().numpy(), z["logp_fixed"], atol=TOL)
     v = pol.get_value(obs, hxs, masks)
     np.testing.assert_allclose(v.cpu().numpy(), z["value"], atol=TOL)
 
@@ -88,7 +88,7 @@ def test_policy_act_matches_numpy_oracle(E, H, D, mode):
     logp = P.log_prob(mean, np.log(std), action)
     np.testing.assert_allclose(out["value"].cpu().numpy(), value, atol=TOL)
     np.testing.assert_allclose(out["action"].cpu().numpy(), action, atol=TOL)
-    np.testing.assert_allclose(out["logp"].cpu().numpy(), logp, atol=2e-4)
+    np.testing.assert_allclose(out["logp"].cpu().numpy(), logp, atol=TOL)
     np.testing.assert_allclose(out["hxs"].cpu().numpy().reshape(E, 128), h_new, atol=TOL)
 
 

@@ -43,7 +43,7 @@ def test_ppo_loss_kernels_match_torch_autograd(n, clipped):
     vg, lg = values.cuda().requires_grad_(), logp.cuda().requires_grad_()
     losses = hip.PPOLoss.apply(vg, lg, old.cuda(), adv.cuda(), vp.cuda(), ret.cuda(), 0.2, clipped)
     (0.5 * losses[0] + losses[1]).backward()
-    np.testing.assert_allclose(losses.cpu().numpy(), [float(vl), float(al)], rtol=2e-6)
+    np.testing.assert_allclose(losses.detach().cpu().numpy(), [float(vl), float(al)], rtol=2e-6)
     np.testing.assert_allclose(vg.grad.cpu().numpy(), vd.grad.float().numpy(), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(lg.grad.cpu().numpy(), ld.grad.float().numpy(), rtol=1e-5, atol=1e-9)
 
@@ -60,12 +60,14 @@ def test_adam_clip_step_matches_torch(n, max_norm):
     norm = torch.zeros(1, device="cuda")
     for step in range(1, 4):
         grad = torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g)))
-        ref.grad = grad.clone()
-        total = torch.nn.utils.clip_grad_norm_([ref], max_norm)
+        # clip_grad_norm_ with the norm accumulated in fp64 (torch's fp32 norm over 2.5 M elements is only good to ~4e-5; the
+        # kernel accumulates block partials in fp64)
+        total = grad.double().norm()
+        ref.grad = (grad.double() * min(1.0, max_norm / (float(total) + 1e-6))).float()
         opt.step()
         gd = grad.clone().cuda()
         hip.adam_clip_step(p, gd, m, v, step, 4e-5, (0.9, 0.999), 1e-5, max_norm, norm_out=norm)
-        assert float(norm) == pytest.approx(float(total), rel=1e-5)
+        assert float(norm) == pytest.approx(float(total), rel=2e-6)
         np.testing.assert_allclose(gd.cpu().numpy(), ref.grad.numpy(), rtol=2e-6, atol=1e-12)   # grads scaled in place like clip_grad_norm_
         np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-7)
     st = opt.state[ref]

@@ -26,7 +26,7 @@ def test_interface_forward_matches_reference():
         np.testing.assert_array_equal(mask, z["out_mask_" + case])
         valid = z["out_mask_" + case][..., 0] > 0
         assert 0 < valid.sum() < valid.size
-        np.testing.assert_allclose(out[valid], z["out_traj_" + case][valid], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(out[valid], z["out_traj_" + case][valid], rtol=1e-4, atol=1e-4)
         # unpredicted humans carry the -999 marker in the position slots
         assert np.all(z["out_traj_" + case][~valid][..., :2] == -999.0) and np.all(out[~valid][..., :2] == -999.0)
 
@@ -37,5 +37,18 @@ def test_wrapper_process_obs_rew_matches_reference():
     w = G.PretextWrapper(sd, E, H)
     for t in range(T):
         se, rews = w.process(z["w_in_robot_node_%d" % t], z["w_in_spatial_edges_%d" % t], z["w_in_visible_masks_%d" % t], z["w_in_rews_%d" % t])
-        np.testing.assert_allclose(se, z["w_out_spatial_edges_%d" % t], rtol=2e-4, atol=2e-4, err_msg="spatial_edges @%d" % t)
+        np.testing.assert_allclose(se, z["w_out_spatial_edges_%d" % t], rtol=1e-4, atol=1e-4, err_msg="spatial_edges @%d" % t)
         np.testing.assert_allclose(rews, z["w_out_rews_%d" % t], atol=1e-5, err_msg="rews @%d" % t)
+
+
+def test_interface_forward_matches_reference_with_the_shipped_weights():
+    """tests/golden/gst_real_e4_h20.npz carries the reference's shipped predictor weights (epoch_100.pt, 67 269 parameters) and
+    its outputs: the oracle at the REAL weight magnitudes."""
+    z = np.load(os.path.join(GOLDEN, "gst_real_e4_h20.npz"))
+    sd = {k[2:]: z[k] for k in z.files if k.startswith("w/")}
+    assert sum(v.size for v in sd.values()) == 67269
+    for case in ("a", "b", "c"):
+        out, mask = G.interface_forward(sd, z["in_traj_" + case], z["in_mask_" + case])
+        np.testing.assert_array_equal(mask, z["out_mask_" + case])
+        valid = z["out_mask_" + case][..., 0] > 0
+        np.testing.assert_allclose(out[valid], z["out_traj_" + case][valid], rtol=1e-4, atol=1e-4)
