@@ -126,8 +126,9 @@ def main():
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: put every rank on GPU 0 (use with --dist-backend gloo)")
-    ap.add_argument("--gemm", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="arithmetic of the three large HH GEMMs: split-precision bf16 MFMA (3 passes, within 2e-5 of fp32; default) or exact fp32 MFMA")
+    ap.add_argument("--gemm", choices=["fused", "bf16x3", "fp32"], default="fused",
+                    help="human-human block: 'fused' = one persistent kernel, bf16x3 split-precision MFMA (default); 'bf16x3' = the same arithmetic "
+                         "as separate launches (round-1 path); 'fp32' = exact fp32 MFMA, separate launches")
     args = ap.parse_args()
 
     import torch
@@ -248,19 +249,24 @@ def main():
     value = total_env_steps / elapsed
     # dominant kernel: the folded QKV projection GEMM [M,512]x[512,1536] (fp32 MFMA), timed with HIP events on its stream
     M = prof_n[1] / max(prof_n[0], 1)      # mean live (env, human) rows per step (device-side counter): padded humans are not computed
-    qkv_flops = 2.0 * M * 512 * 1536
+    fused = args.gemm == "fused"
+    # fused: the timed kernel is the whole human-human block; its algorithmic work = the three dense layers on the live rows
+    # (embedding_layer.2 128->512, folded q|k|v 512->1536, folded out_proj∘spatial_linear 512->256); the D->128 input layer and the
+    # attention core (<2 % of it) are left out of the count
+    qkv_flops = 2.0 * M * (128 * 512 + 512 * 1536 + 512 * 256) if fused else 2.0 * M * 512 * 1536
     qkv_ms = prof_ms[0] / max(prof_n[0], 1)
     achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12 if qkv_ms > 0 else 0.0
     F = flops_per_env_step(H, D)
-    split = args.gemm == "bf16x3"
+    split = args.gemm in ("bf16x3", "fused")
     # the split runs 3 bf16 MFMA passes per algorithmic product, so its attainable algorithmic rate is the bf16 peak / 3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    kname = ("gemm3_nt_kernel<128,NONE> (v_mfma_f32_32x32x16_bf16, 3 passes hi*hi+hi*lo+lo*hi)" if split
-             else "gemm_nt_kernel<128,NONE> (v_mfma_f32_32x32x2_f32)")
+    kname = ("hh_fused_kernel (v_mfma_f32_16x16x32_bf16, 3 passes hi*hi+hi*lo+lo*hi): embedding -> q|k|v -> attention -> out_proj∘spatial_linear in one launch" if fused else
+             "gemm3_nt_kernel<128,NONE> (v_mfma_f32_32x32x16_bf16, 3 passes hi*hi+hi*lo+lo*hi): folded q|k|v projection" if split
+             else "gemm_nt_kernel<128,NONE> (v_mfma_f32_32x32x2_f32): folded q|k|v projection")
     # HBM traffic of the dominant kernel comes from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if split and E == 4096 and H == 20 and os.path.exists(tpath):
+    if args.gemm == "bf16x3" and E == 4096 and H == 20 and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch_corrected"]
     line = {
         "metric": "env-steps/sec (sim+policy fwd) at %d humans" % H, "value": round(value, 1), "unit": "env-steps/s",
@@ -271,10 +277,12 @@ def main():
                                    "BASELINE configs[1]: " if (args.env_name, H, E, args.randomized) == ("CrowdSimVarNum-v0", 20, 4096, False) else ("randomized humans, " if args.randomized else ""), args.env_name, H, E),
                    "envs_per_gpu": E, "humans": H, "parallelism": "dp%d (envs sharded, no rollout collective)" % world,
                    "policy_init": "orthogonal, torch.manual_seed(425)", "sampled_actions": True},
-        "roofline": {"bound": "mfma", "kernel": "%s: folded q|k|v projection, M=%d live rows of %d, N=1536 K=512" % (kname, M, E * H),
+        "roofline": {"bound": "mfma", "kernel": "%s, M=%d live rows of %d%s" % (kname, M, E * H, "" if fused else ", N=1536 K=512"),
                      "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "note": ("achieved = algorithmic 2*M*N*K / launch time (hipEvents on the kernel's stream); peak = 2500 TFLOP/s dense bf16 "
+                     "note": ("achieved = algorithmic 2*M*(128*512+512*1536+512*256) / launch time (hipEvents on the kernel's stream); peak = 2500 TFLOP/s dense bf16 "
+                              "MFMA / 3 passes of the hi/lo split; executed bf16 MFMA rate = %.1f TFLOP/s" % (3 * achieved)) if fused else
+                             ("achieved = algorithmic 2*M*N*K / launch time (hipEvents on the kernel's stream); peak = 2500 TFLOP/s dense bf16 "
                               "MFMA / 3 passes of the hi/lo split; executed bf16 MFMA rate = %.1f TFLOP/s" % (3 * achieved)) if split else
                              "achieved = algorithmic 2*M*N*K / launch time on exact fp32 MFMA",
                      "launch_ms": round(qkv_ms, 4), "launches": int(prof_n[0]), "mean_detected_humans": round(M / E, 3),

@@ -1,0 +1,21 @@
+// hh_fused.h -- internal interface of the fused human-human block (hh_fused.hip), used by policy.hip.
+#pragma once
+#include "common.h"
+
+// Weight images in MFMA-fragment streaming order (built once per weight snapshot by hh_fused_bake) + the fp32 pieces
+struct HhFusedWeights {
+    const void *emb2_frag; // [wave 4][ks 4][j 8][plane 2][lane 64][8 bf16]            256 KB
+    const void *qkv_frag;  // [head 8][wave 4][ks 16][j 3 (q,k,v)][plane 2][64][8]      3 MB
+    const void *os_frag;   // [head 8][wave 4][ks 2][j 4][plane 2][64][8]               512 KB
+    const float *emb0_w, *emb0_b, *emb2_b, *qkv_b, *os_b;
+};
+
+constexpr size_t HH_EMB2_FRAG_BYTES = (size_t)512 * 128 * 4;
+constexpr size_t HH_QKV_FRAG_BYTES = (size_t)1536 * 512 * 4;
+constexpr size_t HH_OS_FRAG_BYTES = (size_t)256 * 512 * 4;
+
+// emb2_w [512,128], qkv_w [1536,512] (folded q|k|v), os_w [256,512] (folded out_proj∘spatial_linear): fp32 row-major, device
+int hh_fused_bake(const float *emb2_w, const float *qkv_w, const float *os_w, void *emb2_frag, void *qkv_frag, void *os_frag, hipStream_t st);
+
+// out_sp [row_off[E], 256] = relu(spatial_linear(out_proj(attention(...)))) on the compacted live rows; row_off [E+1] on the device
+int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const int *row_off, const HhFusedWeights &w, float *out_sp, hipStream_t st);

@@ -1,0 +1,637 @@
+// hh_fused.hip -- the whole human-human block of the policy forward as ONE persistent kernel on gfx950:
+//   embedding_layer (D -> 128 -> 512, ReLU) -> folded q|k|v projection -> 8-head attention over the humans of each env ->
+//   folded out_proj∘spatial_linear (+ReLU)                       rl/networks/selfAttn_srnn_temp_node.py:63-91, :408
+// on the compacted live rows.  Nothing between the observation and out_sp [rows,256] touches HBM: the activations live in
+// LDS / registers, the weights stream from L2 straight into MFMA operand registers.
+//
+// Work split.  One workgroup (4 wavefronts, one per SIMD, 160 KB of LDS) per CU owns a contiguous chunk of ~rows/256 live rows
+// (whole envs) and walks it in tiles of <= 64 rows = <= 4 row blocks of 16.  Per tile:
+//   e0   = relu(x W0^T + b0)                     VALU, written as bf16 hi/lo MFMA fragments into LDS
+//   X    = relu(e0 W2^T + b2)        [64,512]    MFMA; stays in LDS for the whole tile as hi/lo fragments (128 KB)
+//   for each head h:  q|k|v = X Wh^T + bh        [64,192]   MFMA (16 k-steps, the dominant loop)
+//                     S^T = K Q^T, P = softmax over the keys of the query's env     MFMA + VALU (env block mask)
+//                     O^T = V^T P^T              MFMA, V straight from the accumulators
+//                     out += O Wos[:, h]^T       MFMA, accumulators persist over the heads
+//   out_sp = relu(out + b)                       stored to HBM
+// Arithmetic: every product is bf16x3 split precision (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate),
+// the same arithmetic as gemm3.h; softmax in fp32.
+//
+// Layout tricks that keep the chain on chip:
+//   * wavefront w owns OUTPUT FEATURES (q/k/v feature block w of the head, X k-steps 4w..4w+3, out_sp feature blocks 4w..4w+3), never
+//     rows: a weight fragment is needed by exactly one wavefront, so it goes global -> VGPR with one coalesced 1 KB load (the
+//     fragments are stored in streaming order by hh_fused_bake) and is reused by every row block; only activations use LDS.
+//   * products are issued "transposed" (A operand = weight fragment, B operand = activation fragment): the C layout then has
+//     4 consecutive output features of ONE row in a lane, i.e. half of the next product's activation fragment -- a pair of
+//     feature blocks is one 16-byte fragment entry.  The contraction index of every consumer is permuted accordingly
+//     (perm32: element u of lane group g <-> offset 16*(u>>2) + 4*g + (u&3)); weights are baked with the same permutation.
+//   * V is produced in normal form (rows in the C layout) so that it is the A operand of O^T = V^T P^T without leaving the
+//     registers, and S^T (keys in the C layout rows) is exactly the P fragment of the same product.
+//   * LDS holds fragments in fragment-major order [plane][k-step][row block][lane][16 B]: every ds_read_b128 / ds_write_b64 /
+//     ds_write_b128 is lane-linear, hence bank-conflict free by construction.
+#include "hh_fused.h"
+
+#include <climits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FR = 64;                  // rows per tile (4 row blocks of 16)
+constexpr int LDS_X = 0;                // [plane 2][kx 16][rb 4][lane 64][16 B]  = 128 KB
+constexpr int LDS_S = 131072;           // scratch: two halves of 16 KB, [plane 2][ks 2][rb 4][lane 64][16 B] each
+constexpr int LDS_H0 = LDS_S, LDS_H1 = LDS_S + 16384;
+constexpr int LDS_BYTES = 163840;
+
+// weight fragments are read once per tile by exactly one wavefront: stream them past the vector L1
+__device__ __forceinline__ bf16x8 ldw(const char *p)
+{
+#ifndef HH_NT_LOADS
+    return *reinterpret_cast<const bf16x8 *>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(p));
+#endif
+}
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+struct Split8 { bf16x8 hi, lo; };
+__device__ __forceinline__ void split1(float x, __bf16 &hi, __bf16 &lo)
+{
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+__device__ __forceinline__ Split8 split8(f32x4 a, f32x4 b)
+{
+    Split8 s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __bf16 h, l;
+        split1(a[q], h, l); s.hi[q] = h; s.lo[q] = l;
+        split1(b[q], h, l); s.hi[4 + q] = h; s.lo[4 + q] = l;
+    }
+    return s;
+}
+
+// first index e in [0, n] with a[e] >= target (a ascending, a[n] readable); wave-uniform result, 64-ary search
+__device__ __forceinline__ int lower_bound_wave(const int *__restrict__ a, int n, int target, int lane)
+{
+    int lo = 0, hi = n;
+    while (hi > lo) {
+        const int span = hi - lo, step = (span + 63) >> 6;
+        const int idx = lo + lane * step;
+        const int v = idx < hi ? a[idx] : INT_MAX;
+        const unsigned long long m = __ballot(v >= target);
+        const int f = m ? __ffsll(m) - 1 : 64;
+        if (f == 0) { hi = lo; }
+        else {
+            const int nlo = lo + (f - 1) * step + 1;
+            int nhi = lo + f * step;
+            nhi = nhi < hi ? nhi : hi;
+            lo = nlo < nhi ? nlo : nhi; hi = nhi;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
+#ifdef HH_DEBUG
+__device__ int *g_hh_dbg = nullptr;
+#endif
+#ifdef HH_TIMING
+__device__ long long *g_hh_tim = nullptr; // [block][16] phase cycle sums of wavefront 0
+#define HH_T(k) do { const long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define HH_T(k) do {} while (0)
+#endif
+
+struct TileCtx {
+    int e_lo, n_env, r0, nrows; // envs [e_lo, e_lo + n_env), first compacted row, rows
+    int my_env, my_start;       // lane l <-> row l of the tile: env index inside the tile (-1 beyond nrows), its first row
+    int tile_ord;
+};
+
+template <int NRB>
+__device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const float *__restrict__ se, const HhFusedWeights &W,
+                                          float *__restrict__ out_sp, char *lds, int lane, int wave)
+{
+    const int i = lane & 15, g = lane >> 4;
+    const int loff = lane * 16;
+    constexpr int NKS = (NRB + 1) / 2; // key k-steps of 32 rows
+#ifdef HH_TIMING
+    long long tacc[16] = {0}, tlast = clock64();
+#endif
+
+    // ---------------- e0: relu(x W0^T + b0) for feature k-step `wave` (natural k order), all row blocks ----------------
+    {
+        const int c0 = 32 * wave + 8 * g;
+        float b0[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b0[u] = W.emb0_b[c0 + u];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            int row = rb * 16 + i;
+            row = row < t.nrows ? row : t.nrows - 1; // padded rows repeat the last live row: finite values, masked later
+            const int env = __shfl(t.my_env, row, 64), st = __shfl(t.my_start, row, 64);
+            const float *xp = se + ((size_t)(t.e_lo + env) * H + (row - st)) * D;
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = b0[u];
+            for (int d = 0; d < D; ++d) {
+                const float xd = xp[d];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] += xd * W.emb0_w[(c0 + u) * D + d];
+            }
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { __bf16 h, l; split1(fmaxf(v[u], 0.0f), h, l); hi[u] = h; lo[u] = l; }
+            *reinterpret_cast<bf16x8 *>(lds + LDS_S + ((0 * 4 + wave) * 4 + rb) * 1024 + loff) = hi;
+            *reinterpret_cast<bf16x8 *>(lds + LDS_S + ((1 * 4 + wave) * 4 + rb) * 1024 + loff) = lo;
+        }
+    }
+    HH_T(0);
+    __syncthreads();
+    HH_T(1);
+    // ---------------- X = relu(e0 W2^T + b2): wavefront w produces X k-steps 4w..4w+3 (feature blocks 8w..8w+7) ----------------
+    // in two halves of 4 feature blocks (2 X k-steps) so that the accumulators + a prefetched weight k-step stay in registers
+    {
+        const char *wp = (const char *)W.emb2_frag + (size_t)wave * 4 * 16 * 1024 + loff;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[4][NRB];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 wq[2][8]; // [slot][j*2 + plane]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wq[0][2 * j] = ldw(wp + ((0 * 8 + half * 4 + j) * 2 + 0) * 1024);
+                wq[0][2 * j + 1] = ldw(wp + ((0 * 8 + half * 4 + j) * 2 + 1) * 1024);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        wq[(ks + 1) & 1][2 * j] = ldw(wp + (((ks + 1) * 8 + half * 4 + j) * 2 + 0) * 1024);
+                        wq[(ks + 1) & 1][2 * j + 1] = ldw(wp + (((ks + 1) * 8 + half * 4 + j) * 2 + 1) * 1024);
+                    }
+                }
+                bf16x8 xh[NRB], xl[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    xh[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_S + ((0 * 4 + ks) * 4 + rb) * 1024 + loff);
+                    xl[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_S + ((1 * 4 + ks) * 4 + rb) * 1024 + loff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 *w = wq[ks & 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = mfma(w[2 * j + 1], xh[rb], acc[j][rb]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = mfma(w[2 * j], xl[rb], acc[j][rb]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = mfma(w[2 * j], xh[rb], acc[j][rb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int fb0 = 8 * wave + 4 * half + 2 * p;
+                const f32x4 ba = *reinterpret_cast<const f32x4 *>(W.emb2_b + fb0 * 16 + 4 * g);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(W.emb2_b + (fb0 + 1) * 16 + 4 * g);
+                const int kx = 4 * wave + 2 * half + p;
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    f32x4 a = acc[2 * p][rb] + ba, b = acc[2 * p + 1][rb] + bb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.0f); b[q] = fmaxf(b[q], 0.0f); }
+                    const Split8 s = split8(a, b);
+                    *reinterpret_cast<bf16x8 *>(lds + LDS_X + ((0 * 16 + kx) * 4 + rb) * 1024 + loff) = s.hi;
+                    *reinterpret_cast<bf16x8 *>(lds + LDS_X + ((1 * 16 + kx) * 4 + rb) * 1024 + loff) = s.lo;
+                }
+            }
+        }
+    }
+    HH_T(2);
+    __syncthreads();
+    HH_T(3);
+
+    // env block mask of this lane's S^T entries: query = 16*wave + i, keys 16*jb + 4*g + r
+    unsigned vmask = 0;
+    {
+        const int q = 16 * wave + i;
+        const int eq = __shfl(t.my_env, q, 64);
+#pragma unroll
+        for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ek = __shfl(t.my_env, 16 * jb + 4 * g + r, 64);
+                if (ek == eq && eq >= 0) vmask |= 1u << (jb * 4 + r);
+            }
+    }
+
+#ifdef HH_DEBUG
+    if (g_hh_dbg && blockIdx.x == 0 && t.e_lo == 0) {
+        int *d = g_hh_dbg + wave * 64 * 8 + lane * 8;
+        d[0] = t.my_env; d[1] = t.my_start; d[2] = (int)vmask; d[3] = t.nrows; d[4] = t.n_env; d[5] = t.r0; d[6] = NRB; d[7] = t.e_lo;
+    }
+#endif
+    f32x4 acc_os[4][NRB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Head order: every CU of an XCD would otherwise walk the SAME weight lines at the same moment (32 simultaneous readers of a
+    // line, then the next line ...), which serialises on the L2 channel that owns the line.  Staggering the starting head by the
+    // workgroup's index inside its XCD spreads the readers over 8 different streams (the sum over heads is order independent).
+    const int h0 = ((int)blockIdx.x >> 3) & 7;
+    for (int hh = 0; hh < 8; ++hh) {
+        const int h = (h0 + hh) & 7;
+        // ---------------- q|k|v feature block `wave` of head h for every row block: 16 k-steps over X ----------------
+        f32x4 aq[NRB], ak[NRB], av[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) { aq[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[rb] = aq[rb]; av[rb] = aq[rb]; }
+        const char *wp = (const char *)W.qkv_frag + ((size_t)(h * 4 + wave) * 16) * 6 * 1024 + loff;
+        constexpr int PF = 4; // weight prefetch depth (k-steps): the ring holds steps ks .. ks+PF-1
+        bf16x8 wf[PF][6];
+#pragma unroll
+        for (int p = 0; p < PF - 1; ++p)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) wf[p][c] = ldw(wp + (p * 6 + c) * 1024);
+        // X fragments are double buffered: step ks+1 is read from LDS while the MFMAs of step ks run
+        bf16x8 xh[2][NRB], xl[2][NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            xh[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + ((0 * 16 + 0) * 4 + rb) * 1024 + loff);
+            xl[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + ((1 * 16 + 0) * 4 + rb) * 1024 + loff);
+        }
+#pragma unroll 1
+        for (int k4 = 0; k4 < 16; k4 += PF) {
+#pragma unroll
+        for (int ku = 0; ku < PF; ++ku) {
+            const int ks = k4 + ku;
+            {
+                // prefetch k-step ks + PF - 1 into the ring slot consumed last iteration (clamped: the tail re-reads step 15).
+                // The scheduling barrier pins the issue point: left alone, the scheduler sinks these loads next to their use
+                // three k-steps later and the prefetch distance collapses to one L2 round trip per k-step.
+                const int kp = ks + PF - 1 < 16 ? ks + PF - 1 : 15;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) wf[(ku + PF - 1) % PF][c] = ldw(wp + (kp * 6 + c) * 1024);
+                const int kn = ks + 1 < 16 ? ks + 1 : 15;
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    xh[(ku + 1) & 1][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + ((0 * 16 + kn) * 4 + rb) * 1024 + loff);
+                    xl[(ku + 1) & 1][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + ((1 * 16 + kn) * 4 + rb) * 1024 + loff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bf16x8 *w6 = wf[ku]; // q hi, q lo, k hi, k lo, v hi, v lo
+            const bf16x8 *xhc = xh[ku & 1], *xlc = xl[ku & 1];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] = mfma(w6[1], xhc[rb], aq[rb]);
+                ak[rb] = mfma(w6[3], xhc[rb], ak[rb]);
+                av[rb] = mfma(xhc[rb], w6[5], av[rb]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] = mfma(w6[0], xlc[rb], aq[rb]);
+                ak[rb] = mfma(w6[2], xlc[rb], ak[rb]);
+                av[rb] = mfma(xlc[rb], w6[4], av[rb]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] = mfma(w6[0], xhc[rb], aq[rb]);
+                ak[rb] = mfma(w6[2], xhc[rb], ak[rb]);
+                av[rb] = mfma(xhc[rb], w6[4], av[rb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        HH_T(4);
+        {
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(W.qkv_b + h * 64 + 16 * wave + 4 * g);
+            const f32x4 bk = *reinterpret_cast<const f32x4 *>(W.qkv_b + 512 + h * 64 + 16 * wave + 4 * g);
+            const float bv = W.qkv_b[1024 + h * 64 + 16 * wave + i];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] += bq; ak[rb] += bk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[rb][q] += bv;
+            }
+        }
+        HH_T(5);
+        __syncthreads(); // A: the previous head's O fragments (H1) have been consumed by every wavefront
+        HH_T(6);
+        // Q -> H0, K -> H1: this wavefront holds head features 16w + 4g + r = half (w&1) of the fragment entries of k-step w>>1
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            bf16x4 qh, ql, kh, kl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __bf16 a, b;
+                split1(aq[rb][q], a, b); qh[q] = a; ql[q] = b;
+                split1(ak[rb][q], a, b); kh[q] = a; kl[q] = b;
+            }
+            const int o = (((wave >> 1)) * 4 + rb) * 1024 + loff + 8 * (wave & 1);
+            *reinterpret_cast<bf16x4 *>(lds + LDS_H0 + o) = qh;
+            *reinterpret_cast<bf16x4 *>(lds + LDS_H0 + 8192 + o) = ql;
+            *reinterpret_cast<bf16x4 *>(lds + LDS_H1 + o) = kh;
+            *reinterpret_cast<bf16x4 *>(lds + LDS_H1 + 8192 + o) = kl;
+        }
+        HH_T(7);
+        __syncthreads(); // B
+        HH_T(8);
+        // this head's out_proj∘spatial_linear fragments: in flight during the attention phases, consumed after barrier E
+        bf16x8 wos[2][4][2];
+        {
+            const char *op = (const char *)W.os_frag + ((size_t)(h * 4 + wave) * 2) * 8 * 1024 + loff;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wos[ks][j][0] = ldw(op + ((ks * 4 + j) * 2 + 0) * 1024);
+                    wos[ks][j][1] = ldw(op + ((ks * 4 + j) * 2 + 1) * 1024);
+                }
+        }
+        // ---------------- S^T = K Q^T for query block `wave`, masked softmax over the keys of the query's env ----------------
+        float p[4][4]; // [jb][r]
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[jb][r] = 0.0f;
+        if (wave < NRB) {
+            f32x4 s[NRB];
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb) s[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 qh = *reinterpret_cast<const bf16x8 *>(lds + LDS_H0 + (ks * 4 + wave) * 1024 + loff);
+                const bf16x8 ql = *reinterpret_cast<const bf16x8 *>(lds + LDS_H0 + 8192 + (ks * 4 + wave) * 1024 + loff);
+#pragma unroll
+                for (int jb = 0; jb < NRB; ++jb) {
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(lds + LDS_H1 + (ks * 4 + jb) * 1024 + loff);
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(lds + LDS_H1 + 8192 + (ks * 4 + jb) * 1024 + loff);
+                    s[jb] = mfma(kl, qh, s[jb]);
+                    s[jb] = mfma(kh, ql, s[jb]);
+                    s[jb] = mfma(kh, qh, s[jb]);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((vmask >> (jb * 4 + r)) & 1u) mx = fmaxf(mx, s[jb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = ((vmask >> (jb * 4 + r)) & 1u) ? __builtin_amdgcn_exp2f((s[jb][r] - mx) * 1.44269504088896340736f) : 0.0f;
+                    p[jb][r] = e; sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[jb][r] *= inv;
+        }
+        HH_T(9);
+        __syncthreads(); // C: Q (H0) is dead, P may overwrite it
+        HH_T(10);
+        if (wave < NRB) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const Split8 sp = split8(f32x4{p[2 * ks][0], p[2 * ks][1], p[2 * ks][2], p[2 * ks][3]},
+                                         f32x4{p[2 * ks + 1][0], p[2 * ks + 1][1], p[2 * ks + 1][2], p[2 * ks + 1][3]});
+                *reinterpret_cast<bf16x8 *>(lds + LDS_H0 + (ks * 4 + wave) * 1024 + loff) = sp.hi;
+                *reinterpret_cast<bf16x8 *>(lds + LDS_H0 + 8192 + (ks * 4 + wave) * 1024 + loff) = sp.lo;
+            }
+        }
+        __syncthreads(); // D
+        HH_T(11);
+        // ---------------- O^T = V^T P^T: value features 16w..16w+15 of the head for every query block ----------------
+        f32x4 o[NRB];
+#pragma unroll
+        for (int ib = 0; ib < NRB; ++ib) o[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const Split8 vf = split8(av[2 * ks], 2 * ks + 1 < NRB ? av[2 * ks + 1 < NRB ? 2 * ks + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int ib = 0; ib < NRB; ++ib) {
+                const bf16x8 ph = *reinterpret_cast<const bf16x8 *>(lds + LDS_H0 + (ks * 4 + ib) * 1024 + loff);
+                const bf16x8 pl = *reinterpret_cast<const bf16x8 *>(lds + LDS_H0 + 8192 + (ks * 4 + ib) * 1024 + loff);
+                o[ib] = mfma(vf.lo, ph, o[ib]);
+                o[ib] = mfma(vf.hi, pl, o[ib]);
+                o[ib] = mfma(vf.hi, ph, o[ib]);
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < NRB; ++ib) {
+            bf16x4 oh, ol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __bf16 a, b; split1(o[ib][q], a, b); oh[q] = a; ol[q] = b; }
+            const int off = ((wave >> 1) * 4 + ib) * 1024 + loff + 8 * (wave & 1);
+            *reinterpret_cast<bf16x4 *>(lds + LDS_H1 + off) = oh;
+            *reinterpret_cast<bf16x4 *>(lds + LDS_H1 + 8192 + off) = ol;
+        }
+        HH_T(12);
+        __syncthreads(); // E
+        HH_T(13);
+        // ---------------- out += O Wos[:, head h]^T: feature blocks 4w..4w+3 ----------------
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 oh[NRB], ol[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                oh[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_H1 + (ks * 4 + rb) * 1024 + loff);
+                ol[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_H1 + 8192 + (ks * 4 + rb) * 1024 + loff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][1], oh[rb], acc_os[j][rb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][0], ol[rb], acc_os[j][rb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][0], oh[rb], acc_os[j][rb]);
+        }
+        HH_T(14);
+    }
+    // ---------------- out_sp = relu(out + b) ----------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f0 = (4 * wave + j) * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(W.os_b + f0);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const int row = rb * 16 + i;
+            if (row < t.nrows) {
+                f32x4 v = acc_os[j][rb] + b;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
+                *reinterpret_cast<f32x4 *>(out_sp + (size_t)(t.r0 + row) * 256 + f0) = v;
+            }
+        }
+    }
+    __syncthreads(); // the next tile's e0 fragments overwrite the scratch halves
+    HH_T(15);
+#ifdef HH_TIMING
+    if (g_hh_tim && wave == 0 && lane == 0) {
+        long long *d = g_hh_tim + (size_t)blockIdx.x * 20;
+        for (int k = 0; k < 16; ++k) d[k] += tacc[k];
+        d[16] += 1; d[17] += t.nrows; d[18] += NRB;
+        long long *d2 = g_hh_tim + (size_t)256 * 20 + ((size_t)blockIdx.x * 4 + (t.tile_ord < 3 ? t.tile_ord : 3)) * 4;
+        d2[0] += tacc[4]; d2[1] += NRB; d2[2] += 1;
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const int *__restrict__ row_off,
+                                                          HhFusedWeights W, float *__restrict__ out_sp)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = row_off[E];
+    // chunk of this workgroup: rows [c*Q, (c+1)*Q) snapped to env starts
+    int Q = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    Q = Q < 16 ? 16 : Q;
+    const long long lo_row = (long long)blockIdx.x * Q;
+    if (lo_row >= total) return;
+    const long long hi_row = lo_row + Q;
+    int e = lower_bound_wave(row_off, E, (int)lo_row, lane);
+    const int e_end = hi_row >= total ? E : lower_bound_wave(row_off, E, (int)hi_row, lane);
+    int tile_ord = 0;
+    while (e < e_end) {
+        TileCtx t;
+        t.tile_ord = tile_ord++;
+        t.e_lo = e;
+        t.r0 = row_off[e];
+        // greedy: as many whole envs as fit into FR rows (every env has 1..H <= 64 rows)
+        const int probe = e + 1 + lane;
+        const int v = probe <= e_end ? row_off[probe] : INT_MAX;
+        const int n_env = __popcll(__ballot(v <= t.r0 + FR));
+        t.n_env = n_env;
+        t.nrows = __builtin_amdgcn_readfirstlane(__shfl(v, n_env - 1, 64)) - t.r0;
+        // row -> env map: lane k < n_env knows the start of env k, lane l then counts the starts <= l
+        // (the shuffle must run with every lane active: as part of the conditional below the compiler executes it under the
+        // narrowed EXEC mask and a ds_bpermute from an inactive lane returns 0)
+        const int prev_end = __shfl(v, lane >= 1 ? lane - 1 : 0, 64);
+        const int st = lane >= n_env ? INT_MAX : (lane == 0 ? 0 : prev_end - t.r0);
+        int cnt = 0;
+        for (int k = 0; k < n_env; ++k) cnt += lane >= __builtin_amdgcn_readlane(st, k) ? 1 : 0;
+        t.my_env = lane < t.nrows ? cnt - 1 : -1;
+        t.my_start = __shfl(st, cnt - 1 >= 0 ? cnt - 1 : 0, 64);
+        const int nrb = (t.nrows + 15) >> 4;
+        switch (nrb) {
+        case 1: tile_body<1>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        case 2: tile_body<2>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        case 3: tile_body<3>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        default: tile_body<4>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        }
+        e += n_env;
+    }
+}
+
+// ---- weight baking: fp32 row-major [N,K] -> bf16 hi/lo MFMA fragments in the order the kernel streams them ----
+// fragment entry (feature block fb, k-step ks, lane, u) = W[fb*16 + (lane & 15)][32*ks + koff(lane >> 4, u)]
+__device__ __forceinline__ int koff(int g, int u, bool perm) { return perm ? 16 * (u >> 2) + 4 * g + (u & 3) : 8 * g + u; }
+
+__global__ void bake_emb2_kernel(const float *__restrict__ w, __bf16 *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // one fragment entry element
+    if (idx >= 512 * 128) return;
+    const int u = idx & 7, lane = (idx >> 3) & 63, j = (idx >> 9) & 7, ks = (idx >> 12) & 3, wv = idx >> 14;
+    const int fb = 8 * wv + j;
+    const float x = w[(size_t)(fb * 16 + (lane & 15)) * 128 + 32 * ks + koff(lane >> 4, u, false)];
+    const __bf16 hi = (__bf16)x;
+    const size_t base = ((((size_t)wv * 4 + ks) * 8 + j) * 2) * 512 + lane * 8 + u;
+    out[base] = hi;
+    out[base + 512] = (__bf16)(x - (float)hi);
+}
+__global__ void bake_qkv_kernel(const float *__restrict__ w, __bf16 *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 1536 * 512) return;
+    const int u = idx & 7, lane = (idx >> 3) & 63;
+    int rest = idx >> 9;                 // ((h*4 + wv)*16 + ks)*3 + j
+    const int j = rest % 3; rest /= 3;
+    const int ks = rest & 15, wv = (rest >> 4) & 3, h = rest >> 6;
+    const float x = w[(size_t)(j * 512 + h * 64 + 16 * wv + (lane & 15)) * 512 + 32 * ks + koff(lane >> 4, u, true)];
+    const __bf16 hi = (__bf16)x;
+    const size_t base = (((((size_t)h * 4 + wv) * 16 + ks) * 3 + j) * 2) * 512 + lane * 8 + u;
+    out[base] = hi;
+    out[base + 512] = (__bf16)(x - (float)hi);
+}
+__global__ void bake_os_kernel(const float *__restrict__ w, __bf16 *__restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 256 * 512) return;
+    const int u = idx & 7, lane = (idx >> 3) & 63, j = (idx >> 9) & 3, ks = (idx >> 11) & 1, wv = (idx >> 12) & 3, h = idx >> 14;
+    const float x = w[(size_t)((4 * wv + j) * 16 + (lane & 15)) * 512 + h * 64 + 32 * ks + koff(lane >> 4, u, true)];
+    const __bf16 hi = (__bf16)x;
+    const size_t base = (((((size_t)h * 4 + wv) * 2 + ks) * 4 + j) * 2) * 512 + lane * 8 + u;
+    out[base] = hi;
+    out[base + 512] = (__bf16)(x - (float)hi);
+}
+
+} // namespace
+
+int hh_fused_bake(const float *emb2_w, const float *qkv_w, const float *os_w, void *emb2_frag, void *qkv_frag, void *os_frag, hipStream_t st)
+{
+    hipLaunchKernelGGL(bake_emb2_kernel, dim3(512 * 128 / 256), dim3(256), 0, st, emb2_w, (__bf16 *)emb2_frag);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bake_qkv_kernel, dim3(1536 * 512 / 256), dim3(256), 0, st, qkv_w, (__bf16 *)qkv_frag);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bake_os_kernel, dim3(256 * 512 / 256), dim3(256), 0, st, os_w, (__bf16 *)os_frag);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+#ifdef HH_TIMING
+extern "C" int cn_hh_fused_set_timing(long long *buf)
+{
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_hh_tim), &buf, sizeof(buf)));
+    return CN_OK;
+}
+#endif
+#ifdef HH_DEBUG
+extern "C" int cn_hh_fused_set_debug(int *buf)
+{
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_hh_dbg), &buf, sizeof(buf)));
+    return CN_OK;
+}
+#endif
+
+int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const int *row_off, const HhFusedWeights &w, float *out_sp, hipStream_t st)
+{
+    static thread_local int attr_dev = -1; // the opt-in above 64 KB of dynamic LDS is per device
+    int dev = 0;
+    CN_HIP(hipGetDevice(&dev));
+    if (dev != attr_dev) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_dev = dev;
+    }
+    // one workgroup per CU (the LDS footprint admits exactly one); small batches get fewer so that a chunk is >= one row block
+    long long max_rows = (long long)E * H;
+    int grid = (int)((max_rows + 15) / 16);
+    grid = grid > 256 ? 256 : (grid < 1 ? 1 : grid);
+    hipLaunchKernelGGL(hh_fused_kernel, dim3(grid), dim3(256), LDS_BYTES, st, E, H, D, spatial_edges, row_off, w, out_sp);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

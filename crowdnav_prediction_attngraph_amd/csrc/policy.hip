@@ -21,6 +21,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "gemm3.h"
+#include "hh_fused.h"
 
 #include <cmath>
 #include <new>
@@ -69,6 +70,36 @@ __global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const f
     if (t == 1023) {
         row_off[E] = part[1023];
         if (live_total) *live_total += (unsigned long long)part[1023]; // measurement aid: total live rows over the profiled launches
+    }
+}
+
+// The same prefix sum as ONE wavefront (fused mode: no attention size classes needed).  A 1024-thread block needs 16 free wave
+// slots on one CU at once and queues behind the simulator's ORCA wavefronts of the previous step (measured 6 us alone, 34 us on
+// average inside the rollout); a single wavefront is placed immediately.  Lane l owns envs [l*chunk, (l+1)*chunk).
+__global__ __launch_bounds__(64) void row_offsets_wave_kernel(int E, int H, const float *__restrict__ det, int *__restrict__ row_off,
+                                                              unsigned long long *__restrict__ live_total)
+{
+    const int lane = threadIdx.x;
+    const int chunk = (E + 63) >> 6;
+    const int lo = lane * chunk, hi = min(lo + chunk, E);
+    int sum = 0;
+    for (int e = lo; e < hi; ++e) { int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd); sum += nd; }
+    // inclusive wave scan (Hillis-Steele over DPP-free shuffles: 6 steps)
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    int run = incl - sum;
+    for (int e = lo; e < hi; ++e) {
+        row_off[e] = run;
+        int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
+        run += nd;
+    }
+    if (lane == 63) {
+        row_off[E] = incl;
+        if (live_total) *live_total += (unsigned long long)incl;
     }
 }
 
@@ -489,7 +520,8 @@ struct cn_policy {
     // activations
     float *emb1, *emb2, *qkv, *attn, *out_sp;
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
-    int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split (default)
+    void *f_emb2, *f_qkv, *f_os; // MFMA-fragment images of the three big weight matrices for the fused human-human kernel
+    int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split as separate launches, 2 = bf16x3 split, fused human-human kernel (default)
     unsigned long long *live_total; // device counter: sum of live rows over the profiled forwards
     int *row_off; // [maxE + 1]
     int *cls_cnt, *cls_list; // big attention size classes: [2] counts, [2][E] env lists exclusive prefix of live humans per env; row_off[E] = live rows
@@ -555,6 +587,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_tew = carve(320 * 256), o_teb = carve(320), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 384);
     const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
     const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
+    const size_t o_fe2 = carve(HH_EMB2_FRAG_BYTES / 4), o_fqkv = carve(HH_QKV_FRAG_BYTES / 4), o_fos = carve(HH_OS_FRAG_BYTES / 4);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete p; cn_set_error("cn_policy_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -576,7 +609,8 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     (void)hipMemset(p->live_total, 0, 8);
     p->emb2_hi = (__bf16 *)(base + o_e2h); p->emb2_lo = (__bf16 *)(base + o_e2l); p->qkv_hi = (__bf16 *)(base + o_qh); p->qkv_lo = (__bf16 *)(base + o_ql);
     p->os_hi = (__bf16 *)(base + o_osh); p->os_lo = (__bf16 *)(base + o_osl);
-    p->gemm_mode = 1;
+    p->f_emb2 = base + o_fe2; p->f_qkv = base + o_fqkv; p->f_os = base + o_fos;
+    p->gemm_mode = 2;
     p->te_w = F(o_tew); p->te_b = F(o_teb); p->ac0f_w = F(o_acfw); p->ac0f_b = F(o_acfb); p->z = F(o_z);
     p->weights_set = false;
     p->profiling = false;
@@ -642,6 +676,7 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
             CN_CHECK_LAUNCH();
         }
     }
+    if (int rc = hh_fused_bake(p->emb2_w, p->qkv_w, p->os_w, p->f_emb2, p->f_qkv, p->f_os, st)) return rc;
     CN_D2D(p->as_w, w->attn_spatial_w, 64 * 256); CN_D2D(p->as_b, w->attn_spatial_b, 64);
     CN_D2D(p->at_w, w->attn_temporal_w, 64 * 256); CN_D2D(p->at_b, w->attn_temporal_b, 64);
     CN_D2D(p->rl_w, w->robot_linear_w, 256 * 9); CN_D2D(p->rl_b, w->robot_linear_b, 256);
@@ -713,9 +748,20 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_HIP(hipEventRecord(p->ev_join, p->side));
     // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
     const int *m_dev = p->row_off + E;
-    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
-                       p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
+    if (p->gemm_mode == 2)
+        hipLaunchKernelGGL(row_offsets_wave_kernel, dim3(1), dim3(64), 0, st, E, H, obs->detected_human_num, p->row_off,
+                           p->profiling ? p->live_total : (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
+                           p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
     CN_CHECK_LAUNCH();
+    if (p->gemm_mode == 2) {
+        // ONE persistent kernel: embedding -> q|k|v -> attention -> out_proj∘spatial_linear, activations never leave the chip
+        if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
+        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b};
+        if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, p->row_off, fw, p->out_sp, st))) return rc;
+        if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
+    } else {
     {
         int blocks = E < 4096 ? E : 4096;
         hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(128), 0, st, E, H, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->row_off, p->emb1);
@@ -739,6 +785,7 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     if (split) rc = launch_gemm3<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
     else rc = launch_gemm<128, ACT_RELU>(M, 256, 512, p->attn, 512, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
     if (rc) return rc;
+    }
     // ---- robot-human attention (robot node embeddings arrive from the side stream) ----
     CN_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
     {
@@ -793,7 +840,7 @@ extern "C" int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float
 
 extern "C" int cn_policy_set_gemm_mode(cn_policy *p, int mode)
 {
-    CN_REQUIRE(p && (mode == 0 || mode == 1), "cn_policy_set_gemm_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x3 split)");
+    CN_REQUIRE(p && mode >= 0 && mode <= 2, "cn_policy_set_gemm_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 split, separate launches) or 2 (bf16x3 split, fused)");
     p->gemm_mode = mode;
     return CN_OK;
 }

@@ -203,8 +203,9 @@ class HipPolicy:
         return t
 
     def set_gemm_mode(self, mode):
-        """'bf16x3' (default: split-precision bf16 MFMA, ~2e-5 of fp32) or 'fp32' (exact fp32 MFMA)."""
-        A.check(A.lib().cn_policy_set_gemm_mode(self._h, {"fp32": 0, "bf16x3": 1}[mode]), "cn_policy_set_gemm_mode")
+        """'fused' (default: the whole human-human block as one persistent kernel, bf16x3 split-precision MFMA, ~2e-5 of fp32),
+        'bf16x3' (the same arithmetic as separate launches: embedding / q|k|v GEMMs, attention, out_proj) or 'fp32' (exact fp32 MFMA)."""
+        A.check(A.lib().cn_policy_set_gemm_mode(self._h, {"fp32": 0, "bf16x3": 1, "fused": 2}[mode]), "cn_policy_set_gemm_mode")
 
     def set_profiling(self, enabled):
         A.check(A.lib().cn_policy_set_profiling(self._h, int(bool(enabled))), "cn_policy_set_profiling")

@@ -108,6 +108,7 @@ def test_full_batch_fused_rollout_equals_slice_rollout():
     ob_space, act_space = make_spaces(H, 2)
     net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E), base="selfAttn_merge_srnn").cuda()
     pf, pp = HipPolicy(H, 2, E), HipPolicy(H, 2, n)
+    pf.set_gemm_mode("bf16x3"); pp.set_gemm_mode("bf16x3")      # separate launches: a row's arithmetic does not depend on its tile
     pf.set_weights(net.state_dict()); pp.set_weights(net.state_dict())
     of, op = full.reset(), part.reset()
     hf, hp = torch.zeros(E, 1, 128, device="cuda"), torch.zeros(n, 1, 128, device="cuda")
@@ -126,6 +127,48 @@ def test_full_batch_fused_rollout_equals_slice_rollout():
             assert torch.equal(of[k][lo:lo + n], op[k]), (k, t)
         mf, mp = (df == 0).float().view(E, 1), (dp == 0).float().view(n, 1)
     full.close(); part.close()
+
+
+def test_full_batch_fused_kernel_equals_separate_launches_and_slices():
+    """The fused human-human kernel (default mode) at 4096 envs x 20 humans over a 60-step rollout with the real simulator in the loop:
+    every step its outputs are compared (a) with the separate-launch bf16x3 path on the same observations (same arithmetic, different
+    summation order inside the attention: <= 2e-5) and (b) with the fused kernel run on a 512-env slice of the same batch (other chunk /
+    tile boundaries, other neighbours in the tiles: env results must not depend on them beyond summation order)."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    E, H, lo, n = 4096, 20, 1536, 512
+    env = HipEnvBatch(A.default_env_config(human_num=H, nenv=E), E, 425)
+    torch.manual_seed(425)
+    ob_space, act_space = make_spaces(H, 2)
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E), base="selfAttn_merge_srnn").cuda()
+    pf, ps, pl = HipPolicy(H, 2, E), HipPolicy(H, 2, E), HipPolicy(H, 2, n)
+    ps.set_gemm_mode("bf16x3")
+    for p in (pf, ps, pl):
+        p.set_weights(net.state_dict())
+    obs = env.reset()
+    h, m = torch.zeros(E, 1, 128, device="cuda"), torch.ones(E, 1, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    worst = {"sep": 0.0, "slice": 0.0}
+    for t in range(60):
+        eps = torch.randn(E, 2, device="cuda", generator=g)
+        a = pf.act(obs, h, m, eps=eps)
+        ta = pf.taps(E)["spatial_lin"].clone()
+        b = ps.act(obs, h, m, eps=eps)
+        tb = ps.taps(E)["spatial_lin"]
+        sl = {k: v[lo:lo + n].contiguous() for k, v in obs.items()}
+        c = pl.act(sl, h[lo:lo + n].contiguous(), m[lo:lo + n].contiguous(), eps=eps[lo:lo + n].contiguous())
+        tc = pl.taps(n)["spatial_lin"]
+        worst["sep"] = max(worst["sep"], float((ta - tb).abs().max()))
+        worst["slice"] = max(worst["slice"], float((ta[lo:lo + n] - tc).abs().max()))
+        for k in ("value", "action", "logp", "hxs"):
+            assert torch.allclose(a[k], b[k], atol=2e-5, rtol=0), (k, t, float((a[k] - b[k]).abs().max()))
+            assert torch.allclose(a[k][lo:lo + n], c[k], atol=2e-5, rtol=0), (k, t, float((a[k][lo:lo + n] - c[k]).abs().max()))
+        h = a["hxs"].clone()
+        obs, _, d, _, _, _ = env.step(a["action"])
+        m = (d == 0).float().view(E, 1)
+    assert worst["sep"] <= 2e-5 and worst["slice"] <= 2e-5, worst
+    env.close()
 
 
 def test_full_batch_predrealgst_wrapper_kernels_equal_torch_expression():

@@ -25,7 +25,7 @@ def _dev(obs):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in obs.items()}
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("mode", ["fused", "bf16x3", "fp32"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "policy_*_h*.npz"))), ids=lambda p: os.path.basename(p)[7:-4])
 def test_policy_act_matches_reference_golden(path, mode):
     from crowdnav_prediction_attngraph_amd.hip import HipPolicy
@@ -64,7 +64,7 @@ def test_policy_act_matches_reference_golden(path, mode):
     np.testing.assert_allclose(v.cpu().numpy(), z["value"], atol=TOL)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("mode", ["fused", "bf16x3", "fp32"])
 @pytest.mark.parametrize("E,H,D", [(257, 20, 2), (130, 20, 12), (64, 5, 2), (40, 50, 2), (3, 64, 2), (1, 1, 2)])
 def test_policy_act_matches_numpy_oracle(E, H, D, mode):
     """Sizes with ragged tiles (E*H not a multiple of 128), random-looking weights, random detected counts."""
