@@ -124,26 +124,33 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     // ---------------- e0: relu(x W0^T + b0) for feature k-step `wave` (natural k order), all row blocks ----------------
     {
         const int c0 = 32 * wave + 8 * g;
-        float b0[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) b0[u] = W.emb0_b[c0 + u];
+        const float *xp[NRB];
+        float v[NRB][8];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             int row = rb * 16 + i;
             row = row < t.nrows ? row : t.nrows - 1; // padded rows repeat the last live row: finite values, masked later
             const int env = __shfl(t.my_env, row, 64), st = __shfl(t.my_start, row, 64);
-            const float *xp = se + ((size_t)(t.e_lo + env) * H + (row - st)) * D;
-            float v[8];
+            xp[rb] = se + ((size_t)(t.e_lo + env) * H + (row - st)) * D;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = b0[u];
-            for (int d = 0; d < D; ++d) {
-                const float xd = xp[d];
+            for (int u = 0; u < 8; ++u) v[rb][u] = W.emb0_b[c0 + u];
+        }
+        for (int d = 0; d < D; ++d) { // input feature outermost: its 8 weights are loaded once and reused by every row block
+            float w[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] += xd * W.emb0_w[(c0 + u) * D + d];
+            for (int u = 0; u < 8; ++u) w[u] = W.emb0_w[(c0 + u) * D + d];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float xd = xp[rb][d];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[rb][u] += xd * w[u];
             }
+        }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
             bf16x8 hi, lo;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { __bf16 h, l; split1(fmaxf(v[u], 0.0f), h, l); hi[u] = h; lo[u] = l; }
+            for (int u = 0; u < 8; ++u) { __bf16 h, l; split1(fmaxf(v[rb][u], 0.0f), h, l); hi[u] = h; lo[u] = l; }
             *reinterpret_cast<bf16x8 *>(lds + LDS_S + ((0 * 4 + wave) * 4 + rb) * 1024 + loff) = hi;
             *reinterpret_cast<bf16x8 *>(lds + LDS_S + ((1 * 4 + wave) * 4 + rb) * 1024 + loff) = lo;
         }
@@ -281,8 +288,12 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 // The scheduling barrier pins the issue point: left alone, the scheduler sinks these loads next to their use
                 // three k-steps later and the prefetch distance collapses to one L2 round trip per k-step.
                 const int kp = ks + PF - 1 < 16 ? ks + PF - 1 : 15;
+#ifndef HH_EXP_NO_WLOAD
 #pragma unroll
                 for (int c = 0; c < 6; ++c) wf[(ku + PF - 1) % PF][c] = ldw(wp + (kp * 6 + c) * 1024);
+#else
+                asm volatile("" : "+v"(wf[(ku + PF - 1) % PF][0]) : "s"(kp));
+#endif
                 const int kn = ks + 1 < 16 ? ks + 1 : 15;
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
@@ -293,6 +304,13 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
             }
             const bf16x8 *w6 = wf[ku]; // q hi, q lo, k hi, k lo, v hi, v lo
             const bf16x8 *xhc = xh[ku & 1], *xlc = xl[ku & 1];
+#ifdef HH_EXP_NO_MFMA
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb][0] += (float)w6[0][0] + (float)w6[1][0] + (float)xhc[rb][0]; ak[rb][0] += (float)w6[2][0] + (float)w6[3][0] + (float)xlc[rb][0];
+                av[rb][0] += (float)w6[4][0] + (float)w6[5][0];
+            }
+#else
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 aq[rb] = mfma(w6[1], xhc[rb], aq[rb]);
@@ -311,6 +329,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 ak[rb] = mfma(w6[2], xhc[rb], ak[rb]);
                 av[rb] = mfma(xhc[rb], w6[4], av[rb]);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         }
@@ -517,15 +536,22 @@ __global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, c
     int e = lower_bound_wave(row_off, E, (int)lo_row, lane);
     const int e_end = hi_row >= total ? E : lower_bound_wave(row_off, E, (int)hi_row, lane);
     int tile_ord = 0;
+    const int chunk_end_row = row_off[e_end];
     while (e < e_end) {
         TileCtx t;
         t.tile_ord = tile_ord++;
         t.e_lo = e;
         t.r0 = row_off[e];
-        // greedy: as many whole envs as fit into FR rows (every env has 1..H <= 64 rows)
+        // whole envs, at most FR rows (every env has 1..H <= 64 rows); the rows left in the chunk are split evenly over the tiles
+        // they need, because a tile's cost is dominated by terms that do not shrink with its row count (weight stream, barriers)
         const int probe = e + 1 + lane;
         const int v = probe <= e_end ? row_off[probe] : INT_MAX;
-        const int n_env = __popcll(__ballot(v <= t.r0 + FR));
+        const int left = chunk_end_row - t.r0;
+        const int ntile = (left + FR - 1) / FR;
+        int want = (left + ntile - 1) / ntile + 2; // small slack: prefer closing a tile just after the even split
+        want = want > FR ? FR : want;
+        int n_env = __popcll(__ballot(v <= t.r0 + want));
+        n_env = n_env < 1 ? 1 : n_env;             // one env always fits (H <= FR)
         t.n_env = n_env;
         t.nrows = __builtin_amdgcn_readfirstlane(__shfl(v, n_env - 1, 64)) - t.r0;
         // row -> env map: lane k < n_env knows the start of env k, lane l then counts the starts <= l

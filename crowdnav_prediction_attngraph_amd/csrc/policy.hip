@@ -22,6 +22,7 @@
 #include "gemm.h"
 #include "gemm3.h"
 #include "hh_fused.h"
+#include "rn_fused.h"
 
 #include <cmath>
 #include <new>
@@ -520,6 +521,8 @@ struct cn_policy {
     // activations
     float *emb1, *emb2, *qkv, *attn, *out_sp;
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
+    float *r_te, *r_whh, *r_edge, *r_wih, *r_ac0, *r_a2, *r_c2; // MFMA-fragment images of the robot-node weights (rn_fused.hip)
+    bool taps_on;                // fused mode: write the test taps (robot_emb, hr_attn, hr_out, actor_feat) of every forward
     void *f_emb2, *f_qkv, *f_os; // MFMA-fragment images of the three big weight matrices for the fused human-human kernel
     int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split as separate launches, 2 = bf16x3 split, fused human-human kernel (default)
     unsigned long long *live_total; // device counter: sum of live rows over the profiled forwards
@@ -587,6 +590,8 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     const size_t o_tew = carve(320 * 256), o_teb = carve(320), o_acfw = carve(512 * 128), o_acfb = carve(512), o_z = carve(E * 384);
     const size_t o_e2h = carve(512 * 128 / 2), o_e2l = carve(512 * 128 / 2), o_qh = carve(1536 * 512 / 2), o_ql = carve(1536 * 512 / 2);
     const size_t o_osh = carve(256 * 512 / 2), o_osl = carve(256 * 512 / 2);
+    const size_t o_rte = carve(320 * 256), o_rwhh = carve(384 * 128), o_redge = carve(64 * 256), o_rwih = carve(384 * 128), o_rac0 = carve(512 * 128);
+    const size_t o_ra2 = carve(256 * 256), o_rc2 = carve(256 * 256);
     const size_t o_fe2 = carve(HH_EMB2_FRAG_BYTES / 4), o_fqkv = carve(HH_QKV_FRAG_BYTES / 4), o_fos = carve(HH_OS_FRAG_BYTES / 4);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
@@ -609,6 +614,8 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     (void)hipMemset(p->live_total, 0, 8);
     p->emb2_hi = (__bf16 *)(base + o_e2h); p->emb2_lo = (__bf16 *)(base + o_e2l); p->qkv_hi = (__bf16 *)(base + o_qh); p->qkv_lo = (__bf16 *)(base + o_ql);
     p->os_hi = (__bf16 *)(base + o_osh); p->os_lo = (__bf16 *)(base + o_osl);
+    p->r_te = F(o_rte); p->r_whh = F(o_rwhh); p->r_edge = F(o_redge); p->r_wih = F(o_rwih); p->r_ac0 = F(o_rac0); p->r_a2 = F(o_ra2); p->r_c2 = F(o_rc2);
+    p->taps_on = true;
     p->f_emb2 = base + o_fe2; p->f_qkv = base + o_fqkv; p->f_os = base + o_fos;
     p->gemm_mode = 2;
     p->te_w = F(o_tew); p->te_b = F(o_teb); p->ac0f_w = F(o_acfw); p->ac0f_b = F(o_acfb); p->z = F(o_z);
@@ -701,6 +708,13 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
     CN_CHECK_LAUNCH();
     hipLaunchKernelGGL(fold_bias_kernel, dim3(2), dim3(256), 0, st, 512, 256, p->ac0_w, w->out_b, p->ac0_b, 1.0f, p->ac0f_b);
     CN_CHECK_LAUNCH();
+    {
+        struct { int N, K; const float *w; float *out; } bk[7] = {{320, 256, p->te_w, p->r_te}, {384, 128, p->whh, p->r_whh}, {64, 256, p->edge_w, p->r_edge},
+                                                                  {384, 128, p->wih, p->r_wih}, {512, 128, p->ac0f_w, p->r_ac0}, {256, 256, p->a2_w, p->r_a2},
+                                                                  {256, 256, p->c2_w, p->r_c2}};
+        for (auto &b : bk)
+            if (int rc = rn_fused_bake(b.N, b.K, b.w, b.out, st)) return rc;
+    }
     CN_D2D(p->cl_w, w->critic_linear_w, 256); CN_D2D(p->cl_b, w->critic_linear_b, 1);
     CN_D2D(p->fm_w, w->fc_mean_w, 512); CN_D2D(p->fm_b, w->fc_mean_b, 2); CN_D2D(p->logstd, w->logstd, 2);
     p->weights_set = true;
@@ -734,6 +748,26 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_REQUIRE(hxs_in && masks && value, "policy: null pointer");
     const int H = p->H, D = p->D, M = E * H;
     int rc;
+    if (p->gemm_mode == 2) {
+        // fused mode: three launches -- row offsets, the human-human kernel, the robot-node kernel
+        hipLaunchKernelGGL(row_offsets_wave_kernel, dim3(1), dim3(64), 0, st, E, H, obs->detected_human_num, p->row_off,
+                           p->profiling ? p->live_total : (unsigned long long *)nullptr);
+        CN_CHECK_LAUNCH();
+        if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
+        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b};
+        if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, p->row_off, fw, p->out_sp, st))) return rc;
+        if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
+        RnFusedArgs ra{};
+        ra.temporal = obs->temporal_edges; ra.robot_node = obs->robot_node; ra.hxs_in = hxs_in; ra.masks = masks; ra.eps = eps;
+        ra.out_sp = p->out_sp; ra.row_off = p->row_off;
+        ra.rl_w = p->rl_w; ra.rl_b = p->rl_b; ra.f_te = p->r_te; ra.te_b = p->te_b; ra.f_whh = p->r_whh; ra.bhh = p->bhh;
+        ra.f_edge = p->r_edge; ra.edge_b = p->edge_b; ra.f_wih = p->r_wih; ra.bih = p->bih; ra.f_ac0 = p->r_ac0; ra.ac0_b = p->ac0f_b;
+        ra.f_a2 = p->r_a2; ra.a2_b = p->a2_b; ra.f_c2 = p->r_c2; ra.c2_b = p->c2_b;
+        ra.cl_w = p->cl_w; ra.cl_b = p->cl_b; ra.fm_w = p->fm_w; ra.fm_b = p->fm_b; ra.logstd = p->logstd;
+        ra.value = value; ra.action = action; ra.logp = logp; ra.hxs_out = hxs_out ? hxs_out : p->hnew;
+        if (p->taps_on) { ra.tap_robot = p->robot_states; ra.tap_attn = p->hr_attn; ra.tap_hr = p->hr_out; ra.tap_actor = p->ac2; }
+        return rn_fused_forward(E, H, ra, st);
+    }
     // ---- robot node: nothing here depends on the human-human block, so it runs beside it on the side stream ----
     CN_HIP(hipEventRecord(p->ev_fork, st)); // inputs (and the previous forward's readers of z / gh) are ordered before this point
     CN_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
@@ -748,20 +782,10 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_HIP(hipEventRecord(p->ev_join, p->side));
     // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
     const int *m_dev = p->row_off + E;
-    if (p->gemm_mode == 2)
-        hipLaunchKernelGGL(row_offsets_wave_kernel, dim3(1), dim3(64), 0, st, E, H, obs->detected_human_num, p->row_off,
-                           p->profiling ? p->live_total : (unsigned long long *)nullptr);
-    else
-        hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
+    hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
                            p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
     CN_CHECK_LAUNCH();
-    if (p->gemm_mode == 2) {
-        // ONE persistent kernel: embedding -> q|k|v -> attention -> out_proj∘spatial_linear, activations never leave the chip
-        if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
-        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b};
-        if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, p->row_off, fw, p->out_sp, st))) return rc;
-        if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
-    } else {
+    {
     {
         int blocks = E < 4096 ? E : 4096;
         hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(128), 0, st, E, H, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->row_off, p->emb1);
@@ -824,6 +848,7 @@ extern "C" int cn_policy_get_value(cn_policy *p, int E, const cn_obs *obs, const
 extern "C" int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float *hr_attn, float *hr_out, float *robot_emb, float *actor_feat, void *stream)
 {
     CN_REQUIRE(p && E >= 1 && E <= p->maxE, "cn_policy_get_taps: bad argument");
+    if (p->gemm_mode == 2 && !p->taps_on) { cn_set_error("cn_policy_get_taps: taps are switched off (cn_policy_set_taps)"); return CN_ERR_STATE; }
     hipStream_t st = (hipStream_t)stream;
     const size_t M = (size_t)E * p->H;
     (void)M;
@@ -834,7 +859,8 @@ extern "C" int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float
     if (hr_attn) CN_D2D(hr_attn, p->hr_attn, M);
     if (hr_out) CN_D2D(hr_out, p->hr_out, (size_t)E * 256);
     if (robot_emb) CN_D2D(robot_emb, p->robot_states, (size_t)E * 256);
-    if (actor_feat) CN_HIP(hipMemcpy2DAsync(actor_feat, 256 * sizeof(float), p->ac2, 512 * sizeof(float), 256 * sizeof(float), E, hipMemcpyDeviceToDevice, st));
+    if (actor_feat && p->gemm_mode == 2) CN_D2D(actor_feat, p->ac2, (size_t)E * 256); // the fused robot-node kernel taps [E,256] directly
+    else if (actor_feat) CN_HIP(hipMemcpy2DAsync(actor_feat, 256 * sizeof(float), p->ac2, 512 * sizeof(float), 256 * sizeof(float), E, hipMemcpyDeviceToDevice, st));
     return CN_OK;
 }
 
@@ -842,6 +868,13 @@ extern "C" int cn_policy_set_gemm_mode(cn_policy *p, int mode)
 {
     CN_REQUIRE(p && mode >= 0 && mode <= 2, "cn_policy_set_gemm_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 split, separate launches) or 2 (bf16x3 split, fused)");
     p->gemm_mode = mode;
+    return CN_OK;
+}
+
+extern "C" int cn_policy_set_taps(cn_policy *p, int enabled)
+{
+    CN_REQUIRE(p, "cn_policy_set_taps: null handle");
+    p->taps_on = enabled != 0;
     return CN_OK;
 }
 

@@ -1,0 +1,254 @@
+// rn_fused.hip -- the robot-node half of the policy forward as ONE kernel on gfx950 (everything after the human-human block):
+//   robot_linear -> [u = Ws^T temporal_edge_layer(.) | encoder_linear] -> robot-human attention over out_sp ->
+//   edge_attention_embed -> GRU cell (with the done mask) -> actor / critic trunks (output_linear folded in) -> critic_linear +
+//   DiagGaussian head.               rl/networks/selfAttn_srnn_temp_node.py:395-449, srnn_model.py:35-105, model.py:56-80
+// As separate launches this is ~12 small kernels whose M = E products fill a fraction of the chip each and whose LDS-using
+// blocks cannot even co-reside with the 160 KB workgroups of the fused human-human kernel; here one workgroup (8 wavefronts)
+// owns 16 envs, keeps every per-env activation in LDS and walks the ~1.3 MB of weights once, straight from L2 into MFMA operand
+// registers.  All products are EXACT fp32 (v_mfma_f32_16x16x4_f32), like the launches this replaces.
+//
+// Products run "transposed" (A operand = weight fragment, B operand = activations): the C layout then holds 4 consecutive output
+// features of one env per lane, which is a float4 store into the next layer's [env][feature] LDS image; the B operand of the
+// next product is a float4 read of that image (k = 16c + 4*(lane>>4) + m for the m-th of 4 MFMAs, natural order).
+#include "rn_fused.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TE = 16;     // envs per workgroup
+// LDS activation images [16 envs][stride] floats; strides are K + 4 so that the 16 lanes of a float4 read hit distinct banks
+constexpr int S512 = 516, S384 = 388, S128 = 132;
+constexpr int O_R0 = 0;                     // 512: robot_states (256) -> hr (256) -> ac1 (512)
+constexpr int O_R1 = O_R0 + TE * S512;      // 512: z = [u 256 | enc 64 | edge 64] -> ac2 (512)
+constexpr int O_R2 = O_R1 + TE * S512;      // 384: gh
+constexpr int O_R3 = O_R2 + TE * S384;      // 384: gi
+constexpr int O_R4 = O_R3 + TE * S384;      // 128: h_in
+constexpr int O_R5 = O_R4 + TE * S128;      // 128: h_new
+constexpr int LDS_FLOATS = O_R5 + TE * S128;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+enum { A_NONE = 0, A_RELU = 1, A_TANH = 2 };
+
+// tanh(x) = 1 - 2 / (1 + e^{2x}) on v_exp_f32: absolute error < 3e-7 (e^{2x} overflows to inf -> 1, underflows to 0 -> -1)
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f); // 2 * log2(e)
+    return 1.0f - 2.0f / (1.0f + e);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
+
+// out[env][out_off + 16*fb + ..] = act(W[fb] . in[env][in_off ..] + bias) for the feature blocks fb = fb0 + wave, fb0 + wave + 4, ...
+// Wfrag: baked fragments [fb][K/16][64 lanes][4 floats]; NFB = feature blocks of this wavefront
+template <int K, int NFB, int ACT>
+__device__ __forceinline__ void stage(const float *__restrict__ Wfrag, int fb_first, int fb_step, const float *__restrict__ bias, const float *in, int in_stride,
+                                      float *out, int out_stride, int out_off, int relu_from, int lane)
+{
+    const int i = lane & 15, g = lane >> 4;
+    constexpr int KC = K / 16;
+    f32x4 b[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) b[c] = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 16 * c + 4 * g);
+    f32x4 acc[NFB];
+#pragma unroll
+    for (int j = 0; j < NFB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragments: three k-chunks in flight (the scheduling barriers pin the issue points, see hh_fused.hip)
+    constexpr int PF = 3;
+    f32x4 a[PF][NFB];
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) a[p][j] = *reinterpret_cast<const f32x4 *>(Wfrag + (((size_t)(fb_first + j * fb_step) * KC + (p < KC ? p : KC - 1)) * 64 + lane) * 4);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) { // fully unrolled: b[c] must be statically indexed (a runtime index sends the array to scratch)
+        const int cp = c + PF - 1 < KC ? c + PF - 1 : KC - 1;
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) a[(c + PF - 1) % PF][j] = *reinterpret_cast<const f32x4 *>(Wfrag + (((size_t)(fb_first + j * fb_step) * KC + cp) * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NFB; ++j) acc[j] = mfma4(a[c % PF][j][m], b[c][m], acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NFB; ++j) {
+        const int f0 = (fb_first + j * fb_step) * 16 + 4 * g;
+        f32x4 v = acc[j];
+        if (bias) v += *reinterpret_cast<const f32x4 *>(bias + f0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ACT == A_RELU) { if (f0 + q >= relu_from) v[q] = fmaxf(v[q], 0.0f); }
+            if (ACT == A_TANH) v[q] = fast_tanh(v[q]);
+        }
+        *reinterpret_cast<f32x4 *>(out + i * out_stride + out_off + f0) = v;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e0 = blockIdx.x * TE;
+    float *R0 = smem + O_R0, *R1 = smem + O_R1, *R2 = smem + O_R2, *R3 = smem + O_R3, *R4 = smem + O_R4, *R5 = smem + O_R5;
+    // ---- robot_linear.0: relu(W [256,9] . [temporal_edges(2) | robot_node(7)] + b); thread = feature; h_in -> LDS ----
+    const int w4 = wave & 3, hi = wave >> 2; // two groups of four wavefronts run independent products side by side
+    {
+        const int n = tid & 255; // feature; the two thread halves split the envs
+        float w[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) w[d] = a.rl_w[n * 9 + d];
+        const float bn = a.rl_b[n];
+        for (int i = (tid >> 8) * (TE / 2); i < (tid >> 8) * (TE / 2) + TE / 2; ++i) {
+            const int e = e0 + i < E ? e0 + i : E - 1; // the tail workgroup repeats the last env (results discarded)
+            float acc = bn;
+            acc += a.temporal[e * 2] * w[0];
+            acc += a.temporal[e * 2 + 1] * w[1];
+#pragma unroll
+            for (int d = 0; d < 7; ++d) acc += a.robot_node[e * 7 + d] * w[2 + d];
+            acc = fmaxf(acc, 0.0f);
+            R0[i * S512 + n] = acc;
+            if (a.tap_robot && e0 + i < E) a.tap_robot[(size_t)(e0 + i) * 256 + n] = acc;
+        }
+        for (int idx = tid; idx < TE * 128; idx += 512) {
+            const int i = idx >> 7, c = idx & 127;
+            const int e = e0 + i < E ? e0 + i : E - 1;
+            R4[i * S128 + c] = a.hxs_in[(size_t)e * 128 + c];
+        }
+    }
+    __syncthreads();
+    // ---- z = [u (256) | relu(enc) (64)] = te_w [320,256] . robot_states + te_b ;  gh = W_hh [384,128] . h_in (unmasked, no bias) ----
+    if (hi == 0) stage<256, 5, A_RELU>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane);
+    else stage<128, 6, A_NONE>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane);
+    __syncthreads();
+    // ---- robot-human attention (u-form, see hr_attention_kernel in policy.hip): wavefront w owns envs 2w, 2w+1 ----
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * wave + q;
+        const int e = e0 + i < E ? e0 + i : E - 1;
+        const int r0 = a.row_off[e], nd = a.row_off[e + 1] - r0;
+        const float *ue = R1 + i * S512;
+        const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
+        float s = -INFINITY;
+        for (int j = 0; j < nd; ++j) {
+            const float *row = a.out_sp + (size_t)(r0 + j) * 256;
+            const float tot = wv_sum(u0 * row[lane] + u1 * row[64 + lane] + u2 * row[128 + lane] + u3 * row[192 + lane]);
+            if (lane == j) s = tot * ((float)H / 8.0f);
+        }
+        const float mx = wv_max(s);
+        const float p = lane < nd ? expf(s - mx) : 0.0f;
+        const float denom = wv_sum(p);
+        const float at = p / denom;
+        if (a.tap_attn && lane < H && e0 + i < E) a.tap_attn[(size_t)(e0 + i) * H + lane] = at;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        for (int j = 0; j < nd; ++j) {
+            const float aj = wv_readlane(at, j);
+            const float *row = a.out_sp + (size_t)(r0 + j) * 256;
+            o0 += aj * row[lane]; o1 += aj * row[64 + lane]; o2 += aj * row[128 + lane]; o3 += aj * row[192 + lane];
+        }
+        float *o = R0 + i * S512; // robot_states are dead: hr takes their place
+        o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
+        if (a.tap_hr && e0 + i < E) {
+            float *t = a.tap_hr + (size_t)(e0 + i) * 256;
+            t[lane] = o0; t[64 + lane] = o1; t[128 + lane] = o2; t[192 + lane] = o3;
+        }
+    }
+    __syncthreads();
+    // ---- edge = relu(edge_attention_embed [64,256] . hr + b) -> z[320:384] ----
+    if (hi == 0) stage<256, 1, A_RELU>(a.f_edge, w4, 4, a.edge_b, R0, S512, R1, S512, 320, 0, lane);
+    __syncthreads();
+    // ---- gi = W_ih [384,128] . [enc | edge] + b_ih ----
+    stage<128, 3, A_NONE>(a.f_wih, wave, 8, a.bih, R1 + 256, S512, R3, S384, 0, 0, lane);
+    __syncthreads();
+    // ---- GRU cell, pointwise part (gate order r,z,n; h and gh masked by the done mask: srnn_model.py:43-46) ----
+    for (int idx = tid; idx < TE * 128; idx += 512) {
+        const int i = idx >> 7, c = idx & 127;
+        const int e = e0 + i < E ? e0 + i : E - 1;
+        const float m = a.masks[e];
+        const float *gie = R3 + i * S384, *ghe = R2 + i * S384;
+        const float hr = m * ghe[c] + a.bhh[c], hz = m * ghe[128 + c] + a.bhh[128 + c], hn = m * ghe[256 + c] + a.bhh[256 + c];
+        const float r = fast_sigmoid(gie[c] + hr);
+        const float z = fast_sigmoid(gie[128 + c] + hz);
+        const float n = fast_tanh(gie[256 + c] + r * hn);
+        const float h = m * R4[i * S128 + c];
+        const float hnew = (1.0f - z) * n + z * h;
+        R5[i * S128 + c] = hnew;
+        if (e0 + i < E) a.hxs_out[(size_t)(e0 + i) * 128 + c] = hnew;
+    }
+    __syncthreads();
+    // ---- actor / critic trunks: tanh((W0 Wo) h + ..) [512,128], then the two [256,256] second layers ----
+    stage<128, 4, A_TANH>(a.f_ac0, wave, 8, a.ac0_b, R5, S128, R0, S512, 0, 0, lane);
+    __syncthreads();
+    if (hi == 0) stage<256, 4, A_TANH>(a.f_a2, w4, 4, a.a2_b, R0, S512, R1, S512, 0, 0, lane);
+    else stage<256, 4, A_TANH>(a.f_c2, w4, 4, a.c2_b, R0 + 256, S512, R1, S512, 256, 0, lane);
+    __syncthreads();
+    // ---- critic_linear + DiagGaussian head (model.py:64-72): wavefront w owns envs 2w, 2w+1 ----
+    for (int q = 0; q < 2; ++q) {
+        const int i = 2 * wave + q;
+        if (e0 + i >= E) break;
+        const int e = e0 + i;
+        const float *av = R1 + i * S512, *cv = av + 256;
+        float sv = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = lane + 64 * k;
+            sv += cv[d] * a.cl_w[d];
+            s0 += av[d] * a.fm_w[d];
+            s1 += av[d] * a.fm_w[256 + d];
+            if (a.tap_actor) a.tap_actor[(size_t)e * 256 + d] = av[d];
+        }
+        sv = wv_sum(sv); s0 = wv_sum(s0); s1 = wv_sum(s1);
+        if (lane == 0) {
+            a.value[e] = sv + a.cl_b[0];
+            if (a.action) {
+                const float mean0 = s0 + a.fm_b[0], mean1 = s1 + a.fm_b[1];
+                const float ls0 = a.logstd[0], ls1 = a.logstd[1];
+                const float sd0 = expf(ls0), sd1 = expf(ls1);
+                const float a0 = a.eps ? mean0 + sd0 * a.eps[2 * e] : mean0;
+                const float a1 = a.eps ? mean1 + sd1 * a.eps[2 * e + 1] : mean1;
+                a.action[2 * e] = a0; a.action[2 * e + 1] = a1;
+                const float HALF_LOG_2PI = 0.91893853320467274178f;
+                const float d0 = a0 - mean0, d1 = a1 - mean1;
+                a.logp[e] = (-(d0 * d0) / (2.0f * sd0 * sd0) - ls0 - HALF_LOG_2PI) + (-(d1 * d1) / (2.0f * sd1 * sd1) - ls1 - HALF_LOG_2PI);
+            }
+        }
+    }
+}
+
+// fp32 row-major W [N,K] -> [fb = N/16][K/16][64 lanes][4]: lane (f, kk) holds W[16 fb + f][16 c + 4 kk .. +3]
+__global__ void rn_bake_kernel(int N, int K, const float *__restrict__ w, float *__restrict__ out)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * K) return;
+    const int m = idx & 3, lane = (idx >> 2) & 63;
+    const size_t rest = idx >> 8;
+    const int KC = K / 16;
+    const int c = (int)(rest % KC), fb = (int)(rest / KC);
+    out[idx] = w[(size_t)(fb * 16 + (lane & 15)) * K + 16 * c + 4 * (lane >> 4) + m];
+}
+
+} // namespace
+
+int rn_fused_bake(int N, int K, const float *w, float *out, hipStream_t st)
+{
+    CN_REQUIRE(N % 16 == 0 && K % 16 == 0, "rn_fused_bake: N and K must be multiples of 16");
+    const size_t n = (size_t)N * K;
+    hipLaunchKernelGGL(rn_bake_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, K, w, out);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+int rn_fused_forward(int E, int H, const RnFusedArgs &args, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    CN_HIP(hipGetDevice(&dev));
+    if (dev != attr_dev) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_dev = dev;
+    }
+    hipLaunchKernelGGL(rn_fused_kernel, dim3((E + TE - 1) / TE), dim3(512), lds, st, E, H, args);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

@@ -37,8 +37,32 @@ def _summarise(outcomes, steps, path_len, too_close, min_dists, ep_rewards, time
     return m
 
 
+class _batch_invariant(object):
+    """Evaluation is a reproducibility protocol: run the policy with the launches whose per-env results do not depend on which other
+    envs share the batch ('bf16x3'), so that one-env-at-a-time and all-cases-in-one-batch evaluation give bit-identical episodes."""
+
+    def __init__(self, actor_critic):
+        self.ac = actor_critic
+
+    def __enter__(self):
+        if self.ac is not None and hasattr(self.ac, "rollout_gemm_mode"):
+            self.saved = self.ac.rollout_gemm_mode
+            self.ac.rollout_gemm_mode = "bf16x3"
+        return self
+
+    def __exit__(self, *exc):
+        if self.ac is not None and hasattr(self.ac, "rollout_gemm_mode"):
+            self.ac.rollout_gemm_mode = self.saved
+        return False
+
+
 def evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging, config, args, visualize=False):
     """Same call as the reference's `evaluate`.  eval_envs = make_vec_envs(..., num_processes=1, ...) (phase 'test')."""
+    with _batch_invariant(actor_critic):
+        return _evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging, config, args, visualize)
+
+
+def _evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging, config, args, visualize=False):
     if num_processes != 1 or eval_envs.num_envs != 1:
         raise NotImplementedError("the reference evaluates with ONE env (test.py:136); use evaluate_batched for the parallel form")
     if visualize:
@@ -85,6 +109,16 @@ def evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging,
 
 def evaluate_batched(actor_critic, env_name, config, seed, test_size, device=None, logging=None):
     """The same protocol with every distinct test case as one env of one batch (all tensors stay on the GPU)."""
+    if env_name == "CrowdSimPredRealGST-v0":
+        # the raw env observation carries placeholder futures; the policy needs the VecPretextNormalize processing (GST predictions,
+        # distance sort, social penalty), which this function does not run
+        raise NotImplementedError("evaluate_batched does not run the GST wrapper: evaluate CrowdSimPredRealGST-v0 with "
+                                  "evaluate(actor_critic, make_vec_envs(..., pretext_wrapper=True), ...)")
+    with _batch_invariant(actor_critic):
+        return _evaluate_batched(actor_critic, env_name, config, seed, test_size, device, logging)
+
+
+def _evaluate_batched(actor_critic, env_name, config, seed, test_size, device=None, logging=None):
     from .hip import HipEnvBatch
     device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     cfg = to_env_config(config, env_name, 1, "test")          # nenv = 1: case counters advance by one, as in the sequential run

@@ -207,6 +207,10 @@ class HipPolicy:
         'bf16x3' (the same arithmetic as separate launches: embedding / q|k|v GEMMs, attention, out_proj) or 'fp32' (exact fp32 MFMA)."""
         A.check(A.lib().cn_policy_set_gemm_mode(self._h, {"fp32": 0, "bf16x3": 1, "fused": 2}[mode]), "cn_policy_set_gemm_mode")
 
+    def set_taps(self, enabled):
+        """Fused mode: keep / drop the test taps (robot_emb, hr_attn, hr_out, actor_feat) the robot-node kernel writes per forward."""
+        A.check(A.lib().cn_policy_set_taps(self._h, int(bool(enabled))), "cn_policy_set_taps")
+
     def set_profiling(self, enabled):
         A.check(A.lib().cn_policy_set_profiling(self._h, int(bool(enabled))), "cn_policy_set_profiling")
 

@@ -311,11 +311,21 @@ class Policy(nn.Module):
     def _weights_version(self):
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
 
+    # rollout arithmetic / launch structure (cn_policy_set_gemm_mode): 'fused' = two persistent kernels (default, fastest; an env's
+    # result depends on its tile neighbours at the 1e-7 level through the softmax summation order), 'bf16x3' = the same arithmetic as
+    # separate launches whose per-env results are independent of the batch composition, 'fp32' = exact fp32 MFMA
+    rollout_gemm_mode = "fused"
+
     def _hip_policy(self, E, device):
         from .hip import HipPolicy
         if self._hip is None or self._hip.maxE < E or self._hip.device != device:
             self._hip = HipPolicy(self.base.human_num, self.base.edge_width, E, device=device)
+            self._hip.set_taps(False)          # rollout path: nobody reads the test taps
             self._hip_version = None
+            self._hip_mode = None
+        if getattr(self, "_hip_mode", None) != self.rollout_gemm_mode:
+            self._hip.set_gemm_mode(self.rollout_gemm_mode)
+            self._hip_mode = self.rollout_gemm_mode
         ver = self._weights_version()
         if ver != self._hip_version:
             self._hip.set_weights(self.state_dict())

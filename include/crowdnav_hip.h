@@ -198,11 +198,17 @@ int cn_policy_get_value(cn_policy *p, int E, const cn_obs *obs, const float *hxs
  * are spatial_lin [E,H,256], hr_attn [E,H], hr_out [E,256], robot_emb [E,256], actor_feat [E,256] (NULL to skip). */
 int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float *hr_attn, float *hr_out, float *robot_emb,
                        float *actor_feat, void *stream);
+/* Fused mode (cn_policy_set_gemm_mode 2): the robot-node kernel writes the taps above only while they are enabled (default 1);
+ * rollout loops switch them off (17 MB of stores per 4096-env forward that nothing reads). */
+int cn_policy_set_taps(cn_policy *p, int enabled);
 /* Arithmetic of the three large human-human GEMMs (embedding_layer.2, folded q|k|v, folded out_proj∘spatial_linear):
- *   1 (default) = split precision: each fp32 operand as bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 per term, fp32
- *                 accumulation (products exact to ~2^-16 relative; outputs within 2e-5 of the fp32 path, bar 1e-4);
- *   0           = exact fp32 on v_mfma_f32_32x32x2_f32.
- * Everything else always runs in fp32. */
+ *   2 (default) = split precision (each fp32 operand as bf16 hi + lo, three bf16 MFMAs per term, fp32 accumulation; products
+ *                 exact to ~2^-16 relative; outputs within 2e-5 of the fp32 path, bar 1e-4) with the whole human-human block as ONE
+ *                 persistent kernel (activations never leave LDS / registers) and everything after it as ONE robot-node kernel;
+ *   1           = the same split-precision arithmetic as separate launches (embedding / q|k|v / out_proj GEMMs, attention kernels,
+ *                 per-env GEMMs);
+ *   0           = exact fp32 on v_mfma_f32_32x32x2_f32, separate launches.
+ * Everything outside the three large GEMMs always runs in exact fp32. */
 int cn_policy_set_gemm_mode(cn_policy *p, int mode);
 /* Dominant-kernel timing support for bench.py: number of HH-block launches so far and accumulated device time of the
  * QKV projection kernel measured with hipEvents on `stream` when profiling is enabled. */

@@ -69,10 +69,10 @@ def test_adam_clip_step_matches_torch(n, max_norm):
         hip.adam_clip_step(p, gd, m, v, step, 4e-5, (0.9, 0.999), 1e-5, max_norm, norm_out=norm)
         assert float(norm) == pytest.approx(float(total), rel=2e-6)
         np.testing.assert_allclose(gd.cpu().numpy(), ref.grad.numpy(), rtol=2e-6, atol=1e-12)   # grads scaled in place like clip_grad_norm_
-        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-7)
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=5e-7)
     st = opt.state[ref]
-    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-5, atol=1e-12)
-    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-5, atol=1e-20)
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-4, atol=1e-20)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz"))), ids=lambda p: os.path.basename(p)[8:-4])
