@@ -31,84 +31,86 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no 
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline_multi(H, workers, envs=48, steps=60):
-    """The same bounded sample in `workers` independent single-threaded processes at once (the shape of the reference's
-    SubprocVecEnv path: one process per group of envs) -> aggregate rate over the host cores actually used."""
-    import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(H), str(envs), str(steps)]
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT) for _ in range(workers)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    wall = time.perf_counter() - t0
-    recs = [json.loads(o.decode().strip().splitlines()[-1]) for o in outs if o.strip()]
-    if len(recs) != workers:
-        raise RuntimeError("%d of %d CPU workers returned a result" % (len(recs), workers))
-    busy = max(r["seconds"] for r in recs)          # timed region of the slowest worker (start-up and imports excluded)
-    total = sum(r["env_steps"] for r in recs)
-    return {"value": round(total / busy, 1), "unit": "env-steps/s", "cores": workers, "kind": "port",
-            "sample": "%d single-threaded processes x (%d envs x %d steps) of the same workload (H=%d) run concurrently; slowest worker %.1f s "
-                      "(wall incl. start-up %.1f s); one process alone: %s" % (workers, envs, steps, H, busy, wall, recs[0]["sample_single"])}
+def cpu_baseline_threads(H, env_name="CrowdSimVarNum-v0", threads=None, target_s=12.0):
+    """the reference-equivalent CPU path on THIS box's host cores -- scalar C simulator (the oracle, one env per
+    call, envs sharded over P worker threads; ctypes releases the GIL) + the policy forward as a torch CPU fp32 graph with
+    torch.set_num_threads(P) -- on a bounded sample of the same workload.  kind = 'port' (the reference's Python cannot travel)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
 
-
-def cpu_baseline(H, envs=48, steps=60):
-    """The oracle (kind='port': scalar C sim + numpy policy forward) on ONE host core, bounded sample."""
     import numpy as np
+    import torch
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
     from oracle import oracle as O
-    from oracle import policy_oracle as P
-    from tests import policy_util as PU
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
-    shapes = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", "policy_varnum_e4_h20.npz"))["meta"]))["shapes"]
-    sd = PU.formula_state_dict({k: tuple(v) for k, v in shapes.items()})
-    cfg = O.default_config(human_num=H, nenv=envs)
-    oenvs = [O.OracleEnv(cfg, 425 + i) for i in range(envs)]
-    obs = [e.reset() for e in oenvs]
-    h = np.zeros((envs, 128))
-    masks = np.ones((envs, 1))
-    rs = np.random.RandomState(0)
-    std = np.exp(sd["dist.logstd._bias"].astype(np.float64).reshape(1, 2))
+    logical = os.cpu_count() or 2
+    P = threads if threads and threads > 0 else max(1, min(128, logical // 2))     # physical cores (SMT pairs counted once)
+    E = max(8 * P, 4096 // P * P)                 # the GPU run's batch (4096 envs) unless the box has > 512 cores
+    kind = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}[env_name]
+    cfg = O.default_config(human_num=H, nenv=E, env_kind=kind)
+    D = O.obs_width(cfg)
+    envs = [O.OracleEnv(cfg, 425 + i) for i in range(E)]
+    obs0 = [e.reset() for e in envs]
+    L = O.lib()
+    handles = (C.c_void_p * E)(*[e._h for e in envs])
+    buf = dict(robot_node=np.zeros((E, 1, 7), np.float32), temporal_edges=np.zeros((E, 1, 2), np.float32), spatial_edges=np.zeros((E, H, D), np.float32),
+               detected_human_num=np.zeros((E, 1), np.float32), visible=np.zeros((E, H), np.uint8), rewards=np.zeros(E, np.float32),
+               dones=np.zeros(E, np.uint8), infos=np.zeros(E, np.uint8))
+    for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num"):
+        buf[k][:] = np.stack([o[k] for o in obs0]).reshape(buf[k].shape)
+    actions = np.zeros((E, 2), np.float32)
+    fp, u8 = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    per = E // P
 
-    def run(n):
-        nonlocal obs, h, masks
+    def sim_chunk(w):
+        lo = w * per
+        hp = C.cast(C.byref(handles, lo * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p))
+        L.orc_env_batch_step(hp, per, actions[lo:].ctypes.data_as(fp), buf["robot_node"][lo:].ctypes.data_as(fp), buf["temporal_edges"][lo:].ctypes.data_as(fp),
+                             buf["spatial_edges"][lo:].ctypes.data_as(fp), buf["detected_human_num"][lo:].ctypes.data_as(fp), buf["visible"][lo:].ctypes.data_as(u8),
+                             buf["rewards"][lo:].ctypes.data_as(fp), buf["dones"][lo:].ctypes.data_as(u8), buf["infos"][lo:].ctypes.data_as(u8))
+
+    nthreads_before = torch.get_num_threads()
+    torch.set_num_threads(P)
+    torch.manual_seed(425)
+    ob_space, act_space = make_spaces(H, D)
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name=env_name, num_processes=E), base="selfAttn_merge_srnn")
+    hxs = {"human_node_rnn": torch.zeros(E, 1, 128), "human_human_edge_rnn": None}
+    masks = torch.ones(E, 1)
+    pool = ThreadPoolExecutor(P)
+    t_sim = t_pol = 0.0
+
+    def one_step():
+        nonlocal hxs, masks, t_sim, t_pol
+        t0 = time.perf_counter()
+        obs = {k: torch.from_numpy(buf[k]) for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+        _, action, _, h = net.act(obs, hxs, masks)
+        actions[:] = action.numpy()
+        hxs = {"human_node_rnn": h["human_node_rnn"], "human_human_edge_rnn": None}
+        t1 = time.perf_counter()
+        list(pool.map(sim_chunk, range(P)))
+        masks = torch.from_numpy(1.0 - buf["dones"].astype(np.float32)).view(E, 1)
+        t2 = time.perf_counter()
+        t_pol += t1 - t0
+        t_sim += t2 - t1
+
+    try:
+        for _ in range(3):
+            one_step()
+        per_step = (t_sim + t_pol) / 3
+        steps = int(max(5, min(400, target_s / max(per_step, 1e-4))))
         t_sim = t_pol = 0.0
-        for _ in range(n):
-            t0 = time.perf_counter()
-            batch = {k: np.stack([o[k] for o in obs]) for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
-            _, mean, _, h, _ = P.act(sd, batch, h, masks)
-            act = (mean + std * rs.standard_normal((envs, 2))).astype(np.float32)
-            t1 = time.perf_counter()
-            dones = []
-            for i, e in enumerate(oenvs):
-                ob, _, d, _ = e.step(act[i], autoreset=True)
-                obs[i] = ob
-                dones.append(d)
-            masks = 1.0 - np.array(dones, dtype=np.float64).reshape(envs, 1)
-            t2 = time.perf_counter()
-            t_pol += t1 - t0
-            t_sim += t2 - t1
-        return t_sim, t_pol
-
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    try:
-        run(2)
-        t_sim, t_pol = run(steps)
+        for _ in range(steps):
+            one_step()
     finally:
-        if ctx is not None:
-            ctx.unregister() if hasattr(ctx, "unregister") else None
-    n = envs * steps
-    return {"value": round(n / (t_sim + t_pol), 2), "unit": "env-steps/s", "cores": 1, "kind": "port", "seconds": t_sim + t_pol, "env_steps": n,
-            "sample": "%d envs x %d steps of the same workload (H=%d): scalar C sim %.0f env-steps/s, numpy fp64 policy forward %.0f env-steps/s, 1 thread"
-                      % (envs, steps, H, n / t_sim, n / t_pol)}
+        pool.shutdown()
+        torch.set_num_threads(nthreads_before)
+    n = E * steps
+    return {"value": round(n / (t_sim + t_pol), 1), "unit": "env-steps/s", "cores": P, "kind": "port",
+            "sample": "%d envs x %d steps of the same workload (H=%d, %s): scalar C simulator sharded over %d threads %.0f env-steps/s, torch CPU fp32 policy "
+                      "forward (set_num_threads(%d)) %.0f env-steps/s; %.1f s of CPU work" % (E, steps, H, env_name, P, n / t_sim, P, n / t_pol, t_sim + t_pol),
+            "host_logical_cpus": logical}
 
 
 def main():
-    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":      # child of cpu_baseline_multi: no torch, no GPU
-        r = cpu_baseline(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
-        print(json.dumps({"seconds": r["seconds"], "env_steps": r["env_steps"], "sample_single": "%.0f env-steps/s" % r["value"]}))
-        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -121,8 +123,12 @@ def main():
                     help="bound of the reference's unbounded rejection sampling of human positions / goals (0 = library default 65536); dense "
                          "randomised crowds (configs[4]) need a small bound or the batch waits for its unluckiest env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-workers", type=int, default=-1,
-                    help="CPU baseline: number of concurrent single-threaded oracle processes (-1 = min(64, host cores / 2); 1 = one process)")
+    ap.add_argument("--cpu-threads", type=int, default=-1,
+                    help="CPU baseline: worker threads P for the C simulator and torch.set_num_threads (-1 = physical host cores, capped at 128)")
+    ap.add_argument("--dephase", type=int, default=240,
+                    help="untimed pre-roll steps before the warm-up so that the envs are spread over their episodes (all envs start an episode "
+                         "together at reset; SURVEY 8d asks for a de-phased steady-state window)")
+    ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: put every rank on GPU 0 (use with --dist-backend gloo)")
@@ -188,6 +194,8 @@ def main():
 
     masks2 = [torch.ones(E, 1, device="cuda"), torch.ones(E, 1, device="cuda")]
 
+    force_all_detected = [False]
+
     def step(i):
         eps.normal_(generator=gen)
         out["hxs"] = hxs[(i + 1) & 1]
@@ -195,9 +203,16 @@ def main():
         _, reward, done, _, _, _ = env.step(out["action"], not_done=masks2[(i + 1) & 1])   # done mask for the next forward
         if gst is not None:
             gst.wrapper_step(obs, reward, 0.6, -20.0, out=pol_obs["spatial_edges"])
+        if force_all_detected[0]:
+            pol_obs["detected_human_num"].fill_(float(H))     # worst case of the state-dependent work: every (env, human) row is live
 
-    for i in range(args.warmup):
-        step(i)
+    it = 0
+    # untimed pre-roll: every env starts an episode at reset, so the first ~40 steps are a lock-step transient (few humans in sensor
+    # range, no resets); after a few hundred steps of sampled actions the envs are spread over their episodes
+    for _ in range(args.dephase + (args.dephase & 1)):
+        step(it); it += 1
+    for _ in range(args.warmup + (args.warmup & 1)):
+        step(it); it += 1
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -205,13 +220,30 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(it + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     pol.set_profiling(False)
     prof_ms, prof_n = pol.get_profile()
+    it += args.steps + (args.steps & 1)
+    worst = None
+    if not args.no_worst_case and rank == 0:
+        force_all_detected[0] = True
+        pol_obs["detected_human_num"].fill_(float(H))
+        for _ in range(10):
+            step(it); it += 1
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for i in range(args.steps):
+            step(it + i)
+        torch.cuda.synchronize()
+        tw = time.perf_counter() - tw
+        force_all_detected[0] = False
+        worst = {"value": round(E * args.steps / tw, 1), "unit": "env-steps/s (this rank)", "ms_per_step": round(tw / args.steps * 1e3, 4), "mean_detected_humans": float(H),
+                 "note": "second timed window, same steps: every env reports all %d humans detected (%d live rows instead of the natural count) -- "
+                         "the upper bound of the state-dependent human-human work" % (H, E * H)}
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cuda" if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -265,9 +297,12 @@ def main():
              else "gemm_nt_kernel<128,NONE> (v_mfma_f32_32x32x2_f32): folded q|k|v projection")
     # HBM traffic of the dominant kernel comes from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.gemm == "bf16x3" and E == 4096 and H == 20 and os.path.exists(tpath):
-        traffic = json.load(open(tpath))["hbm_bytes_per_launch_corrected"]
+    traffic_note = None
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if fused else "r01_pmc_traffic.json")
+    if args.gemm in ("fused", "bf16x3") and (args.env_name, E, H, args.randomized) == ("CrowdSimVarNum-v0", 4096, 20, False) and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj["hbm_bytes_per_launch_corrected"]
+        traffic_note = "traffic is NOT measured in this run: it is the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE result of the same command (%s)" % os.path.basename(tpath)
     line = {
         "metric": "env-steps/sec (sim+policy fwd) at %d humans" % H, "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -285,29 +320,20 @@ def main():
                              ("achieved = algorithmic 2*M*N*K / launch time (hipEvents on the kernel's stream); peak = 2500 TFLOP/s dense bf16 "
                               "MFMA / 3 passes of the hi/lo split; executed bf16 MFMA rate = %.1f TFLOP/s" % (3 * achieved)) if split else
                              "achieved = algorithmic 2*M*N*K / launch time on exact fp32 MFMA",
-                     "launch_ms": round(qkv_ms, 4), "launches": int(prof_n[0]), "mean_detected_humans": round(M / E, 3),
+                     "traffic_note": traffic_note, "launch_ms": round(qkv_ms, 4), "launches": int(prof_n[0]), "mean_detected_humans": round(M / E, 3),
                      "whole_step": {"reference_graph_flops_per_env_step": F,
                                     "reference_graph_tflops_equivalent": round(value / world * F / 1e12, 2),
                                     "note": "env-steps/s x the FLOPs of the reference's dense, unfolded forward; NOT a hardware utilisation "
                                             "(padded humans are not computed and affine pairs are folded)"}},
     }
+    line["config"]["dephase_steps"] = args.dephase
+    if worst is not None:
+        line["worst_case_all_detected"] = worst
     if ppo is not None:
         line["ppo"] = ppo
     if not args.no_cpu_baseline and world == 1:
-        workers = args.cpu_workers if args.cpu_workers > 0 else max(1, min(64, (os.cpu_count() or 2) // 2))
-        cb = None
-        if workers > 1:
-            try:
-                cb = cpu_baseline_multi(H, workers)
-            except Exception as exc:      # fall back to the single-process measurement
-                cb = None
-                sys.stderr.write("cpu_baseline_multi failed (%s); measuring one process\n" % exc)
-        if cb is None:
-            cb = cpu_baseline(H)
-            cb.pop("seconds", None); cb.pop("env_steps", None)
-        line["cpu_baseline"] = cb
-        line["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        line["gpu_over_cpu"] = round(value / cb["value"], 1)
+        line["cpu_baseline"] = cpu_baseline_threads(H, args.env_name, args.cpu_threads)
+        line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
