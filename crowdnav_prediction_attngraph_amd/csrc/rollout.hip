@@ -3,8 +3,8 @@
 // GAE has a serial dependence over T (30) and none over envs: one lane per env, lanes of a wavefront read
 // consecutive envs of a [T][N] row -> fully coalesced; values stay in registers across the scan.  fp32 with torch's
 // operation order (-ffp-contract=off), so it is bit-identical to the reference loop.
-// Advantage statistics are wavefront-shuffle reductions accumulated in fp64, one atomic per block; the three partial
-// sums are exposed so that data-parallel ranks can all-reduce them before normalising (global mean / unbiased std).
+// Advantage statistics are wavefront-shuffle reductions accumulated in fp64 in a fixed order (bit-reproducible); the three
+// partial sums are exposed so that data-parallel ranks can all-reduce them before normalising (global mean / unbiased std).
 #include "common.h"
 
 namespace {
@@ -26,12 +26,14 @@ __global__ __launch_bounds__(256) void gae_kernel(int T, int N, const float *__r
     }
 }
 
-__global__ __launch_bounds__(256) void adv_stats_kernel(int64_t n, const float *__restrict__ returns, const float *__restrict__ values,
-                                                        double *stats)
+// ONE block, fixed summation order: the statistics (and with them every normalised advantage) are bit-reproducible from run to
+// run, which a resumed training run relies on (floating-point atomics across blocks would sum in arrival order).
+__global__ __launch_bounds__(1024) void adv_stats_kernel(int64_t n, const float *__restrict__ returns, const float *__restrict__ values,
+                                                         double *stats)
 {
-    __shared__ double part[2][4];
+    __shared__ double part[2][16];
     double s = 0.0, ss = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const double a = (double)(returns[i] - values[i]); // fp32 subtraction like torch, accumulated in fp64
         s += a; ss += a * a;
     }
@@ -40,9 +42,9 @@ __global__ __launch_bounds__(256) void adv_stats_kernel(int64_t n, const float *
     if ((threadIdx.x & 63) == 0) { part[0][w] = s; part[1][w] = ss; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&stats[0], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(&stats[1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
-        if (blockIdx.x == 0) atomicAdd(&stats[2], (double)n);
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < 16; ++k) { a += part[0][k]; b += part[1][k]; }
+        stats[0] = a; stats[1] = b; stats[2] = (double)n;
     }
 }
 
@@ -75,10 +77,7 @@ extern "C" int cn_adv_stats(int64_t n, const float *returns, const float *values
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(n > 0 && returns && values && stats, "cn_adv_stats: bad argument");
-    CN_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), (hipStream_t)stream));
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(adv_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, returns, values, stats);
+    hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, returns, values, stats);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

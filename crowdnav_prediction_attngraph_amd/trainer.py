@@ -79,11 +79,56 @@ def bootstrap_value(actor_critic, rollouts):
     return actor_critic.get_value(obs, hxs, rollouts.masks[-1])
 
 
+def save_checkpoint(save_dir, update, actor_critic, agent, envs, rollouts, stats, device):
+    """`<save_dir>/checkpoints/<update:05d>.pt` is the policy state_dict exactly as train.py:213-219 writes it (loadable by the
+    reference's test.py and by --resume); `<update:05d>.resume.pt` beside it holds what a BIT-EXACT continuation needs on top:
+    optimiser state, both torch RNG streams, the simulator snapshot (cn_env_save), row 0 of the rollout storage and the episode
+    statistics accumulator.  One pair per rank under torch.distributed (`.rankN` suffix) since env shards and noise streams differ."""
+    import os
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    d = os.path.join(save_dir, "checkpoints")
+    os.makedirs(d, exist_ok=True)
+    stem = os.path.join(d, "%.5i" % update)
+    if rank == 0:
+        torch.save(actor_critic.state_dict(), stem + ".pt")
+    agent._sync_optimizer_state()
+    ck = {"format": 1, "update": update, "optimizer": agent.optimizer.state_dict(), "rng_cpu": torch.get_rng_state(),
+          "rng_cuda": torch.cuda.get_rng_state(device), "env": envs.state_dict(),
+          "rollout0": {"obs": {k: v[0].clone() for k, v in rollouts.obs.items()},
+                       "hxs": rollouts.recurrent_hidden_states["human_node_rnn"][0].clone(), "masks": rollouts.masks[0].clone(),
+                       "bad_masks": rollouts.bad_masks[0].clone()},
+          "stats": stats.acc.clone()}
+    path = stem + (".resume.pt" if rank == 0 else ".resume.rank%d.pt" % rank)
+    torch.save(ck, path)
+    return stem + ".pt", path
+
+
+def load_checkpoint(policy_path, resume_path, actor_critic, agent, envs, rollouts, stats, device):
+    """Inverse of save_checkpoint; returns the index of the next update."""
+    actor_critic.load_state_dict(torch.load(policy_path, map_location=device))          # train.py:105-108
+    ck = torch.load(resume_path, map_location="cpu")
+    agent.optimizer.load_state_dict(ck["optimizer"])       # PPO re-binds its flat buckets to the restored moments at the next update()
+    envs.load_state_dict(ck["env"])
+    r0 = ck["rollout0"]
+    for k in rollouts.obs:
+        rollouts.obs[k][0].copy_(r0["obs"][k])
+    rollouts.recurrent_hidden_states["human_node_rnn"][0].copy_(r0["hxs"])
+    rollouts.masks[0].copy_(r0["masks"]); rollouts.bad_masks[0].copy_(r0["bad_masks"])
+    stats.acc.copy_(ck["stats"])
+    torch.set_rng_state(ck["rng_cpu"])
+    torch.cuda.set_rng_state(ck["rng_cuda"], device)
+    return int(ck["update"]) + 1
+
+
 def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_updates=10, seed=425, config=None, ppo_epoch=5,
           num_mini_batch=2, lr=4e-5, eps=1e-5, clip_param=0.2, value_loss_coef=0.5, entropy_coef=0.0, max_grad_norm=0.5, gamma=0.99,
-          gae_lambda=0.95, log=print, device=None):
+          gae_lambda=0.95, log=print, device=None, save_dir=None, save_interval=0, resume=None):
     """Returns a list of per-update dicts (losses, timings, episode stats).  Works single- or multi-GPU (one process per
-    GPU, torch.distributed initialised by the caller)."""
+    GPU, torch.distributed initialised by the caller).  save_dir / save_interval: write checkpoints like train.py:213-219 (every
+    `save_interval` updates and after the last one); resume = path of a `NNNNN.pt` written by this function: continue that run
+    (updates NNNNN+1 .. num_updates-1) with results bit-identical to the uninterrupted run."""
     device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(seed)
     envs = make_vec_envs(env_name, seed, num_processes, gamma, None, device, False, config=config, phase="train")
@@ -100,7 +145,12 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
         rollouts.obs[k][0].copy_(obs[k].view_as(rollouts.obs[k][0]) if k != "visible_masks" else obs[k].to(torch.bool))
     stats = EpisodeStats(device)
     history = []
-    for j in range(num_updates):
+    first = 0
+    if resume is not None:
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        side = resume[:-3] + (".resume.pt" if rank == 0 else ".resume.rank%d.pt" % rank)
+        first = load_checkpoint(resume, side, actor_critic, agent, envs, rollouts, stats, device)
+    for j in range(first, num_updates):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         collect_rollout(envs, actor_critic, rollouts, stats)
@@ -117,5 +167,7 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
         history.append(rec)
         if log:
             log(rec)
+        if save_dir is not None and ((save_interval and j % save_interval == 0) or j == num_updates - 1):
+            save_checkpoint(save_dir, j, actor_critic, agent, envs, rollouts, stats, device)
     envs.close()
     return history, actor_critic

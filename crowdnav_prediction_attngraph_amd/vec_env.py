@@ -125,6 +125,17 @@ class BatchedCrowdSim(object):
     def render(self, mode="human"):
         raise NotImplementedError("rendering is out of scope of the accelerated path (use the reference env to visualise)")
 
+    # ---- checkpointing (a bit-exact --resume needs the simulator state, not only the policy: train.py:105-108 restores weights only) ----
+    def state_dict(self):
+        if self._pretext is not None:
+            raise NotImplementedError("checkpointing the GST wrapper's observation history is not implemented")
+        return {"env": self._env.state_dict(), "env_name": self.env_name, "num_envs": self.num_envs}
+
+    def load_state_dict(self, sd):
+        if sd.get("env_name") != self.env_name or sd.get("num_envs") != self.num_envs:
+            raise A.CnError("checkpoint is for %s x %s envs, this vec-env is %s x %d" % (sd.get("env_name"), sd.get("num_envs"), self.env_name, self.num_envs))
+        self._env.load_state_dict(sd["env"])
+
     def close(self):
         if not self._closed:
             self._env.close()

@@ -182,3 +182,70 @@ def test_reference_shaped_train_loop_through_dropin_names(tmp_path):
         envs.close()
     finally:
         sys.argv = old_argv
+
+
+def test_training_resume_is_bit_exact(tmp_path):
+    """train(4 updates) == train(2 updates, checkpoint) + train(resume, updates 2..3): identical losses and final weights, bit for bit
+    (policy + Adam moments + both torch RNG streams + the simulator snapshot + row 0 of the rollout storage are restored).  The policy
+    file alone is the reference's checkpoint format (train.py:213-219) and loads into a fresh Policy."""
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.trainer import train
+    cfg = C.Config(**{"sim.human_num": 10})      # randomised humans + goal changes: the env draws from its MT19937 streams all the time
+    kw = dict(env_name="CrowdSimVarNum-v0", num_processes=64, num_steps=8, seed=3, config=cfg, log=None, lr=1e-3)
+    full, pol_full = train(num_updates=4, **kw)
+    a_dir = str(tmp_path / "a")
+    part, _ = train(num_updates=2, save_dir=a_dir, **kw)
+    ck = os.path.join(a_dir, "checkpoints", "00001.pt")
+    assert os.path.isfile(ck) and os.path.isfile(ck[:-3] + ".resume.pt")
+    rest, pol_res = train(num_updates=4, resume=ck, **kw)
+    assert [r["update"] for r in rest] == [2, 3]
+    for a, b in zip(full[2:], rest):
+        for k in ("value_loss", "action_loss", "entropy", "episodes", "eprewmean"):
+            assert a[k] == b[k], (a["update"], k, a[k], b[k])
+    for (k, x), (_, y) in zip(pol_full.state_dict().items(), pol_res.state_dict().items()):
+        assert torch.equal(x, y), k
+    for a, b in zip(full[:2], part):
+        assert a["value_loss"] == b["value_loss"]     # and the run itself is reproducible
+    sd = torch.load(ck)
+    assert list(sd) == list(pol_full.state_dict())    # reference-format policy checkpoint
+
+
+def test_recurrent_generator_on_the_gpu_matches_reference_layout():
+    """R4 on the device: the vectorised index_select gather of RolloutStorage.recurrent_generator against the reference's per-env
+    Python loop (rl/networks/storage.py:184-253) restated here on the same permutation: T-major flattening, hidden state at t = 0 only."""
+    from crowdnav_prediction_attngraph_amd.policy import make_spaces
+    from crowdnav_prediction_attngraph_amd.storage import RolloutStorage
+    T, E, H, D, nmb = 5, 12, 6, 12, 3
+    ob_space, act_space = make_spaces(H, D)
+    ro = RolloutStorage(T, E, ob_space.spaces, act_space, 128, 256)
+    g = torch.Generator().manual_seed(0)
+    for k, v in ro.obs.items():
+        v.copy_((torch.rand(v.shape, generator=g) > 0.5) if v.dtype == torch.bool else torch.randn(v.shape, generator=g))
+    for name in ("rewards", "value_preds", "returns", "action_log_probs", "actions", "masks"):
+        getattr(ro, name).copy_(torch.randn(getattr(ro, name).shape, generator=g))
+    ro.recurrent_hidden_states["human_node_rnn"].copy_(torch.randn(T + 1, E, 1, 128, generator=g))
+    adv = torch.randn(T, E, 1, generator=g)
+    cpu = {k: v.clone() for k, v in ro.obs.items()}
+    cpu.update(actions=ro.actions.clone(), value_preds=ro.value_preds.clone(), returns=ro.returns.clone(), masks=ro.masks.clone(),
+               logp=ro.action_log_probs.clone(), hxs=ro.recurrent_hidden_states["human_node_rnn"].clone(), adv=adv.clone())
+    ro.to(torch.device("cuda"))
+    torch.manual_seed(17)
+    perm = torch.randperm(E)
+    torch.manual_seed(17)
+    npb = E // nmb
+    n = 0
+    for b, (obs_b, hx_b, act_b, vp_b, ret_b, m_b, lp_b, adv_b) in enumerate(ro.recurrent_generator(adv.cuda(), nmb)):
+        idx = perm[b * npb:(b + 1) * npb]
+        # the reference: per env `ind` stack x[:-1, ind] (or x[:, ind]) along dim 1, then view(T * N, ...)
+        ref = lambda x, cut: torch.stack([x[:T, i] if cut else x[:, i] for i in idx], 1).reshape(T * npb, *x.shape[2:])  # noqa: E731
+        for k in obs_b:
+            assert torch.equal(obs_b[k].cpu(), ref(cpu[k], True)), k
+        assert torch.equal(act_b.cpu(), ref(cpu["actions"], False)) and torch.equal(vp_b.cpu(), ref(cpu["value_preds"], True))
+        assert torch.equal(ret_b.cpu(), ref(cpu["returns"], True)) and torch.equal(m_b.cpu(), ref(cpu["masks"], True))
+        assert torch.equal(lp_b.cpu(), ref(cpu["logp"], False)) and torch.equal(adv_b.cpu(), ref(cpu["adv"], False))
+        assert torch.equal(hx_b["human_node_rnn"].cpu(), torch.stack([cpu["hxs"][0, i] for i in idx], 0))
+        assert hx_b["human_human_edge_rnn"].shape == (npb, H + 1, 256) and obs_b["spatial_edges"].is_cuda
+        n += 1
+    assert n == nmb
+    with pytest.raises(IndexError):
+        next(iter(RolloutStorage(T, 5, ob_space.spaces, act_space, 128, 256).recurrent_generator(torch.zeros(T, 5, 1), 2)))

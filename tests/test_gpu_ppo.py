@@ -71,8 +71,8 @@ def test_adam_clip_step_matches_torch(n, max_norm):
         np.testing.assert_allclose(gd.cpu().numpy(), ref.grad.numpy(), rtol=2e-6, atol=1e-12)   # grads scaled in place like clip_grad_norm_
         np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=5e-7)
     st = opt.state[ref]
-    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-4, atol=1e-12)
-    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-4, atol=1e-20)
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-4, atol=1e-6 * float(st["exp_avg"].abs().max()))  # lerp cancels near zero
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-4, atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz"))), ids=lambda p: os.path.basename(p)[8:-4])
