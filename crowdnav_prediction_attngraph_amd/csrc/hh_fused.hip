@@ -525,6 +525,9 @@ __global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, c
                                                           HhFusedWeights W, float *__restrict__ out_sp)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // this kernel is the critical path of the step; the simulator's ORCA wavefronts of the side stream share the SIMDs with it and
+    // are latency tolerant (81 920 short wavefronts): win the issue arbitration against them
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total = row_off[E];
     // chunk of this workgroup: rows [c*Q, (c+1)*Q) snapped to env starts

@@ -89,6 +89,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ Wfrag, int fb_fi
 __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3); // critical path of the step: win the issue arbitration against the side stream's simulator wavefronts
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e0 = blockIdx.x * TE;
     float *R0 = smem + O_R0, *R1 = smem + O_R1, *R2 = smem + O_R2, *R3 = smem + O_R3, *R4 = smem + O_R4, *R5 = smem + O_R5;
