@@ -62,8 +62,11 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         unsupported.append("humans.policy != 'orca'")
     if float(g("humans", "FOV", 2.)) != 2.0 or float(g("robot", "FOV", 2)) != 2.0:
         unsupported.append("FOV != 2*pi")
-    if env_name == "CrowdSimPred-v0" and g("sim", "predict_method", "const_vel") != "const_vel":
-        unsupported.append("sim.predict_method=%r (only const_vel)" % g("sim", "predict_method", None))
+    pm = g("sim", "predict_method", "const_vel")
+    if env_name == "CrowdSimPred-v0" and pm not in ("const_vel", "truth"):
+        unsupported.append("sim.predict_method=%r (CrowdSimPred-v0 runs with 'const_vel' or 'truth')" % pm)
+    if env_name == "CrowdSimPred-v0" and pm == "truth" and rv:
+        unsupported.append("sim.predict_method='truth' with robot.visible=True")
     rp = g("robot", "policy", "selfAttn_merge_srnn")
     if rp not in ("selfAttn_merge_srnn", "srnn", "orca"):
         unsupported.append("robot.policy=%r (the network policies and 'orca' are implemented)" % rp)
@@ -79,6 +82,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
         sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
+        predict_truth=int(env_name == "CrowdSimPred-v0" and pm == "truth"),
         phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy=1 if rp == "orca" else 0, robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
         time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),
         success_reward=float(g("reward", "success_reward", 10)), collision_penalty=float(g("reward", "collision_penalty", -20)),

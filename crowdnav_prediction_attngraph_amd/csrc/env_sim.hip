@@ -65,6 +65,7 @@ struct EnvDev {
     double *tr;       // [E][P+1][4][H] px,py,vx,vy; slice 0 unused (k = 1 reads the live state)
     uint8_t *vis;     // [E][H]
     double *min_dist; // [E]
+    uint8_t *pend;    // [E] predict_truth only: 1 = the env was reset by the first half of the step (observation still to be written)
 };
 
 // The reference's rejection sampling of human positions / goals is unbounded; after this many attempts the last candidate is
@@ -375,8 +376,21 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
     const double spx = __shfl(px, i, 64), spy = __shfl(py, i, 64), svx = __shfl(vx, i, 64), svy = __shfl(vy, i, 64);
     const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i];
     const size_t ei = (size_t)e * H + i;
-    const float nd = s.sim_nd[ei], self_r = s.sim_self_radius[ei], self_ms = s.sim_self_maxspeed[ei]; // built by orca_kernel just before
-    const float seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + s.cfg.orca_safety_space);
+    float nd, self_r, self_ms, seen_r;
+    if (!s.sim_valid[ei]) {
+        // predict_method 'truth' as the observation predictor: the roll-out of a freshly reset env runs before any ORCA step, and
+        // act_joint_state builds the private simulator exactly like ORCA.predict would (orca.py:83-89)
+        const double safety = s.cfg.orca_safety_space;
+        nd = (float)s.shared_nd[e];
+        self_r = (float)(hum[F_RAD * H + i] + 0.01 + safety);
+        self_ms = (float)hum[F_VPREF * H + i];
+        seen_r = (float)(rad + 0.01 + safety);
+        if (s.sim_seen && isH) s.sim_seen[ei * H + lane] = seen_r;
+        if (lane == 0) { s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1; }
+    } else {
+        nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
+        seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + s.cfg.orca_safety_space);
+    }
     const bool cand = isH && lane != i;
     double gvx = sgx - spx, gvy = sgy - spy;
     const double speed = sqrt(gvx * gvx + gvy * gvy);
@@ -622,9 +636,15 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool
             se[1] = vis ? (float)ey : 15.0f;
         } else {
             double *ft = s.ftraj ? s.ftraj + (size_t)e * P * 2 * H : nullptr;
+            const double *tre = c.predict_truth ? s.tr + (size_t)e * (P + 1) * 4 * H : nullptr;
             for (int k = 0; k <= P; ++k) {
                 double fx = 15.0, fy = 15.0;
-                if (vis) {
+                if (vis && tre && k >= 1) {
+                    // sim.predict_method = 'truth' (crowd_sim_pred.py:81 -> crowd_sim_var_num.py:180-206): the humans' own ORCA rolled
+                    // forward from the state just reached, computed by orca_truth_kernel between the two halves of the step
+                    fx = tre[(k * 4 + 0) * H + lane];
+                    fy = tre[(k * 4 + 1) * H + lane];
+                } else if (vis) {
                     const double t = (double)k * c.time_step * 1.0; // pred_interval == 1 (config.py:130-131)
                     fx = h.px + t * prev_vx;
                     fy = h.py + t * prev_vy;
@@ -669,7 +689,7 @@ __device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int 
 }
 
 // the rest of reset(): belief cleared (:108), case counter advanced (:348), episode statistics, first observation
-__device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, Robot &rb, Lane &h, const cn_obs &ob)
+__device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, Robot &rb, Lane &h, const cn_obs &ob, bool with_obs = true)
 {
     const cn_env_config &c = s.cfg;
     h.l0 = h.l1 = h.l2 = h.l3 = h.l4 = 0.0;
@@ -678,11 +698,12 @@ __device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, R
         s.case_counter[e] = (s.case_counter[e] + (uint64_t)c.nenv) % case_size;
         s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0;
     }
-    write_obs(s, e, lane, true, rb, h, ob);
+    if (with_obs) write_obs(s, e, lane, true, rb, h, ob);
 }
 
 // crowd_sim_var_num.py:303-363 reset.  Uses the pre-generated episode when the side stream has one ready.
-__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, const cn_obs &ob)
+__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, const cn_obs &ob,
+                                         bool with_obs = true)
 {
     if (s.nx_ready[e]) {
         const int H = s.H;
@@ -703,7 +724,7 @@ __device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lan
     } else {
         gen_episode(s, R, e, lane, rb, h, shared_nd);
     }
-    finish_reset(s, e, lane, rb, h, ob);
+    finish_reset(s, e, lane, rb, h, ob, with_obs);
 }
 
 __device__ __forceinline__ void load_env(const EnvDev &s, int e, int lane, Robot &rb, Lane &h)
@@ -736,7 +757,7 @@ __device__ __forceinline__ void store_env(const EnvDev &s, int e, int lane, cons
     }
 }
 
-__global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob)
+__global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int with_obs)
 {
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
@@ -745,7 +766,8 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob)
     Lane h{};
     h.rad = s.cfg.human_radius;
     double shared_nd = s.cfg.orca_neighbor_dist;
-    do_reset(s, R, e, lane, rb, h, shared_nd, ob);
+    do_reset(s, R, e, lane, rb, h, shared_nd, ob, with_obs != 0);
+    if (!with_obs && lane == 0) s.pend[e] = 1;
     store_env(s, e, lane, rb, h);
     if (lane == 0) s.shared_nd[e] = shared_nd;
     rng_store(R, s, e, lane);
@@ -783,6 +805,51 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
 
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
 // (rl/networks/shmem_vec_env.py:139-142).  ORCA velocities for this step were produced by orca_kernel.
+// goal changes every 5 s and respawns of the humans that reached their goal (crowd_sim_var_num.py:446-456): after the observation
+__device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e, int lane, int step_counter, const Robot &rb, Lane &h, double &shared_nd)
+{
+    const cn_env_config &c = s.cfg;
+    const int H = s.H;
+    const bool isH = lane < H;
+    const int period = (int)(5.0 / c.time_step + 0.5);
+    if (c.random_goal_changing && (step_counter % period) == 0) {
+        rng_load(R, s, e, lane);
+        change_goals(s, R, lane, rb, h);
+    }
+    if (c.end_goal_changing) {
+        uint64_t reached = __ballot(isH && norm2(h.gx - h.px, h.gy - h.py) < h.rad);
+        if (reached) rng_load(R, s, e, lane);
+        while (reached) {
+            const int i = __ffsll((unsigned long long)reached) - 1;
+            reached &= reached - 1;
+            gen_human(s, R, lane, i, H, rb, h, shared_nd);
+        }
+    }
+}
+
+// Second half of a step when the observation needs the 'truth' roll-outs of the state just reached (sim.predict_method = 'truth'):
+// observation (reset or step form), then the post-observation updates of the envs that were not reset.
+__global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
+{
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    Rng R{MT_N, false};
+    Robot rb;
+    Lane h;
+    load_env(s, e, lane, rb, h);
+    double shared_nd = s.shared_nd[e];
+    const bool was_reset = s.pend[e] != 0;
+    write_obs(s, e, lane, was_reset, rb, h, ob);
+    if (!was_reset) post_obs_updates(s, R, e, lane, s.step_counter[e], rb, h, shared_nd);
+    if (lane == 0) s.pend[e] = 0;
+    store_env(s, e, lane, rb, h);
+    if (lane == 0) s.shared_nd[e] = shared_nd;
+    rng_store(R, s, e, lane);
+}
+
+// SPLIT = true: first half only (everything up to the kinematics and the reset bookkeeping); env_obs_kernel finishes the step after
+// the roll-out kernels.
+template <bool SPLIT>
 __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
                                                       uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
@@ -908,26 +975,14 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     if (done && c.auto_reset) {
         // vec-env auto-reset: the terminal observation is replaced by the first observation of the next episode.
         // (The terminal step's own goal-change / respawn draws happen before np.random.seed and cannot be observed.)
-        do_reset(s, R, e, lane, rb, h, shared_nd, ob);
+        do_reset(s, R, e, lane, rb, h, shared_nd, ob, !SPLIT);
+        if (SPLIT && lane == 0) s.pend[e] = 1;
     } else {
         // (auto_reset == 0, the single-env gym object: a terminal step is an ordinary step -- terminal observation, goal
         // changes and respawns included, crowd_sim_var_num.py:430-458 -- and the caller resets explicitly)
-        write_obs(s, e, lane, false, rb, h, ob);
-        // crowd_sim_var_num.py:446-448: every 5 s of simulated time
-        const int period = (int)(5.0 / c.time_step + 0.5);
-        if (c.random_goal_changing && (step_counter % period) == 0) {
-            rng_load(R, s, e, lane);
-            change_goals(s, R, lane, rb, h);
-        }
-        // :451-456: humans that reached their goal are replaced by freshly generated ones, in index order
-        if (c.end_goal_changing) {
-            uint64_t reached = __ballot(isH && norm2(h.gx - h.px, h.gy - h.py) < h.rad);
-            if (reached) rng_load(R, s, e, lane);
-            while (reached) {
-                const int i = __ffsll((unsigned long long)reached) - 1;
-                reached &= reached - 1;
-                gen_human(s, R, lane, i, H, rb, h, shared_nd);
-            }
+        if (!SPLIT) {
+            write_obs(s, e, lane, false, rb, h, ob);
+            post_obs_updates(s, R, e, lane, step_counter, rb, h, shared_nd);
         }
         if (lane == 0) { s.step_counter[e] = step_counter; s.ep_ret[e] = ep_ret; s.ep_cnt[e] = ep_cnt; }
     }
@@ -969,6 +1024,20 @@ struct cn_env_batch {
     hipEvent_t ev_state, ev_orca;
     bool orca_ready; // hact for the current state has been enqueued on `side`
 };
+
+// sim.predict_method = 'truth': roll the humans forward P times from the state the first half of the step (or the reset) left, then
+// write the observation and run the post-observation updates
+static int truth_rollout_and_obs(cn_env_batch *env, const cn_obs *obs, hipStream_t st)
+{
+    const int agents = env->d.E * env->d.H;
+    for (int k = 1; k <= env->d.P; ++k) {
+        hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, st, env->d, k);
+        CN_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(env_obs_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 static int prefetch_orca(cn_env_batch *env, hipStream_t main)
 {
@@ -1025,6 +1094,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(!cfg->robot_visible || (cfg->env_kind == CN_ENV_VARNUM && cfg->phase == CN_PHASE_TRAIN && cfg->human_num <= CN_MAX_HUMANS - 1),
                "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num <= %d (the reference rebuilds every private "
                "simulator twice per step in the test phase and breaks in CrowdSimPred)", CN_MAX_HUMANS - 1);
+    CN_REQUIRE(!cfg->predict_truth || (cfg->env_kind == CN_ENV_PRED && !cfg->robot_visible),
+               "cn_env_create: predict_truth (sim.predict_method = 'truth') is CrowdSimPred-v0 with an invisible robot");
     CN_REQUIRE(cfg->time_step > 0 && std::fabs(5.0 / cfg->time_step - std::round(5.0 / cfg->time_step)) < 1e-9,
                "cn_env_create: time_step must divide 5 s");
     cn_env_batch *b = new (std::nothrow) cn_env_batch{};
@@ -1045,9 +1116,11 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
     const size_t o_nh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
     const bool test_phase = cfg->phase == CN_PHASE_TEST;
+    const bool truth_obs = cfg->predict_truth != 0;
     const bool rob_orca = cfg->robot_policy == CN_ROBOT_ORCA;
     const size_t o_rsv = rob_orca ? carve(E) : 0, o_rnd = rob_orca ? carve(E * 4) : 0, o_rsn = rob_orca ? carve(E * H * 4) : 0;
-    const size_t o_tr = test_phase ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = test_phase ? carve(E * H) : 0, o_md = carve(E * 8);
+    const size_t o_tr = (test_phase || truth_obs) ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = (test_phase || truth_obs) ? carve(E * H) : 0, o_md = carve(E * 8);
+    const size_t o_pend = carve(E);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -1065,7 +1138,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
     d.nx_hum = (double *)(base + o_nh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
-    d.tr = test_phase ? (double *)(base + o_tr) : nullptr; d.vis = test_phase ? (uint8_t *)(base + o_vis) : nullptr;
+    d.tr = (test_phase || truth_obs) ? (double *)(base + o_tr) : nullptr; d.vis = (test_phase || truth_obs) ? (uint8_t *)(base + o_vis) : nullptr;
+    d.pend = (uint8_t *)(base + o_pend);
     d.min_dist = (double *)(base + o_md);
     d.rob_sim_valid = rob_orca ? (uint8_t *)(base + o_rsv) : nullptr; d.rob_nd = rob_orca ? (float *)(base + o_rnd) : nullptr;
     d.rob_seen = rob_orca ? (float *)(base + o_rsn) : nullptr;
@@ -1105,8 +1179,10 @@ extern "C" int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream)
     hipStream_t st = (hipStream_t)stream;
     // VecEnv.reset() resets every env; case counters keep running (crowd_sim_var_num.py:348)
     if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // an in-flight prefetch reads the old state
-    hipLaunchKernelGGL(env_reset_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs);
+    const bool split = env->d.cfg.predict_truth != 0;
+    hipLaunchKernelGGL(env_reset_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs, split ? 0 : 1);
     CN_CHECK_LAUNCH();
+    if (split) { if (int rc = truth_rollout_and_obs(env, obs, st)) return rc; }
     env->reset_done = true;
     return prefetch_orca(env, st);
 }
@@ -1121,8 +1197,14 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     hipStream_t st = (hipStream_t)stream;
     if (!env->orca_ready) { if (int rc = prefetch_orca(env, st)) return rc; }
     CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // human velocities for the current state (computed on the side stream)
-    hipLaunchKernelGGL(env_step_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
-    CN_CHECK_LAUNCH();
+    if (env->d.cfg.predict_truth) {
+        hipLaunchKernelGGL(env_step_kernel<true>, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        CN_CHECK_LAUNCH();
+        if (int rc = truth_rollout_and_obs(env, obs, st)) return rc;
+    } else {
+        hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        CN_CHECK_LAUNCH();
+    }
     return prefetch_orca(env, st); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
 }
 

@@ -84,7 +84,9 @@ typedef struct {
     int32_t auto_reset;           /* 1 (default): vec-env semantics, a finished env is reset inside cn_env_step and `obs` holds the
                                    * reset observation (shmem_vec_env.py:139-142); 0: single gym env semantics
                                    * (crowd_sim_var_num.py:366-460 alone): the terminal observation is returned, cn_env_reset restarts */
-    int32_t reserved0;            /* keep 0 */
+    int32_t predict_truth;        /* CrowdSimPred-v0 with sim.predict_method = 'truth' (crowd_sim_pred.py:81, crowd_sim_var_num.py:180-206): the
+                                   * observation carries the humans' TRUE future positions (their own ORCA rolled forward predict_steps
+                                   * times from the state just reached) instead of constant-velocity extrapolations */
     int32_t max_placement_attempts; /* bound of the reference's UNBOUNDED rejection sampling of human positions / goals
                                    * (crowd_sim_var_num.py:116-146, crowd_sim.py:415-450): after this many attempts the last
                                    * candidate is accepted; 0 = 65536.  Dense randomised crowds have seeds where the reference

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_KIND = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
 
 
-ORACLE_ONLY = ("sfhumans", "_range", "unicycle", "truthobs")   # settings the HIP simulator does not implement yet
+ORACLE_ONLY = ("sfhumans", "_range", "unicycle")   # settings the HIP simulator does not implement yet
 
 
 def env_fixtures(device=False):
@@ -34,7 +34,7 @@ def sim_kwargs(meta, oracle=False):
         extra["humans_policy"] = 1
     if oracle and over.get("sim.human_num_range", 0):
         extra["human_num_range"] = int(over["sim.human_num_range"])
-    if oracle and over.get("sim.predict_method", "none") == "truth":
+    if over.get("sim.predict_method", "none") == "truth":
         extra["predict_truth"] = 1
     if oracle and over.get("action_space.kinematics", "holonomic") == "unicycle":
         extra["kinematics"] = 1

@@ -48,6 +48,11 @@ CASES = {
     "varnum_h10_rand_orcarobot_test": dict(human_num=10, robot_policy=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     # robot.visible: the humans' ORCA sees the robot as one more neighbour
     "varnum_h20_robotvisible": dict(human_num=20, robot_visible=1),
+    # sim.predict_method = 'truth' as the observation predictor (the paper's "oracle prediction" variant): the step is split around the
+    # roll-out kernels; train and test phase, fixed and randomised humans
+    "pred_h20_truthobs": dict(human_num=20, env_kind=1, predict_truth=1),
+    "pred_h10_rand_truthobs": dict(human_num=10, env_kind=1, predict_truth=1, randomize_attributes=1, random_goal_changing=1),
+    "pred_h10_rand_truthobs_test": dict(human_num=10, env_kind=1, predict_truth=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     # a tight bound on the (in the reference unbounded) placement rejection loops: the cap path itself is bit-exact too
     "varnum_h50_rand_cap64": dict(human_num=50, randomize_attributes=1, random_goal_changing=1, max_placement_attempts=64),
     "varnum_h63_rand_robotvisible": dict(human_num=63, robot_visible=1, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
