@@ -27,6 +27,7 @@ class EnvConfig(C.Structure):
         ("end_goal_changing", C.c_int32), ("sort_humans", C.c_int32), ("phase", C.c_int32),
         ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32), ("robot_policy", C.c_int32),
         ("robot_visible", C.c_int32), ("auto_reset", C.c_int32), ("predict_truth", C.c_int32), ("max_placement_attempts", C.c_int32),
+        ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("humans_policy", C.c_int32), ("reserved0", C.c_int32),
         ("time_step", C.c_double), ("time_limit", C.c_double),
         ("success_reward", C.c_double), ("collision_penalty", C.c_double),
         ("discomfort_dist", C.c_double), ("discomfort_penalty_factor", C.c_double),
@@ -36,6 +37,7 @@ class EnvConfig(C.Structure):
         ("goal_change_chance", C.c_double), ("end_goal_change_chance", C.c_double),
         ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
+        ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
     ]
 
 
@@ -101,7 +103,7 @@ class PolicyWeights(C.Structure):
 # every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
-    "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
+    "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
@@ -132,6 +134,7 @@ def lib():
         L.cn_env_get_state.argtypes = [vp, vp, vp, vp]
         L.cn_env_get_danger_min_dist.argtypes = [vp, vp, vp]
         L.cn_env_set_case_counters.argtypes = [vp, vp, vp]
+        L.cn_env_get_human_counts.argtypes = [vp, vp, vp]
         L.cn_env_get_human_actions.argtypes = [vp, vp, vp]
         L.cn_env_snapshot_bytes.argtypes = [vp]
         L.cn_env_snapshot_bytes.restype = i64

@@ -51,11 +51,12 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         raise NotImplementedError("env id %r is not on the accelerated path (supported: %s)" % (env_name, sorted(A.ENV_KINDS)))
     g = lambda ns, name, default: getattr(getattr(config, ns, None), name, default)  # noqa: E731
     unsupported = []
-    if g("sim", "human_num_range", 0) != 0:
-        unsupported.append("sim.human_num_range != 0")
+    hn, hr = int(g("sim", "human_num", 20)), int(g("sim", "human_num_range", 0))
+    if not 0 <= hr < hn or hn + hr > 64:
+        unsupported.append("sim.human_num_range outside [0, human_num) or human_num + human_num_range > 64")
     rv = bool(g("robot", "visible", False))
-    if rv and (env_name != "CrowdSimVarNum-v0" or phase != "train" or int(g("sim", "human_num", 20)) > 63):
-        unsupported.append("robot.visible=True outside CrowdSimVarNum-v0 / phase train / human_num <= 63")
+    if rv and (env_name != "CrowdSimVarNum-v0" or phase != "train" or hn + hr > 63):
+        unsupported.append("robot.visible=True outside CrowdSimVarNum-v0 / phase train / human_num + human_num_range <= 63")
     if g("action_space", "kinematics", "holonomic") != "holonomic":
         unsupported.append("unicycle kinematics")
     if g("humans", "policy", "orca") != "orca":
@@ -77,7 +78,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     if unsupported:
         raise NotImplementedError("not implemented on the device path yet: " + "; ".join(unsupported))
     return A.default_env_config(
-        human_num=int(g("sim", "human_num", 20)), predict_steps=int(g("sim", "predict_steps", 5)), env_kind=A.ENV_KINDS[env_name],
+        human_num=hn, human_num_range=hr, predict_steps=int(g("sim", "predict_steps", 5)), env_kind=A.ENV_KINDS[env_name],
         randomize_attributes=int(bool(g("env", "randomize_attributes", True))),
         random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),

@@ -66,7 +66,17 @@ struct EnvDev {
     uint8_t *vis;     // [E][H]
     double *min_dist; // [E]
     uint8_t *pend;    // [E] predict_truth only: 1 = the env was reset by the first half of the step (observation still to be written)
+    // sim.human_num_range > 0 only (all null otherwise): H is then human_num + human_num_range = the lane stride and the number of
+    // observation rows, and the crowd of env e is its first nh[e] slots (crowd_sim_var_num.py:103-104, :404-437)
+    int32_t *nh;        // [E] len(self.humans)
+    int32_t *nx_nh;     // [E] ... of the staged next episode
+    int32_t *obs_cnt;   // [E] len(self.observed_human_ids)
+    int32_t *obs_max;   // [E] max(self.observed_human_ids), -1 when empty
+    uint8_t *sim_n;     // [E][H] agent count human i's private simulator was built for (orca.py:80-82 rebuilds on a change)
+    uint8_t *rob_sim_n; // [E] ... the robot's (robot.policy == 'orca')
 };
+
+__device__ __forceinline__ int crowd_size(const EnvDev &s, int e) { return s.nh ? s.nh[e] : s.H; }
 
 // The reference's rejection sampling of human positions / goals is unbounded; after this many attempts the last candidate is
 // accepted (same constant and rule in the oracle: oracle/crowdsim_oracle.h ORC_MAX_PLACEMENT_ATTEMPTS).
@@ -306,8 +316,10 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
     if (agent >= s.E * s.H) return;
     const int H = s.H;
     const int e = agent / H, i = agent - e * H;
+    const int n = crowd_size(s, e); // humans present (== H unless sim.human_num_range > 0)
+    if (i >= n) return;
     const double *hum = s.hum + (size_t)e * 8 * H;
-    const bool isH = lane < H;
+    const bool isH = lane < n;
     const int lj = isH ? lane : 0;
     const double px = hum[F_PX * H + lj], py = hum[F_PY * H + lj], vx = hum[F_VX * H + lj], vy = hum[F_VY * H + lj];
     const double rad = hum[F_RAD * H + lj];
@@ -318,7 +330,9 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
     // lazily (re)build human i's private simulator: orca.py:83-89
     const size_t ei = (size_t)e * H + i;
     float nd, self_r, self_ms, seen_r;
-    if (!s.sim_valid[ei]) {
+    const bool rv = s.cfg.robot_visible != 0;
+    const int n_agents = n + (rv ? 1 : 0);
+    if (!s.sim_valid[ei] || (s.sim_n && s.sim_n[ei] != n_agents)) {
         nd = (float)s.shared_nd[e];
         self_r = (float)(srad + 0.01 + safety);
         self_ms = (float)svpref;
@@ -326,15 +340,15 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
         if (s.sim_seen && isH) s.sim_seen[ei * H + lane] = seen_r;
         if (lane == 0) {
             s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1;
+            if (s.sim_n) s.sim_n[ei] = (uint8_t)n_agents;
         }
     } else {
         nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
         seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + safety);
     }
     // other humans as seen by i (human FOV = 2*pi: always the true state unless coincident -> dummy (7,7,0,0)); with
-    // robot.visible the robot is appended as the last neighbour on lane H (crowd_sim.py:695-699), same visibility rule
-    const bool rv = s.cfg.robot_visible != 0;
-    const bool isR = rv && lane == H;
+    // robot.visible the robot is appended as the last neighbour on lane n (crowd_sim.py:695-699), same visibility rule
+    const bool isR = rv && lane == n;
     const double *rob = s.rob + (size_t)e * 8;
     const double qx = isR ? rob[R_PX] : px, qy = isR ? rob[R_PY] : py, qvx = isR ? rob[R_VX] : vx, qvy = isR ? rob[R_VY] : vy;
     if (isR) seen_r = (float)(s.cfg.robot_radius + 0.01 + safety); // fixed for the whole run
@@ -347,8 +361,8 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
     const double speed = sqrt(gvx * gvx + gvy * gvy);
     if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
     float ox, oy;
-    orca_wave(lane, rv ? H + 1 : H, cand, opx, opy, ovx, ovy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
-              (float)gvx, (float)gvy, nd, rv ? H : H - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
+    orca_wave(lane, n_agents, cand, opx, opy, ovx, ovy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
+              (float)gvx, (float)gvy, nd, n_agents - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
     if (lane == 0) {
         s.hact[(size_t)e * 2 * H + i] = ox;
         s.hact[(size_t)e * 2 * H + H + i] = oy;
@@ -366,10 +380,12 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
     if (agent >= s.E * s.H) return;
     const int H = s.H;
     const int e = agent / H, i = agent - e * H;
+    const int n = crowd_size(s, e);
+    if (i >= n) return;
     const double *hum = s.hum + (size_t)e * 8 * H;
     double *trk = s.tr + ((size_t)e * (s.P + 1) + k) * 4 * H;
     const double *src = k == 1 ? hum : trk - 4 * H; // F_PX..F_VY are fields 0..3: the live state has the same [4][H] layout
-    const bool isH = lane < H;
+    const bool isH = lane < n;
     const int lj = isH ? lane : 0;
     const double px = src[0 * H + lj], py = src[1 * H + lj], vx = src[2 * H + lj], vy = src[3 * H + lj];
     const double rad = hum[F_RAD * H + lj];
@@ -377,7 +393,7 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
     const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i];
     const size_t ei = (size_t)e * H + i;
     float nd, self_r, self_ms, seen_r;
-    if (!s.sim_valid[ei]) {
+    if (!s.sim_valid[ei] || (s.sim_n && s.sim_n[ei] != n)) {
         // predict_method 'truth' as the observation predictor: the roll-out of a freshly reset env runs before any ORCA step, and
         // act_joint_state builds the private simulator exactly like ORCA.predict would (orca.py:83-89)
         const double safety = s.cfg.orca_safety_space;
@@ -386,7 +402,10 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
         self_ms = (float)hum[F_VPREF * H + i];
         seen_r = (float)(rad + 0.01 + safety);
         if (s.sim_seen && isH) s.sim_seen[ei * H + lane] = seen_r;
-        if (lane == 0) { s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1; }
+        if (lane == 0) {
+            s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1;
+            if (s.sim_n) s.sim_n[ei] = (uint8_t)n;
+        }
     } else {
         nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
         seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + s.cfg.orca_safety_space);
@@ -396,8 +415,8 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
     const double speed = sqrt(gvx * gvx + gvy * gvy);
     if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
     float ox, oy;
-    orca_wave(lane, H, cand, (float)px, (float)py, (float)vx, (float)vy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
-              (float)gvx, (float)gvy, nd, H - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
+    orca_wave(lane, n, cand, (float)px, (float)py, (float)vx, (float)vy, seen_r, (float)spx, (float)spy, (float)svx, (float)svy, self_r, self_ms,
+              (float)gvx, (float)gvy, nd, n - 1, (float)s.cfg.orca_time_horizon, (float)s.cfg.time_step, ox, oy);
     if (lane == 0) {
         trk[0 * H + i] = spx + (double)ox * s.cfg.time_step;
         trk[1 * H + i] = spy + (double)oy * s.cfg.time_step;
@@ -517,6 +536,18 @@ __device__ __forceinline__ double rng_double(Rng &R, int lane)
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 __device__ __forceinline__ double rng_uniform(Rng &R, int lane, double lo, double hi) { return lo + (hi - lo) * rng_double(R, lane); }
+// legacy RandomState.randint(low, high), default int64 dtype (numpy/random/_bounded_integers: _rand_int64 -> masked rejection on 32-bit
+// words): no draw when the range is a single value
+__device__ __forceinline__ int rng_randint(Rng &R, int lane, int low, int high)
+{
+    const uint32_t rng = (uint32_t)(high - 1 - low);
+    if (rng == 0) return low;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    do { v = rng_u32(R, lane) & mask; } while (v > rng);
+    return low + (int)v;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Per-env wavefront state: lane j owns human j.
@@ -564,10 +595,10 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
 }
 
 // crowd_sim.py:415-450 update_human_goals_randomly
-__device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, const Robot &rb, Lane &h)
+__device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, int n, const Robot &rb, Lane &h)
 {
     const cn_env_config &c = s.cfg;
-    const int H = s.H;
+    const int H = n; // the humans present
     for (int i = 0; i < H; ++i) {
         const double vp_i = __shfl(h.vpref, i, 64), rad_i = __shfl(h.rad, i, 64);
         if (vp_i == 0.0) continue;
@@ -594,21 +625,27 @@ __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, 
 
 // crowd_sim_var_num.py:233-279 generate_ob / crowd_sim_pred.py:62-97 / crowd_sim_pred_real_gst.py:76-93,
 // crowd_sim.py:558-572 get_num_human_in_fov, :243-273 update_last_human_states.
-__device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool reset, const Robot &rb, Lane &h, const cn_obs &ob)
+__device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int n, bool reset, const Robot &rb, Lane &h, const cn_obs &ob)
 {
     const cn_env_config &c = s.cfg;
-    const int H = s.H, D = s.D, P = s.P;
-    const bool isH = lane < H;
+    const int H = s.H, D = s.D, P = s.P; // H observation rows (crowd_sim_var_num.py:249, crowd_sim_pred.py:78), n humans present
+    const bool isH = lane < n, isRow = lane < H;
     // robot FOV = 2*pi: visible iff not coincident and within sensor range (detect_visible, crowd_sim.py:513-552)
     const double dx = rb.px - h.px, dy = rb.py - h.py;
     const bool vis = isH && !(dx == 0.0 && dy == 0.0) && (norm2(dx, dy) - c.robot_radius - h.rad <= c.sensor_range);
     const uint64_t vmask = __ballot(vis);
     const int num_visible = __popcll(vmask);
-    if (s.vis && isH) s.vis[(size_t)e * H + lane] = vis ? 1 : 0; // human_visibility, read by the next step's 'truth' blanking
+    if (s.vis && isRow) s.vis[(size_t)e * H + lane] = vis ? 1 : 0; // human_visibility, read by the next step's 'truth' blanking
+    if (s.nh && c.env_kind != CN_ENV_PRED && lane == 0) {
+        // observed_human_ids (crowd_sim_var_num.py:275): who may not leave at the next crowd-size change.  CrowdSimPred's own
+        // generate_ob never refreshes the list (it stays [] from reset)
+        s.obs_cnt[e] = num_visible;
+        s.obs_max[e] = vmask ? 63 - __clzll((long long)vmask) : -1;
+    }
     const double prev_vx = h.l2, prev_vy = h.l3;
     if (vis) { h.l0 = h.px; h.l1 = h.py; h.l2 = h.vx; h.l3 = h.vy; h.l4 = h.rad; }
-    else if (reset) { h.l0 = 15.0; h.l1 = 15.0; h.l2 = 0.0; h.l3 = 0.0; h.l4 = 0.3; }
-    else { h.l0 = h.l0 + h.l2 * c.time_step; h.l1 = h.l1 + h.l3 * c.time_step; }
+    else if (isH && reset) { h.l0 = 15.0; h.l1 = 15.0; h.l2 = 0.0; h.l3 = 0.0; h.l4 = 0.3; }
+    else if (isH) { h.l0 = h.l0 + h.l2 * c.time_step; h.l1 = h.l1 + h.l3 * c.time_step; }
     if (lane == 0) {
         float *rn = ob.robot_node + (size_t)e * 7;
         rn[0] = (float)rb.px; rn[1] = (float)rb.py; rn[2] = (float)c.robot_radius; rn[3] = (float)rb.gx; rn[4] = (float)rb.gy;
@@ -629,7 +666,7 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool
         }
         row = rank;
     }
-    if (isH) {
+    if (isRow) {
         float *se = ob.spatial_edges + ((size_t)e * H + row) * D;
         if (c.env_kind == CN_ENV_VARNUM) {
             se[0] = vis ? (float)ex : 15.0f;
@@ -669,7 +706,7 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, bool
 
 // crowd_sim_var_num.py:303-363 reset (seed, robot, humans, potential, first observation)
 // the RNG-consuming part of reset(): seed, robot, humans (crowd_sim_var_num.py:333-340, :64-146)
-__device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd)
+__device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, int &n)
 {
     const cn_env_config &c = s.cfg;
     const uint64_t offset = c.phase == CN_PHASE_TRAIN ? 2000ull : (c.phase == CN_PHASE_VAL ? 0ull : 1000ull);
@@ -684,12 +721,14 @@ __device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int 
         if (norm2(px - gx, py - gy) >= 8.0) break;
     }
     rb.px = px; rb.py = py; rb.gx = gx; rb.gy = gy; rb.vx = 0.0; rb.vy = 0.0; rb.theta = M_PI / 2.0;
-    for (int i = 0; i < s.H; ++i) gen_human(s, R, lane, i, i, rb, h, shared_nd);
+    // :103-104 randint(human_num - range, human_num + range + 1): consumes no draw when human_num_range == 0
+    n = rng_randint(R, lane, c.human_num - c.human_num_range, c.human_num + c.human_num_range + 1);
+    for (int i = 0; i < n; ++i) gen_human(s, R, lane, i, i, rb, h, shared_nd);
     rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
 }
 
 // the rest of reset(): belief cleared (:108), case counter advanced (:348), episode statistics, first observation
-__device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, Robot &rb, Lane &h, const cn_obs &ob, bool with_obs = true)
+__device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, int n, Robot &rb, Lane &h, const cn_obs &ob, bool with_obs = true)
 {
     const cn_env_config &c = s.cfg;
     h.l0 = h.l1 = h.l2 = h.l3 = h.l4 = 0.0;
@@ -697,15 +736,17 @@ __device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, R
     if (lane == 0) {
         s.case_counter[e] = (s.case_counter[e] + (uint64_t)c.nenv) % case_size;
         s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0;
+        if (s.nh) { s.obs_cnt[e] = 0; s.obs_max[e] = -1; } // :327 observed_human_ids = []
     }
-    if (with_obs) write_obs(s, e, lane, true, rb, h, ob);
+    if (with_obs) write_obs(s, e, lane, n, true, rb, h, ob);
 }
 
 // crowd_sim_var_num.py:303-363 reset.  Uses the pre-generated episode when the side stream has one ready.
-__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, const cn_obs &ob,
+__device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, int &n, const cn_obs &ob,
                                          bool with_obs = true)
 {
     if (s.nx_ready[e]) {
+        n = s.nx_nh ? s.nx_nh[e] : s.H;
         const int H = s.H;
         const int lj = lane < H ? lane : 0;
         const double *hum = s.nx_hum + (size_t)e * 8 * H;
@@ -722,9 +763,9 @@ __device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lan
         __syncthreads();
         if (lane == 0) s.nx_ready[e] = 0;
     } else {
-        gen_episode(s, R, e, lane, rb, h, shared_nd);
+        gen_episode(s, R, e, lane, rb, h, shared_nd, n);
     }
-    finish_reset(s, e, lane, rb, h, ob, with_obs);
+    finish_reset(s, e, lane, n, rb, h, ob, with_obs);
 }
 
 __device__ __forceinline__ void load_env(const EnvDev &s, int e, int lane, Robot &rb, Lane &h)
@@ -766,10 +807,11 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int 
     Lane h{};
     h.rad = s.cfg.human_radius;
     double shared_nd = s.cfg.orca_neighbor_dist;
-    do_reset(s, R, e, lane, rb, h, shared_nd, ob, with_obs != 0);
+    int n = s.H;
+    do_reset(s, R, e, lane, rb, h, shared_nd, n, ob, with_obs != 0);
     if (!with_obs && lane == 0) s.pend[e] = 1;
     store_env(s, e, lane, rb, h);
-    if (lane == 0) s.shared_nd[e] = shared_nd;
+    if (lane == 0) { s.shared_nd[e] = shared_nd; if (s.nh) s.nh[e] = n; }
     rng_store(R, s, e, lane);
 }
 
@@ -784,7 +826,8 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
     Lane h{};
     h.rad = s.cfg.human_radius;
     double shared_nd = s.shared_nd[e]; // overwritten by the first Human() when randomised, unused otherwise
-    gen_episode(s, R, e, lane, rb, h, shared_nd);
+    int n = s.H;
+    gen_episode(s, R, e, lane, rb, h, shared_nd, n);
     const int H = s.H;
     if (lane < H) {
         double *hum = s.nx_hum + (size_t)e * 8 * H;
@@ -796,6 +839,7 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
         r[R_PX] = rb.px; r[R_PY] = rb.py; r[R_GX] = rb.gx; r[R_GY] = rb.gy; r[R_THETA] = rb.theta; r[R_POT] = rb.pot;
         s.nx_shared_nd[e] = shared_nd;
         s.nx_mt_pos[e] = R.pos;
+        if (s.nx_nh) s.nx_nh[e] = n;
     }
     __syncthreads();
     for (int k = lane; k < MT_N; k += 64) s.nx_mt[(size_t)e * MT_N + k] = g_mt_lds[k];
@@ -806,15 +850,15 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
 // (rl/networks/shmem_vec_env.py:139-142).  ORCA velocities for this step were produced by orca_kernel.
 // goal changes every 5 s and respawns of the humans that reached their goal (crowd_sim_var_num.py:446-456): after the observation
-__device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e, int lane, int step_counter, const Robot &rb, Lane &h, double &shared_nd)
+__device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e, int lane, int n, int step_counter, const Robot &rb, Lane &h, double &shared_nd)
 {
     const cn_env_config &c = s.cfg;
-    const int H = s.H;
+    const int H = n; // the humans present
     const bool isH = lane < H;
     const int period = (int)(5.0 / c.time_step + 0.5);
     if (c.random_goal_changing && (step_counter % period) == 0) {
         rng_load(R, s, e, lane);
-        change_goals(s, R, lane, rb, h);
+        change_goals(s, R, lane, n, rb, h);
     }
     if (c.end_goal_changing) {
         uint64_t reached = __ballot(isH && norm2(h.gx - h.px, h.gy - h.py) < h.rad);
@@ -839,8 +883,9 @@ __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
     load_env(s, e, lane, rb, h);
     double shared_nd = s.shared_nd[e];
     const bool was_reset = s.pend[e] != 0;
-    write_obs(s, e, lane, was_reset, rb, h, ob);
-    if (!was_reset) post_obs_updates(s, R, e, lane, s.step_counter[e], rb, h, shared_nd);
+    const int n = crowd_size(s, e);
+    write_obs(s, e, lane, n, was_reset, rb, h, ob);
+    if (!was_reset) post_obs_updates(s, R, e, lane, n, s.step_counter[e], rb, h, shared_nd);
     if (lane == 0) s.pend[e] = 0;
     store_env(s, e, lane, rb, h);
     if (lane == 0) s.shared_nd[e] = shared_nd;
@@ -857,7 +902,8 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     const int e = blockIdx.x;
     const cn_env_config &c = s.cfg;
     const int H = s.H;
-    const bool isH = lane < H;
+    int n = crowd_size(s, e);  // humans present during this step's reward / kinematics
+    const bool isH = lane < n;
     Rng R{MT_N, false};
     Robot rb;
     Lane h;
@@ -871,11 +917,11 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         // crowd_sim_var_num.py:371-375: action = robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the
         // robot's BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path
         float nd, seen_r;
-        if (!s.rob_sim_valid[e]) {
+        if (!s.rob_sim_valid[e] || (s.rob_sim_n && s.rob_sim_n[e] != n + 1)) { // orca.py:80-82: new simulator when the crowd size changed
             nd = (float)shared_nd;
             seen_r = (float)(h.l4 + 0.01 + c.orca_safety_space);
             if (isH) s.rob_seen[(size_t)e * H + lane] = seen_r;
-            if (lane == 0) { s.rob_nd[e] = nd; s.rob_sim_valid[e] = 1; }
+            if (lane == 0) { s.rob_nd[e] = nd; s.rob_sim_valid[e] = 1; if (s.rob_sim_n) s.rob_sim_n[e] = (uint8_t)(n + 1); }
         } else {
             nd = s.rob_nd[e];
             seen_r = s.rob_seen[(size_t)e * H + (isH ? lane : 0)];
@@ -883,8 +929,8 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         double gvx = rb.gx - rb.px, gvy = rb.gy - rb.py;
         const double speed = sqrt(gvx * gvx + gvy * gvy);
         if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
-        orca_wave(lane, H, isH, (float)h.l0, (float)h.l1, (float)h.l2, (float)h.l3, seen_r, (float)rb.px, (float)rb.py, (float)rb.vx, (float)rb.vy,
-                  (float)(c.robot_radius + 0.01 + c.orca_safety_space), (float)c.robot_v_pref, (float)gvx, (float)gvy, nd, H,
+        orca_wave(lane, n, isH, (float)h.l0, (float)h.l1, (float)h.l2, (float)h.l3, seen_r, (float)rb.px, (float)rb.py, (float)rb.vx, (float)rb.vy,
+                  (float)(c.robot_radius + 0.01 + c.orca_safety_space), (float)c.robot_v_pref, (float)gvx, (float)gvy, nd, n,
                   (float)c.orca_time_horizon, (float)c.time_step, ax, ay);
     } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
@@ -974,19 +1020,45 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     }
     if (done && c.auto_reset) {
         // vec-env auto-reset: the terminal observation is replaced by the first observation of the next episode.
-        // (The terminal step's own goal-change / respawn draws happen before np.random.seed and cannot be observed.)
-        do_reset(s, R, e, lane, rb, h, shared_nd, ob, !SPLIT);
+        // (The terminal step's own crowd-size / goal-change / respawn draws happen before np.random.seed and cannot be observed.)
+        do_reset(s, R, e, lane, rb, h, shared_nd, n, ob, !SPLIT);
         if (SPLIT && lane == 0) s.pend[e] = 1;
     } else {
         // (auto_reset == 0, the single-env gym object: a terminal step is an ordinary step -- terminal observation, goal
         // changes and respawns included, crowd_sim_var_num.py:430-458 -- and the caller resets explicitly)
+        if (s.nh && (step_counter % (int)(5.0 / c.time_step + 0.5)) == 0) {
+            // crowd_sim_var_num.py:404-437 / crowd_sim_pred.py:165-190: every 5 s humans leave from the END of the list (only ones the
+            // robot was not looking at) or new ones are appended, before the observation is generated
+            rng_load(R, s, e, lane);
+            if (rng_double(R, lane) < 0.5) {
+                const int oc = s.obs_cnt[e], om = s.obs_max[e];
+                int max_remove;
+                if (c.env_kind == CN_ENV_VARNUM) {
+                    max_remove = n - (c.human_num - c.human_num_range);
+                    if (oc > 0 && (n - 1) - om < max_remove) max_remove = (n - 1) - om;
+                } else {
+                    max_remove = oc == 0 ? n - 1 : (n - 1) - om;
+                    if (c.human_num_range < max_remove) max_remove = c.human_num_range;
+                }
+                n -= rng_randint(R, lane, 0, max_remove + 1);
+            } else {
+                const int add_num = rng_randint(R, lane, 0, c.human_num_range + 1);
+                const int first = n;
+                for (int i = first; i < first + add_num && i < H; ++i) {
+                    gen_human(s, R, lane, i, i, rb, h, shared_nd);
+                    if (lane == i) { h.l0 = 15.0; h.l1 = 15.0; h.l2 = 0.0; h.l3 = 0.0; h.l4 = 0.3; }
+                    n = i + 1;
+                }
+            }
+        }
         if (!SPLIT) {
-            write_obs(s, e, lane, false, rb, h, ob);
-            post_obs_updates(s, R, e, lane, step_counter, rb, h, shared_nd);
+            write_obs(s, e, lane, n, false, rb, h, ob);
+            post_obs_updates(s, R, e, lane, n, step_counter, rb, h, shared_nd);
         }
         if (lane == 0) { s.step_counter[e] = step_counter; s.ep_ret[e] = ep_ret; s.ep_cnt[e] = ep_cnt; }
     }
     store_env(s, e, lane, rb, h);
+    if (lane == 0 && s.nh) s.nh[e] = n;
     if (lane == 0) s.shared_nd[e] = shared_nd;
     rng_store(R, s, e, lane);
 }
@@ -1009,6 +1081,12 @@ __global__ void export_hact_kernel(EnvDev s, float *out)
         const int e = idx / (H * 2), r = idx % (H * 2), j = r / 2, f = r % 2;
         out[idx] = s.hact[((size_t)e * 2 + f) * H + j];
     }
+}
+
+__global__ void fill_i32_kernel(int n, int v, int32_t *out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = v;
 }
 
 } // namespace
@@ -1072,6 +1150,7 @@ extern "C" void cn_env_config_default(cn_env_config *c)
     c->human_radius = 0.3; c->human_v_pref = 1.0; c->robot_radius = 0.3; c->robot_v_pref = 1.0; c->sensor_range = 5.0;
     c->goal_change_chance = 0.5; c->end_goal_change_chance = 1.0;
     c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0; c->orca_time_horizon_obst = 5.0;
+    c->sf_A = 2.0; c->sf_B = 1.0; c->sf_KI = 1.0; // config.py:126-128
 }
 
 extern "C" int cn_env_obs_width(const cn_env_config *cfg)
@@ -1084,15 +1163,19 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(cfg && out, "cn_env_create: null argument");
     CN_REQUIRE(num_envs > 0, "cn_env_create: num_envs must be positive");
-    CN_REQUIRE(cfg->human_num >= 1 && cfg->human_num <= CN_MAX_HUMANS, "cn_env_create: human_num must be in [1,%d]", CN_MAX_HUMANS);
+    CN_REQUIRE(cfg->human_num_range >= 0 && cfg->human_num_range < cfg->human_num, "cn_env_create: human_num_range must be in [0, human_num)");
+    const int HM = cfg->human_num + cfg->human_num_range; // observation rows / lanes per env
+    CN_REQUIRE(cfg->human_num >= 1 && HM <= CN_MAX_HUMANS, "cn_env_create: human_num + human_num_range must be in [1,%d]", CN_MAX_HUMANS);
+    CN_REQUIRE(cfg->kinematics == CN_KIN_HOLONOMIC, "cn_env_create: unicycle kinematics is not implemented on the device");
+    CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA, "cn_env_create: social-force humans are not implemented on the device");
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_PRED_GST, "cn_env_create: unknown env_kind %d", cfg->env_kind);
     CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST,
                "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
     CN_REQUIRE(cfg->robot_policy == CN_ROBOT_NETWORK || cfg->robot_policy == CN_ROBOT_ORCA, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
-    CN_REQUIRE(!cfg->robot_visible || (cfg->env_kind == CN_ENV_VARNUM && cfg->phase == CN_PHASE_TRAIN && cfg->human_num <= CN_MAX_HUMANS - 1),
-               "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num <= %d (the reference rebuilds every private "
+    CN_REQUIRE(!cfg->robot_visible || (cfg->env_kind == CN_ENV_VARNUM && cfg->phase == CN_PHASE_TRAIN && HM <= CN_MAX_HUMANS - 1),
+               "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num + human_num_range <= %d (the reference rebuilds every private "
                "simulator twice per step in the test phase and breaks in CrowdSimPred)", CN_MAX_HUMANS - 1);
     CN_REQUIRE(!cfg->predict_truth || (cfg->env_kind == CN_ENV_PRED && !cfg->robot_visible),
                "cn_env_create: predict_truth (sim.predict_method = 'truth') is CrowdSimPred-v0 with an invisible robot");
@@ -1102,9 +1185,9 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(b, "cn_env_create: out of host memory");
     EnvDev &d = b->d;
     d.cfg = *cfg;
-    d.E = num_envs; d.H = cfg->human_num; d.D = cn_env_obs_width(cfg); d.P = cfg->predict_steps;
+    d.E = num_envs; d.H = HM; d.D = cn_env_obs_width(cfg); d.P = cfg->predict_steps;
     d.seed_base = seed + first_env_index;
-    const size_t E = num_envs, H = cfg->human_num;
+    const size_t E = num_envs, H = HM;
     // one allocation, carved (all sub-buffers 256-byte aligned)
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
@@ -1114,13 +1197,16 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_sv = carve(E * H), o_snd = carve(E * H * 4), o_ssr = carve(E * H * 4), o_ssm = carve(E * H * 4);
     const size_t o_seen = cfg->randomize_attributes ? carve(E * H * H * 4) : 0;
     const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
-    const size_t o_nh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
+    const size_t o_nxh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
     const bool test_phase = cfg->phase == CN_PHASE_TEST;
     const bool truth_obs = cfg->predict_truth != 0;
     const bool rob_orca = cfg->robot_policy == CN_ROBOT_ORCA;
     const size_t o_rsv = rob_orca ? carve(E) : 0, o_rnd = rob_orca ? carve(E * 4) : 0, o_rsn = rob_orca ? carve(E * H * 4) : 0;
     const size_t o_tr = (test_phase || truth_obs) ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = (test_phase || truth_obs) ? carve(E * H) : 0, o_md = carve(E * 8);
     const size_t o_pend = carve(E);
+    const bool var_n = cfg->human_num_range > 0;
+    const size_t o_nh = var_n ? carve(E * 4) : 0, o_nxnh = var_n ? carve(E * 4) : 0, o_oc = var_n ? carve(E * 4) : 0, o_om = var_n ? carve(E * 4) : 0;
+    const size_t o_simn = var_n ? carve(E * H) : 0, o_rsimn = (var_n && rob_orca) ? carve(E) : 0;
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -1136,10 +1222,13 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.sim_self_maxspeed = (float *)(base + o_ssm);
     d.sim_seen = cfg->randomize_attributes ? (float *)(base + o_seen) : nullptr;
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
-    d.nx_hum = (double *)(base + o_nh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
+    d.nx_hum = (double *)(base + o_nxh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
     d.tr = (test_phase || truth_obs) ? (double *)(base + o_tr) : nullptr; d.vis = (test_phase || truth_obs) ? (uint8_t *)(base + o_vis) : nullptr;
     d.pend = (uint8_t *)(base + o_pend);
+    d.nh = var_n ? (int32_t *)(base + o_nh) : nullptr; d.nx_nh = var_n ? (int32_t *)(base + o_nxnh) : nullptr;
+    d.obs_cnt = var_n ? (int32_t *)(base + o_oc) : nullptr; d.obs_max = var_n ? (int32_t *)(base + o_om) : nullptr;
+    d.sim_n = var_n ? (uint8_t *)(base + o_simn) : nullptr; d.rob_sim_n = (var_n && rob_orca) ? (uint8_t *)(base + o_rsimn) : nullptr;
     d.min_dist = (double *)(base + o_md);
     d.rob_sim_valid = rob_orca ? (uint8_t *)(base + o_rsv) : nullptr; d.rob_nd = rob_orca ? (float *)(base + o_rnd) : nullptr;
     d.rob_seen = rob_orca ? (float *)(base + o_rsn) : nullptr;
@@ -1227,6 +1316,19 @@ extern "C" int cn_env_get_human_actions(cn_env_batch *env, float *out, void *str
     const int n = env->d.E * env->d.H * 2;
     hipLaunchKernelGGL(export_hact_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, out);
     CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_env_get_human_counts(cn_env_batch *env, int32_t *out, void *stream)
+{
+    CN_REQUIRE(env && out, "cn_env_get_human_counts: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (env->d.nh) {
+        CN_HIP(hipMemcpyAsync(out, env->d.nh, (size_t)env->d.E * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((env->d.E + 255) / 256), dim3(256), 0, st, env->d.E, env->d.H, out);
+        CN_CHECK_LAUNCH();
+    }
     return CN_OK;
 }
 

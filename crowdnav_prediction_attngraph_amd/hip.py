@@ -18,7 +18,7 @@ class HipEnvBatch:
         _need_cuda()
         self.cfg = cfg
         self.E = int(num_envs)
-        self.H = int(cfg.human_num)
+        self.H = int(cfg.human_num) + int(cfg.human_num_range)   # observation rows (the crowd holds <= H humans)
         self.D = A.lib().cn_env_obs_width(C.byref(cfg))
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         h = C.c_void_p()
@@ -111,6 +111,13 @@ class HipEnvBatch:
         out = torch.zeros(self.E, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_env_get_danger_min_dist(self._h, A.ptr(out), A.stream_ptr()), "cn_env_get_danger_min_dist")
+        return out
+
+    def get_human_counts(self):
+        """len(self.humans) per env (int32 [E]); constant unless sim.human_num_range > 0."""
+        out = torch.zeros(self.E, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_get_human_counts(self._h, A.ptr(out), A.stream_ptr()), "cn_env_get_human_counts")
         return out
 
     def get_human_actions(self):

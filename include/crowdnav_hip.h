@@ -62,12 +62,14 @@ enum { CN_PHASE_TRAIN = 0, CN_PHASE_VAL = 1, CN_PHASE_TEST = 2 };
 enum { CN_INFO_NOTHING = 0, CN_INFO_TIMEOUT = 1, CN_INFO_COLLISION = 2, CN_INFO_REACHGOAL = 3, CN_INFO_DANGER = 4 }; /* crowd_sim/envs/utils/info.py */
 
 enum { CN_ROBOT_NETWORK = 0, CN_ROBOT_ORCA = 1 };
+enum { CN_KIN_HOLONOMIC = 0, CN_KIN_UNICYCLE = 1 };   /* action_space.kinematics */
+enum { CN_HUMANS_ORCA = 0, CN_HUMANS_SOCIAL_FORCE = 1 }; /* humans.policy */
 #define CN_MAX_HUMANS 64 /* one wavefront lane per human */
 #define CN_MAX_PRED 8
 
 /* Mirrors the fields of crowd_nav/configs/config.py that the path reads (same names, same meaning). */
 typedef struct {
-    int32_t human_num;            /* sim.human_num; sim.human_num_range must be 0 */
+    int32_t human_num;            /* sim.human_num */
     int32_t predict_steps;        /* sim.predict_steps */
     int32_t env_kind;             /* CN_ENV_* */
     int32_t randomize_attributes; /* env.randomize_attributes */
@@ -91,6 +93,12 @@ typedef struct {
                                    * (crowd_sim_var_num.py:116-146, crowd_sim.py:415-450): after this many attempts the last
                                    * candidate is accepted; 0 = 65536.  Dense randomised crowds have seeds where the reference
                                    * loop runs for minutes, and a batch waits for its slowest env. */
+    int32_t human_num_range;      /* sim.human_num_range: the crowd holds human_num - range .. human_num + range humans (drawn at reset,
+                                   * changed every 5 s: crowd_sim_var_num.py:103-104, :404-437, crowd_sim_pred.py:165-190); observations
+                                   * always have human_num + human_num_range rows, which must be <= CN_MAX_HUMANS */
+    int32_t kinematics;           /* CN_KIN_* (action_space.kinematics) */
+    int32_t humans_policy;        /* CN_HUMANS_* (humans.policy) */
+    int32_t reserved0;
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;
@@ -98,6 +106,7 @@ typedef struct {
     double robot_radius, robot_v_pref, sensor_range;
     double goal_change_chance, end_goal_change_chance;
     double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
+    double sf_A, sf_B, sf_KI;     /* config.sf.* (crowd_nav/policy/social_force.py) */
 } cn_env_config;
 
 /* Observation tensors exactly as VecPyTorch returns them (float32, contiguous):
@@ -142,6 +151,9 @@ int cn_env_get_human_actions(cn_env_batch *env, float *out, void *stream);
  * own ORCA policies, calc_human_future_traj('truth') :152-206); 0 for every other info and in the train phase.
  * out [E] float64 (device). */
 int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream);
+/* len(self.humans) of every env: out [E] int32 (device).  Constant human_num unless sim.human_num_range > 0; the slots beyond it in
+ * cn_env_get_state / cn_env_get_human_actions hold no human. */
+int cn_env_get_human_counts(cn_env_batch *env, int32_t *out, void *stream);
 /* Overwrite the per-env case counters (crowd_sim_var_num.py:316-318 `case_counter[phase] = test_case`, :337
  * rand_seed = offset[phase] + case_counter + thisSeed): the NEXT reset of env e generates the scenario of that case.
  * counters [E] uint64 (device).  Lets a batch replay chosen test cases (one per env) instead of consecutive ones. */

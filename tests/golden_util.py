@@ -9,12 +9,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_KIND = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
 
 
-ORACLE_ONLY = ("sfhumans", "_range", "unicycle")   # settings the HIP simulator does not implement yet
+ORACLE_ONLY = ("sfhumans", "unicycle")   # settings the HIP simulator does not implement yet
 
 
 def env_fixtures(device=False):
-    """All env traces; device=True leaves out the ones that exercise oracle-only settings (social-force humans, varying crowd
-    size, unicycle robot)."""
+    """All env traces; device=True leaves out the ones that exercise oracle-only settings (social-force humans, unicycle robot)."""
     paths = sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
     return [p for p in paths if not (device and any(t in os.path.basename(p) for t in ORACLE_ONLY))]
 
@@ -32,7 +31,7 @@ def sim_kwargs(meta, oracle=False):
     extra = {}
     if oracle and over.get("humans.policy", "orca") == "social_force":
         extra["humans_policy"] = 1
-    if oracle and over.get("sim.human_num_range", 0):
+    if over.get("sim.human_num_range", 0):
         extra["human_num_range"] = int(over["sim.human_num_range"])
     if over.get("sim.predict_method", "none") == "truth":
         extra["predict_truth"] = 1

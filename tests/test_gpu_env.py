@@ -55,6 +55,16 @@ CASES = {
     "pred_h10_rand_truthobs_test": dict(human_num=10, env_kind=1, predict_truth=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     # a tight bound on the (in the reference unbounded) placement rejection loops: the cap path itself is bit-exact too
     "varnum_h50_rand_cap64": dict(human_num=50, randomize_attributes=1, random_goal_changing=1, max_placement_attempts=64),
+    # sim.human_num_range > 0: the crowd size is drawn at reset and changes every 5 s; human_num + range observation rows
+    "varnum_h15_range5": dict(human_num=15, human_num_range=5),
+    "varnum_h10_rand_range4": dict(human_num=10, human_num_range=4, randomize_attributes=1, random_goal_changing=1),
+    "pred_h12_range3": dict(human_num=12, human_num_range=3, env_kind=1),
+    "predgst_h12_rand_range4": dict(human_num=12, human_num_range=4, env_kind=2, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h15_range5_test": dict(human_num=15, human_num_range=5, phase=2),
+    "pred_h8_rand_range2_truthobs": dict(human_num=8, human_num_range=2, env_kind=1, predict_truth=1, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h12_range3_orcarobot": dict(human_num=12, human_num_range=3, robot_policy=1),
+    "varnum_h12_rand_range3_robotvisible": dict(human_num=12, human_num_range=3, robot_visible=1, randomize_attributes=1),
+    "varnum_h40_range24": dict(human_num=40, human_num_range=24, circle_radius=16.0),
     "varnum_h63_rand_robotvisible": dict(human_num=63, robot_visible=1, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
 }
 
@@ -64,7 +74,7 @@ def test_hip_env_matches_oracle_bit_exact(name):
     from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch
     from oracle import oracle as O
     kw = dict(CASES[name])
-    E, T, seed = 48, 260 if kw["human_num"] < 50 else 110, 425
+    E, T, seed = 48, 260 if kw["human_num"] + kw.get("human_num_range", 0) < 50 else 110, 425
     kw["nenv"] = E
     ccfg, ocfg = _cfgs(**kw)
     env = HipEnvBatch(ccfg, E, seed)
@@ -78,6 +88,7 @@ def test_hip_env_matches_oracle_bit_exact(name):
             np.testing.assert_array_equal(host[k][i].astype(ob[k].dtype).reshape(ob[k].shape), ob[k], err_msg="reset %s env %d" % (k, i))
     n_done = 0
     infos_seen = set()
+    counts_seen = set()
     for t in range(T):
         act = _actions(host, t, E)
         nd = torch.full((E, 1), -1.0, device=env.device)
@@ -86,8 +97,11 @@ def test_hip_env_matches_oracle_bit_exact(name):
         host = {k: obs[k].cpu().numpy() for k in keys}
         rew_h, done_h, info_h, epr_h, epl_h = rew.cpu().numpy(), done.cpu().numpy(), info.cpu().numpy(), epr.cpu().numpy(), epl.cpu().numpy()
         md_h = env.get_danger_min_dist().cpu().numpy()
+        cnt_h = env.get_human_counts().cpu().numpy()
         for i, oe in enumerate(oenvs):
             ob, r, d, inf = oe.step(act[i], autoreset=True)
+            assert int(cnt_h[i]) == oe.human_count, "len(humans) t=%d env=%d" % (t, i)
+            counts_seen.add(int(cnt_h[i]))
             assert md_h[i] == inf["min_dist"], "min_dist t=%d env=%d" % (t, i)
             assert bool(done_h[i]) == d, "done t=%d env=%d" % (t, i)
             assert int(info_h[i]) == inf["info"], "info t=%d env=%d" % (t, i)
@@ -101,6 +115,10 @@ def test_hip_env_matches_oracle_bit_exact(name):
                 np.testing.assert_array_equal(host[k][i].astype(ob[k].dtype).reshape(ob[k].shape), ob[k],
                                               err_msg="%s t=%d env=%d" % (k, t, i))
     assert n_done > 0
+    if kw.get("human_num_range", 0):
+        assert len(counts_seen) > 2   # the crowd really grew and shrank
+    else:
+        assert counts_seen == {kw["human_num"]}
     env.close()
 
 
