@@ -57,8 +57,9 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     rv = bool(g("robot", "visible", False))
     if rv and (env_name != "CrowdSimVarNum-v0" or phase != "train" or hn + hr > 63):
         unsupported.append("robot.visible=True outside CrowdSimVarNum-v0 / phase train / human_num + human_num_range <= 63")
-    if g("action_space", "kinematics", "holonomic") != "holonomic":
-        unsupported.append("unicycle kinematics")
+    kin = g("action_space", "kinematics", "holonomic")
+    if kin not in ("holonomic", "unicycle"):
+        unsupported.append("action_space.kinematics=%r" % kin)
     if g("humans", "policy", "orca") != "orca":
         unsupported.append("humans.policy != 'orca'")
     if float(g("humans", "FOV", 2.)) != 2.0 or float(g("robot", "FOV", 2)) != 2.0:
@@ -71,6 +72,8 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     rp = g("robot", "policy", "selfAttn_merge_srnn")
     if rp not in ("selfAttn_merge_srnn", "srnn", "orca"):
         unsupported.append("robot.policy=%r (the network policies and 'orca' are implemented)" % rp)
+    if kin == "unicycle" and (env_name != "CrowdSimVarNum-v0" or rp == "orca"):
+        unsupported.append("unicycle kinematics outside CrowdSimVarNum-v0 with a network-driven robot")
     if phase not in ("train", "test"):
         unsupported.append("phase=%r (train.py / test.py only use 'train' and 'test')" % phase)
     if float(g("env", "time_step", 0.25)) != float(g("data", "pred_timestep", 0.25)):
@@ -78,7 +81,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     if unsupported:
         raise NotImplementedError("not implemented on the device path yet: " + "; ".join(unsupported))
     return A.default_env_config(
-        human_num=hn, human_num_range=hr, predict_steps=int(g("sim", "predict_steps", 5)), env_kind=A.ENV_KINDS[env_name],
+        human_num=hn, human_num_range=hr, kinematics=int(kin == "unicycle"), predict_steps=int(g("sim", "predict_steps", 5)), env_kind=A.ENV_KINDS[env_name],
         randomize_attributes=int(bool(g("env", "randomize_attributes", True))),
         random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),

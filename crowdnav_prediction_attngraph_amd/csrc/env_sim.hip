@@ -74,6 +74,7 @@ struct EnvDev {
     int32_t *obs_max;   // [E] max(self.observed_human_ids), -1 when empty
     uint8_t *sim_n;     // [E][H] agent count human i's private simulator was built for (orca.py:80-82 rebuilds on a change)
     uint8_t *rob_sim_n; // [E] ... the robot's (robot.policy == 'orca')
+    double *desired_v;  // [E] unicycle robot only: self.desiredVelocity[0] (crowd_sim.py:82: set at construction, never reset)
 };
 
 __device__ __forceinline__ int crowd_size(const EnvDev &s, int e) { return s.nh ? s.nh[e] : s.H; }
@@ -582,7 +583,8 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
         det_sincos(angle, sn, cs);
         px = c.circle_radius * cs + px_noise;
         py = c.circle_radius * sn + py_noise;
-        const double md_r = radius + c.robot_radius + c.discomfort_dist;
+        // :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal
+        const double md_r = c.kinematics == CN_KIN_UNICYCLE ? c.circle_radius / 2.0 : radius + c.robot_radius + c.discomfort_dist;
         const bool coll_r = norm2(px - rb.px, py - rb.py) < md_r || norm2(px - rb.gx, py - rb.gy) < md_r;
         const double md = radius + h.rad + c.discomfort_dist;
         const bool coll_h = lane < n_existing && (norm2(px - h.px, py - h.py) < md || norm2(px - h.gx, py - h.gy) < md);
@@ -594,15 +596,18 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
     }
 }
 
-// crowd_sim.py:415-450 update_human_goals_randomly
-__device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, int n, const Robot &rb, Lane &h)
+// crowd_sim.py:415-450 update_human_goals_randomly (every human, goal_change_chance) and :453-485 update_human_goal (one human,
+// end_goal_change_chance: `only` >= 0 selects it)
+__device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, int n, const Robot &rb, Lane &h, int only = -1)
 {
     const cn_env_config &c = s.cfg;
     const int H = n; // the humans present
-    for (int i = 0; i < H; ++i) {
-        const double vp_i = __shfl(h.vpref, i, 64), rad_i = __shfl(h.rad, i, 64);
-        if (vp_i == 0.0) continue;
-        if (rng_double(R, lane) <= c.goal_change_chance) {
+    for (int i = only >= 0 ? only : 0; i < (only >= 0 ? only + 1 : H); ++i) {
+        double vp_i = __shfl(h.vpref, i, 64);
+        const double rad_i = __shfl(h.rad, i, 64);
+        if (only < 0 && vp_i == 0.0) continue;
+        if (vp_i == 0.0) vp_i = 1.0;
+        if (rng_double(R, lane) <= (only >= 0 ? c.end_goal_change_chance : c.goal_change_chance)) {
             double gx, gy;
             for (int attempt = 0;; ++attempt) {
                 const double angle = rng_double(R, lane) * M_PI * 2.0;
@@ -713,16 +718,33 @@ __device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int 
     const uint64_t seed = offset + s.case_counter[e] + (uint64_t)(s.seed_base + e);
     rng_seed(R, (uint32_t)seed, lane);
     double px, py, gx, gy;
-    for (;;) { // :97-100
-        px = rng_uniform(R, lane, -c.arena_size, c.arena_size);
-        py = rng_uniform(R, lane, -c.arena_size, c.arena_size);
-        gx = rng_uniform(R, lane, -c.arena_size, c.arena_size);
-        gy = rng_uniform(R, lane, -c.arena_size, c.arena_size);
-        if (norm2(px - gx, py - gy) >= 8.0) break;
+    if (c.kinematics == CN_KIN_UNICYCLE) {
+        // generate_robot_humans, sim2real branch :78-91: start on the arena circle, goal >= 4 m away, random heading,
+        // 1 .. human_num + human_num_range humans
+        const double angle = rng_uniform(R, lane, 0.0, M_PI * 2.0);
+        double sn, cs;
+        det_sincos(angle, sn, cs);
+        px = c.arena_size * cs; py = c.arena_size * sn;
+        for (;;) {
+            gx = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            gy = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            if (norm2(px - gx, py - gy) >= 4.0) break;
+        }
+        rb.theta = rng_uniform(R, lane, 0.0, 2.0 * M_PI);
+        n = rng_randint(R, lane, 1, c.human_num + c.human_num_range + 1);
+    } else {
+        for (;;) { // :97-100
+            px = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            py = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            gx = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            gy = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            if (norm2(px - gx, py - gy) >= 8.0) break;
+        }
+        rb.theta = M_PI / 2.0;
+        // :103-104 randint(human_num - range, human_num + range + 1): consumes no draw when human_num_range == 0
+        n = rng_randint(R, lane, c.human_num - c.human_num_range, c.human_num + c.human_num_range + 1);
     }
-    rb.px = px; rb.py = py; rb.gx = gx; rb.gy = gy; rb.vx = 0.0; rb.vy = 0.0; rb.theta = M_PI / 2.0;
-    // :103-104 randint(human_num - range, human_num + range + 1): consumes no draw when human_num_range == 0
-    n = rng_randint(R, lane, c.human_num - c.human_num_range, c.human_num + c.human_num_range + 1);
+    rb.px = px; rb.py = py; rb.gx = gx; rb.gy = gy; rb.vx = 0.0; rb.vy = 0.0;
     for (int i = 0; i < n; ++i) gen_human(s, R, lane, i, i, rb, h, shared_nd);
     rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
 }
@@ -866,7 +888,9 @@ __device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e,
         while (reached) {
             const int i = __ffsll((unsigned long long)reached) - 1;
             reached &= reached - 1;
-            gen_human(s, R, lane, i, H, rb, h, shared_nd);
+            // :451-456 respawned (holonomic robot) or given a new goal (unicycle robot)
+            if (c.kinematics == CN_KIN_UNICYCLE) change_goals(s, R, lane, n, rb, h, i);
+            else gen_human(s, R, lane, i, H, rb, h, shared_nd);
         }
     }
 }
@@ -913,6 +937,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
 
     // srnn.clip_action (crowd_nav/policy/srnn.py:17-34), float32 like the numpy action array
     float ax = actions[2 * e], ay = actions[2 * e + 1];
+    double uni_v = 0.0, uni_r = 0.0; // ActionRot(v, r) of the unicycle robot
     if (c.robot_policy == CN_ROBOT_ORCA) {
         // crowd_sim_var_num.py:371-375: action = robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the
         // robot's BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path
@@ -932,6 +957,14 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         orca_wave(lane, n, isH, (float)h.l0, (float)h.l1, (float)h.l2, (float)h.l3, seen_r, (float)rb.px, (float)rb.py, (float)rb.vx, (float)rb.vy,
                   (float)(c.robot_radius + 0.01 + c.orca_safety_space), (float)c.robot_v_pref, (float)gvx, (float)gvy, nd, n,
                   (float)c.orca_time_horizon, (float)c.time_step, ax, ay);
+    } else if (c.kinematics == CN_KIN_UNICYCLE) {
+        // srnn.py:36-43: (change of v, change of theta) clipped in float32; crowd_sim_var_num.py:379-381: the commanded speed is the
+        // running sum self.desiredVelocity[0], clipped to +-v_pref (float64 from there on, as with the numpy the reference pins)
+        const float dv = fminf(fmaxf(ax, (float)-0.1), (float)0.087);
+        ay = fminf(fmaxf(ay, (float)-0.06), (float)0.06);
+        uni_v = fmin(fmax(s.desired_v[e] + (double)dv, -c.robot_v_pref), c.robot_v_pref);
+        uni_r = (double)ay;
+        if (lane == 0) s.desired_v[e] = uni_v;
     } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c.robot_v_pref;
@@ -944,7 +977,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     const bool collision = wv_any(closest < 0.0);
     const double dmin = wv_min(closest);
     const double goal_dist = norm2(rb.px - rb.gx, rb.py - rb.gy);
-    const bool reaching_goal = goal_dist < c.robot_radius;
+    const bool reaching_goal = goal_dist < (c.kinematics == CN_KIN_UNICYCLE ? 0.6 : c.robot_radius); // :487-492
     const double global_time = (double)step_counter * c.time_step;
     double reward;
     int done, info;
@@ -979,7 +1012,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         reward = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * c.time_step;
         done = 0; info = CN_INFO_DANGER;
     } else {
-        reward = 2.0 * (-fabs(goal_dist) - rb.pot);
+        reward = (c.kinematics == CN_KIN_UNICYCLE ? 3.0 : 2.0) * (-fabs(goal_dist) - rb.pot); // :536-542 pot_factor
         rb.pot = -fabs(goal_dist);
         done = 0; info = CN_INFO_NOTHING;
     }
@@ -1000,10 +1033,31 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         }
         reward = reward + wv_min(rf);
     }
-    // kinematics (crowd_sim/envs/utils/agent.py:170-183, holonomic)
-    rb.px = rb.px + (double)(ax * (float)c.time_step);
-    rb.py = rb.py + (double)(ay * (float)c.time_step);
-    rb.vx = (double)ax; rb.vy = (double)ay;
+    if (c.kinematics == CN_KIN_UNICYCLE) {
+        // :548-559 rotation penalty and reversing penalty, added to every outcome
+        const double r_spin = -4.5 * (uni_r * uni_r);
+        const double r_back = uni_v < 0.0 ? -2.0 * fabs(uni_v) : 0.0;
+        reward = reward + r_spin + r_back;
+        // differential drive, agent.py:148-165.  A rotation below 1e-4 sets R = 0, i.e. the robot does not translate on that step
+        // (the reference's formula, restated as it is)
+        double Rr = 0.0;
+        if (!(fabs(uni_r) < 0.0001)) { const double w = uni_r / c.time_step; Rr = uni_v / w; }
+        double s0, c0, s1, c1;
+        det_sincos(rb.theta, s0, c0);
+        det_sincos(rb.theta + uni_r, s1, c1);
+        rb.px = rb.px - Rr * s0 + Rr * s1;
+        rb.py = rb.py + Rr * c0 - Rr * c1;
+        double th = fmod(rb.theta + uni_r, 2.0 * M_PI); // Python %: the result takes the divisor's sign
+        if (th != 0.0 && th < 0.0) th += 2.0 * M_PI;
+        rb.theta = th;
+        det_sincos(th, s0, c0);
+        rb.vx = uni_v * c0; rb.vy = uni_v * s0;
+    } else {
+        // kinematics (crowd_sim/envs/utils/agent.py:170-183, holonomic)
+        rb.px = rb.px + (double)(ax * (float)c.time_step);
+        rb.py = rb.py + (double)(ay * (float)c.time_step);
+        rb.vx = (double)ax; rb.vy = (double)ay;
+    }
     if (isH) {
         const float hax = s.hact[(size_t)e * 2 * H + lane], hay = s.hact[(size_t)e * 2 * H + H + lane];
         h.px = h.px + (double)hax * c.time_step;
@@ -1026,7 +1080,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     } else {
         // (auto_reset == 0, the single-env gym object: a terminal step is an ordinary step -- terminal observation, goal
         // changes and respawns included, crowd_sim_var_num.py:430-458 -- and the caller resets explicitly)
-        if (s.nh && (step_counter % (int)(5.0 / c.time_step + 0.5)) == 0) {
+        if (c.human_num_range > 0 && (step_counter % (int)(5.0 / c.time_step + 0.5)) == 0) {
             // crowd_sim_var_num.py:404-437 / crowd_sim_pred.py:165-190: every 5 s humans leave from the END of the list (only ones the
             // robot was not looking at) or new ones are appended, before the observation is generated
             rng_load(R, s, e, lane);
@@ -1166,7 +1220,9 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(cfg->human_num_range >= 0 && cfg->human_num_range < cfg->human_num, "cn_env_create: human_num_range must be in [0, human_num)");
     const int HM = cfg->human_num + cfg->human_num_range; // observation rows / lanes per env
     CN_REQUIRE(cfg->human_num >= 1 && HM <= CN_MAX_HUMANS, "cn_env_create: human_num + human_num_range must be in [1,%d]", CN_MAX_HUMANS);
-    CN_REQUIRE(cfg->kinematics == CN_KIN_HOLONOMIC, "cn_env_create: unicycle kinematics is not implemented on the device");
+    CN_REQUIRE(cfg->kinematics == CN_KIN_HOLONOMIC || (cfg->kinematics == CN_KIN_UNICYCLE && cfg->env_kind == CN_ENV_VARNUM && cfg->robot_policy == CN_ROBOT_NETWORK),
+               "cn_env_create: kinematics must be holonomic, or unicycle with CrowdSimVarNum-v0 and a network-driven robot (the only "
+               "combination the reference runs: crowd_sim_var_num.py:78-91, :379-381)");
     CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA, "cn_env_create: social-force humans are not implemented on the device");
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_PRED_GST, "cn_env_create: unknown env_kind %d", cfg->env_kind);
@@ -1204,9 +1260,11 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_rsv = rob_orca ? carve(E) : 0, o_rnd = rob_orca ? carve(E * 4) : 0, o_rsn = rob_orca ? carve(E * H * 4) : 0;
     const size_t o_tr = (test_phase || truth_obs) ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = (test_phase || truth_obs) ? carve(E * H) : 0, o_md = carve(E * 8);
     const size_t o_pend = carve(E);
-    const bool var_n = cfg->human_num_range > 0;
+    const bool unicycle = cfg->kinematics == CN_KIN_UNICYCLE;
+    const bool var_n = cfg->human_num_range > 0 || unicycle; // a unicycle episode holds randint(1, H + 1) humans
     const size_t o_nh = var_n ? carve(E * 4) : 0, o_nxnh = var_n ? carve(E * 4) : 0, o_oc = var_n ? carve(E * 4) : 0, o_om = var_n ? carve(E * 4) : 0;
     const size_t o_simn = var_n ? carve(E * H) : 0, o_rsimn = (var_n && rob_orca) ? carve(E) : 0;
+    const size_t o_dv = unicycle ? carve(E * 8) : 0;
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -1228,6 +1286,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.pend = (uint8_t *)(base + o_pend);
     d.nh = var_n ? (int32_t *)(base + o_nh) : nullptr; d.nx_nh = var_n ? (int32_t *)(base + o_nxnh) : nullptr;
     d.obs_cnt = var_n ? (int32_t *)(base + o_oc) : nullptr; d.obs_max = var_n ? (int32_t *)(base + o_om) : nullptr;
+    d.desired_v = unicycle ? (double *)(base + o_dv) : nullptr;
     d.sim_n = var_n ? (uint8_t *)(base + o_simn) : nullptr; d.rob_sim_n = (var_n && rob_orca) ? (uint8_t *)(base + o_rsimn) : nullptr;
     d.min_dist = (double *)(base + o_md);
     d.rob_sim_valid = rob_orca ? (uint8_t *)(base + o_rsv) : nullptr; d.rob_nd = rob_orca ? (float *)(base + o_rnd) : nullptr;

@@ -9,11 +9,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_KIND = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
 
 
-ORACLE_ONLY = ("sfhumans", "unicycle")   # settings the HIP simulator does not implement yet
+ORACLE_ONLY = ("sfhumans",)   # settings the HIP simulator does not implement yet
 
 
 def env_fixtures(device=False):
-    """All env traces; device=True leaves out the ones that exercise oracle-only settings (social-force humans, unicycle robot)."""
+    """All env traces; device=True leaves out the ones that exercise oracle-only settings (social-force humans)."""
     paths = sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
     return [p for p in paths if not (device and any(t in os.path.basename(p) for t in ORACLE_ONLY))]
 
@@ -35,7 +35,7 @@ def sim_kwargs(meta, oracle=False):
         extra["human_num_range"] = int(over["sim.human_num_range"])
     if over.get("sim.predict_method", "none") == "truth":
         extra["predict_truth"] = 1
-    if oracle and over.get("action_space.kinematics", "holonomic") == "unicycle":
+    if over.get("action_space.kinematics", "holonomic") == "unicycle":
         extra["kinematics"] = 1
     return dict(extra,
         human_num=int(over.get("sim.human_num", 20)),

@@ -29,6 +29,18 @@ def _actions(obs_host, t, E):
     return a.astype(np.float32)
 
 
+def _unicycle_actions(t, E):
+    """(change of speed, change of heading): accelerate / brake into reverse / exactly straight (|r| < 1e-4) / saturated."""
+    mode = (np.arange(E) + t // 25) % 5
+    a = np.zeros((E, 2))
+    a[mode == 0] = [0.06, 0.03 * np.sin(0.3 * t)]
+    a[mode == 1] = [-0.09, 0.05 * np.cos(0.17 * t)]
+    a[mode == 2] = [0.02, 0.0]
+    a[mode == 3] = [0.5 * np.sin(0.9 * t), -0.4]
+    a[mode == 4] = [0.04 * np.cos(0.05 * t), 0.00005]
+    return a.astype(np.float32)
+
+
 CASES = {
     "varnum_h20_nonrand": dict(human_num=20),
     "varnum_h5_rand": dict(human_num=5, randomize_attributes=1, random_goal_changing=1),
@@ -65,6 +77,12 @@ CASES = {
     "varnum_h12_range3_orcarobot": dict(human_num=12, human_num_range=3, robot_policy=1),
     "varnum_h12_rand_range3_robotvisible": dict(human_num=12, human_num_range=3, robot_visible=1, randomize_attributes=1),
     "varnum_h40_range24": dict(human_num=40, human_num_range=24, circle_radius=16.0),
+    # action_space.kinematics = 'unicycle' (the sim2real preset): differential drive, speed integrated from the action, spin / reverse
+    # penalties, 1..H humans per episode, humans at their goal get a new goal instead of being respawned
+    "varnum_h5_unicycle": dict(human_num=5, kinematics=1),
+    "varnum_h3_range2_unicycle": dict(human_num=3, human_num_range=2, kinematics=1),
+    "varnum_h6_rand_range5_unicycle": dict(human_num=6, human_num_range=5, kinematics=1, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h6_rand_unicycle_test": dict(human_num=6, kinematics=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     "varnum_h63_rand_robotvisible": dict(human_num=63, robot_visible=1, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
 }
 
@@ -90,7 +108,7 @@ def test_hip_env_matches_oracle_bit_exact(name):
     infos_seen = set()
     counts_seen = set()
     for t in range(T):
-        act = _actions(host, t, E)
+        act = _unicycle_actions(t, E) if kw.get("kinematics", 0) else _actions(host, t, E)
         nd = torch.full((E, 1), -1.0, device=env.device)
         obs, rew, done, info, epr, epl = env.step(torch.from_numpy(act).to(env.device), not_done=nd)
         assert torch.equal(nd.view(-1), (done == 0).to(torch.float32)), "not_done mask t=%d" % t
@@ -115,7 +133,7 @@ def test_hip_env_matches_oracle_bit_exact(name):
                 np.testing.assert_array_equal(host[k][i].astype(ob[k].dtype).reshape(ob[k].shape), ob[k],
                                               err_msg="%s t=%d env=%d" % (k, t, i))
     assert n_done > 0
-    if kw.get("human_num_range", 0):
+    if kw.get("human_num_range", 0) or kw.get("kinematics", 0):
         assert len(counts_seen) > 2   # the crowd really grew and shrank
     else:
         assert counts_seen == {kw["human_num"]}
