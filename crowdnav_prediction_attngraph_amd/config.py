@@ -27,6 +27,7 @@ class Config(object):
         self.robot = _ns(visible=False, policy="selfAttn_merge_srnn", radius=0.3, v_pref=1, sensor="coordinates", FOV=2, sensor_range=5)
         self.action_space = _ns(kinematics="holonomic")
         self.orca = _ns(neighbor_dist=10, safety_space=0.15, time_horizon=5, time_horizon_obst=5)
+        self.sf = _ns(A=2., B=1, KI=1)
         self.data = _ns(pred_timestep=0.25)
         self.pred = _ns(model_dir="gst_updated/results/100-gumbel_social_transformer-faster_lstm-lr_0.001-init_temp_0.5-edge_head_0-ebd_64-snl_1-snh_8-seed_1000_rand/sj")
         for k, v in overrides.items():
@@ -60,8 +61,9 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     kin = g("action_space", "kinematics", "holonomic")
     if kin not in ("holonomic", "unicycle"):
         unsupported.append("action_space.kinematics=%r" % kin)
-    if g("humans", "policy", "orca") != "orca":
-        unsupported.append("humans.policy != 'orca'")
+    hp = g("humans", "policy", "orca")
+    if hp not in ("orca", "social_force"):
+        unsupported.append("humans.policy=%r" % hp)
     if float(g("humans", "FOV", 2.)) != 2.0 or float(g("robot", "FOV", 2)) != 2.0:
         unsupported.append("FOV != 2*pi")
     pm = g("sim", "predict_method", "const_vel")
@@ -70,9 +72,11 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     if env_name == "CrowdSimPred-v0" and pm == "truth" and rv:
         unsupported.append("sim.predict_method='truth' with robot.visible=True")
     rp = g("robot", "policy", "selfAttn_merge_srnn")
-    if rp not in ("selfAttn_merge_srnn", "srnn", "orca"):
-        unsupported.append("robot.policy=%r (the network policies and 'orca' are implemented)" % rp)
-    if kin == "unicycle" and (env_name != "CrowdSimVarNum-v0" or rp == "orca"):
+    if rp not in ("selfAttn_merge_srnn", "srnn", "orca", "social_force"):
+        unsupported.append("robot.policy=%r (the network policies, 'orca' and 'social_force' are implemented)" % rp)
+    if hp == "social_force" and (phase != "train" or (env_name == "CrowdSimPred-v0" and pm == "truth")):
+        unsupported.append("humans.policy='social_force' in the test phase or with sim.predict_method='truth'")
+    if kin == "unicycle" and (env_name != "CrowdSimVarNum-v0" or rp in ("orca", "social_force")):
         unsupported.append("unicycle kinematics outside CrowdSimVarNum-v0 with a network-driven robot")
     if phase not in ("train", "test"):
         unsupported.append("phase=%r (train.py / test.py only use 'train' and 'test')" % phase)
@@ -87,7 +91,8 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
         sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
         predict_truth=int(env_name == "CrowdSimPred-v0" and pm == "truth"),
-        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy=1 if rp == "orca" else 0, robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
+        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy={"orca": 1, "social_force": 2}.get(rp, 0), humans_policy=int(hp == "social_force"),
+        sf_A=float(g("sf", "A", 2.)), sf_B=float(g("sf", "B", 1.)), sf_KI=float(g("sf", "KI", 1.)), robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
         time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),
         success_reward=float(g("reward", "success_reward", 10)), collision_penalty=float(g("reward", "collision_penalty", -20)),
         discomfort_dist=float(g("reward", "discomfort_dist", 0.25)),

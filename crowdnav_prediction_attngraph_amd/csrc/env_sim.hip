@@ -126,6 +126,25 @@ __device__ __forceinline__ void det_sincos(double x, double &s, double &c)
     }
 }
 
+// deterministic exp: Cody-Waite reduction by ln 2 + degree-5 minimax kernel, +,-,*,/ only; the twin of the oracle's orc_exp.
+// Stands in for np.exp in the social-force policy (crowd_nav/policy/social_force.py:37).
+__device__ __forceinline__ double det_exp(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, INV_LN2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x > 700.0) x = 700.0;
+    if (x < -700.0) return 0.0;
+    const int k = (int)(INV_LN2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double fk = (double)k;
+    const double hi = x - fk * LN2_HI, lo = fk * LN2_LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, k);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Wave-cooperative RVO2 linear programs.  Lane k holds line k = (point, direction); `valid` marks live lines
 // (bit k).  All scalars (result, t bounds, ...) are wave-uniform: every lane computes them identically.
@@ -938,7 +957,25 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     // srnn.clip_action (crowd_nav/policy/srnn.py:17-34), float32 like the numpy action array
     float ax = actions[2 * e], ay = actions[2 * e + 1];
     double uni_v = 0.0, uni_r = 0.0; // ActionRot(v, r) of the unicycle robot
-    if (c.robot_policy == CN_ROBOT_ORCA) {
+    double axd = 0.0, ayd = 0.0;     // float64 action of the social-force robot
+    if (c.robot_policy == CN_ROBOT_SOCIAL_FORCE) {
+        // SOCIAL_FORCE.predict (crowd_nav/policy/social_force.py:11-52) on the robot's beliefs, all in float64; lane j evaluates the
+        // push of human j, the sum runs in list order
+        const double dxg = rb.gx - rb.px, dyg = rb.gy - rb.py;
+        const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
+        const double desired_vx = (dxg / dist_to_goal) * c.robot_v_pref, desired_vy = (dyg / dist_to_goal) * c.robot_v_pref;
+        const double curr_dvx = c.sf_KI * (desired_vx - rb.vx), curr_dvy = c.sf_KI * (desired_vy - rb.vy);
+        const double dx = rb.px - h.l0, dy = rb.py - h.l1;
+        const double d = sqrt(dx * dx + dy * dy);
+        const double f = c.sf_A * det_exp((c.robot_radius + h.l4 - d) / c.sf_B);
+        const double fx = f * (dx / d), fy = f * (dy / d);
+        double ivx = 0.0, ivy = 0.0;
+        for (int j = 0; j < n; ++j) { ivx += __shfl(fx, j, 64); ivy += __shfl(fy, j, 64); }
+        const double nvx = rb.vx + (curr_dvx + ivx) * c.time_step, nvy = rb.vy + (curr_dvy + ivy) * c.time_step;
+        const double act_norm = sqrt(nvx * nvx + nvy * nvy);
+        if (act_norm > c.robot_v_pref) { axd = nvx / act_norm * c.robot_v_pref; ayd = nvy / act_norm * c.robot_v_pref; }
+        else { axd = nvx; ayd = nvy; }
+    } else if (c.robot_policy == CN_ROBOT_ORCA) {
         // crowd_sim_var_num.py:371-375: action = robot.act(copy of last_human_states) -> ORCA.predict (orca.py:64-117) on the
         // robot's BELIEFS about all H humans (never-seen ones sit at the (15,15) dummy); no clip_action on this path
         float nd, seen_r;
@@ -969,6 +1006,32 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c.robot_v_pref;
         if (act_norm > vp) { ax = ax / act_norm * vp; ay = ay / act_norm * vp; }
+    }
+    // humans.policy = 'social_force' (SOCIAL_FORCE.predict for every human, float64): lane i is human i and walks the list of the
+    // other agents get_human_actions passes -- every other human (true state unless coincident -> the dummy at (7,7) with the
+    // config radius), then the robot when robot.visible
+    double sfx = 0.0, sfy = 0.0;
+    if (c.humans_policy == CN_HUMANS_SOCIAL_FORCE) {
+        const double dxg = h.gx - h.px, dyg = h.gy - h.py;
+        const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
+        const double desired_vx = (dxg / dist_to_goal) * h.vpref, desired_vy = (dyg / dist_to_goal) * h.vpref;
+        const double curr_dvx = c.sf_KI * (desired_vx - h.vx), curr_dvy = c.sf_KI * (desired_vy - h.vy);
+        double ivx = 0.0, ivy = 0.0;
+        for (int j = 0; j <= n; ++j) {
+            if (j == n && !c.robot_visible) break;
+            const int src = j < n ? j : 0; // the shuffles stay outside any conditional (they read inactive lanes as 0 otherwise)
+            const double jx = __shfl(h.px, src, 64), jy = __shfl(h.py, src, 64), jr = __shfl(h.rad, src, 64);
+            double ox = j < n ? jx : rb.px, oy = j < n ? jy : rb.py, orad = j < n ? jr : c.robot_radius;
+            if (ox == h.px && oy == h.py) { ox = 7.0; oy = 7.0; if (j < n) orad = c.human_radius; }
+            const double dx = h.px - ox, dy = h.py - oy;
+            const double d = sqrt(dx * dx + dy * dy);
+            const double f = c.sf_A * det_exp((h.rad + orad - d) / c.sf_B);
+            if (j != lane) { ivx += f * (dx / d); ivy += f * (dy / d); }
+        }
+        const double nvx = h.vx + (curr_dvx + ivx) * c.time_step, nvy = h.vy + (curr_dvy + ivy) * c.time_step;
+        const double act_norm = sqrt(nvx * nvx + nvy * nvy);
+        if (act_norm > h.vpref) { sfx = nvx / act_norm * h.vpref; sfy = nvy / act_norm * h.vpref; }
+        else { sfx = nvx; sfy = nvy; }
     }
     // calc_reward (crowd_sim_var_num.py:465-561), pre-move positions.  "first collision in list order, break":
     // dmin is only consumed when there is no collision at all, so the lane-parallel min is equivalent.
@@ -1052,13 +1115,21 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         rb.theta = th;
         det_sincos(th, s0, c0);
         rb.vx = uni_v * c0; rb.vy = uni_v * s0;
+    } else if (c.robot_policy == CN_ROBOT_SOCIAL_FORCE) {
+        rb.px = rb.px + axd * c.time_step; rb.py = rb.py + ayd * c.time_step;
+        rb.vx = axd; rb.vy = ayd;
     } else {
         // kinematics (crowd_sim/envs/utils/agent.py:170-183, holonomic)
         rb.px = rb.px + (double)(ax * (float)c.time_step);
         rb.py = rb.py + (double)(ay * (float)c.time_step);
         rb.vx = (double)ax; rb.vy = (double)ay;
     }
-    if (isH) {
+    if (isH && c.humans_policy == CN_HUMANS_SOCIAL_FORCE) {
+        h.px = h.px + sfx * c.time_step;
+        h.py = h.py + sfy * c.time_step;
+        h.vx = sfx; h.vy = sfy;
+        s.hact[(size_t)e * 2 * H + lane] = (float)sfx; s.hact[(size_t)e * 2 * H + H + lane] = (float)sfy; // for cn_env_get_human_actions
+    } else if (isH) {
         const float hax = s.hact[(size_t)e * 2 * H + lane], hay = s.hact[(size_t)e * 2 * H + H + lane];
         h.px = h.px + (double)hax * c.time_step;
         h.py = h.py + (double)hay * c.time_step;
@@ -1176,8 +1247,10 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
     CN_HIP(hipEventRecord(env->ev_state, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
     const int agents = env->d.E * env->d.H;
-    hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
-    CN_CHECK_LAUNCH();
+    if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
+        hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
+        CN_CHECK_LAUNCH();
+    }
     if (env->d.cfg.phase == CN_PHASE_TEST)
         for (int k = 1; k <= env->d.P; ++k) { // 'truth' roll-out for the next step's Danger decision
             hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d, k);
@@ -1223,13 +1296,15 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(cfg->kinematics == CN_KIN_HOLONOMIC || (cfg->kinematics == CN_KIN_UNICYCLE && cfg->env_kind == CN_ENV_VARNUM && cfg->robot_policy == CN_ROBOT_NETWORK),
                "cn_env_create: kinematics must be holonomic, or unicycle with CrowdSimVarNum-v0 and a network-driven robot (the only "
                "combination the reference runs: crowd_sim_var_num.py:78-91, :379-381)");
-    CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA, "cn_env_create: social-force humans are not implemented on the device");
+    CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA || (cfg->humans_policy == CN_HUMANS_SOCIAL_FORCE && cfg->phase == CN_PHASE_TRAIN && !cfg->predict_truth),
+               "cn_env_create: humans_policy must be ORCA, or social force in the train phase without 'truth' predictions (those roll the "
+               "humans' policies forward, which is only implemented for ORCA humans)");
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_PRED_GST, "cn_env_create: unknown env_kind %d", cfg->env_kind);
     CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST,
                "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
-    CN_REQUIRE(cfg->robot_policy == CN_ROBOT_NETWORK || cfg->robot_policy == CN_ROBOT_ORCA, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
+    CN_REQUIRE(cfg->robot_policy >= CN_ROBOT_NETWORK && cfg->robot_policy <= CN_ROBOT_SOCIAL_FORCE, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
     CN_REQUIRE(!cfg->robot_visible || (cfg->env_kind == CN_ENV_VARNUM && cfg->phase == CN_PHASE_TRAIN && HM <= CN_MAX_HUMANS - 1),
                "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num + human_num_range <= %d (the reference rebuilds every private "
                "simulator twice per step in the test phase and breaks in CrowdSimPred)", CN_MAX_HUMANS - 1);

@@ -61,7 +61,7 @@ enum { CN_ENV_VARNUM = 0, CN_ENV_PRED = 1, CN_ENV_PRED_GST = 2 };   /* gym ids C
 enum { CN_PHASE_TRAIN = 0, CN_PHASE_VAL = 1, CN_PHASE_TEST = 2 };
 enum { CN_INFO_NOTHING = 0, CN_INFO_TIMEOUT = 1, CN_INFO_COLLISION = 2, CN_INFO_REACHGOAL = 3, CN_INFO_DANGER = 4 }; /* crowd_sim/envs/utils/info.py */
 
-enum { CN_ROBOT_NETWORK = 0, CN_ROBOT_ORCA = 1 };
+enum { CN_ROBOT_NETWORK = 0, CN_ROBOT_ORCA = 1, CN_ROBOT_SOCIAL_FORCE = 2 };
 enum { CN_KIN_HOLONOMIC = 0, CN_KIN_UNICYCLE = 1 };   /* action_space.kinematics */
 enum { CN_HUMANS_ORCA = 0, CN_HUMANS_SOCIAL_FORCE = 1 }; /* humans.policy */
 #define CN_MAX_HUMANS 64 /* one wavefront lane per human */
@@ -80,7 +80,8 @@ typedef struct {
     int32_t nenv;                 /* TOTAL number of envs across all GPUs: the case_counter stride (crowd_sim_var_num.py:348) */
     uint32_t val_size, test_size;
     int32_t robot_policy;         /* CN_ROBOT_NETWORK: cn_env_step's action drives the robot; CN_ROBOT_ORCA: robot.policy = 'orca'
-                                   * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored */
+                                   * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored;
+                                   * CN_ROBOT_SOCIAL_FORCE: robot.policy = 'social_force' (crowd_nav/policy/social_force.py), likewise */
     int32_t robot_visible;        /* robot.visible: every human's ORCA sees the robot as one more neighbour (crowd_sim.py:695-699);
                                    * CrowdSimVarNum-v0, train phase, human_num <= 63 */
     int32_t auto_reset;           /* 1 (default): vec-env semantics, a finished env is reset inside cn_env_step and `obs` holds the
@@ -97,7 +98,7 @@ typedef struct {
                                    * changed every 5 s: crowd_sim_var_num.py:103-104, :404-437, crowd_sim_pred.py:165-190); observations
                                    * always have human_num + human_num_range rows, which must be <= CN_MAX_HUMANS */
     int32_t kinematics;           /* CN_KIN_* (action_space.kinematics) */
-    int32_t humans_policy;        /* CN_HUMANS_* (humans.policy) */
+    int32_t humans_policy;        /* CN_HUMANS_* (humans.policy); social force: train phase, no 'truth' predictions */
     int32_t reserved0;
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;

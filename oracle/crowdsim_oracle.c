@@ -121,6 +121,26 @@ void orc_sincos(double x, double *s, double *c)
     }
 }
 
+/* deterministic exp: Cody-Waite reduction by ln 2 + the classic degree-5 minimax kernel, plain +,-,*,/ only (no FMA) so the HIP
+ * twin is bit-identical.  < 1 ulp.  Stands in for np.exp at crowd_nav/policy/social_force.py:37 (arguments there are
+ * (r_i + r_j - d) / B, a few units at most). */
+double orc_exp(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, INV_LN2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x > 700.0) x = 700.0;
+    if (x < -700.0) return 0.0;
+    const int k = (int)(INV_LN2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double fk = (double)k;
+    const double hi = x - fk * LN2_HI, lo = fk * LN2_LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, k);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * ORCA -- restatement of RVO2 Library v2.0.2 (Agent.cpp), fp32, RVO_EPSILON = 1e-5.
  * Reference call site: crowd_nav/policy/orca.py:80-114 (only agent 0's velocity is read, :114).
@@ -631,7 +651,7 @@ static void human_sf_action(const OrcEnv *e, int i, double *avx, double *avy)
         }
         const double dx = me->px - ox, dy = me->py - oy;
         const double d = sqrt(dx * dx + dy * dy);
-        const double f = c->sf_A * exp((me->radius + orad - d) / c->sf_B);
+        const double f = c->sf_A * orc_exp((me->radius + orad - d) / c->sf_B);
         ivx += f * (dx / d);
         ivy += f * (dy / d);
     }
@@ -745,7 +765,7 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         for (int j = 0; j < H; ++j) {
             const double dx = e->rpx - e->last_human_states[j][0], dy = e->rpy - e->last_human_states[j][1];
             const double d = sqrt(dx * dx + dy * dy);
-            const double f = c->sf_A * exp((c->robot_radius + e->last_human_states[j][4] - d) / c->sf_B);
+            const double f = c->sf_A * orc_exp((c->robot_radius + e->last_human_states[j][4] - d) / c->sf_B);
             ivx += f * (dx / d);
             ivy += f * (dy / d);
         }

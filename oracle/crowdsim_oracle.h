@@ -168,6 +168,7 @@ double orc_mt_double(OrcMT *mt);
 
 /* ---- deterministic sin/cos on [0, 2*pi) (shared algorithm with the HIP path) ---- */
 void orc_sincos(double x, double *s, double *c);
+double orc_exp(double x);
 
 /* ---- ORCA (RVO2 v2.0.2 semantics, fp32) ----
  * Computes agent 0's new velocity given n_other other agents (already in the observer's order).

@@ -82,6 +82,8 @@ def lib():
         L.orc_mt_double.restype = C.c_double
         L.orc_mt_double.argtypes = [C.c_void_p]
         L.orc_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_exp.restype = C.c_double
+        L.orc_exp.argtypes = [C.c_double]
         fp = C.POINTER(C.c_float)
         L.orc_orca_velocity.restype = C.c_int
         L.orc_orca_velocity.argtypes = [C.c_float] * 9 + [C.c_int, C.c_float, C.c_float, C.c_int, fp, fp, fp, fp, fp,

@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ENV_KIND = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
 
 
-ORACLE_ONLY = ("sfhumans",)   # settings the HIP simulator does not implement yet
+ORACLE_ONLY = ()   # settings the HIP simulator does not implement (none left)
 
 
 def env_fixtures(device=False):
@@ -29,7 +29,7 @@ def sim_kwargs(meta, oracle=False):
     settings only the oracle implements)."""
     over = meta["over"]
     extra = {}
-    if oracle and over.get("humans.policy", "orca") == "social_force":
+    if over.get("humans.policy", "orca") == "social_force":
         extra["humans_policy"] = 1
     if over.get("sim.human_num_range", 0):
         extra["human_num_range"] = int(over["sim.human_num_range"])
@@ -46,6 +46,6 @@ def sim_kwargs(meta, oracle=False):
         sort_humans=int(bool(meta.get("sort_humans", True))),
         nenv=int(meta["nenv"]),
         phase=0 if meta["nenv"] > 1 else 2,
-        robot_policy=1 if over.get("robot.policy", "selfAttn_merge_srnn") == "orca" else 0,
+        robot_policy={"orca": 1, "social_force": 2}.get(over.get("robot.policy", "selfAttn_merge_srnn"), 0),
         robot_visible=int(bool(over.get("robot.visible", False))),
     )

@@ -83,6 +83,13 @@ CASES = {
     "varnum_h3_range2_unicycle": dict(human_num=3, human_num_range=2, kinematics=1),
     "varnum_h6_rand_range5_unicycle": dict(human_num=6, human_num_range=5, kinematics=1, randomize_attributes=1, random_goal_changing=1),
     "varnum_h6_rand_unicycle_test": dict(human_num=6, kinematics=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    # humans.policy = 'social_force' (float64 forces, no solver) and robot.policy = 'social_force'
+    "varnum_h20_sfhumans": dict(human_num=20, humans_policy=1),
+    "varnum_h10_rand_sfhumans_robotvisible": dict(human_num=10, humans_policy=1, robot_visible=1, randomize_attributes=1, random_goal_changing=1),
+    "pred_h12_rand_range3_sfhumans": dict(human_num=12, human_num_range=3, env_kind=1, humans_policy=1, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h20_sfrobot": dict(human_num=20, robot_policy=2),
+    "varnum_h10_rand_sfrobot_test": dict(human_num=10, robot_policy=2, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h10_sfrobot_sfhumans": dict(human_num=10, robot_policy=2, humans_policy=1),
     "varnum_h63_rand_robotvisible": dict(human_num=63, robot_visible=1, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
 }
 

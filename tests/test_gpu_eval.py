@@ -37,18 +37,20 @@ def test_sequential_and_batched_evaluation_agree(env_name, over):
     assert seq["collision_rate"] + seq["timeout_rate"] + seq["success_rate"] == pytest.approx(1.0)
 
 
-def test_device_evaluation_reproduces_the_shipped_orca_robot_log():
-    """The reference's own end-to-end fixture (trained_models/ORCA_no_rand/test/test_00000.pt.log, real Python-RVO2), replayed
+@pytest.mark.parametrize("fixture,robot", [("ref_eval_orca_robot_log.json", "orca"), ("ref_eval_sf_robot_log.json", "social_force")])
+def test_device_evaluation_reproduces_the_shipped_scripted_robot_logs(fixture, robot):
+    """The reference's own end-to-end fixtures (trained_models/ORCA_no_rand and SF_no_rand test logs, real Python-RVO2), replayed
     through the reference-shaped `evaluate` on the HIP simulator: all 500 outcomes and the six logged metrics."""
     import json
     import os
     from crowdnav_prediction_attngraph_amd import config as C
     from crowdnav_prediction_attngraph_amd.evaluation import evaluate
     from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
-    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_eval_orca_robot_log.json")))
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture)))
     c = ref["config"]
-    cfg = C.Config(**{"sim.human_num": c["human_num"], "robot.policy": "orca", "env.randomize_attributes": True,
-                      "humans.random_goal_changing": True, "humans.end_goal_changing": True, "env.test_size": c["test_size"]})
+    cfg = C.Config(**{"sim.human_num": c["human_num"], "robot.policy": robot, "env.randomize_attributes": bool(c["randomize_attributes"]),
+                      "humans.random_goal_changing": bool(c["random_goal_changing"]), "humans.end_goal_changing": bool(c["end_goal_changing"]),
+                      "env.test_size": c["test_size"]})
     dev = torch.device("cuda", 0)
     envs = make_vec_envs(c["env_name"], c["seed"], 1, 0.99, None, dev, True, config=cfg)
     m = evaluate(None, envs, 1, dev, c["test_size"], logging.getLogger("eval-test"), cfg, None)

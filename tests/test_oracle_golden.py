@@ -36,6 +36,16 @@ def test_sincos_accuracy():
     assert np.max(np.abs(got[:, 1] - np.cos(xs))) <= 2.3e-16
 
 
+def test_exp_accuracy():
+    """The deterministic exp that stands in for np.exp in the social-force policy: within 1 ulp of libm over the arguments it sees."""
+    xs = np.concatenate([np.linspace(-40.0, 3.0, 40001), np.linspace(-1e-3, 1e-3, 2001), [0.0, -700.5, 12.25]])
+    got = np.array([O.lib().orc_exp(float(x)) for x in xs])
+    want = np.exp(xs)
+    ok = xs >= -700.0   # below that the stand-in flushes to zero (never reached: the argument is (r_i + r_j - d) / B)
+    assert np.max(np.abs(got[ok] - want[ok]) / np.spacing(want[ok])) <= 1.0
+    assert got[xs == 0.0][0] == 1.0 and got[xs == -700.5][0] == 0.0
+
+
 @pytest.mark.parametrize("path", G.env_fixtures(), ids=lambda p: p.split("env_")[-1][:-4])
 def test_env_trace_matches_reference(path):
     z, meta = G.load(path)
