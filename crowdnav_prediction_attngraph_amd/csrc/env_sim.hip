@@ -5,10 +5,13 @@
 // Python reference, so results are reproducible bit for bit against the scalar CPU restatement used by the tests.
 //
 // Mapping (one wavefront = 64 lanes everywhere in this file; a lane is a human):
-//   orca_kernel      one wavefront per (env, human i): lanes = the other humans.  Lanes build their ORCA half-plane
-//                    in parallel, a rank sort orders them by distance, and the linear programs run wave-cooperatively
-//                    (outer loop over lines is the serial dependence of RVO2's LP; the inner clip of a line against all
-//                    earlier lines is one lane-parallel min/max reduction).
+//   orca_lane_kernel one LANE per (env, human i) for crowds of <= 32 agents: neighbour keys ordered by a sorting network, ORCA lines
+//                    and linearProgram2 in per-lane register vectors (no LDS: co-resides with the policy kernels); the agents
+//                    whose program is infeasible (about a third in a dense crossing) hand their lines to
+//   orca_lp3_kernel  one wavefront per such agent: lane k = line k, RVO2's linearProgram3 wave-cooperatively (the outer loop over
+//                    lines is its serial dependence; the inner clip of a line against all earlier lines is one lane-parallel
+//                    min/max reduction)
+//   orca_kernel      the whole solve one wavefront per agent (crowds of more than 32 agents; also the 'truth' roll-outs)
 //   env_step_kernel  one wavefront per env: robot clip + reward/collision (lane-parallel distances, ballot/any),
 //                    kinematics, visibility, belief update, distance rank sort + observation scatter, goal changes,
 //                    respawns and the in-launch auto-reset.  The MT19937 stream of the env lives in HBM ([E][624]) and
@@ -18,6 +21,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -25,6 +29,8 @@ namespace {
 
 constexpr int MT_N = 624;
 constexpr float RVO_EPS = 0.00001f;
+
+struct Lp3Hdr { int32_t agent, nn, line_fail; float rx, ry, radius; };
 
 struct EnvDev {
     cn_env_config cfg;
@@ -74,6 +80,9 @@ struct EnvDev {
     int32_t *obs_max;   // [E] max(self.observed_human_ids), -1 when empty
     uint8_t *sim_n;     // [E][H] agent count human i's private simulator was built for (orca.py:80-82 rebuilds on a change)
     uint8_t *rob_sim_n; // [E] ... the robot's (robot.policy == 'orca')
+    int32_t *lp3_cnt;   // [1] agents of this step's ORCA pass whose linear program was infeasible (orca_lane_kernel -> orca_lp3_kernel)
+    struct Lp3Hdr *lp3_hdr; // [E*H] where linearProgram2 stopped
+    float4 *lp3_lines;  // [E*H][32] their ORCA lines (point, direction) in neighbour order
     double *desired_v;  // [E] unicycle robot only: self.desiredVelocity[0] (crowd_sim.py:82: set at construction, never reset)
 };
 
@@ -329,11 +338,8 @@ __device__ __forceinline__ void orca_wave(int lane, int nl, bool cand, float opx
 // ------------------------------------------------------------------------------------------------------------------
 // ORCA for every human of every env.  crowd_sim.py:680-703 get_human_actions + crowd_nav/policy/orca.py:64-117.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
+__device__ __forceinline__ void orca_agent(const EnvDev &s, int agent, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int agent = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (agent >= s.E * s.H) return;
     const int H = s.H;
     const int e = agent / H, i = agent - e * H;
     const int n = crowd_size(s, e); // humans present (== H unless sim.human_num_range > 0)
@@ -386,6 +392,260 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
     if (lane == 0) {
         s.hact[(size_t)e * 2 * H + i] = ox;
         s.hact[(size_t)e * 2 * H + H + i] = oy;
+    }
+}
+
+// The grid is capped (prefetch_orca): this kernel shares the chip with the policy forward on the caller's stream, and a resident-sized
+// grid of wavefronts that walk the agents keeps its share of the issue slots bounded instead of flooding every SIMD.
+__global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
+{
+    const int lane = threadIdx.x & 63;
+    const int total = s.E * s.H;
+    for (int agent = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); agent < total; agent += gridDim.x * 4)
+        orca_agent(s, agent, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One LANE per agent (the common case of <= 32 agents in a crowd): the scalar RVO2 algorithm exactly as a CPU would run it,
+// 64 agents per wavefront, no cross-lane traffic and no LDS (so it co-resides with the policy kernels that hold all 160 KB).
+// Everything a lane indexes at run time lives in global memory (the env's agent records, L1-resident); everything it keeps in
+// registers is indexed statically: the neighbour keys are ordered by a sorting network, the ORCA lines are built in that order,
+// and the linear programs are fully unrolled over (line i, earlier line j).  linearProgram3 (the infeasible case, a few agents
+// per thousand) would unroll to O(NB^3) code: those agents are put on a list and redone by the wave-cooperative routine above.
+// Same arithmetic, same operation order as orca_wave / the oracle: results are bit-identical.
+// ------------------------------------------------------------------------------------------------------------------
+#include "orca_sortnet.inc"
+
+template <int W> struct LaneVec;
+template <> struct LaneVec<8> { typedef float f __attribute__((ext_vector_type(8))); };
+template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(32))); };
+
+// NB = slots the sorting network orders (>= candidate neighbours incl. self), VW = width of the register vectors that hold the
+// per-lane arrays.  The loops over neighbours / lines are ROLLED with wave-uniform counters: a vector element is then selected by
+// a uniform register index (s_set_gpr_idx), not by 20-32 unrolled copies -- fully unrolled the kernel was 85 KB of straight-line
+// code that every wavefront fetched exactly once (instruction-fetch bound, slower than the cooperative kernel).
+template <int NB, int VW>
+__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s)
+{
+    typedef typename LaneVec<VW>::f vec;
+    const int agent = blockIdx.x * 64 + threadIdx.x;
+    const int H = s.H;
+    const bool live_lane = agent < s.E * H;
+    const int e = live_lane ? agent / H : 0, i = live_lane ? agent - e * H : 0;
+    const int n = crowd_size(s, e);
+    const bool active = live_lane && i < n; // (inactive lanes run along with nn = 0: the loop counters below must stay wave-uniform)
+    const cn_env_config &c = s.cfg;
+    const double *hum = s.hum + (size_t)e * 8 * H;
+    const double *rob = s.rob + (size_t)e * 8;
+    const double spx = hum[F_PX * H + i], spy = hum[F_PY * H + i], svx = hum[F_VX * H + i], svy = hum[F_VY * H + i];
+    const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i], srad = hum[F_RAD * H + i], svpref = hum[F_VPREF * H + i];
+    const double safety = c.orca_safety_space;
+    const bool rv = c.robot_visible != 0;
+    const int n_agents = n + (rv ? 1 : 0);
+    const size_t ei = (size_t)e * H + i;
+    // lazily (re)build human i's private simulator: orca.py:80-89
+    float nd = 0.0f, self_r = 0.0f, self_ms = 0.0f;
+    if (active) {
+        const bool rebuild = !s.sim_valid[ei] || (s.sim_n && s.sim_n[ei] != n_agents);
+        if (rebuild) {
+            nd = (float)s.shared_nd[e];
+            self_r = (float)(srad + 0.01 + safety);
+            self_ms = (float)svpref;
+            if (s.sim_seen)
+                for (int j = 0; j < n; ++j) s.sim_seen[ei * H + j] = (float)(hum[F_RAD * H + j] + 0.01 + safety);
+            s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1;
+            if (s.sim_n) s.sim_n[ei] = (uint8_t)n_agents;
+        } else {
+            nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
+        }
+    }
+    const float fpx = (float)spx, fpy = (float)spy, fvx = (float)svx, fvy = (float)svy;
+    // pass 1: distance keys of the candidates in index order (slot j = agent j; self and empty slots get +inf)
+    vec key, idx; // idx holds small integers as floats (exact)
+    int nn = 0;
+#pragma unroll 1
+    for (int j = 0; j < NB; ++j) {
+        const bool isR = rv && j == n;
+        const bool cand = active && ((j < n && j != i) || isR);
+        const int lj = j < n ? j : 0;
+        const double qx = isR ? rob[R_PX] : hum[F_PX * H + lj], qy = isR ? rob[R_PY] : hum[F_PY * H + lj];
+        const bool coincident = (qx == spx) && (qy == spy);
+        const float opx = coincident ? 7.0f : (float)qx, opy = coincident ? 7.0f : (float)qy;
+        const float ddx0 = fpx - opx, ddy0 = fpy - opy;
+        const float dq = ddx0 * ddx0 + ddy0 * ddy0;
+        const bool inrange = cand && dq < nd * nd;
+        key[j] = inrange ? dq : INFINITY;
+        idx[j] = (float)j;
+        nn += inrange ? 1 : 0;
+    }
+    // ascending (distSq, index): RVO2's insertion order; the +inf slots end up behind the nn real neighbours
+#define ORCA_CE(a, b)                                                                                  \
+    {                                                                                                  \
+        const float ka0 = key[a], kb0 = key[b], ia0 = idx[a], ib0 = idx[b];                             \
+        const bool sw = kb0 < ka0 || (kb0 == ka0 && ib0 < ia0);                                         \
+        key[a] = sw ? kb0 : ka0; key[b] = sw ? ka0 : kb0; idx[a] = sw ? ib0 : ia0; idx[b] = sw ? ia0 : ib0; \
+    }
+    if constexpr (NB == 8) { ORCA_SORTNET_8(ORCA_CE) }
+    else if constexpr (NB == 20) { ORCA_SORTNET_20(ORCA_CE) }
+    else { static_assert(NB == 32, "sorting networks exist for 8, 20 and 32 slots"); ORCA_SORTNET_32(ORCA_CE) }
+#undef ORCA_CE
+    int nmax = nn; // wave-uniform loop bound
+    for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    // pass 2: the ORCA half-plane of the k-th nearest neighbour (Agent::computeNewVelocity)
+    const float th = (float)c.orca_time_horizon, dt = (float)c.time_step;
+    vec Lpx, Lpy, Ldx, Ldy;
+#pragma unroll 1
+    for (int k = 0; k < nmax; ++k) {
+        float o_px = 0.0f, o_py = 0.0f, o_dx = 1.0f, o_dy = 0.0f;
+        const int j = (int)idx[k];
+        if (k < nn) {
+            const bool isR = j == n; // only reachable when rv
+            const int lj = isR ? 0 : j;
+            const double qx = isR ? rob[R_PX] : hum[F_PX * H + lj], qy = isR ? rob[R_PY] : hum[F_PY * H + lj];
+            const double qvx = isR ? rob[R_VX] : hum[F_VX * H + lj], qvy = isR ? rob[R_VY] : hum[F_VY * H + lj];
+            float orad;
+            if (isR) orad = (float)(c.robot_radius + 0.01 + safety); // fixed for the whole run
+            else if (s.sim_seen) orad = s.sim_seen[ei * H + lj];
+            else orad = (float)(hum[F_RAD * H + lj] + 0.01 + safety);
+            const bool coincident = (qx == spx) && (qy == spy);
+            const float opx = coincident ? 7.0f : (float)qx, opy = coincident ? 7.0f : (float)qy;
+            const float ovx = coincident ? 0.0f : (float)qvx, ovy = coincident ? 0.0f : (float)qvy;
+            const float rpx = opx - fpx, rpy = opy - fpy;   // relativePosition
+            const float rvx = fvx - ovx, rvy = fvy - ovy;   // relativeVelocity
+            const float distSq = rpx * rpx + rpy * rpy;
+            const float cr = self_r + orad;
+            const float crSq = cr * cr;
+            float ldx, ldy, ux, uy;
+            if (distSq > crSq) {
+                const float invTH = 1.0f / th;
+                const float wx = rvx - invTH * rpx, wy = rvy - invTH * rpy;
+                const float wLenSq = wx * wx + wy * wy;
+                const float dot1 = wx * rpx + wy * rpy;
+                if (dot1 < 0.0f && dot1 * dot1 > crSq * wLenSq) {
+                    const float wLen = sqrtf(wLenSq);
+                    const float inv = 1.0f / wLen;
+                    const float uwx = wx * inv, uwy = wy * inv;
+                    ldx = uwy; ldy = -uwx;
+                    const float sc = cr * invTH - wLen;
+                    ux = sc * uwx; uy = sc * uwy;
+                } else {
+                    const float leg = sqrtf(distSq - crSq);
+                    const float invD = 1.0f / distSq;
+                    if (rpx * wy - rpy * wx > 0.0f) {
+                        ldx = (rpx * leg - rpy * cr) * invD;
+                        ldy = (rpx * cr + rpy * leg) * invD;
+                    } else {
+                        ldx = -((rpx * leg + rpy * cr) * invD);
+                        ldy = -((-rpx * cr + rpy * leg) * invD);
+                    }
+                    const float dot2 = rvx * ldx + rvy * ldy;
+                    ux = dot2 * ldx - rvx; uy = dot2 * ldy - rvy;
+                }
+            } else {
+                const float invDT = 1.0f / dt;
+                const float wx = rvx - invDT * rpx, wy = rvy - invDT * rpy;
+                const float wLen = sqrtf(wx * wx + wy * wy);
+                const float inv = 1.0f / wLen;
+                const float uwx = wx * inv, uwy = wy * inv;
+                ldx = uwy; ldy = -uwx;
+                const float sc = cr * invDT - wLen;
+                ux = sc * uwx; uy = sc * uwy;
+            }
+            o_px = fvx + 0.5f * ux; o_py = fvy + 0.5f * uy; o_dx = ldx; o_dy = ldy;
+        }
+        Lpx[k] = o_px; Lpy[k] = o_py; Ldx[k] = o_dx; Ldy[k] = o_dy;
+    }
+    // preferred velocity: orca.py:97-100
+    double gvx = sgx - spx, gvy = sgy - spy;
+    const double speed = sqrt(gvx * gvx + gvy * gvy);
+    if (speed > 1.0) { gvx = gvx / speed; gvy = gvy / speed; }
+    const float optx = (float)gvx, opty = (float)gvy, radius = self_ms;
+    // linearProgram2 (optimise the preferred velocity, directionOpt = false)
+    float rx, ry;
+    if (optx * optx + opty * opty > radius * radius) {
+        const float inv = 1.0f / sqrtf(optx * optx + opty * opty);
+        rx = radius * (optx * inv); ry = radius * (opty * inv);
+    } else {
+        rx = optx; ry = opty;
+    }
+    bool failed = false;
+    int line_fail = 0;
+#pragma unroll 1
+    for (int li = 0; li < nmax; ++li) {
+        const float ipx = Lpx[li], ipy = Lpy[li], idx_ = Ldx[li], idy = Ldy[li];
+        const bool viol = li < nn && !failed && idx_ * (ipy - ry) - idy * (ipx - rx) > 0.0f;
+        if (__ballot(viol) == 0ull) continue; // wave-uniform: nobody has to re-optimise on this line
+        // linearProgram1 on line li against the disc and the earlier lines
+        const float dotProduct = ipx * idx_ + ipy * idy;
+        const float discriminant = dotProduct * dotProduct + radius * radius - (ipx * ipx + ipy * ipy);
+        bool ok = !(discriminant < 0.0f);
+        const float sq = sqrtf(discriminant);
+        float tLeft = -dotProduct - sq, tRight = -dotProduct + sq;
+        bool pfail = false;
+#pragma unroll 1
+        for (int lj = 0; lj < li; ++lj) {
+            const float jpx = Lpx[lj], jpy = Lpy[lj], jdx = Ldx[lj], jdy = Ldy[lj];
+            const float denominator = idx_ * jdy - idy * jdx;
+            const float numerator = jdx * (ipy - jpy) - jdy * (ipx - jpx);
+            const bool parallel = fabsf(denominator) <= RVO_EPS;
+            pfail = pfail || (parallel && numerator < 0.0f);
+            const float t = numerator / denominator;
+            if (!parallel && denominator >= 0.0f) tRight = fminf(tRight, t);
+            if (!parallel && denominator < 0.0f) tLeft = fmaxf(tLeft, t);
+        }
+        // (sequential RVO2 fails at the first prefix that crosses; the bounds are monotone, so this is the same decision)
+        ok = ok && !pfail && !(tLeft > tRight);
+        if (viol) {
+            if (ok) {
+                const float tt = idx_ * (optx - ipx) + idy * (opty - ipy);
+                const float t_opt = tt < tLeft ? tLeft : (tt > tRight ? tRight : tt);
+                rx = ipx + t_opt * idx_;
+                ry = ipy + t_opt * idy;
+            } else {
+                failed = true; // linearProgram3 needed
+                line_fail = li;
+            }
+        }
+    }
+    // infeasible program: hand the lines and the state linearProgram2 stopped in to the wave-cooperative linearProgram3
+    int slot = -1;
+    if (active && failed) {
+        slot = atomicAdd(s.lp3_cnt, 1);
+        Lp3Hdr hd;
+        hd.agent = agent; hd.nn = nn; hd.line_fail = line_fail; hd.rx = rx; hd.ry = ry; hd.radius = radius;
+        s.lp3_hdr[slot] = hd;
+    } else if (active) {
+        s.hact[(size_t)e * 2 * H + i] = rx;
+        s.hact[(size_t)e * 2 * H + H + i] = ry;
+    }
+    if (__ballot(slot >= 0) != 0ull) {
+#pragma unroll 1
+        for (int k = 0; k < nmax; ++k) {
+            const float4 ln = make_float4(Lpx[k], Lpy[k], Ldx[k], Ldy[k]);
+            if (slot >= 0 && k < nn) s.lp3_lines[(size_t)slot * 32 + k] = ln;
+        }
+    }
+}
+
+// the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): one wavefront each, lane k = line k
+__global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
+{
+    const int lane = threadIdx.x & 63;
+    const int total = *s.lp3_cnt;
+    const int H = s.H;
+    for (int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); k < total; k += gridDim.x * 4) {
+        const Lp3Hdr hd = s.lp3_hdr[k];
+        const float4 ln = lane < hd.nn ? s.lp3_lines[(size_t)k * 32 + lane] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        LpLine L;
+        L.px = ln.x; L.py = ln.y; L.dx = ln.z; L.dy = ln.w;
+        float rx = hd.rx, ry = hd.ry;
+        lp3_wave(L, hd.nn, hd.line_fail, hd.radius, lane, rx, ry);
+        if (lane == 0) {
+            const int e = hd.agent / H, i = hd.agent - e * H;
+            s.hact[(size_t)e * 2 * H + i] = rx;
+            s.hact[(size_t)e * 2 * H + H + i] = ry;
+        }
     }
 }
 
@@ -1220,7 +1480,7 @@ struct cn_env_batch {
     EnvDev d;
     bool reset_done;
     void *blob;
-    size_t blob_bytes;
+    size_t blob_bytes; // the persistent state (what a snapshot holds); per-step scratch is carved behind it
     // ORCA of step t+1 only needs the simulator state left by step t, not the robot's next action: it is launched on a
     // side stream as soon as step t (or a reset) is enqueued and overlaps the caller's policy forward.
     hipStream_t side;
@@ -1248,8 +1508,27 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
     const int agents = env->d.E * env->d.H;
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
-        hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
-        CN_CHECK_LAUNCH();
+        const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0); // candidate neighbours per agent (self included)
+        static int coop = -1; // CN_ORCA_COOP=1 forces the one-wavefront-per-agent kernel (A/B measurements)
+        if (coop < 0) { const char *v = getenv("CN_ORCA_COOP"); coop = v ? atoi(v) : 0; }
+        if (slots <= 32 && !coop) {
+            // one lane per agent; the rare infeasible programs are finished by the cooperative routine
+            CN_HIP(hipMemsetAsync(env->d.lp3_cnt, 0, sizeof(int32_t), env->side));
+            const dim3 grid((agents + 63) / 64), blk(64);
+            if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, env->side, env->d);
+            else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, env->side, env->d);
+            else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, env->side, env->d);
+            CN_CHECK_LAUNCH();
+            // the list length is only known on the device: a grid for a quarter of the agents (one per wavefront; the rest of the
+            // wavefronts exit at once, longer lists are walked with a stride) keeps enough wavefronts in flight to hide the latency
+            // of the cooperative routine
+            const int blocks = (agents + 15) / 16;
+            hipLaunchKernelGGL(orca_lp3_kernel, dim3(blocks), dim3(256), 0, env->side, env->d);
+            CN_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
+            CN_CHECK_LAUNCH();
+        }
     }
     if (env->d.cfg.phase == CN_PHASE_TEST)
         for (int k = 1; k <= env->d.P; ++k) { // 'truth' roll-out for the next step's Danger decision
@@ -1340,13 +1619,16 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_nh = var_n ? carve(E * 4) : 0, o_nxnh = var_n ? carve(E * 4) : 0, o_oc = var_n ? carve(E * 4) : 0, o_om = var_n ? carve(E * 4) : 0;
     const size_t o_simn = var_n ? carve(E * H) : 0, o_rsimn = (var_n && rob_orca) ? carve(E) : 0;
     const size_t o_dv = unicycle ? carve(E * 8) : 0;
+    const bool lane_orca = HM + (cfg->robot_visible ? 1 : 0) <= 32 && cfg->humans_policy == CN_HUMANS_ORCA;
+    const size_t state_bytes = off; // everything below is per-step scratch of the ORCA pass: not part of a snapshot
+    const size_t o_l3c = carve(4), o_l3h = lane_orca ? carve(E * H * sizeof(Lp3Hdr)) : 0, o_l3l = lane_orca ? carve(E * H * 32 * sizeof(float4)) : 0;
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete b; cn_set_error("cn_env_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
     herr = hipMemset(base, 0, off);
     if (herr != hipSuccess) { (void)hipFree(base); delete b; cn_set_error("cn_env_create: hipMemset failed: %s", hipGetErrorString(herr)); return CN_ERR_HIP; }
     b->blob = base;
-    b->blob_bytes = off;
+    b->blob_bytes = state_bytes;
     d.hum = (double *)(base + o_hum); d.rob = (double *)(base + o_rob); d.lhs = (double *)(base + o_lhs);
     d.ftraj = cfg->env_kind == CN_ENV_PRED ? (double *)(base + o_ft) : nullptr;
     d.step_counter = (int32_t *)(base + o_sc); d.case_counter = (uint64_t *)(base + o_cc);
@@ -1362,6 +1644,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.nh = var_n ? (int32_t *)(base + o_nh) : nullptr; d.nx_nh = var_n ? (int32_t *)(base + o_nxnh) : nullptr;
     d.obs_cnt = var_n ? (int32_t *)(base + o_oc) : nullptr; d.obs_max = var_n ? (int32_t *)(base + o_om) : nullptr;
     d.desired_v = unicycle ? (double *)(base + o_dv) : nullptr;
+    d.lp3_cnt = (int32_t *)(base + o_l3c);
+    d.lp3_hdr = lane_orca ? (Lp3Hdr *)(base + o_l3h) : nullptr; d.lp3_lines = lane_orca ? (float4 *)(base + o_l3l) : nullptr;
     d.sim_n = var_n ? (uint8_t *)(base + o_simn) : nullptr; d.rob_sim_n = (var_n && rob_orca) ? (uint8_t *)(base + o_rsimn) : nullptr;
     d.min_dist = (double *)(base + o_md);
     d.rob_sim_valid = rob_orca ? (uint8_t *)(base + o_rsv) : nullptr; d.rob_nd = rob_orca ? (float *)(base + o_rnd) : nullptr;

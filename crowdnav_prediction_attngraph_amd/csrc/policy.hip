@@ -251,73 +251,123 @@ static int launch_hh_attention(int E, int cap_lo, const float *qkv, const int *r
     return CN_OK;
 }
 
+// Size classes of the (sample, head) units for the training kernels: class c holds the samples with cap_lo(c) < nd <= cap(c),
+// caps 8 / 16 / 32 / 64.  cls = [4] counts followed by [4][B] sample lists (order inside a list is arbitrary -- a unit writes
+// only its own rows).  One launch per class then walks exactly its own units with an LDS footprint sized for that class.
+__global__ __launch_bounds__(256) void hh_classify_kernel(int B, const int *__restrict__ row_off, int *__restrict__ cls)
+{
+    __shared__ int cnt[4], base[4];
+    const int t = threadIdx.x;
+    if (t < 4) cnt[t] = 0;
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + t;
+    int c = -1, slot = 0;
+    if (b < B) {
+        const int nd = row_off[b + 1] - row_off[b];
+        c = nd <= 8 ? 0 : (nd <= 16 ? 1 : (nd <= 32 ? 2 : 3));
+        slot = atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    if (t < 4) base[t] = cnt[t] ? atomicAdd(&cls[t], cnt[t]) : 0;
+    __syncthreads();
+    if (c >= 0) cls[4 + (size_t)c * B + base[c] + slot] = b;
+}
+
 // Backward of the attention core for training (PPO update): per (sample, head) on the compacted rows.
 //   S = scale * Q K^T, P = softmax(S), O = P V ;   given dO:
 //   dV = P^T dO ; dP = dO V^T ; dS = scale * P .* (dP - rowsum(dP .* P)) ; dQ = dS K ; dK = dS^T Q
-// One wavefront per unit; Q, K, V, dO rows in LDS (stride 68), P and dS as nd x nd matrices (stride H) in LDS.
-__global__ __launch_bounds__(128) void hh_attention_bwd_kernel(int B, int H, const float *__restrict__ qkv, const int *__restrict__ row_off,
+// One wavefront per unit; Q, K, V, dO rows in LDS (stride 68), P and dS as nd x nd matrices (stride CAP) in LDS.  CAP is the size
+// class (see hh_classify_kernel): the common class of <= 8 detected humans needs 9 KB per wavefront instead of the 25 KB of H = 20,
+// so 16 wavefronts are resident per CU instead of 6.
+template <int CAP>
+__global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const float *__restrict__ qkv, const int *__restrict__ row_off,
+                                                               const int *__restrict__ cls_cnt, const int *__restrict__ cls_list,
                                                                const float *__restrict__ d_out, float *__restrict__ d_qkv, float scale)
 {
     constexpr int RS = 68;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int unit = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (unit >= B * 8) return;
-    const int b = unit >> 3, head = unit & 7;
-    const int r0 = row_off[b], nd = row_off[b + 1] - r0;
-    float *Qs = smem + (size_t)wave * (4 * H * RS + 2 * H * H);
-    float *Ks = Qs + H * RS, *Vs = Ks + H * RS, *Gs = Vs + H * RS; // Gs = dO rows
-    float *P = Gs + H * RS, *dS = P + H * H;
-    const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
-    const float *gbase = d_out + (size_t)r0 * 512 + head * 64 + lane;
-    for (int j = 0; j < nd; ++j) {
-        Qs[j * RS + lane] = base[(size_t)j * 1536];
-        Ks[j * RS + lane] = base[(size_t)j * 1536 + 512];
-        Vs[j * RS + lane] = base[(size_t)j * 1536 + 1024];
-        Gs[j * RS + lane] = gbase[(size_t)j * 512];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    const int npairs = nd * nd;
-    for (int q = lane; q < npairs; q += 64) {
-        const int qi = q / nd, qj = q - qi * nd;
-        const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qs + qi * RS), *kp = reinterpret_cast<const f32x4 *>(Ks + qj * RS);
-        const f32x4 *gp = reinterpret_cast<const f32x4 *>(Gs + qi * RS), *vp = reinterpret_cast<const f32x4 *>(Vs + qj * RS);
-        float s = 0.0f, dp = 0.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int n_units = (cls_list ? *cls_cnt : B) * 8;
+    float *Qs = smem + (size_t)wave * (4 * CAP * RS + 2 * CAP * CAP);
+    float *Ks = Qs + CAP * RS, *Vs = Ks + CAP * RS, *Gs = Vs + CAP * RS; // Gs = dO rows
+    float *P = Gs + CAP * RS, *dS = P + CAP * CAP;
+    for (int unit = blockIdx.x * wpb + wave; unit < n_units; unit += gridDim.x * wpb) {
+        const int b = cls_list ? cls_list[unit >> 3] : unit >> 3, head = unit & 7;
+        const int r0 = row_off[b], nd = row_off[b + 1] - r0;
+        if (nd > CAP) continue; // (only without a class list: another launch handles it)
+        const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
+        const float *gbase = d_out + (size_t)r0 * 512 + head * 64 + lane;
+#pragma unroll 4
+        for (int j = 0; j < nd; ++j) {
+            const float q = base[(size_t)j * 1536], k = base[(size_t)j * 1536 + 512], v = base[(size_t)j * 1536 + 1024], g = gbase[(size_t)j * 512];
+            Qs[j * RS + lane] = q; Ks[j * RS + lane] = k; Vs[j * RS + lane] = v; Gs[j * RS + lane] = g;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const int npairs = nd * nd;
+        for (int q = lane; q < npairs; q += 64) {
+            const int qi = q / nd, qj = q - qi * nd;
+            const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qs + qi * RS), *kp = reinterpret_cast<const f32x4 *>(Ks + qj * RS);
+            const f32x4 *gp = reinterpret_cast<const f32x4 *>(Gs + qi * RS), *vp = reinterpret_cast<const f32x4 *>(Vs + qj * RS);
+            float s = 0.0f, dp = 0.0f;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const f32x4 a = qp[d], bb = kp[d], g = gp[d], v = vp[d];
-            s += a[0] * bb[0]; s += a[1] * bb[1]; s += a[2] * bb[2]; s += a[3] * bb[3];
-            dp += g[0] * v[0]; dp += g[1] * v[1]; dp += g[2] * v[2]; dp += g[3] * v[3];
+            for (int d = 0; d < 16; ++d) {
+                const f32x4 a = qp[d], bb = kp[d], g = gp[d], v = vp[d];
+                s += a[0] * bb[0]; s += a[1] * bb[1]; s += a[2] * bb[2]; s += a[3] * bb[3];
+                dp += g[0] * v[0]; dp += g[1] * v[1]; dp += g[2] * v[2]; dp += g[3] * v[3];
+            }
+            P[qi * CAP + qj] = s * scale;
+            dS[qi * CAP + qj] = dp;
         }
-        P[qi * H + qj] = s * scale;
-        dS[qi * H + qj] = dp;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    if (lane < nd) {
-        float *prow = P + lane * H, *drow = dS + lane * H;
-        float mx = -INFINITY;
-        for (int j = 0; j < nd; ++j) mx = fmaxf(mx, prow[j]);
-        float sum = 0.0f;
-        for (int j = 0; j < nd; ++j) { const float e = expf(prow[j] - mx); prow[j] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        float rd = 0.0f;
-        for (int j = 0; j < nd; ++j) { prow[j] *= inv; rd += drow[j] * prow[j]; }
-        for (int j = 0; j < nd; ++j) drow[j] = scale * prow[j] * (drow[j] - rd);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    float *ob = d_qkv + (size_t)r0 * 1536 + head * 64 + lane;
-    for (int j = 0; j < nd; ++j) {
-        float dq = 0.0f, dk = 0.0f, dv = 0.0f; // row j of dQ, dK, dV, column `lane`
-        for (int i = 0; i < nd; ++i) {
-            dq += dS[j * H + i] * Ks[i * RS + lane];
-            dk += dS[i * H + j] * Qs[i * RS + lane];
-            dv += P[i * H + j] * Gs[i * RS + lane];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane < nd) {
+            float *prow = P + lane * CAP, *drow = dS + lane * CAP;
+            float mx = -INFINITY;
+            for (int j = 0; j < nd; ++j) mx = fmaxf(mx, prow[j]);
+            float sum = 0.0f;
+            for (int j = 0; j < nd; ++j) { const float e = expf(prow[j] - mx); prow[j] = e; sum += e; }
+            const float inv = 1.0f / sum;
+            float rd = 0.0f;
+            for (int j = 0; j < nd; ++j) { prow[j] *= inv; rd += drow[j] * prow[j]; }
+            for (int j = 0; j < nd; ++j) drow[j] = scale * prow[j] * (drow[j] - rd);
         }
-        ob[(size_t)j * 1536] = dq; ob[(size_t)j * 1536 + 512] = dk; ob[(size_t)j * 1536 + 1024] = dv;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        float *ob = d_qkv + (size_t)r0 * 1536 + head * 64 + lane;
+        for (int j = 0; j < nd; ++j) {
+            float dq = 0.0f, dk = 0.0f, dv = 0.0f; // row j of dQ, dK, dV, column `lane`
+            for (int i = 0; i < nd; ++i) {
+                dq += dS[j * CAP + i] * Ks[i * RS + lane];
+                dk += dS[i * CAP + j] * Qs[i * RS + lane];
+                dv += P[i * CAP + j] * Gs[i * RS + lane];
+            }
+            ob[(size_t)j * 1536] = dq; ob[(size_t)j * 1536 + 512] = dk; ob[(size_t)j * 1536 + 1024] = dv;
+        }
+        __builtin_amdgcn_wave_barrier(); // the next unit reuses this wavefront's LDS slices
     }
+}
+
+template <int CAP>
+static int launch_hh_attention_bwd(int B, const float *qkv, const int *row_off, const int *cls, int c, const float *d_out, float *d_qkv, float scale,
+                                   hipStream_t st)
+{
+    const size_t per_wave = (size_t)(4 * CAP * 68 + 2 * CAP * CAP) * sizeof(float);
+    int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+    int per_cu = (int)((160 * 1024) / (per_wave * wpb)); per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
+    int blocks = (B * 8 + wpb - 1) / wpb;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu; // resident-sized grid walking the class list
+    if (per_wave * wpb > 65536) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_attention_bwd_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(hh_attention_bwd_kernel<CAP>, dim3(blocks), dim3(64 * wpb), per_wave * wpb, st, B, qkv, row_off, cls + c, cls + 4 + (size_t)c * B,
+                       d_out, d_qkv, scale);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }
 
 // Robot-human attention (EdgeAttention_M.att_func, selfAttn_srnn_temp_node.py:145-177) on the compacted rows: one
@@ -897,16 +947,26 @@ extern "C" int cn_policy_get_profile(cn_policy *p, double *ms_out, int64_t *laun
 }
 
 // ---- stand-alone attention core (training path: autograd Function in the host mirror) ----
-extern "C" int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, void *stream)
+extern "C" int64_t cn_hh_attention_workspace_ints(int B) { return B > 0 ? 4 + 4 * (int64_t)B : 0; }
+
+// cls (optional, cn_hh_attention_workspace_ints(B) ints): when given, the size-class lists are built here and each class launch walks
+// only its own units; cn_hh_attention_bwd can reuse the same lists (pass the buffer back, unchanged).
+extern "C" int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, int *cls, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && qkv && row_off && out, "cn_hh_attention_fwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = launch_hh_attention<8>(B, 0, qkv, row_off, out, st, scale))) return rc;
-    if (H > 8 && (rc = launch_hh_attention<16>(B, 8, qkv, row_off, out, st, scale))) return rc;
-    if (H > 16 && (rc = launch_hh_attention<32>(B, 16, qkv, row_off, out, st, scale))) return rc;
-    if (H > 32 && (rc = launch_hh_attention<64>(B, 32, qkv, row_off, out, st, scale))) return rc;
+    if (cls) {
+        CN_HIP(hipMemsetAsync(cls, 0, 4 * sizeof(int), st));
+        hipLaunchKernelGGL(hh_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, row_off, cls);
+        CN_CHECK_LAUNCH();
+    }
+    const int *cc = cls, *cl = cls ? cls + 4 : nullptr;
+    if ((rc = launch_hh_attention<8>(B, 0, qkv, row_off, out, st, scale, cc, cl))) return rc;
+    if (H > 8 && (rc = launch_hh_attention<16>(B, 8, qkv, row_off, out, st, scale, cc ? cc + 1 : nullptr, cl ? cl + (size_t)B : nullptr))) return rc;
+    if (H > 16 && (rc = launch_hh_attention<32>(B, 16, qkv, row_off, out, st, scale, cc ? cc + 2 : nullptr, cl ? cl + 2 * (size_t)B : nullptr))) return rc;
+    if (H > 32 && (rc = launch_hh_attention<64>(B, 32, qkv, row_off, out, st, scale, cc ? cc + 3 : nullptr, cl ? cl + 3 * (size_t)B : nullptr))) return rc;
     return CN_OK;
 }
 
@@ -929,22 +989,21 @@ extern "C" int cn_hr_attention_bwd(int B, int H, const float *u, const float *ou
     return CN_OK;
 }
 
-extern "C" int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, void *stream)
+extern "C" int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, int *cls,
+                                   int cls_ready, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
-    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && qkv && row_off && d_out && d_qkv, "cn_hh_attention_bwd: bad argument");
-    const size_t per_wave = (size_t)(4 * H * 68 + 2 * H * H) * sizeof(float);
-    int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 2 ? 2 : wpb);
-    CN_REQUIRE(per_wave <= 160 * 1024, "cn_hh_attention_bwd: H too large for the LDS working set");
-    if (per_wave > 65536) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && qkv && row_off && d_out && d_qkv && cls, "cn_hh_attention_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!cls_ready) { // lists not built by a preceding cn_hh_attention_fwd on the same row_off
+        CN_HIP(hipMemsetAsync(cls, 0, 4 * sizeof(int), st));
+        hipLaunchKernelGGL(hh_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, row_off, cls);
+        CN_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(hh_attention_bwd_kernel, dim3((B * 8 + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, (hipStream_t)stream, B, H, qkv, row_off,
-                       d_out, d_qkv, scale);
-    CN_CHECK_LAUNCH();
+    int rc;
+    if ((rc = launch_hh_attention_bwd<8>(B, qkv, row_off, cls, 0, d_out, d_qkv, scale, st))) return rc;
+    if (H > 8 && (rc = launch_hh_attention_bwd<16>(B, qkv, row_off, cls, 1, d_out, d_qkv, scale, st))) return rc;
+    if (H > 16 && (rc = launch_hh_attention_bwd<32>(B, qkv, row_off, cls, 2, d_out, d_qkv, scale, st))) return rc;
+    if (H > 32 && (rc = launch_hh_attention_bwd<64>(B, qkv, row_off, cls, 3, d_out, d_qkv, scale, st))) return rc;
     return CN_OK;
 }

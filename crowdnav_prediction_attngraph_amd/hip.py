@@ -302,18 +302,20 @@ class HHAttention(torch.autograd.Function):
     def forward(ctx, qkv, row_off, B, H, scale):
         qkv = qkv.contiguous()
         out = torch.empty(qkv.shape[0], 512, device=qkv.device)
-        A.check(A.lib().cn_hh_attention_fwd(int(B), int(H), A.ptr(qkv), A.ptr(row_off), float(scale), A.ptr(out), A.stream_ptr()), "cn_hh_attention_fwd")
-        ctx.save_for_backward(qkv, row_off)
+        cls = torch.empty(int(A.lib().cn_hh_attention_workspace_ints(int(B))), dtype=torch.int32, device=qkv.device)   # size-class lists
+        A.check(A.lib().cn_hh_attention_fwd(int(B), int(H), A.ptr(qkv), A.ptr(row_off), float(scale), A.ptr(out), A.ptr(cls), A.stream_ptr()),
+                "cn_hh_attention_fwd")
+        ctx.save_for_backward(qkv, row_off, cls)
         ctx.meta = (int(B), int(H), float(scale))
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        qkv, row_off = ctx.saved_tensors
+        qkv, row_off, cls = ctx.saved_tensors
         B, H, scale = ctx.meta
         d_qkv = torch.empty_like(qkv)
-        A.check(A.lib().cn_hh_attention_bwd(B, H, A.ptr(qkv), A.ptr(row_off), A.ptr(d_out.contiguous()), scale, A.ptr(d_qkv), A.stream_ptr()),
-                "cn_hh_attention_bwd")
+        A.check(A.lib().cn_hh_attention_bwd(B, H, A.ptr(qkv), A.ptr(row_off), A.ptr(d_out.contiguous()), scale, A.ptr(d_qkv), A.ptr(cls), 1,
+                                            A.stream_ptr()), "cn_hh_attention_bwd")
         return d_qkv, None, None, None, None
 
 

@@ -234,8 +234,14 @@ int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launche
  * The (env, head) units of torch.nn.MultiheadAttention's scaled-dot-product core (selfAttn_srnn_temp_node.py:89) on COMPACTED
  * rows: sample b owns rows row_off[b] .. row_off[b+1]-1 (its detected humans); qkv [R,1536] = [q | k | v] (8 heads x 64).
  * fwd: out [R,512] = softmax(scale * q k^T) v per unit.  bwd: d_qkv [R,1536] from d_out [R,512] (softmax recomputed). */
-int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, void *stream);
-int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, void *stream);
+/* cls: device workspace of cn_hh_attention_workspace_ints(B) int32 holding the size-class lists of the samples (<= 8 / 16 / 32 / 64 live
+ * humans): each class is one launch that walks only its own (sample, head) units with an LDS footprint sized for it.  The forward builds
+ * the lists when cls != NULL (NULL: every launch inspects every unit); the backward needs the buffer and rebuilds the lists unless
+ * cls_ready != 0 (= the buffer was filled by the forward call on the same row_off). */
+int64_t cn_hh_attention_workspace_ints(int B);
+int cn_hh_attention_fwd(int B, int H, const float *qkv, const int *row_off, float scale, float *out, int *cls, void *stream);
+int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *row_off, const float *d_out, float scale, float *d_qkv, int *cls, int cls_ready,
+                        void *stream);
 
 /* ---- robot-human attention, stand-alone (training path) ----
  * EdgeAttention_M.att_func (rl/networks/selfAttn_srnn_temp_node.py:145-177) on COMPACTED rows: sample b owns rows

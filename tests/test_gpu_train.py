@@ -27,10 +27,19 @@ def test_vec_env_api_contract():
     assert n_ep >= 16        # everything times out after 197 steps at the latest
     assert envs.talk2Env(None) == [True] * 16
     envs.close()
+    with pytest.raises(NotImplementedError):   # settings outside what the reference itself runs fail loudly instead of falling back
+        make_vec_envs("CrowdSimPred-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"action_space.kinematics": "unicycle"}))
     with pytest.raises(NotImplementedError):
-        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"action_space.kinematics": "unicycle"}))
-    with pytest.raises(NotImplementedError):
-        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"sim.human_num_range": 2}))
+        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"robot.FOV": 1.0}))
+    # a varying crowd (sim.human_num_range) and the unicycle robot run on the device: observations carry human_num + range rows
+    var = make_vec_envs("CrowdSimVarNum-v0", 425, 8, 0.99, None, torch.device("cuda"), False,
+                        config=C.Config(**{"sim.human_num": 6, "sim.human_num_range": 5, "action_space.kinematics": "unicycle"}))
+    ob = var.reset()
+    assert ob["spatial_edges"].shape == (8, 11, 2) and var.observation_space.spaces["spatial_edges"].shape == (11, 2)
+    for t in range(30):
+        ob, rew, done, infos = var.step(torch.full((8, 2), 0.03, device="cuda"))
+    assert float(ob["detected_human_num"].min()) >= 1 and float(ob["detected_human_num"].max()) <= 11
+    var.close()
     one = make_vec_envs("CrowdSimVarNum-v0", 425, 1, 0.99, None, torch.device("cuda"), False)   # num_processes=1 -> phase 'test' (envs.py:55-58)
     assert one.cfg.phase == 2
     ob = one.reset()
@@ -147,6 +156,43 @@ def test_hip_attention_forward_backward_matches_torch_autograd(mode):
     for k in g_c:
         scale = max(float(g_c[k].abs().max()), 1e-3)
         assert float((g_c[k] - g_g[k]).abs().max()) <= 2e-4 * scale + 1e-5, (k, float((g_c[k] - g_g[k]).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,B", [(20, 700), (64, 300), (5, 1000)])
+def test_hh_attention_size_classes_match_fp64_autograd(H, B):
+    """cn_hh_attention_fwd/bwd through their size-class lists (<= 8 / 16 / 32 / 64 live humans, one launch per class walking only
+    its own units) vs an fp64 torch graph of softmax(scale q k^T) v per (sample, head): every class is populated."""
+    from crowdnav_prediction_attngraph_amd import hip
+    g = torch.Generator().manual_seed(H * 1000 + B)
+    nd = torch.randint(1, H + 1, (B,), generator=g)
+    nd[:4] = torch.tensor([1, min(H, 8), min(H, 9), H])
+    row_off = torch.zeros(B + 1, dtype=torch.int32)
+    row_off[1:] = torch.cumsum(nd, 0)
+    R = int(row_off[-1])
+    qkv = torch.randn(R, 1536, generator=g)
+    d_out = torch.randn(R, 512, generator=g)
+    qg = qkv.cuda().requires_grad_()
+    out = hip.HHAttention.apply(qg, row_off.cuda(), B, H, 0.125)
+    out.backward(d_out.cuda())
+    torch.cuda.synchronize()
+    qr = qkv.double().requires_grad_()
+    outs = []
+    for b in range(B):
+        r0, r1 = int(row_off[b]), int(row_off[b + 1])
+        blk = qr[r0:r1].view(r1 - r0, 3, 8, 64)
+        q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)     # [8, nd, 64]
+        p = torch.softmax(0.125 * q @ k.transpose(1, 2), dim=-1)
+        outs.append((p @ v).transpose(0, 1).reshape(r1 - r0, 512))
+    ref = torch.cat(outs)
+    ref.backward(d_out.double())
+    assert float((out.detach().cpu() - ref.detach().float()).abs().max()) <= 2e-5
+    assert float((qg.grad.cpu() - qr.grad.float()).abs().max()) <= 5e-5 * max(1.0, float(qr.grad.abs().max()))
+    # the lists only steer which launch handles a unit: a second run (lists rebuilt in another atomic order) is bit-identical
+    qg2 = qkv.cuda().requires_grad_()
+    out2 = hip.HHAttention.apply(qg2, row_off.cuda(), B, H, 0.125)
+    out2.backward(d_out.cuda())
+    assert torch.equal(out, out2) and torch.equal(qg.grad, qg2.grad)
 
 
 @pytest.mark.gpu
