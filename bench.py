@@ -190,16 +190,20 @@ def main():
     hxs = [torch.zeros(E, 1, 128, device="cuda"), torch.zeros(E, 1, 128, device="cuda")]
     out = dict(value=torch.empty(E, 1, device="cuda"), action=torch.empty(E, 2, device="cuda"), logp=torch.empty(E, 1, device="cuda"), hxs=hxs[1])
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    eps = torch.empty(E, 2, device="cuda")
+    NOISE_BLOCK = 30                      # action noise is drawn a rollout's worth (30 steps, train.py --num-steps) at a time, like the trainer does
+    eps = torch.empty(NOISE_BLOCK, E, 2, device="cuda")
 
     masks2 = [torch.ones(E, 1, device="cuda"), torch.ones(E, 1, device="cuda")]
 
     force_all_detected = [False]
+    noise_i = [0]
 
     def step(i):
-        eps.normal_(generator=gen)
+        if noise_i[0] % NOISE_BLOCK == 0:
+            eps.normal_(generator=gen)
         out["hxs"] = hxs[(i + 1) & 1]
-        pol.act(pol_obs, hxs[i & 1], masks2[i & 1], eps=eps, out=out)
+        pol.act(pol_obs, hxs[i & 1], masks2[i & 1], eps=eps[noise_i[0] % NOISE_BLOCK], out=out)
+        noise_i[0] += 1
         _, reward, done, _, _, _ = env.step(out["action"], not_done=masks2[(i + 1) & 1])   # done mask for the next forward
         if gst is not None:
             gst.wrapper_step(obs, reward, 0.6, -20.0, out=pol_obs["spatial_edges"])

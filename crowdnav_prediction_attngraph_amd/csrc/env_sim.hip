@@ -6,7 +6,7 @@
 //
 // Mapping (one wavefront = 64 lanes everywhere in this file; a lane is a human):
 //   orca_lane_kernel one LANE per (env, human i) for crowds of <= 32 agents: neighbour keys ordered by a sorting network, ORCA lines
-//                    and linearProgram2 in per-lane register vectors (no LDS: co-resides with the policy kernels); the agents
+//                    and linearProgram2 in per-lane register vectors; the agents
 //                    whose program is infeasible (about a third in a dense crossing) hand their lines to
 //   orca_lp3_kernel  one wavefront per such agent: lane k = line k, RVO2's linearProgram3 wave-cooperatively (the outer loop over
 //                    lines is its serial dependence; the inner clip of a line against all earlier lines is one lane-parallel
@@ -407,7 +407,9 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
 
 // ------------------------------------------------------------------------------------------------------------------
 // One LANE per agent (the common case of <= 32 agents in a crowd): the scalar RVO2 algorithm exactly as a CPU would run it,
-// 64 agents per wavefront, no cross-lane traffic and no LDS (so it co-resides with the policy kernels that hold all 160 KB).
+// 64 agents per wavefront.  The kernel runs BEFORE the policy forward of the same step (prefetch_orca puts it on the caller's
+// stream): next to the human-human kernel both slow down several-fold (that kernel saturates the L2 -> CU path this one's
+// dependent loads queue behind), alone it takes ~1/10 of the step.
 // Everything a lane indexes at run time lives in global memory (the env's agent records, L1-resident); everything it keeps in
 // registers is indexed statically: the neighbour keys are ordered by a sorting network, the ORCA lines are built in that order,
 // and the linear programs are fully unrolled over (line i, earlier line j).  linearProgram3 (the infeasible case, a few agents
@@ -431,14 +433,34 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s)
     const int agent = blockIdx.x * 64 + threadIdx.x;
     const int H = s.H;
     const bool live_lane = agent < s.E * H;
-    const int e = live_lane ? agent / H : 0, i = live_lane ? agent - e * H : 0;
+    const int e = live_lane ? agent / H : (int)(blockIdx.x * 64) / H, i = live_lane ? agent - e * H : 0;
     const int n = crowd_size(s, e);
     const bool active = live_lane && i < n; // (inactive lanes run along with nn = 0: the loop counters below must stay wave-uniform)
     const cn_env_config &c = s.cfg;
+    // the agent records of the 1 + 63/H (+1) envs this wavefront's lanes belong to, staged once: every later access -- uniform in
+    // pass 1, a per-lane gather in pass 2 -- is an LDS read instead of an L2 round trip (the kernel is a chain of dependent loads)
+    __shared__ double s_px[128], s_py[128], s_vx[128], s_vy[128], s_rad[128], s_rob[65][4];
+    {
+        const int a0 = blockIdx.x * 64;
+        const int e0 = a0 / H, e1 = (min(a0 + 63, s.E * H - 1)) / H;
+        const int nrows = (e1 - e0 + 1) * H; // <= 63 + 2 H <= 127 (H <= 32)
+        for (int r = threadIdx.x; r < nrows; r += 64) {
+            const int ee = e0 + r / H, j = r - (r / H) * H;
+            const double *hm = s.hum + (size_t)ee * 8 * H;
+            s_px[r] = hm[F_PX * H + j]; s_py[r] = hm[F_PY * H + j]; s_vx[r] = hm[F_VX * H + j]; s_vy[r] = hm[F_VY * H + j];
+            s_rad[r] = hm[F_RAD * H + j];
+        }
+        if (c.robot_visible)
+            for (int q = threadIdx.x; q <= e1 - e0; q += 64) {
+                const double *rb = s.rob + (size_t)(e0 + q) * 8;
+                s_rob[q][0] = rb[R_PX]; s_rob[q][1] = rb[R_PY]; s_rob[q][2] = rb[R_VX]; s_rob[q][3] = rb[R_VY];
+            }
+        __syncthreads();
+    }
+    const int eq = e - (int)(blockIdx.x * 64) / H, eb = eq * H; // this lane's env inside the staged block
     const double *hum = s.hum + (size_t)e * 8 * H;
-    const double *rob = s.rob + (size_t)e * 8;
-    const double spx = hum[F_PX * H + i], spy = hum[F_PY * H + i], svx = hum[F_VX * H + i], svy = hum[F_VY * H + i];
-    const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i], srad = hum[F_RAD * H + i], svpref = hum[F_VPREF * H + i];
+    const double spx = s_px[eb + i], spy = s_py[eb + i], svx = s_vx[eb + i], svy = s_vy[eb + i], srad = s_rad[eb + i];
+    const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i], svpref = hum[F_VPREF * H + i];
     const double safety = c.orca_safety_space;
     const bool rv = c.robot_visible != 0;
     const int n_agents = n + (rv ? 1 : 0);
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s)
             self_r = (float)(srad + 0.01 + safety);
             self_ms = (float)svpref;
             if (s.sim_seen)
-                for (int j = 0; j < n; ++j) s.sim_seen[ei * H + j] = (float)(hum[F_RAD * H + j] + 0.01 + safety);
+                for (int j = 0; j < n; ++j) s.sim_seen[ei * H + j] = (float)(s_rad[eb + j] + 0.01 + safety);
             s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1;
             if (s.sim_n) s.sim_n[ei] = (uint8_t)n_agents;
         } else {
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s)
         const bool isR = rv && j == n;
         const bool cand = active && ((j < n && j != i) || isR);
         const int lj = j < n ? j : 0;
-        const double qx = isR ? rob[R_PX] : hum[F_PX * H + lj], qy = isR ? rob[R_PY] : hum[F_PY * H + lj];
+        const double qx = isR ? s_rob[eq][0] : s_px[eb + lj], qy = isR ? s_rob[eq][1] : s_py[eb + lj];
         const bool coincident = (qx == spx) && (qy == spy);
         const float opx = coincident ? 7.0f : (float)qx, opy = coincident ? 7.0f : (float)qy;
         const float ddx0 = fpx - opx, ddy0 = fpy - opy;
@@ -502,12 +524,12 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s)
         if (k < nn) {
             const bool isR = j == n; // only reachable when rv
             const int lj = isR ? 0 : j;
-            const double qx = isR ? rob[R_PX] : hum[F_PX * H + lj], qy = isR ? rob[R_PY] : hum[F_PY * H + lj];
-            const double qvx = isR ? rob[R_VX] : hum[F_VX * H + lj], qvy = isR ? rob[R_VY] : hum[F_VY * H + lj];
+            const double qx = isR ? s_rob[eq][0] : s_px[eb + lj], qy = isR ? s_rob[eq][1] : s_py[eb + lj];
+            const double qvx = isR ? s_rob[eq][2] : s_vx[eb + lj], qvy = isR ? s_rob[eq][3] : s_vy[eb + lj];
             float orad;
             if (isR) orad = (float)(c.robot_radius + 0.01 + safety); // fixed for the whole run
             else if (s.sim_seen) orad = s.sim_seen[ei * H + lj];
-            else orad = (float)(hum[F_RAD * H + lj] + 0.01 + safety);
+            else orad = (float)(s_rad[eb + lj] + 0.01 + safety);
             const bool coincident = (qx == spx) && (qy == spy);
             const float opx = coincident ? 7.0f : (float)qx, opy = coincident ? 7.0f : (float)qy;
             const float ovx = coincident ? 0.0f : (float)qvx, ovy = coincident ? 0.0f : (float)qvy;
@@ -1109,6 +1131,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int 
     h.rad = s.cfg.human_radius;
     double shared_nd = s.cfg.orca_neighbor_dist;
     int n = s.H;
+    if (e == 0 && lane == 0) *s.lp3_cnt = 0; // the ORCA pass that follows starts with an empty linearProgram3 list
     do_reset(s, R, e, lane, rb, h, shared_nd, n, ob, with_obs != 0);
     if (!with_obs && lane == 0) s.pend[e] = 1;
     store_env(s, e, lane, rb, h);
@@ -1213,6 +1236,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     load_env(s, e, lane, rb, h);
     double shared_nd = s.shared_nd[e];
     int step_counter = s.step_counter[e];
+    if (e == 0 && lane == 0) *s.lp3_cnt = 0; // the ORCA pass that follows starts with an empty linearProgram3 list
 
     // srnn.clip_action (crowd_nav/policy/srnn.py:17-34), float32 like the numpy action array
     float ax = actions[2 * e], ay = actions[2 * e + 1];
@@ -1484,7 +1508,7 @@ struct cn_env_batch {
     // ORCA of step t+1 only needs the simulator state left by step t, not the robot's next action: it is launched on a
     // side stream as soon as step t (or a reset) is enqueued and overlaps the caller's policy forward.
     hipStream_t side;
-    hipEvent_t ev_state, ev_orca;
+    hipEvent_t ev_state, ev_orca, ev_pre;
     bool orca_ready; // hact for the current state has been enqueued on `side`
 };
 
@@ -1504,21 +1528,32 @@ static int truth_rollout_and_obs(cn_env_batch *env, const cn_obs *obs, hipStream
 
 static int prefetch_orca(cn_env_batch *env, hipStream_t main)
 {
+    const int agents = env->d.E * env->d.H;
+    const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0); // candidate neighbours per agent (self included)
+    static int coop = -1; // CN_ORCA_COOP=1 forces the one-wavefront-per-agent kernel (A/B measurements)
+    if (coop < 0) { const char *v = getenv("CN_ORCA_COOP"); coop = v ? atoi(v) : 0; }
+    const bool lane_path = env->d.cfg.humans_policy == CN_HUMANS_ORCA && slots <= 32 && !coop;
+    // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial
+    // fp64 work per such env).  It only depends on the step that just ran, needs a little LDS, and is light: it runs beside the lane
+    // kernel, before the policy kernels take the whole LDS of every CU
+    CN_HIP(hipEventRecord(env->ev_pre, main));
+    CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
+    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
+    CN_CHECK_LAUNCH();
+    if (lane_path) {
+        // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
+        // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
+        const dim3 grid((agents + 63) / 64), blk(64);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, env->d);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, env->d);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, env->d);
+        CN_CHECK_LAUNCH();
+    }
     CN_HIP(hipEventRecord(env->ev_state, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
-    const int agents = env->d.E * env->d.H;
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
-        const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0); // candidate neighbours per agent (self included)
-        static int coop = -1; // CN_ORCA_COOP=1 forces the one-wavefront-per-agent kernel (A/B measurements)
-        if (coop < 0) { const char *v = getenv("CN_ORCA_COOP"); coop = v ? atoi(v) : 0; }
-        if (slots <= 32 && !coop) {
-            // one lane per agent; the rare infeasible programs are finished by the cooperative routine
-            CN_HIP(hipMemsetAsync(env->d.lp3_cnt, 0, sizeof(int32_t), env->side));
-            const dim3 grid((agents + 63) / 64), blk(64);
-            if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, env->side, env->d);
-            else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, env->side, env->d);
-            else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, env->side, env->d);
-            CN_CHECK_LAUNCH();
+        if (lane_path) {
+            // the infeasible programs are finished by the cooperative routine on the side stream, next to the policy forward.
             // the list length is only known on the device: a grid for a quarter of the agents (one per wavefront; the rest of the
             // wavefronts exit at once, longer lists are walked with a stride) keeps enough wavefronts in flight to hide the latency
             // of the cooperative routine
@@ -1535,9 +1570,6 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
             hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d, k);
             CN_CHECK_LAUNCH();
         }
-    // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step)
-    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
-    CN_CHECK_LAUNCH();
     CN_HIP(hipEventRecord(env->ev_orca, env->side));
     env->orca_ready = true;
     return CN_OK;
@@ -1655,7 +1687,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest); // side work yields to the caller's stream (critical path)
     if (hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio_least) != hipSuccess || hipEventCreateWithFlags(&b->ev_state, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_pre, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(base); delete b; cn_set_error("cn_env_create: stream/event creation failed"); return CN_ERR_HIP;
     }
     *out = b;
@@ -1666,7 +1698,7 @@ extern "C" int cn_env_destroy(cn_env_batch *env)
 {
     if (!env) return CN_OK;
     (void)hipStreamSynchronize(env->side);
-    (void)hipEventDestroy(env->ev_state); (void)hipEventDestroy(env->ev_orca); (void)hipStreamDestroy(env->side);
+    (void)hipEventDestroy(env->ev_state); (void)hipEventDestroy(env->ev_orca); (void)hipEventDestroy(env->ev_pre); (void)hipStreamDestroy(env->side);
     if (env->blob) CN_HIP(hipFree(env->blob));
     delete env;
     return CN_OK;
@@ -1806,6 +1838,7 @@ extern "C" int cn_env_load(cn_env_batch *env, const void *src, void *stream)
                "(E=%d H=%d seed_base=%lld vs E=%d H=%d seed_base=%lld)", h.E, h.H, (long long)h.seed_base, env->d.E, env->d.H, (long long)env->d.seed_base);
     CN_HIP(hipStreamSynchronize(env->side)); // nothing of ours may still be writing the blob
     CN_HIP(hipMemcpyAsync(env->blob, (const char *)src + sizeof(h), env->blob_bytes, hipMemcpyDeviceToDevice, st));
+    CN_HIP(hipMemsetAsync(env->d.lp3_cnt, 0, sizeof(int32_t), st)); // scratch of the ORCA pass (normally cleared by the step / reset kernels)
     env->reset_done = h.reset_done != 0;
     // the snapshot holds the prefetched velocities of its state, but the event that orders them is gone: recompute on demand
     // (orca_kernel / env_pregen_kernel are pure functions of the restored state, so the continuation is bit-identical)

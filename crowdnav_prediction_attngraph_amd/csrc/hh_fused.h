@@ -8,6 +8,7 @@ struct HhFusedWeights {
     const void *qkv_frag;  // [head 8][wave 4][ks 16][j 3 (q,k,v)][plane 2][64][8]      3 MB
     const void *os_frag;   // [head 8][wave 4][ks 2][j 4][plane 2][64][8]               512 KB
     const float *emb0_w, *emb0_b, *emb2_b, *qkv_b, *os_b;
+    int prio; // raise the wavefront priority (s_setprio 3) against co-resident side-stream work
 };
 
 constexpr size_t HH_EMB2_FRAG_BYTES = (size_t)512 * 128 * 4;
@@ -17,5 +18,8 @@ constexpr size_t HH_OS_FRAG_BYTES = (size_t)256 * 512 * 4;
 // emb2_w [512,128], qkv_w [1536,512] (folded q|k|v), os_w [256,512] (folded out_proj∘spatial_linear): fp32 row-major, device
 int hh_fused_bake(const float *emb2_w, const float *qkv_w, const float *os_w, void *emb2_frag, void *qkv_frag, void *os_frag, hipStream_t st);
 
-// out_sp [row_off[E], 256] = relu(spatial_linear(out_proj(attention(...)))) on the compacted live rows; row_off [E+1] on the device
-int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const int *row_off, const HhFusedWeights &w, float *out_sp, hipStream_t st);
+// out_sp [row_off[E], 256] = relu(spatial_linear(out_proj(attention(...)))) on the compacted live rows.  det != NULL: the kernel first
+// builds row_off [E+1] (exclusive prefix of clamp(detected_human_num, 1, H)) itself and leaves it behind for the caller's next kernels
+// (live_total, optional, accumulates row_off[E]); det == NULL: row_off is an input.
+int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const float *det, int *row_off, unsigned long long *live_total,
+                     const HhFusedWeights &w, float *out_sp, hipStream_t st);

@@ -74,13 +74,19 @@ __device__ __forceinline__ Split8 split8(f32x4 a, f32x4 b)
 }
 
 // first index e in [0, n] with a[e] >= target (a ascending, a[n] readable); wave-uniform result, 64-ary search
-__device__ __forceinline__ int lower_bound_wave(const int *__restrict__ a, int n, int target, int lane)
+// row offsets: the workgroup may have written them itself a moment ago (fused prefix sum below).  Writer and readers are wavefronts of
+// ONE workgroup, i.e. one CU and one write-through L1: a workgroup-scope release / barrier / acquire orders them (waitcnt only), no
+// cache maintenance -- a device-scope fence here costs an L2 write-back per workgroup and device-scope loads miss the L2 (the
+// first version of this did both and lost 50 us per launch).
+__device__ __forceinline__ int ld_ro(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ int lower_bound_wave(const int *a, int n, int target, int lane)
 {
     int lo = 0, hi = n;
     while (hi > lo) {
         const int span = hi - lo, step = (span + 63) >> 6;
         const int idx = lo + lane * step;
-        const int v = idx < hi ? a[idx] : INT_MAX;
+        const int v = idx < hi ? ld_ro(a + idx) : INT_MAX;
         const unsigned long long m = __ballot(v >= target);
         const int f = m ? __ffsll(m) - 1 : 64;
         if (f == 0) { hi = lo; }
@@ -521,15 +527,49 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #endif
 }
 
-__global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const int *__restrict__ row_off,
-                                                          HhFusedWeights W, float *__restrict__ out_sp)
+__global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
+                                                          int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (det) {
+        // Row compaction fused into this launch: row_off[e] = sum_{e' < e} clamp(detected_human_num[e'], 1, H).  EVERY workgroup
+        // computes the whole prefix sum (E values: a few microseconds next to ~200) and writes the whole array -- all workgroups
+        // write identical values, so nobody has to wait for anybody, and the separate 16 us single-wavefront launch (plus its
+        // launch gap) is gone from the critical path.  The robot-node kernel behind this one reads the same array.
+        int *part = reinterpret_cast<int *>(lds);
+        const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+        const int chunk = (E + 255) >> 8;
+        const int lo = tid * chunk < E ? tid * chunk : E, hi = lo + chunk < E ? lo + chunk : E;
+        int sum = 0;
+        for (int e = lo; e < hi; ++e) { int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd); sum += nd; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (ln >= o) incl += v;
+        }
+        if (ln == 63) part[wv] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int w = 0; w < wv; ++w) run += part[w];
+        for (int e = lo; e < hi; ++e) {
+            row_off[e] = run;
+            int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
+            run += nd;
+        }
+        if (tid == 255) {
+            row_off[E] = run;
+            if (live_total && blockIdx.x == 0) *live_total += (unsigned long long)run; // measurement aid: live rows over the profiled launches
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     // this kernel is the critical path of the step; the simulator's ORCA wavefronts of the side stream share the SIMDs with it and
     // are latency tolerant (81 920 short wavefronts): win the issue arbitration against them
-    __builtin_amdgcn_s_setprio(3);
+    if (W.prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int total = row_off[E];
+    const int total = ld_ro(row_off + E);
     // chunk of this workgroup: rows [c*Q, (c+1)*Q) snapped to env starts
     int Q = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     Q = Q < 16 ? 16 : Q;
@@ -539,16 +579,16 @@ __global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, c
     int e = lower_bound_wave(row_off, E, (int)lo_row, lane);
     const int e_end = hi_row >= total ? E : lower_bound_wave(row_off, E, (int)hi_row, lane);
     int tile_ord = 0;
-    const int chunk_end_row = row_off[e_end];
+    const int chunk_end_row = ld_ro(row_off + e_end);
     while (e < e_end) {
         TileCtx t;
         t.tile_ord = tile_ord++;
         t.e_lo = e;
-        t.r0 = row_off[e];
+        t.r0 = ld_ro(row_off + e);
         // whole envs, at most FR rows (every env has 1..H <= 64 rows); the rows left in the chunk are split evenly over the tiles
         // they need, because a tile's cost is dominated by terms that do not shrink with its row count (weight stream, barriers)
         const int probe = e + 1 + lane;
-        const int v = probe <= e_end ? row_off[probe] : INT_MAX;
+        const int v = probe <= e_end ? ld_ro(row_off + probe) : INT_MAX;
         const int left = chunk_end_row - t.r0;
         const int ntile = (left + FR - 1) / FR;
         int want = (left + ntile - 1) / ntile + 2; // small slack: prefer closing a tile just after the even split
@@ -647,7 +687,8 @@ extern "C" int cn_hh_fused_set_debug(int *buf)
 }
 #endif
 
-int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const int *row_off, const HhFusedWeights &w, float *out_sp, hipStream_t st)
+int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const float *det, int *row_off, unsigned long long *live_total,
+                     const HhFusedWeights &w, float *out_sp, hipStream_t st)
 {
     static thread_local int attr_dev = -1; // the opt-in above 64 KB of dynamic LDS is per device
     int dev = 0;
@@ -660,7 +701,7 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const int 
     long long max_rows = (long long)E * H;
     int grid = (int)((max_rows + 15) / 16);
     grid = grid > 256 ? 256 : (grid < 1 ? 1 : grid);
-    hipLaunchKernelGGL(hh_fused_kernel, dim3(grid), dim3(256), LDS_BYTES, st, E, H, D, spatial_edges, row_off, w, out_sp);
+    hipLaunchKernelGGL(hh_fused_kernel, dim3(grid), dim3(256), LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -25,6 +25,7 @@
 #include "rn_fused.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 namespace {
@@ -71,36 +72,6 @@ __global__ __launch_bounds__(1024) void row_offsets_kernel(int E, int H, const f
     if (t == 1023) {
         row_off[E] = part[1023];
         if (live_total) *live_total += (unsigned long long)part[1023]; // measurement aid: total live rows over the profiled launches
-    }
-}
-
-// The same prefix sum as ONE wavefront (fused mode: no attention size classes needed).  A 1024-thread block needs 16 free wave
-// slots on one CU at once and queues behind the simulator's ORCA wavefronts of the previous step (measured 6 us alone, 34 us on
-// average inside the rollout); a single wavefront is placed immediately.  Lane l owns envs [l*chunk, (l+1)*chunk).
-__global__ __launch_bounds__(64) void row_offsets_wave_kernel(int E, int H, const float *__restrict__ det, int *__restrict__ row_off,
-                                                              unsigned long long *__restrict__ live_total)
-{
-    const int lane = threadIdx.x;
-    const int chunk = (E + 63) >> 6;
-    const int lo = lane * chunk, hi = min(lo + chunk, E);
-    int sum = 0;
-    for (int e = lo; e < hi; ++e) { int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd); sum += nd; }
-    // inclusive wave scan (Hillis-Steele over DPP-free shuffles: 6 steps)
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    int run = incl - sum;
-    for (int e = lo; e < hi; ++e) {
-        row_off[e] = run;
-        int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
-        run += nd;
-    }
-    if (lane == 63) {
-        row_off[E] = incl;
-        if (live_total) *live_total += (unsigned long long)incl;
     }
 }
 
@@ -799,13 +770,13 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     const int H = p->H, D = p->D, M = E * H;
     int rc;
     if (p->gemm_mode == 2) {
-        // fused mode: three launches -- row offsets, the human-human kernel, the robot-node kernel
-        hipLaunchKernelGGL(row_offsets_wave_kernel, dim3(1), dim3(64), 0, st, E, H, obs->detected_human_num, p->row_off,
-                           p->profiling ? p->live_total : (unsigned long long *)nullptr);
-        CN_CHECK_LAUNCH();
+        // fused mode: two launches -- the human-human kernel (which also builds the row offsets) and the robot-node kernel
         if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
-        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b};
-        if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, p->row_off, fw, p->out_sp, st))) return rc;
+        static int hh_prio = -1;
+        if (hh_prio < 0) { const char *v = getenv("CN_HH_PRIO"); hh_prio = v ? atoi(v) : 1; }
+        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b, hh_prio};
+        if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, obs->detected_human_num, p->row_off,
+                                   p->profiling ? p->live_total : (unsigned long long *)nullptr, fw, p->out_sp, st))) return rc;
         if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
         RnFusedArgs ra{};
         ra.temporal = obs->temporal_edges; ra.robot_node = obs->robot_node; ra.hxs_in = hxs_in; ra.masks = masks; ra.eps = eps;

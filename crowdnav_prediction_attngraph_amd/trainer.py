@@ -45,12 +45,11 @@ def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
     pol = actor_critic._hip_policy(E, dev)
     T = rollouts.num_steps
     hx = rollouts.recurrent_hidden_states["human_node_rnn"]
-    eps = torch.empty(E, 2, device=dev)
+    eps = torch.empty(T, E, 2, device=dev).normal_(generator=generator)   # the action noise of the whole rollout in one launch
     for t in range(T):
         obs_t = {k: rollouts.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
-        eps.normal_(generator=generator)
         out = dict(value=rollouts.value_preds[t], action=rollouts.actions[t], logp=rollouts.action_log_probs[t], hxs=hx[t + 1])
-        pol.act(obs_t, hx[t], rollouts.masks[t], eps=eps, out=out)
+        pol.act(obs_t, hx[t], rollouts.masks[t], eps=eps[t], out=out)
         obs_n = {k: rollouts.obs[k][t + 1] for k in obs_t}
         obs_n["visible_masks"] = None
         if "visible_masks" in rollouts.obs:

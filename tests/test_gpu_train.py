@@ -107,9 +107,10 @@ def test_fused_rollout_equals_reference_style_stepping():
     torch.manual_seed(0)
     g = torch.Generator(device="cuda").manual_seed(3)
     hip_pol = pol._hip_policy(E, torch.device("cuda", torch.cuda.current_device()))
+    eps_all = torch.empty(T, E, 2, device="cuda").normal_(generator=g)   # collect_rollout draws the noise of a rollout in one call
     for t in range(T):
         obs_t = {k: rb.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
-        eps = torch.empty(E, 2, device="cuda").normal_(generator=g)
+        eps = eps_all[t]
         out = hip_pol.act(obs_t, rb.recurrent_hidden_states["human_node_rnn"][t], rb.masks[t], eps=eps)
         obs, reward, done, infos = eb.step(out["action"])
         masks = torch.FloatTensor([[0.0] if d else [1.0] for d in done])
@@ -159,7 +160,7 @@ def test_hip_attention_forward_backward_matches_torch_autograd(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,B", [(20, 700), (64, 300), (5, 1000)])
+@pytest.mark.parametrize("H,B", [(20, 96), (64, 48), (5, 120)])   # the fp64 reference is a Python loop over samples: keep B small
 def test_hh_attention_size_classes_match_fp64_autograd(H, B):
     """cn_hh_attention_fwd/bwd through their size-class lists (<= 8 / 16 / 32 / 64 live humans, one launch per class walking only
     its own units) vs an fp64 torch graph of softmax(scale q k^T) v per (sample, head): every class is populated."""
