@@ -593,7 +593,15 @@ __global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, c
         const int ntile = (left + FR - 1) / FR;
         int want = (left + ntile - 1) / ntile + 2; // small slack: prefer closing a tile just after the even split
         want = want > FR ? FR : want;
-        int n_env = __popcll(__ballot(v <= t.r0 + want));
+        // ... but never so early that the rest no longer fits the remaining ntile - 1 tiles: an extra tile for a handful of rows costs a
+        // whole pass over the weights, and the launch lasts as long as its slowest workgroup (measured: one such workgroup in most
+        // launches, +15 % on the kernel).  If the even split falls short of `lo` rows, one env more is taken when it still fits.
+        const int lo = left - FR * (ntile - 1);
+        const int n1 = __popcll(__ballot(v <= t.r0 + want));
+        const int p1 = n1 >= 1 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 - 1, 64)) - t.r0 : 0;
+        const int v2 = n1 < 64 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 < 64 ? n1 : 63, 64)) : INT_MAX; // INT_MAX beyond the chunk
+        int n_env = n1;
+        if ((n1 < 1 || p1 < lo) && v2 != INT_MAX && v2 - t.r0 <= FR) n_env = n1 + 1;
         n_env = n_env < 1 ? 1 : n_env;             // one env always fits (H <= FR)
         t.n_env = n_env;
         t.nrows = __builtin_amdgcn_readfirstlane(__shfl(v, n_env - 1, 64)) - t.r0;
