@@ -12,6 +12,7 @@ every rank owns 4096 envs (weak scaling, global env indices rank*4096.., no data
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -152,9 +153,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(minutes=10))
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(minutes=10))
 
     from crowdnav_prediction_attngraph_amd import _abi as A
     from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
@@ -265,18 +266,28 @@ def main():
         if args.env_name == "CrowdSimPred-v0":
             over["sim.predict_method"] = "const_vel"
         tcfg = CFG.Config(**dict(over, **{"humans.end_goal_changing": True})) if args.randomized else CFG.non_randomized(**over)
+        # a failure on ONE rank (out of memory, a collective error) must not leave the others waiting in a collective forever: the
+        # process group was created with a finite timeout, every rank reports an error flag, and the leg counts only if all succeeded
+        err, last = None, None
         try:
             hist, _ = train(env_name=args.env_name, num_processes=E, num_steps=30, num_updates=3, seed=425, config=tcfg, log=None)
             last = hist[-1]
-            tt = torch.tensor([last["rollout_s"], last["update_s"]], device="cuda" if (dist is None or args.dist_backend == "nccl") else "cpu", dtype=torch.float64)
-            if dist is not None:
+        except Exception as exc:
+            err = "%s: %s" % (type(exc).__name__, exc)
+        tdev = "cuda" if (dist is None or args.dist_backend == "nccl") else "cpu"
+        tt = torch.tensor([last["rollout_s"] if last else 0.0, last["update_s"] if last else 0.0, 1.0 if err else 0.0], device=tdev, dtype=torch.float64)
+        if dist is not None:
+            try:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            except Exception as exc:
+                err = err or "%s: %s" % (type(exc).__name__, exc)
+        if err or float(tt[2]) > 0:
+            ppo = {"error": err or "the PPO leg failed on another rank"}
+        else:
             r_s, u_s = float(tt[0]), float(tt[1])
             ppo = {"samples_per_s": round(30 * E * world / (r_s + u_s), 1), "rollout_s": round(r_s, 5), "update_s": round(u_s, 5),
                    "config": "T=30 steps x %d envs per GPU, ppo_epoch 5, num_mini_batch 2, Adam; 3 updates run, the last one timed" % E,
                    "value_loss": round(last["value_loss"], 6)}
-        except Exception as exc:   # the headline line is still printed; a failure here is the same on every rank
-            ppo = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -32,6 +32,13 @@ class EpisodeStats:
             self.acc[2 + code] += ((info == code).to(torch.float64) * d).sum()
 
     def pop(self):
+        """Aggregate since the last pop, over ALL ranks when torch.distributed is initialised (each rank steps its own shard of envs)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            acc = self.acc if dist.get_backend() == "nccl" else self.acc.cpu()
+            dist.all_reduce(acc)
+            if acc is not self.acc:
+                self.acc.copy_(acc)
         a = self.acc.cpu().tolist()
         self.acc.zero_()
         n = max(a[0], 1.0)
