@@ -124,34 +124,81 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     else stage<128, 6, A_NONE>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane);
     __syncthreads();
     // ---- robot-human attention (u-form, see hr_attention_kernel in policy.hip): wavefront w owns envs 2w, 2w+1 ----
-    for (int q = 0; q < 2; ++q) {
-        const int i = 2 * wave + q;
-        const int e = e0 + i < E ? e0 + i : E - 1;
-        const int r0 = a.row_off[e], nd = a.row_off[e + 1] - r0;
-        const float *ue = R1 + i * S512;
-        const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
-        float s = -INFINITY;
-        for (int j = 0; j < nd; ++j) {
-            const float *row = a.out_sp + (size_t)(r0 + j) * 256;
-            const float tot = wv_sum(u0 * row[lane] + u1 * row[64 + lane] + u2 * row[128 + lane] + u3 * row[192 + lane]);
-            if (lane == j) s = tot * ((float)H / 8.0f);
+    // out_sp was written a moment ago by the human-human kernel on (mostly) other XCDs: every row read is a trip to the fabric.  A
+    // row-by-row loop is a chain of such trips (two passes x nd rows x 2 envs: ~25 of them, the largest single item of this kernel),
+    // so the first 8 rows of BOTH envs are fetched up front into registers; envs with more rows walk the rest in chunks of 8.
+    {
+        constexpr int CH = 8;
+        int r0q[2], ndq[2];
+        float x[2][CH][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = 2 * wave + q;
+            const int e = e0 + i < E ? e0 + i : E - 1;
+            r0q[q] = a.row_off[e]; ndq[q] = a.row_off[e + 1] - r0q[q];
         }
-        const float mx = wv_max(s);
-        const float p = lane < nd ? expf(s - mx) : 0.0f;
-        const float denom = wv_sum(p);
-        const float at = p / denom;
-        if (a.tap_attn && lane < H && e0 + i < E) a.tap_attn[(size_t)(e0 + i) * H + lane] = at;
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-        for (int j = 0; j < nd; ++j) {
-            const float aj = wv_readlane(at, j);
-            const float *row = a.out_sp + (size_t)(r0 + j) * 256;
-            o0 += aj * row[lane]; o1 += aj * row[64 + lane]; o2 += aj * row[128 + lane]; o3 += aj * row[192 + lane];
-        }
-        float *o = R0 + i * S512; // robot_states are dead: hr takes their place
-        o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
-        if (a.tap_hr && e0 + i < E) {
-            float *t = a.tap_hr + (size_t)(e0 + i) * 256;
-            t[lane] = o0; t[64 + lane] = o1; t[128 + lane] = o2; t[192 + lane] = o3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float *row = a.out_sp + (size_t)(r0q[q] + (u < ndq[q] ? u : ndq[q] - 1)) * 256;
+                x[q][u][0] = row[lane]; x[q][u][1] = row[64 + lane]; x[q][u][2] = row[128 + lane]; x[q][u][3] = row[192 + lane];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = 2 * wave + q;
+            const int r0 = r0q[q], nd = ndq[q];
+            const float *ue = R1 + i * S512;
+            const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
+            float s = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float tot = wv_sum(u0 * x[q][u][0] + u1 * x[q][u][1] + u2 * x[q][u][2] + u3 * x[q][u][3]);
+                if (lane == u && u < nd) s = tot * ((float)H / 8.0f);
+            }
+            for (int j0 = CH; j0 < nd; j0 += CH) {
+                float y[CH][4];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float *row = a.out_sp + (size_t)(r0 + (j0 + u < nd ? j0 + u : nd - 1)) * 256;
+                    y[u][0] = row[lane]; y[u][1] = row[64 + lane]; y[u][2] = row[128 + lane]; y[u][3] = row[192 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float tot = wv_sum(u0 * y[u][0] + u1 * y[u][1] + u2 * y[u][2] + u3 * y[u][3]);
+                    if (lane == j0 + u && j0 + u < nd) s = tot * ((float)H / 8.0f);
+                }
+            }
+            const float mx = wv_max(s);
+            const float p = lane < nd ? expf(s - mx) : 0.0f;
+            const float denom = wv_sum(p);
+            const float at = p / denom;
+            if (a.tap_attn && lane < H && e0 + i < E) a.tap_attn[(size_t)(e0 + i) * H + lane] = at;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float aj = u < nd ? wv_readlane(at, u) : 0.0f;
+                if (u < nd) { o0 += aj * x[q][u][0]; o1 += aj * x[q][u][1]; o2 += aj * x[q][u][2]; o3 += aj * x[q][u][3]; }
+            }
+            for (int j0 = CH; j0 < nd; j0 += CH) {
+                float y[CH][4];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float *row = a.out_sp + (size_t)(r0 + (j0 + u < nd ? j0 + u : nd - 1)) * 256;
+                    y[u][0] = row[lane]; y[u][1] = row[64 + lane]; y[u][2] = row[128 + lane]; y[u][3] = row[192 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const float aj = wv_readlane(at, j0 + u < nd ? j0 + u : 0);
+                    if (j0 + u < nd) { o0 += aj * y[u][0]; o1 += aj * y[u][1]; o2 += aj * y[u][2]; o3 += aj * y[u][3]; }
+                }
+            }
+            float *o = R0 + i * S512; // robot_states are dead: hr takes their place
+            o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
+            if (a.tap_hr && e0 + i < E) {
+                float *t = a.tap_hr + (size_t)(e0 + i) * 256;
+                t[lane] = o0; t[64 + lane] = o1; t[128 + lane] = o2; t[192 + lane] = o3;
+            }
         }
     }
     __syncthreads();
