@@ -5,16 +5,20 @@
 // As separate launches this is ~12 small kernels whose M = E products fill a fraction of the chip each and whose LDS-using
 // blocks cannot even co-reside with the 160 KB workgroups of the fused human-human kernel; here one workgroup (8 wavefronts)
 // owns 16 envs, keeps every per-env activation in LDS and walks the ~1.3 MB of weights once, straight from L2 into MFMA operand
-// registers.  All products are EXACT fp32 (v_mfma_f32_16x16x4_f32), like the launches this replaces.
+// registers.  The products run in the same bf16x3 split precision as the human-human kernel (fp32 operand = hi + lo bf16, products
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulation): with exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the
+// bf16 rate) the seven stages were bound by the fp32 matrix pipe -- in-kernel timers: 83 k of the kernel's 118 k cycles, at ~60 % pipe
+// utilisation -- now they are bound by streaming the 1.3 MB weight image.
 //
 // Products run "transposed" (A operand = weight fragment, B operand = activations): the C layout then holds 4 consecutive output
 // features of one env per lane, which is a float4 store into the next layer's [env][feature] LDS image; the B operand of the
-// next product is a float4 read of that image (k = 16c + 4*(lane>>4) + m for the m-th of 4 MFMAs, natural order).
+// next product is two float4 reads of that image (k = 32 ks + 8*(lane>>4) + 0..7), split to bf16 hi / lo once per stage.
 #include "rn_fused.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TE = 16;     // envs per workgroup
 // LDS activation images [16 envs][stride] floats; strides are K + 4 so that the 16 lanes of a float4 read hit distinct banks
@@ -27,7 +31,7 @@ constexpr int O_R4 = O_R3 + TE * S384;      // 128: h_in
 constexpr int O_R5 = O_R4 + TE * S128;      // 128: h_new
 constexpr int LDS_FLOATS = O_R5 + TE * S128;
 
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 enum { A_NONE = 0, A_RELU = 1, A_TANH = 2 };
 
@@ -40,36 +44,55 @@ __device__ __forceinline__ float fast_tanh(float x)
 __device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
 // out[env][out_off + 16*fb + ..] = act(W[fb] . in[env][in_off ..] + bias) for the feature blocks fb = fb0 + wave, fb0 + wave + 4, ...
-// Wfrag: baked fragments [fb][K/16][64 lanes][4 floats]; NFB = feature blocks of this wavefront
+// Wfrag: baked fragments [fb][K/32][plane hi,lo][64 lanes][8 bf16]; NFB = feature blocks of this wavefront
 template <int K, int NFB, int ACT>
-__device__ __forceinline__ void stage(const float *__restrict__ Wfrag, int fb_first, int fb_step, const float *__restrict__ bias, const float *in, int in_stride,
+__device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_first, int fb_step, const float *__restrict__ bias, const float *in, int in_stride,
                                       float *out, int out_stride, int out_off, int relu_from, int lane)
 {
+    const bf16x8 *__restrict__ Wfrag = reinterpret_cast<const bf16x8 *>(Wfrag_);
     const int i = lane & 15, g = lane >> 4;
-    constexpr int KC = K / 16;
-    f32x4 b[KC];
+    constexpr int KS = K / 32;
+    // activations of env i, k = 32 ks + 8 g .. + 7, as bf16 hi / lo (the B operand of every feature block of this stage)
+    bf16x8 bh[KS], bl[KS];
 #pragma unroll
-    for (int c = 0; c < KC; ++c) b[c] = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 16 * c + 4 * g);
+    for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 32 * ks + 8 * g);
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 32 * ks + 8 * g + 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const __bf16 h0 = (__bf16)x0[u], h1 = (__bf16)x1[u];
+            bh[ks][u] = h0; bh[ks][4 + u] = h1;
+            bl[ks][u] = (__bf16)(x0[u] - (float)h0); bl[ks][4 + u] = (__bf16)(x1[u] - (float)h1);
+        }
+    }
     f32x4 acc[NFB];
 #pragma unroll
     for (int j = 0; j < NFB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // weight fragments: three k-chunks in flight (the scheduling barriers pin the issue points, see hh_fused.hip)
-    constexpr int PF = 3;
-    f32x4 a[PF][NFB];
+    // weight fragments: PF k-steps in flight (the scheduling barriers pin the issue points, see hh_fused.hip)
+    constexpr int PF = KS < 3 ? KS : 3;
+    bf16x8 ah[PF][NFB], al[PF][NFB];
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p)
 #pragma unroll
-        for (int j = 0; j < NFB; ++j) a[p][j] = *reinterpret_cast<const f32x4 *>(Wfrag + (((size_t)(fb_first + j * fb_step) * KC + (p < KC ? p : KC - 1)) * 64 + lane) * 4);
+        for (int j = 0; j < NFB; ++j) {
+            const size_t base = ((size_t)(fb_first + j * fb_step) * KS + (p < KS ? p : KS - 1)) * 128 + lane;
+            ah[p][j] = Wfrag[base]; al[p][j] = Wfrag[base + 64];
+        }
 #pragma unroll
-    for (int c = 0; c < KC; ++c) { // fully unrolled: b[c] must be statically indexed (a runtime index sends the array to scratch)
-        const int cp = c + PF - 1 < KC ? c + PF - 1 : KC - 1;
+    for (int ks = 0; ks < KS; ++ks) { // fully unrolled: bh / bl must be statically indexed (a runtime index sends the arrays to scratch)
+        const int kp = ks + PF - 1 < KS ? ks + PF - 1 : KS - 1;
 #pragma unroll
-        for (int j = 0; j < NFB; ++j) a[(c + PF - 1) % PF][j] = *reinterpret_cast<const f32x4 *>(Wfrag + (((size_t)(fb_first + j * fb_step) * KC + cp) * 64 + lane) * 4);
+        for (int j = 0; j < NFB; ++j) {
+            const size_t base = ((size_t)(fb_first + j * fb_step) * KS + kp) * 128 + lane;
+            ah[(ks + PF - 1) % PF][j] = Wfrag[base]; al[(ks + PF - 1) % PF][j] = Wfrag[base + 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int j = 0; j < NFB; ++j) acc[j] = mfma4(a[c % PF][j][m], b[c][m], acc[j]);
+        for (int j = 0; j < NFB; ++j) {
+            acc[j] = mfma32(al[ks % PF][j], bh[ks], acc[j]);
+            acc[j] = mfma32(ah[ks % PF][j], bl[ks], acc[j]);
+            acc[j] = mfma32(ah[ks % PF][j], bh[ks], acc[j]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -263,25 +286,29 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
 }
 
-// fp32 row-major W [N,K] -> [fb = N/16][K/16][64 lanes][4]: lane (f, kk) holds W[16 fb + f][16 c + 4 kk .. +3]
-__global__ void rn_bake_kernel(int N, int K, const float *__restrict__ w, float *__restrict__ out)
+// fp32 row-major W [N,K] -> [fb = N/16][K/32][plane hi,lo][64 lanes][8 bf16]: lane (f, kk) holds W[16 fb + f][32 ks + 8 kk .. +7]
+__global__ void rn_bake_kernel(int N, int K, const float *__restrict__ w, __bf16 *__restrict__ out)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one weight
     if (idx >= (size_t)N * K) return;
-    const int m = idx & 3, lane = (idx >> 2) & 63;
-    const size_t rest = idx >> 8;
-    const int KC = K / 16;
-    const int c = (int)(rest % KC), fb = (int)(rest / KC);
-    out[idx] = w[(size_t)(fb * 16 + (lane & 15)) * K + 16 * c + 4 * (lane >> 4) + m];
+    const int u = idx & 7, lane = (idx >> 3) & 63;
+    const size_t rest = idx >> 9;
+    const int KS = K / 32;
+    const int ks = (int)(rest % KS), fb = (int)(rest / KS);
+    const float x = w[(size_t)(fb * 16 + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + u];
+    const __bf16 hi = (__bf16)x;
+    const size_t base = (((size_t)fb * KS + ks) * 2) * 512 + lane * 8 + u;
+    out[base] = hi;
+    out[base + 512] = (__bf16)(x - (float)hi);
 }
 
 } // namespace
 
 int rn_fused_bake(int N, int K, const float *w, float *out, hipStream_t st)
 {
-    CN_REQUIRE(N % 16 == 0 && K % 16 == 0, "rn_fused_bake: N and K must be multiples of 16");
+    CN_REQUIRE(N % 16 == 0 && K % 32 == 0, "rn_fused_bake: N must be a multiple of 16, K of 32");
     const size_t n = (size_t)N * K;
-    hipLaunchKernelGGL(rn_bake_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, K, w, out);
+    hipLaunchKernelGGL(rn_bake_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, K, w, reinterpret_cast<__bf16 *>(out));
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
