@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcrowdnav_hip.so")
 
 CN_MAX_HUMANS = 64
-ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2}
+ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2, "CrowdSimVarNumCollect-v0": 3}
 INFO_NOTHING, INFO_TIMEOUT, INFO_COLLISION, INFO_REACHGOAL, INFO_DANGER = range(5)
 
 

@@ -28,7 +28,8 @@ class Config(object):
         self.action_space = _ns(kinematics="holonomic")
         self.orca = _ns(neighbor_dist=10, safety_space=0.15, time_horizon=5, time_horizon_obst=5)
         self.sf = _ns(A=2., B=1, KI=1)
-        self.data = _ns(pred_timestep=0.25)
+        self.data = _ns(tot_steps=40000, render=False, collect_train_data=False, num_processes=5,
+                        data_save_dir="gst_updated/datasets/orca_20humans_no_rand", pred_timestep=0.25)   # config.py:129-136 (collect_data.py)
         self.pred = _ns(model_dir="gst_updated/results/100-gumbel_social_transformer-faster_lstm-lr_0.001-init_temp_0.5-edge_head_0-ebd_64-snl_1-snh_8-seed_1000_rand/sj")
         for k, v in overrides.items():
             ns, attr = k.split(".")
@@ -56,7 +57,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     if not 0 <= hr < hn or hn + hr > 64:
         unsupported.append("sim.human_num_range outside [0, human_num) or human_num + human_num_range > 64")
     rv = bool(g("robot", "visible", False))
-    if rv and (env_name != "CrowdSimVarNum-v0" or phase != "train" or hn + hr > 63):
+    if rv and (env_name not in ("CrowdSimVarNum-v0", "CrowdSimVarNumCollect-v0") or phase != "train" or hn + hr > 63):
         unsupported.append("robot.visible=True outside CrowdSimVarNum-v0 / phase train / human_num + human_num_range <= 63")
     kin = g("action_space", "kinematics", "holonomic")
     if kin not in ("holonomic", "unicycle"):
@@ -78,6 +79,8 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         unsupported.append("humans.policy='social_force' in the test phase or with sim.predict_method='truth'")
     if kin == "unicycle" and (env_name != "CrowdSimVarNum-v0" or rp in ("orca", "social_force")):
         unsupported.append("unicycle kinematics outside CrowdSimVarNum-v0 with a network-driven robot")
+    if env_name == "CrowdSimVarNumCollect-v0" and (rp != "orca" or hr != 0 or kin != "holonomic" or phase != "train"):
+        unsupported.append("CrowdSimVarNumCollect-v0 outside collect_data.py's set-up (robot.policy='orca', fixed crowd size, holonomic, phase train)")
     if phase not in ("train", "test"):
         unsupported.append("phase=%r (train.py / test.py only use 'train' and 'test')" % phase)
     if float(g("env", "time_step", 0.25)) != float(g("data", "pred_timestep", 0.25)):

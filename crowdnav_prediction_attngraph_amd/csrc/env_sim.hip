@@ -80,6 +80,10 @@ struct EnvDev {
     int32_t *obs_max;   // [E] max(self.observed_human_ids), -1 when empty
     uint8_t *sim_n;     // [E][H] agent count human i's private simulator was built for (orca.py:80-82 rebuilds on a change)
     uint8_t *rob_sim_n; // [E] ... the robot's (robot.policy == 'orca')
+    // CrowdSimVarNumCollect-v0 only (crowd_sim_var_num_collect.py): prediction ids for the GST dataset
+    int32_t *pred_id;   // [E][H] self.human_pred_id
+    int32_t *max_pid;   // [E]    self.max_human_id
+    uint8_t *last_obs;  // [E][H] self.last_human_observability
     int32_t *lp3_cnt;   // [1] agents of this step's ORCA pass whose linear program was infeasible (orca_lane_kernel -> orca_lp3_kernel)
     struct Lp3Hdr *lp3_hdr; // [E*H] where linearProgram2 stopped
     float4 *lp3_lines;  // [E*H][32] their ORCA lines (point, direction) in neighbour order
@@ -931,7 +935,7 @@ __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, 
 
 // crowd_sim_var_num.py:233-279 generate_ob / crowd_sim_pred.py:62-97 / crowd_sim_pred_real_gst.py:76-93,
 // crowd_sim.py:558-572 get_num_human_in_fov, :243-273 update_last_human_states.
-__device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int n, bool reset, const Robot &rb, Lane &h, const cn_obs &ob)
+__device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int n, bool reset, const Robot &rb, Lane &h, const cn_obs &ob, int step_counter)
 {
     const cn_env_config &c = s.cfg;
     const int H = s.H, D = s.D, P = s.P; // H observation rows (crowd_sim_var_num.py:249, crowd_sim_pred.py:78), n humans present
@@ -958,6 +962,28 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int 
         rn[5] = (float)c.robot_v_pref; rn[6] = (float)rb.theta;
         ob.temporal_edges[(size_t)e * 2] = (float)rb.vx; ob.temporal_edges[(size_t)e * 2 + 1] = (float)rb.vy;
         ob.detected_human_num[e] = (float)(num_visible == 0 ? 1 : num_visible);
+    }
+    if (c.env_kind == CN_ENV_COLLECT) {
+        // crowd_sim_var_num_collect.py:100-133: humans that were visible at the last observation and are not now get fresh prediction
+        // ids (ascending, in list order); row i = (frame, id, ABSOLUTE believed position) if visible, (frame, id, inf, inf) otherwise
+        const bool was = isRow && s.last_obs[(size_t)e * H + lane] != 0;
+        const bool out = isH && was && !vis;
+        const uint64_t omask = __ballot(out);
+        const int base = s.max_pid[e];
+        int pid = isRow ? s.pred_id[(size_t)e * H + lane] : 0;
+        if (out) pid = base + __popcll(omask & ((1ull << lane) - 1ull));
+        if (isRow) {
+            s.pred_id[(size_t)e * H + lane] = pid;
+            s.last_obs[(size_t)e * H + lane] = vis ? 1 : 0;
+            float *se = ob.spatial_edges + ((size_t)e * H + lane) * 4;
+            se[0] = (float)(((double)step_counter * c.time_step) / c.time_step); // global_time / data.pred_timestep (== env.time_step)
+            se[1] = (float)pid;
+            se[2] = vis ? (float)h.l0 : INFINITY;
+            se[3] = vis ? (float)h.l1 : INFINITY;
+            if (ob.visible_masks) ob.visible_masks[(size_t)e * H + lane] = vis ? 1 : 0;
+        }
+        if (lane == 0 && omask) s.max_pid[e] = base + __popcll(omask);
+        return;
     }
     const double ex = h.l0 - rb.px, ey = h.l1 - rb.py; // == true relative position for visible humans
     const bool do_sort = c.sort_humans && c.env_kind != CN_ENV_PRED_GST;
@@ -1060,8 +1086,10 @@ __device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, i
         s.case_counter[e] = (s.case_counter[e] + (uint64_t)c.nenv) % case_size;
         s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0;
         if (s.nh) { s.obs_cnt[e] = 0; s.obs_max[e] = -1; } // :327 observed_human_ids = []
+        if (s.max_pid) s.max_pid[e] = n; // crowd_sim_var_num_collect.py:79-81
     }
-    if (with_obs) write_obs(s, e, lane, n, true, rb, h, ob);
+    if (s.pred_id && lane < s.H) { s.pred_id[(size_t)e * s.H + lane] = lane; s.last_obs[(size_t)e * s.H + lane] = 0; }
+    if (with_obs) write_obs(s, e, lane, n, true, rb, h, ob, 0);
 }
 
 // crowd_sim_var_num.py:303-363 reset.  Uses the pre-generated episode when the side stream has one ready.
@@ -1210,7 +1238,7 @@ __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
     double shared_nd = s.shared_nd[e];
     const bool was_reset = s.pend[e] != 0;
     const int n = crowd_size(s, e);
-    write_obs(s, e, lane, n, was_reset, rb, h, ob);
+    write_obs(s, e, lane, n, was_reset, rb, h, ob, was_reset ? 0 : s.step_counter[e]);
     if (!was_reset) post_obs_updates(s, R, e, lane, n, s.step_counter[e], rb, h, shared_nd);
     if (lane == 0) s.pend[e] = 0;
     store_env(s, e, lane, rb, h);
@@ -1352,7 +1380,39 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         danger_cond = best < INFINITY;
         min_danger = danger_cond ? best : 0.0;
     }
-    if (global_time >= c.time_limit - 1.0) { reward = 0.0; done = 1; info = CN_INFO_TIMEOUT; }
+    if (c.env_kind == CN_ENV_COLLECT) {
+        // crowd_sim_var_num_collect.py:139-188: the data-collection env never ends an episode (global_time >= 40000 aside) and pays no
+        // reward; a robot that reaches its goal gets a new one -- the median of the humans' positions or a uniform point of the
+        // arena, each with probability 1/2 (np.random draws in this order: uniform(0, 1), then uniform(-a, a, size = 2))
+        reward = 0.0; done = 0; info = CN_INFO_NOTHING;
+        if (global_time >= 40000.0) { done = 1; info = CN_INFO_TIMEOUT; }
+        else if (collision) info = CN_INFO_COLLISION;
+        else if (goal_dist < c.robot_radius) {
+            info = CN_INFO_REACHGOAL;
+            rng_load(R, s, e, lane);
+            if (rng_uniform(R, lane, 0.0, 1.0) < 0.5) {
+                // np.median(axis = 0): the middle element of the sorted column, or the mean of the two middle ones (lane-parallel rank)
+                double med[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const double v = isH ? (d == 0 ? h.px : h.py) : INFINITY;
+                    int rank = 0;
+                    for (int m = 0; m < n; ++m) {
+                        const double vm = __shfl(v, m, 64);
+                        rank += (vm < v || (vm == v && m < lane)) ? 1 : 0;
+                    }
+                    const uint64_t hi_m = __ballot(isH && rank == n / 2), lo_m = __ballot(isH && rank == (n - 1) / 2);
+                    const double vhi = __shfl(v, __ffsll((unsigned long long)hi_m) - 1, 64), vlo = __shfl(v, __ffsll((unsigned long long)lo_m) - 1, 64);
+                    med[d] = (n & 1) ? vhi : (vlo + vhi) / 2.0;
+                }
+                rb.gx = med[0]; rb.gy = med[1];
+            } else {
+                rb.gx = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+                rb.gy = rng_uniform(R, lane, -c.arena_size, c.arena_size);
+            }
+        }
+    }
+    else if (global_time >= c.time_limit - 1.0) { reward = 0.0; done = 1; info = CN_INFO_TIMEOUT; }
     else if (collision) { reward = c.collision_penalty; done = 1; info = CN_INFO_COLLISION; }
     else if (reaching_goal) { reward = c.success_reward; done = 1; info = CN_INFO_REACHGOAL; }
     else if (danger_cond) {
@@ -1461,7 +1521,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
             }
         }
         if (!SPLIT) {
-            write_obs(s, e, lane, n, false, rb, h, ob);
+            write_obs(s, e, lane, n, false, rb, h, ob, step_counter);
             post_obs_updates(s, R, e, lane, n, step_counter, rb, h, shared_nd);
         }
         if (lane == 0) { s.step_counter[e] = step_counter; s.ep_ret[e] = ep_ret; s.ep_cnt[e] = ep_cnt; }
@@ -1593,6 +1653,7 @@ extern "C" void cn_env_config_default(cn_env_config *c)
 
 extern "C" int cn_env_obs_width(const cn_env_config *cfg)
 {
+    if (cfg->env_kind == CN_ENV_COLLECT) return 4; // pred_info: frame id, prediction id, px, py
     return cfg->env_kind == CN_ENV_VARNUM ? 2 : 2 * (cfg->predict_steps + 1);
 }
 
@@ -1611,12 +1672,16 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
                "cn_env_create: humans_policy must be ORCA, or social force in the train phase without 'truth' predictions (those roll the "
                "humans' policies forward, which is only implemented for ORCA humans)");
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
-    CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_PRED_GST, "cn_env_create: unknown env_kind %d", cfg->env_kind);
+    CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_COLLECT, "cn_env_create: unknown env_kind %d", cfg->env_kind);
+    CN_REQUIRE(cfg->env_kind != CN_ENV_COLLECT || (cfg->human_num_range == 0 && cfg->kinematics == CN_KIN_HOLONOMIC && cfg->phase == CN_PHASE_TRAIN &&
+                                                   cfg->robot_policy == CN_ROBOT_ORCA && !cfg->predict_truth),
+               "cn_env_create: CrowdSimVarNumCollect-v0 runs with a fixed crowd size, a holonomic ORCA-driven robot and phase train "
+               "(what collect_data.py sets up; the reference's pred_info needs human_num_range == 0)");
     CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST,
                "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
     CN_REQUIRE(cfg->robot_policy >= CN_ROBOT_NETWORK && cfg->robot_policy <= CN_ROBOT_SOCIAL_FORCE, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
-    CN_REQUIRE(!cfg->robot_visible || (cfg->env_kind == CN_ENV_VARNUM && cfg->phase == CN_PHASE_TRAIN && HM <= CN_MAX_HUMANS - 1),
+    CN_REQUIRE(!cfg->robot_visible || ((cfg->env_kind == CN_ENV_VARNUM || cfg->env_kind == CN_ENV_COLLECT) && cfg->phase == CN_PHASE_TRAIN && HM <= CN_MAX_HUMANS - 1),
                "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num + human_num_range <= %d (the reference rebuilds every private "
                "simulator twice per step in the test phase and breaks in CrowdSimPred)", CN_MAX_HUMANS - 1);
     CN_REQUIRE(!cfg->predict_truth || (cfg->env_kind == CN_ENV_PRED && !cfg->robot_visible),
@@ -1652,6 +1717,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_simn = var_n ? carve(E * H) : 0, o_rsimn = (var_n && rob_orca) ? carve(E) : 0;
     const size_t o_dv = unicycle ? carve(E * 8) : 0;
     const bool lane_orca = HM + (cfg->robot_visible ? 1 : 0) <= 32 && cfg->humans_policy == CN_HUMANS_ORCA;
+    const bool collect = cfg->env_kind == CN_ENV_COLLECT;
+    const size_t o_pid = collect ? carve(E * H * 4) : 0, o_mpid = collect ? carve(E * 4) : 0, o_lobs = collect ? carve(E * H) : 0;
     const size_t state_bytes = off; // everything below is per-step scratch of the ORCA pass: not part of a snapshot
     const size_t o_l3c = carve(4), o_l3h = lane_orca ? carve(E * H * sizeof(Lp3Hdr)) : 0, o_l3l = lane_orca ? carve(E * H * 32 * sizeof(float4)) : 0;
     char *base = nullptr;
@@ -1676,6 +1743,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.nh = var_n ? (int32_t *)(base + o_nh) : nullptr; d.nx_nh = var_n ? (int32_t *)(base + o_nxnh) : nullptr;
     d.obs_cnt = var_n ? (int32_t *)(base + o_oc) : nullptr; d.obs_max = var_n ? (int32_t *)(base + o_om) : nullptr;
     d.desired_v = unicycle ? (double *)(base + o_dv) : nullptr;
+    d.pred_id = collect ? (int32_t *)(base + o_pid) : nullptr; d.max_pid = collect ? (int32_t *)(base + o_mpid) : nullptr;
+    d.last_obs = collect ? (uint8_t *)(base + o_lobs) : nullptr;
     d.lp3_cnt = (int32_t *)(base + o_l3c);
     d.lp3_hdr = lane_orca ? (Lp3Hdr *)(base + o_l3h) : nullptr; d.lp3_lines = lane_orca ? (float4 *)(base + o_l3l) : nullptr;
     d.sim_n = var_n ? (uint8_t *)(base + o_simn) : nullptr; d.rob_sim_n = (var_n && rob_orca) ? (uint8_t *)(base + o_rsimn) : nullptr;

@@ -138,9 +138,26 @@ class CrowdSimPredRealGST(_SingleCrowdSim):
     env_id = "CrowdSimPredRealGST-v0"
 
 
+class CrowdSimVarNumCollect(_SingleCrowdSim):
+    """crowd_sim/envs/crowd_sim_var_num_collect.py: the GST dataset generator.  Observation = {'pred_info': [H, 4]} (frame id, prediction
+    id, absolute px, py; +inf for humans the robot does not see); the robot is ORCA-driven (collect_data.py:14 sets robot.policy = 'orca')."""
+    env_id = "CrowdSimVarNumCollect-v0"
+
+    def configure(self, config):
+        super().configure(config)
+        from .collect import _Box, _DictSpace
+        self.observation_space = _DictSpace({"pred_info": _Box((self.max_human_num, 4))})     # crowd_sim_var_num_collect.py:36
+
+    def _ensure(self, phase):
+        return super()._ensure("train" if phase is None else phase)
+
+    def _export(self, obs):
+        return {"pred_info": obs["spatial_edges"][0].cpu().numpy()}
+
+
 # crowd_sim/__init__.py:8-26 -- id -> entry point, for the ids that are on the accelerated path
-registry = {cls.env_id: cls for cls in (CrowdSimVarNum, CrowdSimPred, CrowdSimPredRealGST)}
-_NOT_ACCELERATED = ("CrowdSim-v0", "CrowdSimVarNumCollect-v0", "rosTurtlebot2iEnv-v0")
+registry = {cls.env_id: cls for cls in (CrowdSimVarNum, CrowdSimPred, CrowdSimPredRealGST, CrowdSimVarNumCollect)}
+_NOT_ACCELERATED = ("CrowdSim-v0", "rosTurtlebot2iEnv-v0")
 
 
 def make(env_id):

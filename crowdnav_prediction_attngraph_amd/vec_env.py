@@ -153,4 +153,7 @@ def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_e
     # test_case: rl/networks/envs.py:60-63 only forwards it to the env inside `if ax:` (rendering), so without an axis the
     # reference ignores the argument -- same here.  Replaying chosen cases: HipEnvBatch.set_case_counters /
     # evaluation.evaluate_batched, or the single-env objects of gym_env (env.test_case = k).
+    if env_name == "CrowdSimVarNumCollect-v0":      # the GST dataset generator (collect_data.py): its own observation dict
+        from .collect import CollectVecEnv
+        return CollectVecEnv(seed, num_processes, device, config=config, wrap_pytorch=wrap_pytorch)
     return BatchedCrowdSim(env_name, seed, num_processes, device, config=config, phase=phase, pretext_wrapper=pretext_wrapper, predictor=predictor)

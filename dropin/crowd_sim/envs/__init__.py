@@ -1,2 +1,5 @@
 """Entry points of the gym registry (`crowd_sim.envs:CrowdSimVarNum` ..., crowd_sim/envs/__init__.py in the reference)."""
-from crowdnav_prediction_attngraph_amd.gym_env import CrowdSimPred, CrowdSimPredRealGST, CrowdSimVarNum  # noqa: F401
+from crowdnav_prediction_attngraph_amd.gym_env import (CrowdSimPred, CrowdSimPredRealGST, CrowdSimVarNum,  # noqa: F401
+                                                       CrowdSimVarNumCollect)
+
+__all__ = ["CrowdSimVarNum", "CrowdSimPred", "CrowdSimPredRealGST", "CrowdSimVarNumCollect"]

@@ -57,7 +57,8 @@ typedef enum {
     CN_ERR_STATE = -4      /* call sequence error (e.g. step before reset, weights not set) */
 } cn_status;
 
-enum { CN_ENV_VARNUM = 0, CN_ENV_PRED = 1, CN_ENV_PRED_GST = 2 };   /* gym ids CrowdSimVarNum-v0 / CrowdSimPred-v0 / CrowdSimPredRealGST-v0 */
+enum { CN_ENV_VARNUM = 0, CN_ENV_PRED = 1, CN_ENV_PRED_GST = 2, CN_ENV_COLLECT = 3 };   /* gym ids CrowdSimVarNum-v0 / CrowdSimPred-v0 /
+                                                                                          * CrowdSimPredRealGST-v0 / CrowdSimVarNumCollect-v0 */
 enum { CN_PHASE_TRAIN = 0, CN_PHASE_VAL = 1, CN_PHASE_TEST = 2 };
 enum { CN_INFO_NOTHING = 0, CN_INFO_TIMEOUT = 1, CN_INFO_COLLISION = 2, CN_INFO_REACHGOAL = 3, CN_INFO_DANGER = 4 }; /* crowd_sim/envs/utils/info.py */
 
@@ -110,6 +111,9 @@ typedef struct {
     double sf_A, sf_B, sf_KI;     /* config.sf.* (crowd_nav/policy/social_force.py) */
 } cn_env_config;
 
+/* CN_ENV_COLLECT (crowd_sim/envs/crowd_sim_var_num_collect.py, driven by collect_data.py): the dataset generator of the GST predictor.
+ * spatial_edges is then pred_info [E,H,4] = (frame id, prediction id, absolute px, py of the robot's belief; +inf for humans the
+ * robot does not see); reward is 0, an episode never ends, a robot at its goal draws a new one. */
 /* Observation tensors exactly as VecPyTorch returns them (float32, contiguous):
  * robot_node [E,1,7], temporal_edges [E,1,2], spatial_edges [E,H,D] (D = 2 or 2*(predict_steps+1)),
  * detected_human_num [E,1], visible_masks [E,H] (uint8 0/1; may be NULL). */

@@ -348,7 +348,11 @@ void orc_config_default(OrcConfig *c)
     c->orca_time_horizon_obst = 5.0;
 }
 
-int orc_obs_width(const OrcConfig *cfg) { return cfg->env_kind == ORC_ENV_VARNUM ? 2 : 2 * (cfg->predict_steps + 1); }
+int orc_obs_width(const OrcConfig *cfg)
+{
+    if (cfg->env_kind == ORC_ENV_COLLECT) return 4; /* pred_info: frame id, prediction id, px, py (crowd_sim_var_num_collect.py:36) */
+    return cfg->env_kind == ORC_ENV_VARNUM ? 2 : 2 * (cfg->predict_steps + 1);
+}
 
 void orc_env_init(OrcEnv *e, const OrcConfig *cfg, int64_t this_seed)
 {
@@ -430,6 +434,41 @@ static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
     if (c->env_kind != ORC_ENV_PRED) { /* :275 -- CrowdSimPred's own generate_ob never refreshes the list (stays [] from reset) */
         e->observed_count = num_visible; e->observed_max = -1;
         for (int i = 0; i < H; ++i) if (e->human_visibility[i]) e->observed_max = i;
+    }
+    if (c->env_kind == ORC_ENV_COLLECT) {
+        /* crowd_sim_var_num_collect.py:100-133: humans that were visible at the last observation and are not now get fresh prediction
+         * ids (ascending, in list order); pred_info row i = (frame, id, ABSOLUTE position of the robot's belief) for visible humans,
+         * (frame, id, inf, inf) for the others; the belief update is the usual one */
+        for (int i = 0; i < H; ++i)
+            if (e->last_observability[i] && !e->human_visibility[i]) e->human_pred_id[i] = e->max_human_id++;
+        for (int i = 0; i < H; ++i) {
+            double *s = e->last_human_states[i];
+            if (e->human_visibility[i]) {
+                const OrcHuman *h = &e->humans[i];
+                s[0] = h->px; s[1] = h->py; s[2] = h->vx; s[3] = h->vy; s[4] = h->radius;
+            } else if (reset) {
+                s[0] = 15.0; s[1] = 15.0; s[2] = 0.0; s[3] = 0.0; s[4] = 0.3;
+            } else {
+                s[0] = s[0] + s[2] * c->time_step;
+                s[1] = s[1] + s[3] * c->time_step;
+            }
+        }
+        const double frame = ((double)e->step_counter * c->time_step) / c->time_step; /* global_time / data.pred_timestep (== env.time_step) */
+        for (int i = 0; i < HM; ++i) {
+            float *row = obs->spatial_edges + 4 * i;
+            row[0] = (float)frame; row[1] = (float)e->human_pred_id[i];
+            row[2] = (i < H && e->human_visibility[i]) ? (float)e->last_human_states[i][0] : INFINITY;
+            row[3] = (i < H && e->human_visibility[i]) ? (float)e->last_human_states[i][1] : INFINITY;
+        }
+        for (int i = 0; i < HM; ++i) e->last_observability[i] = i < H ? e->human_visibility[i] : 0;
+        obs->robot_node[0] = (float)e->rpx; obs->robot_node[1] = (float)e->rpy; obs->robot_node[2] = (float)c->robot_radius;
+        obs->robot_node[3] = (float)e->rgx; obs->robot_node[4] = (float)e->rgy; obs->robot_node[5] = (float)c->robot_v_pref;
+        obs->robot_node[6] = (float)e->rtheta;
+        obs->temporal_edges[0] = (float)e->rvx; obs->temporal_edges[1] = (float)e->rvy;
+        memset(obs->visible_masks, 0, sizeof(obs->visible_masks));
+        for (int i = 0; i < H; ++i) obs->visible_masks[i] = (uint8_t)e->human_visibility[i];
+        obs->detected_human_num = (float)(num_visible == 0 ? 1 : num_visible);
+        return;
     }
     /* robot_node = get_full_state_list_noV (agent.py:105): px, py, r, gx, gy, v_pref, theta */
     obs->robot_node[0] = (float)e->rpx; obs->robot_node[1] = (float)e->rpy; obs->robot_node[2] = (float)c->robot_radius;
@@ -565,6 +604,10 @@ void orc_env_reset(OrcEnv *e, OrcObs *obs)
     e->case_counter[ph] = (e->case_counter[ph] + (uint64_t)c->nenv) % case_size[ph];
     e->potential = -fabs(norm2(e->rgx - e->rpx, e->rgy - e->rpy));
     e->ep_return = 0.0; e->ep_len = 0;
+    if (c->env_kind == ORC_ENV_COLLECT) { /* crowd_sim_var_num_collect.py:79-81 */
+        for (int i = 0; i < ORC_MAX_HUMANS; ++i) { e->last_observability[i] = 0; e->human_pred_id[i] = i; }
+        e->max_human_id = e->n_humans;
+    }
     write_obs(e, obs, 1);
 }
 
@@ -847,7 +890,31 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
                 if (d < c->robot_radius + c->human_radius) { if (!danger_cond || d < mind) mind = d; danger_cond = 1; }
             }
     }
-    if (global_time >= c->time_limit - 1.0) { reward = 0.0; done = 1; info = ORC_INFO_TIMEOUT; }
+    if (c->env_kind == ORC_ENV_COLLECT) {
+        /* crowd_sim_var_num_collect.py:139-188: the data-collection env never ends an episode (global_time >= 40000 aside) and pays
+         * no reward; a robot that reaches its goal gets a new one -- the median of the humans' positions or a uniform point of
+         * the arena, each with probability 1/2 (np.random draws in this order: uniform(0, 1), then uniform(-a, a, size = 2)) */
+        reward = 0.0; done = 0; info = ORC_INFO_NOTHING;
+        if (global_time >= 40000.0) { done = 1; info = ORC_INFO_TIMEOUT; }
+        else if (collision) info = ORC_INFO_COLLISION;
+        else if (norm2(e->rpx - e->rgx, e->rpy - e->rgy) < c->robot_radius) {
+            info = ORC_INFO_REACHGOAL;
+            if (env_uniform(e, 0.0, 1.0) < 0.5) {
+                double med[2];
+                for (int d = 0; d < 2; ++d) { /* np.median(axis = 0): middle element, or the mean of the two middle ones */
+                    double v[ORC_MAX_HUMANS];
+                    for (int i = 0; i < H; ++i) v[i] = d == 0 ? e->humans[i].px : e->humans[i].py;
+                    for (int i = 1; i < H; ++i) { const double x = v[i]; int j = i - 1; while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; } v[j + 1] = x; }
+                    med[d] = (H & 1) ? v[H / 2] : (v[H / 2 - 1] + v[H / 2]) / 2.0;
+                }
+                e->rgx = med[0]; e->rgy = med[1];
+            } else {
+                e->rgx = env_uniform(e, -c->arena_size, c->arena_size);
+                e->rgy = env_uniform(e, -c->arena_size, c->arena_size);
+            }
+        }
+    }
+    else if (global_time >= c->time_limit - 1.0) { reward = 0.0; done = 1; info = ORC_INFO_TIMEOUT; }
     else if (collision) { reward = c->collision_penalty; done = 1; info = ORC_INFO_COLLISION; }
     else if (reaching_goal) { reward = c->success_reward; done = 1; info = ORC_INFO_REACHGOAL; }
     else if (danger_cond) {

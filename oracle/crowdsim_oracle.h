@@ -67,7 +67,7 @@ extern "C" {
 #define ORC_MAX_PLACEMENT_ATTEMPTS (1 << 16)
 #define ORC_MAX_PRED 8
 
-enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2 };
+enum { ORC_ENV_VARNUM = 0, ORC_ENV_PRED = 1, ORC_ENV_PRED_GST = 2, ORC_ENV_COLLECT = 3 };  /* 3: CrowdSimVarNumCollect-v0 (collect_data.py) */
 enum { ORC_PHASE_TRAIN = 0, ORC_PHASE_VAL = 1, ORC_PHASE_TEST = 2 };
 enum { ORC_ROBOT_NETWORK = 0, ORC_ROBOT_ORCA = 1, ORC_ROBOT_SOCIAL_FORCE = 2 };
 enum { ORC_HUMANS_ORCA = 0, ORC_HUMANS_SOCIAL_FORCE = 1 };
@@ -148,6 +148,9 @@ typedef struct OrcEnv {
     /* bench.Monitor stand-in (envs.py:70-73) */
     double ep_return;
     int32_t ep_len;
+    /* CrowdSimVarNumCollect-v0 (crowd_sim_var_num_collect.py): prediction ids for the GST dataset -- a human that leaves the robot's view
+     * comes back under a fresh id */
+    int32_t human_pred_id[ORC_MAX_HUMANS], max_human_id, last_observability[ORC_MAX_HUMANS];
     /* last human actions (diagnostics for tests) */
     float last_human_actions[ORC_MAX_HUMANS][2];
 } OrcEnv;

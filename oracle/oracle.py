@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(_HERE, "libcrowdsim_oracle.so")
 
 MAX_HUMANS = 64
 MAX_PRED = 8
-ENV_VARNUM, ENV_PRED, ENV_PRED_GST = 0, 1, 2
+ENV_VARNUM, ENV_PRED, ENV_PRED_GST, ENV_COLLECT = 0, 1, 2, 3
 PHASE_TRAIN, PHASE_VAL, PHASE_TEST = 0, 1, 2
 INFO_NAMES = {0: "Nothing", 1: "Timeout", 2: "Collision", 3: "ReachGoal", 4: "Danger"}
 
@@ -108,6 +108,8 @@ def default_config(**over):
         raise ValueError("human_num + human_num_range must be <= %d and human_num > human_num_range (crowd_sim.py:158)" % MAX_HUMANS)
     if cfg.predict_truth and (cfg.env_kind != ENV_PRED or cfg.robot_visible or cfg.humans_policy != 0):
         raise NotImplementedError("predict_method='truth': CrowdSimPred-v0 with ORCA humans and an invisible robot")
+    if cfg.env_kind == ENV_COLLECT and (cfg.human_num_range or cfg.kinematics or cfg.phase != 0 or cfg.robot_policy != 1):
+        raise NotImplementedError("CrowdSimVarNumCollect-v0: fixed crowd size, holonomic ORCA-driven robot, phase train (what collect_data.py runs)")
     if cfg.kinematics == 1 and cfg.env_kind != ENV_VARNUM:
         raise NotImplementedError("unicycle robot: CrowdSimVarNum-v0 only (CrowdSimPred.step adds the noisy wheel model)")
     if cfg.kinematics == 1 and cfg.robot_policy != 0:
@@ -116,6 +118,8 @@ def default_config(**over):
 
 
 def obs_width(cfg):
+    if cfg.env_kind == ENV_COLLECT:
+        return 4
     return 2 if cfg.env_kind == ENV_VARNUM else 2 * (cfg.predict_steps + 1)
 
 

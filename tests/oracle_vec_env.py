@@ -66,8 +66,35 @@ class OracleVecEnv(object):
         self.envs = []
 
 
+class OracleCollectVecEnv(object):
+    """Stand-in for crowdnav_prediction_attngraph_amd.collect.CollectVecEnv (CrowdSimVarNumCollect-v0, numpy observations)."""
+
+    def __init__(self, seed, num_envs, device, config=None):
+        config = config if config is not None else Config()
+        cn = to_env_config(config, "CrowdSimVarNumCollect-v0", num_envs, "train")
+        self.cfg = O.default_config(**{k: getattr(cn, k) for k in _FIELDS})
+        self.num_envs = int(num_envs)
+        self.envs = [O.OracleEnv(self.cfg, int(seed) + i) for i in range(self.num_envs)]
+
+    def reset(self):
+        return {"pred_info": np.stack([e.reset()["spatial_edges"] for e in self.envs])}
+
+    def step(self, actions):
+        outs = [e.step(np.zeros(2, np.float32)) for e in self.envs]
+        return ({"pred_info": np.stack([o[0]["spatial_edges"] for o in outs])}, np.array([o[1] for o in outs], dtype=np.float32),
+                np.array([o[2] for o in outs], dtype=bool), [{"info": I.from_code(o[3]["info"])} for o in outs])
+
+    def render(self, mode="human"):
+        raise NotImplementedError
+
+    def close(self):
+        self.envs = []
+
+
 def make_vec_envs(env_name, seed, num_processes, gamma, log_dir, device, allow_early_resets, num_frame_stack=None, config=None,
                   ax=None, test_case=-1, wrap_pytorch=True, pretext_wrapper=False, phase=None, predictor=None):
     if pretext_wrapper:
         raise NotImplementedError("the oracle-backed test vec-env has no GST wrapper")
+    if env_name == "CrowdSimVarNumCollect-v0":
+        return OracleCollectVecEnv(seed, num_processes, device, config=config)
     return OracleVecEnv(env_name, seed, num_processes, device, config=config, phase=phase)

@@ -23,7 +23,7 @@ REF = "/root/reference"
 
 pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train.py")), reason="needs the reference checkout (build container only)")
 
-THIRD_PARTY = {"os", "shutil", "time", "collections", "numpy", "torch", "pandas", "matplotlib", "logging", "argparse", "sys", "importlib"}
+THIRD_PARTY = {"os", "shutil", "time", "collections", "numpy", "torch", "pandas", "matplotlib", "logging", "argparse", "sys", "importlib", "copy", "tqdm"}
 
 
 @pytest.fixture()
@@ -37,7 +37,7 @@ def dropin_path():
             del sys.modules[m]
 
 
-@pytest.mark.parametrize("script", ["train.py", "test.py"])
+@pytest.mark.parametrize("script", ["train.py", "test.py", "collect_data.py"])
 def test_every_import_of_the_reference_scripts_resolves_against_dropin(script, dropin_path):
     tree = ast.parse(open(os.path.join(REF, script)).read())
     checked = 0
@@ -53,7 +53,7 @@ def test_every_import_of_the_reference_scripts_resolves_against_dropin(script, d
                 else:
                     assert hasattr(mod, alias.name) or importlib.import_module(node.module + "." + alias.name), (node.module, alias.name)
                 checked += 1
-    assert checked >= 6
+    assert checked >= (3 if script == "collect_data.py" else 6)
 
 
 def _attr_chains(tree, roots):
@@ -134,3 +134,33 @@ def test_reference_train_py_runs_unchanged_for_one_update(dropin_path, tmp_path,
     moved = sum(int(not torch.equal(sd[k], v)) for k, v in fresh.state_dict().items())
     assert moved > 30, "one PPO update must have changed (almost) every parameter tensor; changed: %d" % moved
     fresh.load_state_dict(sd)
+
+
+def test_reference_collect_data_py_runs_unchanged_and_writes_the_collector_s_files(dropin_path, tmp_path, monkeypatch):
+    """collect_data.py's collectData(), executed where it lies, against dropin/ (make_vec_envs, Config, crowd_sim.envs); the only
+    substitution is the simulator behind make_vec_envs (C oracle instead of the device batch).  The files it writes must be the lines
+    the product's collector (crowdnav_prediction_attngraph_amd.collect.format_rows) produces from the same observations."""
+    import numpy as np
+    import rl.networks.envs as shim_envs
+    from tests import oracle_vec_env
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.collect import format_rows
+    monkeypatch.setattr(shim_envs, "make_vec_envs", oracle_vec_env.make_vec_envs)
+    monkeypatch.setattr(sys, "argv", ["collect_data.py"])
+    mod = runpy.run_path(os.path.join(REF, "collect_data.py"), run_name="collect_data_under_test")
+    cfg = C.non_randomized(**{"sim.human_num": 20, "data.tot_steps": 40, "data.num_processes": 3, "data.data_save_dir": str(tmp_path / "ds")})
+    np.random.seed(11)
+    mod["collectData"](torch.device("cpu"), False, cfg)
+    assert cfg.robot.policy == "orca"
+    np.random.seed(11)
+    seed = np.random.randint(0, np.iinfo(np.uint32).max)
+    envs = oracle_vec_env.OracleCollectVecEnv(seed, 3, "cpu", config=cfg)
+    ob = envs.reset()["pred_info"]
+    want = [[] for _ in range(3)]
+    for t in range(40):
+        for i in range(3):
+            want[i] += format_rows(ob[i])
+        ob = envs.step(None)[0]["pred_info"]
+    for i in range(3):
+        got = open(str(tmp_path / "ds" / "test" / ("%d.txt" % i))).read().split("\n")
+        assert got[-1] == "" and got[:-1] == want[i] and len(want[i]) > 100

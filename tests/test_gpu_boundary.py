@@ -68,7 +68,19 @@ def test_single_env_gym_object_matches_oracle_without_autoreset(env_id, kind, ra
     assert env.talk2Env(np.zeros((H, 10))) is True
     env.close()
     with pytest.raises(NotImplementedError):
-        crowd_sim.make("CrowdSimVarNumCollect-v0")
+        crowd_sim.make("rosTurtlebot2iEnv-v0")            # registered by the reference, outside the accelerated path
+    # the dataset-generation env is a gym object too (collect_data.py sets robot.policy = 'orca'; vec-env use: phase 'train')
+    col = crowd_sim.make("CrowdSimVarNumCollect-v0")
+    ccfg = C.non_randomized(**{"sim.human_num": 20, "robot.policy": "orca"})
+    col.configure(ccfg)
+    col.thisSeed, col.nenv, col.phase = 425, 5, "train"
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collect_h20_nonrand_r0.npz"))
+    np.testing.assert_array_equal(col.reset()["pred_info"], z["reset_pred_info"])
+    for t in range(40):
+        ob, r, d, inf = col.step(np.zeros(2))
+        np.testing.assert_array_equal(ob["pred_info"], z["pred_info"][t])
+    assert col.observation_space.spaces["pred_info"].shape == (20, 4) and r == 0.0 and d is False
+    col.close()
 
 
 def test_env_snapshot_resume_is_bit_exact():

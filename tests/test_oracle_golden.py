@@ -3,6 +3,8 @@
 Bar: flags / indices / sort order exact; float32 observations equal to <= 1e-6 (the oracle's sin/cos is its own
 deterministic <=1ulp(fp64) implementation, numpy's is libm -- see DESIGN.md); fp64 state <= 1e-9.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -79,3 +81,32 @@ def test_env_trace_matches_reference(path):
             np.testing.assert_array_equal(ob["visible_masks"], z["visible_masks"][t], err_msg="visible_masks @%d" % t)
     # float32 observations are bit-identical except where a 1ulp(fp64) sin/cos difference crosses a rounding boundary
     assert n_bit_equal / n_vals > 0.999
+
+
+COLLECT = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collect_*.npz")))
+
+
+@pytest.mark.parametrize("path", COLLECT, ids=lambda p: os.path.basename(p)[8:-4])
+def test_collect_env_trace_matches_reference_exactly(path):
+    """CrowdSimVarNumCollect-v0 (crowd_sim_var_num_collect.py, stepped like collect_data.py does): every pred_info entry -- frame ids,
+    prediction ids (fresh id after a human left the robot's view), float32 positions, the inf pattern --, the info codes and the
+    robot's re-drawn goals (median of the humans / uniform point) equal the reference's, 600 steps."""
+    import json
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    over = meta["over"]
+    cfg = O.default_config(human_num=int(over["sim.human_num"]), env_kind=O.ENV_COLLECT, robot_policy=1, nenv=meta["nenv"], phase=0,
+                           randomize_attributes=int(bool(over["env.randomize_attributes"])),
+                           random_goal_changing=int(bool(over["humans.random_goal_changing"])),
+                           end_goal_changing=int(bool(over["humans.end_goal_changing"])))
+    env = O.OracleEnv(cfg, meta["seed"] + meta["rank"])
+    np.testing.assert_array_equal(env.reset()["spatial_edges"], z["reset_pred_info"])
+    goal_changes = 0
+    for t in range(len(z["info"])):
+        ob, r, d, inf = env.step(np.zeros(2, np.float32))
+        np.testing.assert_array_equal(ob["spatial_edges"], z["pred_info"][t], err_msg="pred_info @%d" % t)
+        assert inf["info"] == int(z["info"][t]) and r == 0.0 and not d
+        rn, rs = ob["robot_node"].ravel(), z["robot_state"][t]
+        assert rn[3] == np.float32(rs[5]) and rn[4] == np.float32(rs[6]), "goal @%d" % t
+        goal_changes += int(inf["info"] == 3)
+    assert goal_changes >= 4
