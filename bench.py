@@ -288,6 +288,8 @@ def main():
             ppo = {"samples_per_s": round(30 * E * world / (r_s + u_s), 1), "rollout_s": round(r_s, 5), "update_s": round(u_s, 5),
                    "config": "T=30 steps x %d envs per GPU, ppo_epoch 5, num_mini_batch 2, Adam; 3 updates run, the last one timed" % E,
                    "value_loss": round(last["value_loss"], 6)}
+            if last.get("allreduce_ms") is not None:   # N > 1: one flat 10 MB gradient all-reduce per optimiser step (this rank's mean)
+                ppo["grad_allreduce_ms_per_step"] = round(float(last["allreduce_ms"]), 4)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -143,6 +143,8 @@ class PPO():
         if on_gpu:
             self._bind_flat()
         num_steps = 0
+        ar_events = []
+        self.last_allreduce_ms = None
         for e in range(self.ppo_epoch):
             if not self.actor_critic.is_recurrent:
                 raise NotImplementedError("feed-forward policies are out of scope")
@@ -161,7 +163,11 @@ class PPO():
                             p.grad = gv
                     scale = 1.0
                     if d is not None:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record()
                         d.all_reduce(flat["g"])               # ONE collective per optimiser step (RCCL over xGMI)
+                        ev[1].record()
+                        ar_events.append(ev)
                         scale = 1.0 / d.get_world_size()
                     g = self.optimizer.param_groups[0]
                     self._step += 1
@@ -186,6 +192,9 @@ class PPO():
                 num_steps += 1
         if on_gpu:
             self._sync_optimizer_state()
+        if ar_events:      # mean duration of the gradient all-reduce on this rank's stream (the events complete with the host sync below)
+            torch.cuda.synchronize()
+            self.last_allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
         num_updates = self.ppo_epoch * self.num_mini_batch
         if d is not None:
             d.all_reduce(sums)

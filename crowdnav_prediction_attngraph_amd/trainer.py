@@ -169,6 +169,7 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
         rec = dict(update=j, value_loss=value_loss, action_loss=action_loss, entropy=dist_entropy, rollout_s=t1 - t0, update_s=t2 - t1,
+                   allreduce_ms=getattr(agent, "last_allreduce_ms", None),
                    samples_per_s=num_steps * num_processes / (t2 - t0), **stats.pop())
         history.append(rec)
         if log:
