@@ -35,3 +35,7 @@ soak(dict(human_num=20), 4096, 1500, 40)
 soak(dict(human_num=50, randomize_attributes=1, random_goal_changing=1), 2048, 400, 24)
 soak(dict(human_num=20, env_kind=1, phase=2), 1024, 600, 24)
 soak(dict(human_num=10, robot_policy=1, randomize_attributes=1, random_goal_changing=1, phase=2), 1024, 600, 24)
+soak(dict(human_num=15, human_num_range=5, randomize_attributes=1, random_goal_changing=1), 2048, 600, 24)
+soak(dict(human_num=6, human_num_range=5, kinematics=1, randomize_attributes=1), 2048, 600, 24)
+soak(dict(human_num=20, humans_policy=1, robot_visible=1), 2048, 500, 24)
+soak(dict(human_num=20, env_kind=1, predict_truth=1), 1024, 400, 16)
