@@ -12,6 +12,7 @@
 // between them is wave-per-row / wave-per-(env, t) kernels.  All work is enqueued on the caller's stream.
 #include "common.h"
 #include "gemm.h"
+#include "rn_fused.h" // rn_fused_bake: bf16 hi/lo MFMA-fragment image of a weight matrix
 
 #include <cmath>
 #include <new>
@@ -140,6 +141,247 @@ __global__ __launch_bounds__(256) void gst_attention_kernel(int groups, int H, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The whole NodeEncoderLayer + the LSTM's input projection as ONE kernel (round 2): embedding -> LayerNorm * mask -> in_proj -> 8-head
+// attention (multiplicative mask + renormalisation) -> out_proj + residual -> LayerNorm -> FFN 64-128-64 + residual -> gx = xs W_ih^T.
+// As eight launches (three of them K = 64 GEMMs that move 1-3 KB per row through HBM for 25-50 kFLOP) this chain was 2/3 of the
+// GST step; here a workgroup (4 wavefronts) owns a tile of TG whole groups (<= 80 rows), keeps every activation of the tile in LDS
+// (108 KB; 8 wavefronts) and streams the 196 KB weight image (bf16 hi/lo MFMA fragments, the bake of rn_fused.hip) from L2 once per tile.  Products
+// run in bf16x3 split precision on v_mfma_f32_16x16x32_bf16, "transposed" (A = weights, B = activations): the C layout is 4
+// consecutive output features of one row per lane = a float4 store into the next stage's [row][feature] image.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GL_RT = 5, GL_ROWS = 16 * GL_RT;            // row tiles / rows per workgroup tile
+constexpr int GL_SA = 68, GL_SQ = 196;                    // LDS row strides (floats): 16-byte aligned, lanes of a float4 read on distinct banks
+constexpr int GL_OA = 0, GL_OQ = GL_OA + GL_ROWS * GL_SA, GL_OT = GL_OQ + GL_ROWS * GL_SQ, GL_OM = GL_OT + GL_ROWS * GL_SA;
+constexpr int GL_OX = GL_OM + GL_ROWS, GL_OC = GL_OX + 2 * GL_ROWS; // staged (x, y) inputs; constants of the embedding's LayerNorm
+constexpr int GL_OB = GL_OC + 16;            // biases: in_proj 192 | out_proj 64 | linear1 128 | linear2 64 (read by every tile: staged once)
+constexpr int GL_LDS_FLOATS = GL_OB + 448;
+
+struct GstLayerArgs {
+    const float *x2, *mask;                                   // [rows,2], [rows]
+    const float *emb_w, *emb_b, *n_w, *n_b, *n1_w, *n1_b;     // fp32 small tensors
+    const float *f_in, *in_b, *f_out, *out_b, *f_l1, *l1_b, *f_l2, *l2_b, *f_wih; // baked fragments + biases
+    float *gx;                                                // [rows,256]
+};
+
+// The weight fragments of a stage for the feature blocks fb_first, fb_first + fb_step, ... of this wavefront.  Wfrag: [fb][K/32][hi,lo]
+// [64 lanes][8 bf16].  Loaded one phase AHEAD of their use (the kernel is a chain of short dependent phases at one workgroup per CU:
+// fetched at the start of its own stage, every stage began with a cold L2 round trip -- 90 of them per workgroup and step).
+template <int K, int NFB>
+struct GlW { bf16x8 h[K / 32][NFB], l[K / 32][NFB]; };
+
+template <int K, int NFB>
+__device__ __forceinline__ void gl_load(GlW<K, NFB> &w, const float *__restrict__ Wfrag_, int fb_first, int fb_step, int lane)
+{
+    const bf16x8 *__restrict__ Wfrag = reinterpret_cast<const bf16x8 *>(Wfrag_);
+#pragma unroll
+    for (int ks = 0; ks < K / 32; ++ks)
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) {
+            const size_t base = ((size_t)(fb_first + j * fb_step) * (K / 32) + ks) * 128 + lane;
+            w.h[ks][j] = Wfrag[base]; w.l[ks][j] = Wfrag[base + 64];
+        }
+}
+
+// out[row][out_off + f] = act(W[f] . in[row] + bias[f] (+ res[row][f])) for this wavefront's feature blocks and all row tiles.
+// `out` may be LDS or global.
+template <int K, int NFB, bool RELU>
+__device__ __forceinline__ void gl_stage(const GlW<K, NFB> &w, int fb_first, int fb_step, const float *__restrict__ bias, const float *in,
+                                         int in_stride, float *out, size_t out_stride, int out_off, const float *res, int res_stride, int nrows, int lane,
+                                         int rt_first)
+{
+    const int i = lane & 15, g = lane >> 4;
+    constexpr int KS = K / 32;
+    // the biases are read BEFORE the row-tile loop: inside it every load of them would have to wait for the previous tile's stores
+    // (the compiler cannot prove that `out` does not alias them) -- one global round trip per row tile and stage
+    f32x4 bv[NFB];
+#pragma unroll
+    for (int j = 0; j < NFB; ++j) bv[j] = bias ? *reinterpret_cast<const f32x4 *>(bias + (fb_first + j * fb_step) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // the workgroup's two wavefront teams (4 wavefronts each, same feature blocks) take the even / the odd row tiles
+#pragma unroll
+    for (int rt2 = 0; rt2 < (GL_RT + 1) / 2; ++rt2) {
+        const int rt = 2 * rt2 + rt_first;
+        if (16 * rt >= nrows) break; // wave-uniform
+        f32x4 acc[NFB];
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *inr = in + (16 * rt + i) * in_stride + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(inr + 32 * ks), x1 = *reinterpret_cast<const f32x4 *>(inr + 32 * ks + 4);
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const __bf16 h0 = (__bf16)x0[u], h1 = (__bf16)x1[u];
+                bh[u] = h0; bh[4 + u] = h1;
+                bl[u] = (__bf16)(x0[u] - (float)h0); bl[4 + u] = (__bf16)(x1[u] - (float)h1);
+            }
+#pragma unroll
+            for (int j = 0; j < NFB; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[ks][j], bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[ks][j], bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[ks][j], bh, acc[j], 0, 0, 0);
+            }
+        }
+        const int row = 16 * rt + i;
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) {
+            const int f0 = (fb_first + j * fb_step) * 16 + 4 * g;
+            f32x4 v = acc[j] + bv[j];
+            if (res) v += *reinterpret_cast<const f32x4 *>(res + row * res_stride + f0);
+            if (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (row < nrows) *reinterpret_cast<f32x4 *>(out + (size_t)row * out_stride + out_off + f0) = v;
+        }
+    }
+}
+
+#ifdef GST_TIMING
+__device__ long long *g_gst_tim = nullptr; // [block][10] phase cycle sums of thread 0 (measurement build only)
+#define GL_T(k) do { if (g_gst_tim && threadIdx.x == 0) { const long long now_ = clock64(); g_gst_tim[(size_t)blockIdx.x * 10 + (k)] += now_ - tlast_; tlast_ = now_; } } while (0)
+#else
+#define GL_T(k) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(512, 1) void gst_layer_kernel(int rows, int H, int TG, GstLayerArgs a)
+{
+#ifdef GST_TIMING
+    long long tlast_ = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float *A0 = lds_f + GL_OA, *QKV = lds_f + GL_OQ, *ATT = lds_f + GL_OT, *MSK = lds_f + GL_OM, *XY = lds_f + GL_OX, *EC = lds_f + GL_OC;
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, team = wave8 >> 2; // feature-block owner; row-tile parity (8 wavefronts: two per SIMD hide each other's latencies)
+    const int tile_rows = TG * H;
+    const int n_tiles = (rows + tile_rows - 1) / tile_rows;
+    // LayerNorm of the embedding v_f = We[f][0] x + We[f][1] y + be[f] needs no reduction per row: its mean and variance over the 64
+    // features are a linear / quadratic form of (x, y) with nine constants of the weight snapshot (computed here once per workgroup)
+    if (wave8 == 0) {
+        const float w0 = a.emb_w[2 * lane], w1 = a.emb_w[2 * lane + 1], b0 = a.emb_b[lane];
+        const float m0 = wv_sum(w0) * (1.0f / 64.0f), m1 = wv_sum(w1) * (1.0f / 64.0f), mb = wv_sum(b0) * (1.0f / 64.0f);
+        const float d0 = w0 - m0, d1 = w1 - m1, db = b0 - mb;
+        const float c00 = wv_sum(d0 * d0) * (1.0f / 64.0f), c11 = wv_sum(d1 * d1) * (1.0f / 64.0f), cbb = wv_sum(db * db) * (1.0f / 64.0f);
+        const float c01 = wv_sum(d0 * d1) * (1.0f / 64.0f), c0b = wv_sum(d0 * db) * (1.0f / 64.0f), c1b = wv_sum(d1 * db) * (1.0f / 64.0f);
+        if (lane == 0) { EC[0] = m0; EC[1] = m1; EC[2] = mb; EC[3] = c00; EC[4] = c11; EC[5] = cbb; EC[6] = c01; EC[7] = c0b; EC[8] = c1b; }
+    }
+    float *BI = lds_f + GL_OB;
+    if (tid < 192) BI[tid] = a.in_b[tid];
+    else if (tid < 256) BI[tid] = a.out_b[tid - 192];
+    else if (tid < 384) BI[tid] = a.l1_b[tid - 256];
+    else if (tid < 448) BI[tid] = a.l2_b[tid - 384];
+    const float ew0 = a.emb_w[2 * lane], ew1 = a.emb_w[2 * lane + 1], eb = a.emb_b[lane], ng = a.n_w[lane], nb = a.n_b[lane];
+    const float n1g = a.n1_w[lane], n1b = a.n1_b[lane];
+    GlW<64, 3> w_in;
+    gl_load<64, 3>(w_in, a.f_in, wave, 4, lane);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * tile_rows;
+        const int nrows = min(tile_rows, rows - r0);   // whole groups (rows is a multiple of H)
+        const int nrows16 = (nrows + 15) & ~15;
+        // ---- stage the tile's inputs (coalesced), then node_embedding (2 -> 64) + LayerNorm(norm_node) * mask -> A0 (padding rows = 0) ----
+        for (int r = tid; r < nrows16; r += 512) {
+            const bool live = r < nrows;
+            XY[2 * r] = live ? a.x2[2 * (size_t)(r0 + r)] : 0.0f;
+            XY[2 * r + 1] = live ? a.x2[2 * (size_t)(r0 + r) + 1] : 0.0f;
+            MSK[r] = live ? a.mask[r0 + r] : 0.0f;
+        }
+        __syncthreads();
+        for (int r = wave8; r < nrows16; r += 8) {
+            const float x = XY[2 * r], y = XY[2 * r + 1], m = MSK[r];
+            const float mean = EC[0] * x + EC[1] * y + EC[2];
+            const float var = EC[3] * x * x + EC[4] * y * y + EC[5] + 2.0f * (EC[6] * x * y + EC[7] * x + EC[8] * y);
+            const float v = ew0 * x + ew1 * y + eb;
+            A0[r * GL_SA + lane] = ((v - mean) * rsqrtf(fmaxf(var, 0.0f) + 1e-5f) * ng + nb) * m;
+        }
+        GlW<64, 1> w_out;
+        gl_load<64, 1>(w_out, a.f_out, wave, 4, lane);
+        __syncthreads();
+        GL_T(0);
+        // ---- in_proj: [q | k | v] = W_in x0 + b_in -> QKV ----
+        gl_stage<64, 3, false>(w_in, wave, 4, BI, A0, GL_SA, QKV, GL_SQ, 0, nullptr, 0, nrows16, lane, team);
+        __syncthreads();
+        GL_T(1);
+        GlW<64, 2> w_l1;
+        gl_load<64, 2>(w_l1, a.f_l1, wave, 4, lane);
+        // ---- attention core per group (mha.py:236-242): wavefront w takes groups w, w + 4, ...; lanes enumerate (node, head) ----
+        {
+            const float scale = 0.35355339059327373f; // 8^-0.5
+            for (int pq = tid; pq < nrows * 8; pq += 512) { // (row, head) pairs of the whole tile over all threads
+                const int row = pq >> 3, hd = pq & 7;
+                const int gq = row / H;
+                const float *qb = QKV + gq * H * GL_SQ;
+                const float *ms = MSK + gq * H;
+                const f32x4 qa = *reinterpret_cast<const f32x4 *>(QKV + row * GL_SQ + hd * 8) * scale;
+                const f32x4 qc = *reinterpret_cast<const f32x4 *>(QKV + row * GL_SQ + hd * 8 + 4) * scale;
+                float mx = -INFINITY;
+#pragma unroll 4
+                for (int j = 0; j < H; ++j) {
+                    const f32x4 ka = *reinterpret_cast<const f32x4 *>(qb + j * GL_SQ + 64 + hd * 8), kc = *reinterpret_cast<const f32x4 *>(qb + j * GL_SQ + 68 + hd * 8);
+                    float sc = 0.0f;
+                    sc += qa[0] * ka[0]; sc += qa[1] * ka[1]; sc += qa[2] * ka[2]; sc += qa[3] * ka[3];
+                    sc += qc[0] * kc[0]; sc += qc[1] * kc[1]; sc += qc[2] * kc[2]; sc += qc[3] * kc[3];
+                    mx = fmaxf(mx, sc);
+                }
+                float Z = 0.0f, Zm = 0.0f;
+                f32x4 aa = f32x4{0.f, 0.f, 0.f, 0.f}, ac = aa;
+#pragma unroll 4
+                for (int j = 0; j < H; ++j) {
+                    const f32x4 ka = *reinterpret_cast<const f32x4 *>(qb + j * GL_SQ + 64 + hd * 8), kc = *reinterpret_cast<const f32x4 *>(qb + j * GL_SQ + 68 + hd * 8);
+                    float sc = 0.0f;
+                    sc += qa[0] * ka[0]; sc += qa[1] * ka[1]; sc += qa[2] * ka[2]; sc += qa[3] * ka[3];
+                    sc += qc[0] * kc[0]; sc += qc[1] * kc[1]; sc += qc[2] * kc[2]; sc += qc[3] * kc[3];
+                    const float ex = expf(sc - mx);
+                    Z += ex;
+                    const float em = ex * ms[j];
+                    Zm += em;
+                    aa += em * *reinterpret_cast<const f32x4 *>(qb + j * GL_SQ + 128 + hd * 8);
+                    ac += em * *reinterpret_cast<const f32x4 *>(qb + j * GL_SQ + 132 + hd * 8);
+                }
+                const float mi = MSK[row];
+                const float denom = mi * Zm / Z + 1e-10f;
+                const float f = mi / (Z * denom);
+                float *o = ATT + row * GL_SA + hd * 8;
+                *reinterpret_cast<f32x4 *>(o) = aa * f;
+                *reinterpret_cast<f32x4 *>(o + 4) = ac * f;
+            }
+        }
+        // padding rows of ATT (read by the next product's fragments) must be finite
+        for (int r = nrows + wave8; r < nrows16; r += 8) ATT[r * GL_SA + lane] = 0.0f;
+        __syncthreads();
+        GL_T(2);
+        // ---- out_proj + residual: x1 = x0 + W_out att + b_out, in place over x0 ----
+        gl_stage<64, 1, false>(w_out, wave, 4, BI + 192, ATT, GL_SA, A0, GL_SA, 0, A0, GL_SA, nrows16, lane, team);
+        __syncthreads();
+        GL_T(3);
+        GlW<128, 1> w_l2;
+        gl_load<128, 1>(w_l2, a.f_l2, wave, 4, lane);
+        // ---- LayerNorm(norm1_node): x2 -> ATT (the attention output is dead) ----
+        for (int r = wave8; r < nrows16; r += 8) {
+            const float v = A0[r * GL_SA + lane];
+            const float mean = wv_sum(v) * (1.0f / 64.0f);
+            const float d = v - mean;
+            const float var = wv_sum(d * d) * (1.0f / 64.0f);
+            ATT[r * GL_SA + lane] = d * rsqrtf(var + 1e-5f) * n1g + n1b;
+        }
+        __syncthreads();
+        GL_T(4);
+        // ---- FFN: ff = relu(W_1 x2 + b_1) -> QKV region (q|k|v are dead); xs = x1 + W_2 ff + b_2, in place over x1 ----
+        gl_stage<64, 2, true>(w_l1, wave, 4, BI + 256, ATT, GL_SA, QKV, GL_SQ, 0, nullptr, 0, nrows16, lane, team);
+        __syncthreads();
+        GL_T(5);
+        GlW<64, 4> w_ih;
+        gl_load<64, 4>(w_ih, a.f_wih, wave, 4, lane);
+        gl_stage<128, 1, false>(w_l2, wave, 4, BI + 384, QKV, GL_SQ, A0, GL_SA, 0, A0, GL_SA, nrows16, lane, team);
+        __syncthreads();
+        GL_T(6);
+        // ---- the LSTM's input projection of the encoded rows: gx = W_ih xs (biases are added by the pointwise kernel) -> HBM ----
+        gl_stage<64, 4, false>(w_ih, wave, 4, nullptr, A0, GL_SA, a.gx + (size_t)r0 * 256, 256, 0, nullptr, 0, nrows, lane, team);
+        if (tile + (int)gridDim.x < n_tiles) gl_load<64, 3>(w_in, a.f_in, wave, 4, lane); // (w_in's registers were free since the in_proj stage)
+        __syncthreads(); // the next tile overwrites A0 / MSK
+        GL_T(7);
+    }
+}
+
 // LSTM pointwise (PyTorch gate order i,f,g,o).  gx row for (e,h) = gx[((e*S + t)*H + h)*256]; in_mask scales the input
 // contribution ((x*m) W = m (x W) for m in {0,1}); blend (decode steps): h = h' m + h (1-m); post: h,c *= post_mask.
 __global__ __launch_bounds__(64) void gst_lstm_pointwise_kernel(int E, int H, int S, int t, const float *__restrict__ gx,
@@ -262,6 +504,7 @@ struct cn_gst {
     char *blob;
     float *emb_w, *emb_b, *in_w, *in_b, *out_w, *out_b, *n_w, *n_b, *n1_w, *n1_b, *l1_w, *l1_b, *l2_w, *l2_b;
     float *wih, *whh, *bih, *bhh, *h2p_w, *h2p_b;
+    float *f_in, *f_out, *f_l1, *f_l2, *f_wih; // bf16 hi/lo MFMA-fragment images of in_proj / out_proj / linear1 / linear2 / W_ih (gst_layer_kernel)
     // workspace (rows = maxE * 5 * H)
     float *m_rel, *lm_fp, *rel, *last_pos, *x0, *qkv, *att, *x1, *x2, *ff, *xs, *gx, *gh, *h, *c, *acc, *x_sample;
     float *out_traj, *out_mask; // internal buffers for the wrapper path
@@ -287,6 +530,7 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     const size_t o_x1 = carve(R * 64), o_x2 = carve(R * 64), o_ff = carve(R * 128), o_xs = carve(R * 64), o_gx = carve(R * 256), o_gh = carve(N * 256);
     const size_t o_h = carve(N * 64), o_c = carve(N * 64), o_acc = carve(N * 5), o_xsamp = carve(N * 2), o_ot = carve(N * GP * 5), o_om = carve(N);
     const size_t o_rt = carve((size_t)GT * N * 2), o_rm = carve(((size_t)GT * N + 3) / 4);
+    const size_t o_fin = carve(192 * 64), o_fout = carve(64 * 64), o_fl1 = carve(128 * 64), o_fl2 = carve(64 * 128), o_fwih = carve(256 * 64);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete g; cn_set_error("cn_gst_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -298,6 +542,7 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     g->m_rel = F(o_mrel); g->lm_fp = F(o_lm); g->rel = F(o_rel); g->last_pos = F(o_lp); g->x0 = F(o_x0); g->qkv = F(o_qkv); g->att = F(o_att);
     g->x1 = F(o_x1); g->x2 = F(o_x2); g->ff = F(o_ff); g->xs = F(o_xs); g->gx = F(o_gx); g->gh = F(o_gh); g->h = F(o_h); g->c = F(o_c);
     g->acc = F(o_acc); g->x_sample = F(o_xsamp); g->out_traj = F(o_ot); g->out_mask = F(o_om);
+    g->f_in = F(o_fin); g->f_out = F(o_fout); g->f_l1 = F(o_fl1); g->f_l2 = F(o_fl2); g->f_wih = F(o_fwih);
     g->ring_traj = F(o_rt); g->ring_mask = (uint8_t *)(base + o_rm);
     g->ring_E = 0; g->ring_pos = 0; g->weights_set = false;
     *out = g;
@@ -323,7 +568,40 @@ extern "C" int cn_gst_set_weights(cn_gst *g, const cn_gst_weights *w, void *stre
         CN_REQUIRE(src[i] != nullptr, "cn_gst_set_weights: weight pointer #%d is null", i);
         CN_HIP(hipMemcpyAsync(dst[i], src[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = rn_fused_bake(192, 64, g->in_w, g->f_in, st)) || (rc = rn_fused_bake(64, 64, g->out_w, g->f_out, st)) ||
+        (rc = rn_fused_bake(128, 64, g->l1_w, g->f_l1, st)) || (rc = rn_fused_bake(64, 128, g->l2_w, g->f_l2, st)) ||
+        (rc = rn_fused_bake(256, 64, g->wih, g->f_wih, st))) return rc;
     g->weights_set = true;
+    return CN_OK;
+}
+
+#ifdef GST_TIMING
+extern "C" int cn_gst_set_timing(long long *buf)
+{
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gst_tim), &buf, sizeof(buf)));
+    return CN_OK;
+}
+#endif
+
+// NodeEncoderLayer + W_ih over `rows` rows in groups of H nodes: x2 [rows,2], mask [rows] -> g->gx [rows,256] (one launch)
+static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hipStream_t st)
+{
+    const int H = g->H;
+    int TG = GL_ROWS / H; TG = TG < 1 ? 1 : TG;
+    CN_REQUIRE(TG * H <= GL_ROWS, "cn_gst: more than %d humans per group is not supported by the fused encoder layer", GL_ROWS);
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    CN_HIP(hipGetDevice(&dev));
+    if (dev != attr_dev) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gst_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GL_LDS_FLOATS * sizeof(float))));
+        attr_dev = dev;
+    }
+    const int n_tiles = (rows + TG * H - 1) / (TG * H);
+    GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b, g->f_wih, g->gx};
+    hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
+    CN_CHECK_LAUNCH();
     return CN_OK;
 }
 
@@ -361,8 +639,7 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
                        g->m_rel, g->lm_fp, g->rel, g->last_pos);
     CN_CHECK_LAUNCH();
     // observation period: spatial encoding of all 5 slices at once, then the LSTM over time
-    if ((rc = gst_transformer(g, R, E * GT, g->rel, g->m_rel, st))) return rc;
-    if ((rc = launch_gemm_t<128, 64, ACT_NONE>(R, 256, 64, g->xs, 64, g->wih, nullptr, g->gx, 256, st, nullptr, 1, nb, 1 << 30))) return rc;
+    if ((rc = gst_layer(g, R, g->rel, g->m_rel, st))) return rc;
     CN_HIP(hipMemsetAsync(g->h, 0, (size_t)N * 64 * sizeof(float), st));
     CN_HIP(hipMemsetAsync(g->c, 0, (size_t)N * 64 * sizeof(float), st));
     for (int t = 0; t < GT; ++t) {
@@ -374,8 +651,7 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
     // prediction period (recursive decoding on the mean)
     for (int tt = 0; tt < GP; ++tt) {
         if (tt > 0) {
-            if ((rc = gst_transformer(g, N, E, g->x_sample, g->lm_fp, st))) return rc;
-            if ((rc = launch_gemm_t<128, 64, ACT_NONE>(N, 256, 64, g->xs, 64, g->wih, nullptr, g->gx, 256, st, nullptr, 1, nb, 1 << 30))) return rc;
+            if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st))) return rc;
             if ((rc = launch_gemm_t<64, 64, ACT_NONE>(N, 256, 64, g->h, 64, g->whh, nullptr, g->gh, 256, st, nullptr, 1, nb, 1 << 30))) return rc;
             hipLaunchKernelGGL(gst_lstm_pointwise_kernel, dim3(N), dim3(64), 0, st, E, H, 1, 0, g->gx, g->lm_fp, g->gh, g->bih, g->bhh, g->h, g->c,
                                g->lm_fp, (const float *)nullptr);
