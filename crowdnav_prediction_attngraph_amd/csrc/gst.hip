@@ -8,10 +8,11 @@
 // Shipped hyper-parameters only: embedding 64, 8 heads x 8, 1 encoder layer, FFN 128, LSTM 64, obs 5 / pred 5, output 5.
 //
 // Row index space: a "slab" has S time slices (S = 5 for the observation pass, 1 for each decode step);
-// row = (env * S + t) * H + human.  Dense contractions (K = 64 / 128) run on the fp32 MFMA GEMM of gemm.h; everything
-// between them is wave-per-row / wave-per-(env, t) kernels.  All work is enqueued on the caller's stream.
+// row = (env * S + t) * H + human.  Round 2: a forward is 16 launches instead of ~66 -- the NodeEncoderLayer is ONE kernel
+// (gst_layer_kernel: activations of a tile of whole groups in LDS, bf16x3 MFMA), the LSTM over a slab is ONE kernel (gst_lstm_kernel:
+// weights in registers, h / c on chip across the slices); the head and the wrapper kernels are wave-per-row.  All work is enqueued on
+// the caller's stream.
 #include "common.h"
-#include "gemm.h"
 #include "rn_fused.h" // rn_fused_bake: bf16 hi/lo MFMA-fragment image of a weight matrix
 
 #include <cmath>
@@ -55,95 +56,9 @@ __global__ __launch_bounds__(256) void gst_obs_prep_kernel(int E, int H, const f
     last_pos[2 * idx] = px[GT - 1]; last_pos[2 * idx + 1] = py[GT - 1];
 }
 
-// node_embedding (2 -> 64) + LayerNorm(norm_node) + pedestrian mask: one wavefront per row, lane = feature.
-// attn_mask_ped = (row of the adjacency has any 1) == the row's own mask (adjacency = outer product of the masks).
-__global__ __launch_bounds__(256) void gst_embed_ln_kernel(int rows, const float *__restrict__ x2, const float *__restrict__ mask,
-                                                           const float *__restrict__ We, const float *__restrict__ be,
-                                                           const float *__restrict__ g, const float *__restrict__ b, float *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const float v = We[2 * lane] * x2[2 * r] + We[2 * lane + 1] * x2[2 * r + 1] + be[lane];
-    const float mean = wv_sum(v) * (1.0f / 64.0f);
-    const float d = v - mean;
-    const float var = wv_sum(d * d) * (1.0f / 64.0f);
-    out[(size_t)r * 64 + lane] = (d * rsqrtf(var + 1e-5f) * g[lane] + b[lane]) * mask[r];
-}
-
-// plain LayerNorm(norm1_node), one wavefront per row
-__global__ __launch_bounds__(256) void gst_ln_kernel(int rows, const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
-                                                     float *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const float v = x[(size_t)r * 64 + lane];
-    const float mean = wv_sum(v) * (1.0f / 64.0f);
-    const float d = v - mean;
-    const float var = wv_sum(d * d) * (1.0f / 64.0f);
-    out[(size_t)r * 64 + lane] = d * rsqrtf(var + 1e-5f) * g[lane] + b[lane];
-}
-
-// VanillaMultiheadAttention core for one group (env, time slice) of H nodes: 8 heads x 8 dims.
-// p = softmax(q k^T / sqrt(8)) over ALL nodes, then p *= m_i * m_j, p /= (sum_j p + 1e-10)   (mha.py:236-242).
-// One wavefront per group; K and V rows in LDS; lanes enumerate (node i, head) pairs.
-__global__ __launch_bounds__(256) void gst_attention_kernel(int groups, int H, const float *__restrict__ qkv, const float *__restrict__ mask,
-                                                            float *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (g >= groups) return;
-    float *Ks = smem + (size_t)wave * (2 * H * 65 + 64);
-    float *Vs = Ks + H * 65;
-    float *Ms = Vs + H * 65;
-    const float *base = qkv + (size_t)g * H * 192;
-    for (int j = 0; j < H; ++j) {
-        Ks[j * 65 + lane] = base[(size_t)j * 192 + 64 + lane];
-        Vs[j * 65 + lane] = base[(size_t)j * 192 + 128 + lane];
-    }
-    if (lane < H) Ms[lane] = mask[(size_t)g * H + lane];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    const float scale = 0.35355339059327373f; // 8^-0.5
-    for (int pq = lane; pq < H * 8; pq += 64) {
-        const int i = pq >> 3, hd = pq & 7;
-        float q[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) q[d] = base[(size_t)i * 192 + hd * 8 + d] * scale;
-        float mx = -INFINITY;
-        for (int j = 0; j < H; ++j) {
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) s += q[d] * Ks[j * 65 + hd * 8 + d];
-            mx = fmaxf(mx, s);
-        }
-        float Z = 0.0f, Zm = 0.0f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < H; ++j) {
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) s += q[d] * Ks[j * 65 + hd * 8 + d];
-            const float ex = expf(s - mx);
-            Z += ex;
-            const float em = ex * Ms[j];
-            Zm += em;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) acc[d] += em * Vs[j * 65 + hd * 8 + d];
-        }
-        // softmax p_j = ex_j / Z ; masked p'_j = p_j m_i m_j ; renormalised by (sum_j p'_j + 1e-10)
-        const float mi = Ms[i];
-        const float denom = mi * Zm / Z + 1e-10f;
-        const float f = mi / (Z * denom);
-        float *o = out + ((size_t)g * H + i) * 64 + hd * 8;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) o[d] = acc[d] * f;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// The whole NodeEncoderLayer + the LSTM's input projection as ONE kernel (round 2): embedding -> LayerNorm * mask -> in_proj -> 8-head
-// attention (multiplicative mask + renormalisation) -> out_proj + residual -> LayerNorm -> FFN 64-128-64 + residual -> gx = xs W_ih^T.
+// The whole NodeEncoderLayer as ONE kernel (round 2): embedding -> LayerNorm * mask -> in_proj -> 8-head attention (multiplicative mask
+// + renormalisation) -> out_proj + residual -> LayerNorm -> FFN 64-128-64 + residual -> xs.
 // As eight launches (three of them K = 64 GEMMs that move 1-3 KB per row through HBM for 25-50 kFLOP) this chain was 2/3 of the
 // GST step; here a workgroup (4 wavefronts) owns a tile of TG whole groups (<= 80 rows), keeps every activation of the tile in LDS
 // (108 KB; 8 wavefronts) and streams the 196 KB weight image (bf16 hi/lo MFMA fragments, the bake of rn_fused.hip) from L2 once per tile.  Products
@@ -162,8 +77,8 @@ constexpr int GL_LDS_FLOATS = GL_OB + 448;
 struct GstLayerArgs {
     const float *x2, *mask;                                   // [rows,2], [rows]
     const float *emb_w, *emb_b, *n_w, *n_b, *n1_w, *n1_b;     // fp32 small tensors
-    const float *f_in, *in_b, *f_out, *out_b, *f_l1, *l1_b, *f_l2, *l2_b, *f_wih; // baked fragments + biases
-    float *gx;                                                // [rows,256]
+    const float *f_in, *in_b, *f_out, *out_b, *f_l1, *l1_b, *f_l2, *l2_b; // baked fragments + biases
+    float *xs;                                                // [rows,64] encoded rows (input of the LSTM)
 };
 
 // The weight fragments of a stage for the feature blocks fb_first, fb_first + fb_step, ... of this wavefront.  Wfrag: [fb][K/32][hi,lo]
@@ -369,42 +284,141 @@ __global__ __launch_bounds__(512, 1) void gst_layer_kernel(int rows, int H, int 
         gl_stage<64, 2, true>(w_l1, wave, 4, BI + 256, ATT, GL_SA, QKV, GL_SQ, 0, nullptr, 0, nrows16, lane, team);
         __syncthreads();
         GL_T(5);
-        GlW<64, 4> w_ih;
-        gl_load<64, 4>(w_ih, a.f_wih, wave, 4, lane);
-        gl_stage<128, 1, false>(w_l2, wave, 4, BI + 384, QKV, GL_SQ, A0, GL_SA, 0, A0, GL_SA, nrows16, lane, team);
-        __syncthreads();
-        GL_T(6);
-        // ---- the LSTM's input projection of the encoded rows: gx = W_ih xs (biases are added by the pointwise kernel) -> HBM ----
-        gl_stage<64, 4, false>(w_ih, wave, 4, nullptr, A0, GL_SA, a.gx + (size_t)r0 * 256, 256, 0, nullptr, 0, nrows, lane, team);
+        // xs = x1 + W_2 ff + b_2 -> HBM (64 floats per row; the LSTM kernel applies W_ih itself: its [rows, 256] image would be 4x the bytes)
+        gl_stage<128, 1, false>(w_l2, wave, 4, BI + 384, QKV, GL_SQ, a.xs + (size_t)r0 * 64, 64, 0, A0, GL_SA, nrows, lane, team);
         if (tile + (int)gridDim.x < n_tiles) gl_load<64, 3>(w_in, a.f_in, wave, 4, lane); // (w_in's registers were free since the in_proj stage)
         __syncthreads(); // the next tile overwrites A0 / MSK
         GL_T(7);
     }
 }
 
-// LSTM pointwise (PyTorch gate order i,f,g,o).  gx row for (e,h) = gx[((e*S + t)*H + h)*256]; in_mask scales the input
-// contribution ((x*m) W = m (x W) for m in {0,1}); blend (decode steps): h = h' m + h (1-m); post: h,c *= post_mask.
-__global__ __launch_bounds__(64) void gst_lstm_pointwise_kernel(int E, int H, int S, int t, const float *__restrict__ gx,
-                                                                const float *__restrict__ in_mask, const float *__restrict__ gh,
-                                                                const float *__restrict__ b_ih, const float *__restrict__ b_hh,
-                                                                float *__restrict__ h, float *__restrict__ c,
-                                                                const float *__restrict__ blend_mask, const float *__restrict__ post_mask)
+// ------------------------------------------------------------------------------------------------------------------
+// The LSTM over S time slices as ONE kernel: gates = [W_ih | W_hh] [m x_t ; h] + b on the matrix cores (bf16x3), the cell's pointwise
+// part, the decode-step blend / the post mask -- h and c never leave the chip between the S steps.  A workgroup owns 64 nodes; its
+// 256 x 128 weight image stays in registers (128 VGPRs per wavefront) for all its tiles and steps.  Replaces, per step, a K = 64 GEMM
+// whose [N, 256] result went through HBM, the pointwise kernel, and the [rows, 256] input projection of the whole slab.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LS_ROWS = 64, LS_SX = 132, LS_SG = 260;
+constexpr int LS_OX = 0, LS_OG = LS_OX + LS_ROWS * LS_SX, LS_OB = LS_OG + LS_ROWS * LS_SG, LS_LDS_FLOATS = LS_OB + 256;
+
+struct GstLstmArgs {
+    const float *xs, *in_mask;      // [E*S*H, 64] encoded rows, [E*S*H] input mask
+    const float *f_w, *bih, *bhh;   // baked [256,128] = [W_ih | W_hh]; biases
+    float *h, *c;                   // [E*H, 64] state, updated in place
+    const float *blend_mask, *post_mask; // [E*H] or null
+};
+
+// tanh / sigmoid on v_exp_f32 (|err| < 3e-7; e^{2x} overflowing to inf gives 1, underflowing to 0 gives -1)
+__device__ __forceinline__ float gl_tanh(float x) { return 1.0f - 2.0f / (1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681472f)); }
+__device__ __forceinline__ float gl_sigmoid(float x) { return 1.0f / (1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
+
+__global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, GstLstmArgs a)
 {
-    const int n = blockIdx.x, d = threadIdx.x; // n = e*H + hh
-    const int e = n / H, hh = n - e * H;
-    const size_t r = ((size_t)e * S + t) * H + hh;
-    const float m = in_mask[r];
-    const float *gxr = gx + r * 256, *ghr = gh + (size_t)n * 256;
-    const float gi = m * gxr[d] + b_ih[d] + ghr[d] + b_hh[d];
-    const float gf = m * gxr[64 + d] + b_ih[64 + d] + ghr[64 + d] + b_hh[64 + d];
-    const float gg = m * gxr[128 + d] + b_ih[128 + d] + ghr[128 + d] + b_hh[128 + d];
-    const float go = m * gxr[192 + d] + b_ih[192 + d] + ghr[192 + d] + b_hh[192 + d];
-    const float c0 = c[(size_t)n * 64 + d], h0 = h[(size_t)n * 64 + d];
-    float cn = 1.0f / (1.0f + expf(-gf)) * c0 + 1.0f / (1.0f + expf(-gi)) * tanhf(gg);
-    float hn = 1.0f / (1.0f + expf(-go)) * tanhf(cn);
-    if (blend_mask) { const float bm = blend_mask[n]; hn = hn * bm + h0 * (1.0f - bm); cn = cn * bm + c0 * (1.0f - bm); }
-    if (post_mask) { const float pm = post_mask[n]; hn *= pm; cn *= pm; }
-    h[(size_t)n * 64 + d] = hn; c[(size_t)n * 64 + d] = cn;
+#ifdef GST_TIMING
+    long long tlast_ = clock64();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float *X = lds_f + LS_OX, *G = lds_f + LS_OG, *B = lds_f + LS_OB;
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = E * H, n_tiles = (N + LS_ROWS - 1) / LS_ROWS;
+    const int d = tid & 63, q = tid >> 6; // pointwise mapping: hidden unit d of the nodes q, q + 8, ... (8 per thread)
+    if (tid < 256) B[tid] = a.bih[tid] + a.bhh[tid];
+    // wavefront w owns the feature blocks w and w + 8 of the 16 (64 VGPRs of weights: the whole 256 x 128 image in the registers of the
+    // workgroup, never re-read; four blocks per wavefront did not fit beside the rest and spilled into the MFMA loop)
+    GlW<128, 2> w;
+    gl_load<128, 2>(w, a.f_w, wave8, 8, lane);
+    const int i = lane & 15, g = lane >> 4;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n0 = tile * LS_ROWS;
+        float creg[8], xn[8], hreg[8];
+        int rbase[8]; // row of slice 0 of this thread's nodes (slice t is rbase + t * H); out-of-range nodes clamp to the last one (never stored)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int n = min(n0 + q + 8 * k, N - 1);
+            const int e = n / H;
+            rbase[k] = e * S * H + (n - e * H);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { // all loads issued back to back, no control flow between them
+            const int n = min(n0 + q + 8 * k, N - 1);
+            creg[k] = a.c[(size_t)n * 64 + d];
+            hreg[k] = a.h[(size_t)n * 64 + d];
+            xn[k] = a.in_mask[rbase[k]] * a.xs[(size_t)rbase[k] * 64 + d]; // m * x_0 ((x m) W = m (x W) for m in {0, 1})
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[(q + 8 * k) * LS_SX + 64 + d] = hreg[k];
+        GL_T(0);
+        for (int t = 0; t < S; ++t) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) X[(q + 8 * k) * LS_SX + d] = xn[k];
+            __syncthreads();
+            GL_T(1);
+            if (t + 1 < S) { // the next slice's rows travel while this slice is computed
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = rbase[k] + (t + 1) * H;
+                    xn[k] = a.in_mask[r] * a.xs[(size_t)r * 64 + d];
+                }
+            }
+            // gates[node][f] for the feature blocks wave8 and wave8 + 8, all four row tiles
+            f32x4 bv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(B + (wave8 + 8 * j) * 16 + 4 * g);
+#pragma unroll
+            for (int rt = 0; rt < LS_ROWS / 16; ++rt) {
+                f32x4 acc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *inr = X + (16 * rt + i) * LS_SX + 8 * g;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(inr + 32 * ks), x1 = *reinterpret_cast<const f32x4 *>(inr + 32 * ks + 4);
+                    bf16x8 bh, bl;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const __bf16 h0 = (__bf16)x0[u], h1 = (__bf16)x1[u];
+                        bh[u] = h0; bh[4 + u] = h1;
+                        bl[u] = (__bf16)(x0[u] - (float)h0); bl[4 + u] = (__bf16)(x1[u] - (float)h1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[ks][j], bh, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[ks][j], bl, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[ks][j], bh, acc[j], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4 *>(G + (16 * rt + i) * LS_SG + (wave8 + 8 * j) * 16 + 4 * g) = acc[j] + bv[j];
+            }
+            __syncthreads();
+            GL_T(2);
+            // the cell (PyTorch gate order i, f, g, o), decode-step blend h = h' m + h (1 - m), post mask after the last slice
+            const bool last = t == S - 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int nl = q + 8 * k, n = n0 + nl;
+                const float *gr = G + nl * LS_SG;
+                const float gi = gr[d], gf = gr[64 + d], gg = gr[128 + d], go = gr[192 + d];
+                const float c0 = creg[k], h0 = X[nl * LS_SX + 64 + d];
+                float cn = gl_sigmoid(gf) * c0 + gl_sigmoid(gi) * gl_tanh(gg);
+                float hn = gl_sigmoid(go) * gl_tanh(cn);
+                if (a.blend_mask && n < N) { const float bm = a.blend_mask[n]; hn = hn * bm + h0 * (1.0f - bm); cn = cn * bm + c0 * (1.0f - bm); }
+                if (last && a.post_mask && n < N) { const float pm = a.post_mask[n]; hn *= pm; cn *= pm; }
+                creg[k] = cn;
+                X[nl * LS_SX + 64 + d] = hn;
+            }
+            // (the next slice's staging only writes the x half of X, which nobody reads before the barrier that follows it)
+            GL_T(3);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int nl = q + 8 * k, n = n0 + nl;
+            if (n < N) { a.c[(size_t)n * 64 + d] = creg[k]; a.h[(size_t)n * 64 + d] = X[nl * LS_SX + 64 + d]; }
+        }
+        __syncthreads(); // the next tile refills X
+        GL_T(4);
+    }
 }
 
 // hidden2pos + raw2gaussian + the running sums of crowd_nav_interface_parallel.py:99-113 for decode step tt.
@@ -504,9 +518,10 @@ struct cn_gst {
     char *blob;
     float *emb_w, *emb_b, *in_w, *in_b, *out_w, *out_b, *n_w, *n_b, *n1_w, *n1_b, *l1_w, *l1_b, *l2_w, *l2_b;
     float *wih, *whh, *bih, *bhh, *h2p_w, *h2p_b;
-    float *f_in, *f_out, *f_l1, *f_l2, *f_wih; // bf16 hi/lo MFMA-fragment images of in_proj / out_proj / linear1 / linear2 / W_ih (gst_layer_kernel)
+    float *w_cat, *f_lstm; // [256,128] = [W_ih | W_hh] and its fragment image (gst_lstm_kernel)
+    float *f_in, *f_out, *f_l1, *f_l2; // bf16 hi/lo MFMA-fragment images of in_proj / out_proj / linear1 / linear2 (gst_layer_kernel)
     // workspace (rows = maxE * 5 * H)
-    float *m_rel, *lm_fp, *rel, *last_pos, *x0, *qkv, *att, *x1, *x2, *ff, *xs, *gx, *gh, *h, *c, *acc, *x_sample;
+    float *m_rel, *lm_fp, *rel, *last_pos, *xs, *h, *c, *acc, *x_sample;
     float *out_traj, *out_mask; // internal buffers for the wrapper path
     // VecPretextNormalize history
     float *ring_traj;  // [5][maxE][H][2]
@@ -526,11 +541,11 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     auto carve = [&](size_t nfloat) { size_t o = off; off += g_align(nfloat * sizeof(float)); return o; };
     const size_t o_w[] = {carve(128), carve(64), carve(192 * 64), carve(192), carve(64 * 64), carve(64), carve(64), carve(64), carve(64), carve(64),
                           carve(128 * 64), carve(128), carve(64 * 128), carve(64), carve(256 * 64), carve(256 * 64), carve(256), carve(256), carve(320), carve(5)};
-    const size_t o_mrel = carve(R), o_lm = carve(N), o_rel = carve(2 * R), o_lp = carve(2 * N), o_x0 = carve(R * 64), o_qkv = carve(R * 192), o_att = carve(R * 64);
-    const size_t o_x1 = carve(R * 64), o_x2 = carve(R * 64), o_ff = carve(R * 128), o_xs = carve(R * 64), o_gx = carve(R * 256), o_gh = carve(N * 256);
+    const size_t o_mrel = carve(R), o_lm = carve(N), o_rel = carve(2 * R), o_lp = carve(2 * N), o_xs = carve(R * 64);
     const size_t o_h = carve(N * 64), o_c = carve(N * 64), o_acc = carve(N * 5), o_xsamp = carve(N * 2), o_ot = carve(N * GP * 5), o_om = carve(N);
     const size_t o_rt = carve((size_t)GT * N * 2), o_rm = carve(((size_t)GT * N + 3) / 4);
-    const size_t o_fin = carve(192 * 64), o_fout = carve(64 * 64), o_fl1 = carve(128 * 64), o_fl2 = carve(64 * 128), o_fwih = carve(256 * 64);
+    const size_t o_wcat = carve(256 * 128), o_flstm = carve(256 * 128);
+    const size_t o_fin = carve(192 * 64), o_fout = carve(64 * 64), o_fl1 = carve(128 * 64), o_fl2 = carve(64 * 128);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
     if (herr != hipSuccess) { delete g; cn_set_error("cn_gst_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(herr)); return CN_ERR_HIP; }
@@ -539,10 +554,10 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     float **wp[] = {&g->emb_w, &g->emb_b, &g->in_w, &g->in_b, &g->out_w, &g->out_b, &g->n_w, &g->n_b, &g->n1_w, &g->n1_b,
                     &g->l1_w, &g->l1_b, &g->l2_w, &g->l2_b, &g->wih, &g->whh, &g->bih, &g->bhh, &g->h2p_w, &g->h2p_b};
     for (int i = 0; i < 20; ++i) *wp[i] = F(o_w[i]);
-    g->m_rel = F(o_mrel); g->lm_fp = F(o_lm); g->rel = F(o_rel); g->last_pos = F(o_lp); g->x0 = F(o_x0); g->qkv = F(o_qkv); g->att = F(o_att);
-    g->x1 = F(o_x1); g->x2 = F(o_x2); g->ff = F(o_ff); g->xs = F(o_xs); g->gx = F(o_gx); g->gh = F(o_gh); g->h = F(o_h); g->c = F(o_c);
+    g->m_rel = F(o_mrel); g->lm_fp = F(o_lm); g->rel = F(o_rel); g->last_pos = F(o_lp); g->xs = F(o_xs); g->h = F(o_h); g->c = F(o_c);
     g->acc = F(o_acc); g->x_sample = F(o_xsamp); g->out_traj = F(o_ot); g->out_mask = F(o_om);
-    g->f_in = F(o_fin); g->f_out = F(o_fout); g->f_l1 = F(o_fl1); g->f_l2 = F(o_fl2); g->f_wih = F(o_fwih);
+    g->w_cat = F(o_wcat); g->f_lstm = F(o_flstm);
+    g->f_in = F(o_fin); g->f_out = F(o_fout); g->f_l1 = F(o_fl1); g->f_l2 = F(o_fl2);
     g->ring_traj = F(o_rt); g->ring_mask = (uint8_t *)(base + o_rm);
     g->ring_E = 0; g->ring_pos = 0; g->weights_set = false;
     *out = g;
@@ -571,8 +586,10 @@ extern "C" int cn_gst_set_weights(cn_gst *g, const cn_gst_weights *w, void *stre
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = rn_fused_bake(192, 64, g->in_w, g->f_in, st)) || (rc = rn_fused_bake(64, 64, g->out_w, g->f_out, st)) ||
-        (rc = rn_fused_bake(128, 64, g->l1_w, g->f_l1, st)) || (rc = rn_fused_bake(64, 128, g->l2_w, g->f_l2, st)) ||
-        (rc = rn_fused_bake(256, 64, g->wih, g->f_wih, st))) return rc;
+        (rc = rn_fused_bake(128, 64, g->l1_w, g->f_l1, st)) || (rc = rn_fused_bake(64, 128, g->l2_w, g->f_l2, st))) return rc;
+    CN_HIP(hipMemcpy2DAsync(g->w_cat, 128 * sizeof(float), g->wih, 64 * sizeof(float), 64 * sizeof(float), 256, hipMemcpyDeviceToDevice, st));
+    CN_HIP(hipMemcpy2DAsync(g->w_cat + 64, 128 * sizeof(float), g->whh, 64 * sizeof(float), 64 * sizeof(float), 256, hipMemcpyDeviceToDevice, st));
+    if ((rc = rn_fused_bake(256, 128, g->w_cat, g->f_lstm, st))) return rc;
     g->weights_set = true;
     return CN_OK;
 }
@@ -585,7 +602,7 @@ extern "C" int cn_gst_set_timing(long long *buf)
 }
 #endif
 
-// NodeEncoderLayer + W_ih over `rows` rows in groups of H nodes: x2 [rows,2], mask [rows] -> g->gx [rows,256] (one launch)
+// NodeEncoderLayer over `rows` rows in groups of H nodes: x2 [rows,2], mask [rows] -> g->xs [rows,64] (one launch)
 static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hipStream_t st)
 {
     const int H = g->H;
@@ -599,32 +616,26 @@ static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hi
         attr_dev = dev;
     }
     const int n_tiles = (rows + TG * H - 1) / (TG * H);
-    GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b, g->f_wih, g->gx};
+    GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b, g->xs};
     hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
 
-// one NodeEncoderLayer over `rows` rows grouped in `groups` groups of H nodes; x2 [rows,2], mask [rows] -> g->xs [rows,64]
-static int gst_transformer(cn_gst *g, int rows, int groups, const float *x2, const float *mask, hipStream_t st)
+// the LSTM over S slices of the encoded rows g->xs (S = 5: the observation period from h = c = 0 set by the caller; S = 1: one decode step)
+static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *blend_mask, const float *post_mask, hipStream_t st)
 {
-    const int H = g->H;
-    int rc;
-    hipLaunchKernelGGL(gst_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->x0);
-    CN_CHECK_LAUNCH();
-    const GemmBatch nb{0, 0, 0, 0, nullptr, 0};
-    if ((rc = launch_gemm_t<128, 64, ACT_NONE>(rows, 192, 64, g->x0, 64, g->in_w, g->in_b, g->qkv, 192, st, nullptr, 1, nb, 1 << 30))) return rc;
-    {
-        const size_t per_wave = (size_t)(2 * H * 65 + 64) * sizeof(float);
-        int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-        hipLaunchKernelGGL(gst_attention_kernel, dim3((groups + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, st, groups, H, g->qkv, mask, g->att);
-        CN_CHECK_LAUNCH();
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    CN_HIP(hipGetDevice(&dev));
+    if (dev != attr_dev) {
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gst_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_LDS_FLOATS * sizeof(float))));
+        attr_dev = dev;
     }
-    if ((rc = launch_gemm_t<128, 64, ACT_NONE>(rows, 64, 64, g->att, 64, g->out_w, g->out_b, g->x1, 64, st, nullptr, 1, GemmBatch{0, 0, 0, 0, g->x0, 64}, 1 << 30))) return rc;
-    hipLaunchKernelGGL(gst_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, g->x1, g->n1_w, g->n1_b, g->x2);
+    const int n_tiles = (E * g->H + LS_ROWS - 1) / LS_ROWS;
+    GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask};
+    hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
     CN_CHECK_LAUNCH();
-    if ((rc = launch_gemm_t<128, 64, ACT_RELU>(rows, 128, 64, g->x2, 64, g->l1_w, g->l1_b, g->ff, 128, st, nullptr, 1, nb, 1 << 30))) return rc;
-    if ((rc = launch_gemm_t<128, 64, ACT_NONE>(rows, 64, 128, g->ff, 128, g->l2_w, g->l2_b, g->xs, 64, st, nullptr, 1, GemmBatch{0, 0, 0, 0, g->x1, 64}, 1 << 30))) return rc;
     return CN_OK;
 }
 
@@ -634,7 +645,6 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
     if (!g->weights_set) { cn_set_error("cn_gst: call cn_gst_set_weights first"); return CN_ERR_STATE; }
     const int H = g->H, N = E * H, R = N * GT;
     int rc;
-    const GemmBatch nb{0, 0, 0, 0, nullptr, 0};
     hipLaunchKernelGGL(gst_obs_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, st, E, H, traj, se, sh, stt, mask_u8, mask_f, me, mh, mt, rot,
                        g->m_rel, g->lm_fp, g->rel, g->last_pos);
     CN_CHECK_LAUNCH();
@@ -642,20 +652,12 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
     if ((rc = gst_layer(g, R, g->rel, g->m_rel, st))) return rc;
     CN_HIP(hipMemsetAsync(g->h, 0, (size_t)N * 64 * sizeof(float), st));
     CN_HIP(hipMemsetAsync(g->c, 0, (size_t)N * 64 * sizeof(float), st));
-    for (int t = 0; t < GT; ++t) {
-        if ((rc = launch_gemm_t<64, 64, ACT_NONE>(N, 256, 64, g->h, 64, g->whh, nullptr, g->gh, 256, st, nullptr, 1, nb, 1 << 30))) return rc;
-        hipLaunchKernelGGL(gst_lstm_pointwise_kernel, dim3(N), dim3(64), 0, st, E, H, GT, t, g->gx, g->m_rel, g->gh, g->bih, g->bhh, g->h, g->c,
-                           (const float *)nullptr, t == GT - 1 ? g->lm_fp : (const float *)nullptr);
-        CN_CHECK_LAUNCH();
-    }
+    if ((rc = gst_lstm(g, E, GT, g->m_rel, nullptr, g->lm_fp, st))) return rc;
     // prediction period (recursive decoding on the mean)
     for (int tt = 0; tt < GP; ++tt) {
         if (tt > 0) {
             if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st))) return rc;
-            if ((rc = launch_gemm_t<64, 64, ACT_NONE>(N, 256, 64, g->h, 64, g->whh, nullptr, g->gh, 256, st, nullptr, 1, nb, 1 << 30))) return rc;
-            hipLaunchKernelGGL(gst_lstm_pointwise_kernel, dim3(N), dim3(64), 0, st, E, H, 1, 0, g->gx, g->lm_fp, g->gh, g->bih, g->bhh, g->h, g->c,
-                               g->lm_fp, (const float *)nullptr);
-            CN_CHECK_LAUNCH();
+            if ((rc = gst_lstm(g, E, 1, g->lm_fp, g->lm_fp, nullptr, st))) return rc;
         }
         hipLaunchKernelGGL(gst_head_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, tt, g->h, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos, g->acc, out_traj,
                            g->x_sample);
