@@ -92,6 +92,36 @@ def test_hip_gst_predict_matches_reference_golden_and_torch_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,E", [(1, 70), (5, 301), (12, 130), (16, 97), (33, 41), (50, 23), (64, 17)])
+def test_hip_gst_kernels_match_torch_expression_for_other_crowd_sizes(H, E):
+    """The fused encoder-layer / LSTM kernels tile whole groups of H nodes (<= 80 rows per tile, ragged last tiles, padding rows):
+    every group size class against the torch expression of the same model, seeded random weights."""
+    from crowdnav_prediction_attngraph_amd.gst import GSTPredictor
+    from crowdnav_prediction_attngraph_amd.hip import HipGST
+    torch.manual_seed(100 + H)
+    m = GSTPredictor().cuda()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)
+    g = HipGST(H, E)
+    g.set_weights(m.state_dict())
+    rs = np.random.RandomState(H)
+    pos0 = rs.uniform(-6, 6, (E, H, 1, 2)); vel = rs.uniform(-0.3, 0.3, (E, H, 1, 2))
+    traj = (pos0 + vel * np.arange(5).reshape(1, 1, 5, 1) + 0.02 * rs.standard_normal((E, H, 5, 2))).astype(np.float32)
+    mask = (rs.uniform(size=(E, H, 5, 1)) > 0.3)
+    mask[0] = True
+    mask[-1] = False
+    traj = np.where(mask, traj, -999.0).astype(np.float32)
+    t_d, m_d = torch.from_numpy(traj).cuda(), torch.from_numpy(mask.astype(np.float32)).cuda()
+    ref_out, ref_mask = m(t_d, m_d)
+    out, om = g.predict(t_d, m_d)
+    assert torch.equal(om, ref_mask)
+    v = ref_mask[..., 0] > 0
+    assert int(v.sum()) > 0 and torch.allclose(out[v], ref_out[v], rtol=1e-4, atol=1e-4)
+    assert bool((out[~v][..., :2] == -999.0).all())
+
+
+@pytest.mark.gpu
 def test_predrealgst_env_with_wrapper_steps_on_device():
     from crowdnav_prediction_attngraph_amd import config as C
     from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
