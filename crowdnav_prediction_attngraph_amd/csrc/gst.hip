@@ -306,6 +306,11 @@ struct GstLstmArgs {
     const float *f_w, *bih, *bhh;   // baked [256,128] = [W_ih | W_hh]; biases
     float *h, *c;                   // [E*H, 64] state, updated in place
     const float *blend_mask, *post_mask; // [E*H] or null
+    // decode head of the step that follows this LSTM pass (hidden2pos + raw2gaussian + the running sums of
+    // crowd_nav_interface_parallel.py:99-113), tt = decode step index; head_w == null: no head
+    int tt;
+    const float *head_w, *head_b, *lm_fp, *last_pos;
+    float *acc, *out_traj, *x_sample;
 };
 
 // tanh / sigmoid on v_exp_f32 (|err| < 3e-7; e^{2x} overflowing to inf gives 1, underflowing to 0 gives -1)
@@ -416,37 +421,37 @@ __global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, G
             const int nl = q + 8 * k, n = n0 + nl;
             if (n < N) { a.c[(size_t)n * 64 + d] = creg[k]; a.h[(size_t)n * 64 + d] = X[nl * LS_SX + 64 + d]; }
         }
+        if (a.head_w) {
+            // the head on the hidden state this thread's wavefront just wrote (node rows q, q + 8, ...: lane = hidden unit)
+            const float w0 = a.head_w[d], w1 = a.head_w[64 + d], w2 = a.head_w[128 + d], w3 = a.head_w[192 + d], w4 = a.head_w[256 + d];
+            float raw[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // lane k keeps node row q + 8 k, so the eight scalar tails below run side by side
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float hv = X[(q + 8 * k) * LS_SX + 64 + d];
+                const float s0 = wv_sum(hv * w0), s1 = wv_sum(hv * w1), s2 = wv_sum(hv * w2), s3 = wv_sum(hv * w3), s4 = wv_sum(hv * w4);
+                if (d == k) { raw[0] = s0; raw[1] = s1; raw[2] = s2; raw[3] = s3; raw[4] = s4; }
+            }
+            const int n = n0 + q + 8 * d;
+            if (d < 8 && n < N) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) raw[k] += a.head_b[k];
+                const int tt = a.tt;
+                const float lm = a.lm_fp[n];
+                const float sx = expf(raw[2]), sy = expf(raw[3]), corr = tanhf(raw[4]);
+                float *ac = a.acc + (size_t)n * 5;
+                const float a0 = (tt ? ac[0] : 0.f) + raw[0], a1 = (tt ? ac[1] : 0.f) + raw[1];
+                const float a2 = (tt ? ac[2] : 0.f) + sx * sx, a3 = (tt ? ac[3] : 0.f) + sy * sy, a4 = (tt ? ac[4] : 0.f) + corr * sx * sy;
+                ac[0] = a0; ac[1] = a1; ac[2] = a2; ac[3] = a3; ac[4] = a4;
+                const float sxc = sqrtf(a2), syc = sqrtf(a3);
+                float *o = a.out_traj + ((size_t)n * GP + tt) * 5;
+                o[0] = (a0 + a.last_pos[2 * n]) * lm + GST_INVALID * (1.0f - lm);
+                o[1] = (a1 + a.last_pos[2 * n + 1]) * lm + GST_INVALID * (1.0f - lm);
+                o[2] = sxc; o[3] = syc; o[4] = a4 / (sxc * syc);
+                a.x_sample[2 * n] = raw[0] * lm; a.x_sample[2 * n + 1] = raw[1] * lm; // sampling = False: the mean, masked for the next step
+            }
+        }
         __syncthreads(); // the next tile refills X
         GL_T(4);
-    }
-}
-
-// hidden2pos + raw2gaussian + the running sums of crowd_nav_interface_parallel.py:99-113 for decode step tt.
-// acc[n][5] = running (mu_x, mu_y, sx^2, sy^2, corr*sx*sy).  One wavefront per pedestrian, lane = hidden unit.
-__global__ __launch_bounds__(256) void gst_head_kernel(int N, int tt, const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ b,
-                                                       const float *__restrict__ lm_fp, const float *__restrict__ last_pos, float *__restrict__ acc,
-                                                       float *__restrict__ out_traj, float *__restrict__ x_sample)
-{
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const float hv = h[(size_t)n * 64 + lane];
-    float raw[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) raw[k] = wv_sum(hv * W[k * 64 + lane]) + b[k];
-    if (lane == 0) {
-        const float lm = lm_fp[n];
-        const float sx = expf(raw[2]), sy = expf(raw[3]), corr = tanhf(raw[4]);
-        float *a = acc + (size_t)n * 5;
-        const float a0 = (tt ? a[0] : 0.f) + raw[0], a1 = (tt ? a[1] : 0.f) + raw[1];
-        const float a2 = (tt ? a[2] : 0.f) + sx * sx, a3 = (tt ? a[3] : 0.f) + sy * sy, a4 = (tt ? a[4] : 0.f) + corr * sx * sy;
-        a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3; a[4] = a4;
-        const float sxc = sqrtf(a2), syc = sqrtf(a3);
-        float *o = out_traj + ((size_t)n * GP + tt) * 5;
-        o[0] = (a0 + last_pos[2 * n]) * lm + GST_INVALID * (1.0f - lm);
-        o[1] = (a1 + last_pos[2 * n + 1]) * lm + GST_INVALID * (1.0f - lm);
-        o[2] = sxc; o[3] = syc; o[4] = a4 / (sxc * syc);
-        x_sample[2 * n] = raw[0] * lm; x_sample[2 * n + 1] = raw[1] * lm; // sampling = False: the mean, masked for the next step
     }
 }
 
@@ -623,7 +628,7 @@ static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hi
 }
 
 // the LSTM over S slices of the encoded rows g->xs (S = 5: the observation period from h = c = 0 set by the caller; S = 1: one decode step)
-static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *blend_mask, const float *post_mask, hipStream_t st)
+static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *blend_mask, const float *post_mask, int tt, float *out_traj, hipStream_t st)
 {
     static thread_local int attr_dev = -1;
     int dev = 0;
@@ -633,7 +638,8 @@ static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *
         attr_dev = dev;
     }
     const int n_tiles = (E * g->H + LS_ROWS - 1) / LS_ROWS;
-    GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask};
+    GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
+                  g->acc, out_traj, g->x_sample};
     hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -652,16 +658,11 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
     if ((rc = gst_layer(g, R, g->rel, g->m_rel, st))) return rc;
     CN_HIP(hipMemsetAsync(g->h, 0, (size_t)N * 64 * sizeof(float), st));
     CN_HIP(hipMemsetAsync(g->c, 0, (size_t)N * 64 * sizeof(float), st));
-    if ((rc = gst_lstm(g, E, GT, g->m_rel, nullptr, g->lm_fp, st))) return rc;
+    if ((rc = gst_lstm(g, E, GT, g->m_rel, nullptr, g->lm_fp, 0, out_traj, st))) return rc; // + the head of decode step 0
     // prediction period (recursive decoding on the mean)
-    for (int tt = 0; tt < GP; ++tt) {
-        if (tt > 0) {
-            if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st))) return rc;
-            if ((rc = gst_lstm(g, E, 1, g->lm_fp, g->lm_fp, nullptr, st))) return rc;
-        }
-        hipLaunchKernelGGL(gst_head_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, tt, g->h, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos, g->acc, out_traj,
-                           g->x_sample);
-        CN_CHECK_LAUNCH();
+    for (int tt = 1; tt < GP; ++tt) {
+        if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st))) return rc;
+        if ((rc = gst_lstm(g, E, 1, g->lm_fp, g->lm_fp, nullptr, tt, out_traj, st))) return rc; // + the head of decode step tt
     }
     if (out_mask != g->lm_fp) CN_HIP(hipMemcpyAsync(out_mask, g->lm_fp, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st));
     return CN_OK;
