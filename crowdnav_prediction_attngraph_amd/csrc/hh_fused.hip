@@ -510,7 +510,13 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 f32x4 v = acc_os[j][rb] + b;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
+                // streamed past this XCD's L2: the reader (rn_fused) runs on other XCDs anyway, and the 24 MB of rows would push
+                // the 3.9 MB weight image, which every tile of every WG on the XCD re-reads, out of the 4 MB L2
+#ifndef HH_NO_NT_STORE
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out_sp + (size_t)(t.r0 + row) * 256 + f0));
+#else
                 *reinterpret_cast<f32x4 *>(out_sp + (size_t)(t.r0 + row) * 256 + f0) = v;
+#endif
             }
         }
     }
