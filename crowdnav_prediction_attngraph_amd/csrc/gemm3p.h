@@ -1,0 +1,228 @@
+// gemm3p.h -- the split-precision ("bf16x3") NT GEMM of gemm3.h for the PPO update's row counts (M = 3e5 .. 5e5 live rows).
+//
+// Why a second kernel.  Knock-out runs of the 128 x 128 / two-barrier kernel on the q|k|v shape (M = 400 k, N = 1536, K = 512;
+// 2.83 ms) showed its four components adding up instead of overlapping: MFMA 0.95 ms + LDS / convert / barrier skeleton 0.81
+// + global loads 0.65 + C stores 0.45.  Neither more workgroups per CU, larger tiles nor a double-buffered K loop changed the
+// sum (all within 7 %): every wavefront of a workgroup is in the same phase at the same time and a wavefront that is issuing
+// MFMAs issues nothing else; and the stores sat one per basic block behind an s_waitcnt vmcnt(0) (see the epilogue).
+// This kernel puts the phases into ONE instruction stream per wavefront and takes each operand over the path that suits it:
+//   * workgroup tile 128 x (128 NB), four wavefronts side by side: each owns all 128 rows (MI = 4) and 32 NB columns,
+//   * A (fp32 activations): coalesced 128-byte row segments -> registers -> hi/lo -> LDS (20 KB per K tile of 32, two buffers),
+//     read back as fragments by all four wavefronts; W (bf16 hi/lo, L2 resident): stored by cn_split_bf16 in MFMA FRAGMENT
+//     ORDER, so a wavefront's fragment is one contiguous 1 KB load straight into registers -- no LDS, no redundancy,
+//   * ONE barrier per K tile; phase A: MFMAs of k-step 0 run over { A fragment reads of k-step 1, conversion + LDS stores of the
+//     next A tile, global loads of the tile after it }; phase B: MFMAs of k-step 1 over { A fragment reads of the next tile's
+//     k-step 0, W fragment loads two tiles ahead }; groups of three MFMAs fenced with sched_barrier keep the side work spread.
+// LDS traffic per K tile: 16 KB written + 64 KB read for 48 MFMAs (1536 cycles) per wavefront = 40 % of the LDS peak.
+#pragma once
+#include "gemm3.h"
+
+namespace {
+
+// W in fragment order: element (cb, kk, lane, e) = W'[cb * 32 + (lane & 31)][kk * 16 + (lane >> 5) * 8 + e], W' = w or w^T
+__global__ void split_bf16_frag_kernel(int Nw, int Kw, int transpose, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Nw * Kw) return;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const size_t blk = idx >> 9;
+    const int kk = (int)(blk % (Kw / 16)), cb = (int)(blk / (Kw / 16));
+    const int n = cb * 32 + (lane & 31), k = kk * 16 + (lane >> 5) * 8 + e;
+    const float x = transpose ? w[(size_t)k * Nw + n] : w[(size_t)n * Kw + k];
+    const __bf16 h = (__bf16)x;
+    hi[idx] = h;
+    lo[idx] = (__bf16)(x - (float)h);
+}
+
+// KO (experiments only): bit 0 = no C stores, bit 2 = no MFMA, bit 3 = no global loads in the loop
+template <int NB, int ACT, bool GATE, int KO = 0>
+__global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ Agate,
+                                                           const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
+                                                           const float *__restrict__ bias, float *__restrict__ C, int ldc)
+{
+    constexpr int TBM = 128, MI = 4, BN = 128 * NB;
+    constexpr int PK = 32, PS = 40;     // K tile (two k-steps), LDS row stride in bf16 (80 B: conflict-free 16-byte fragment reads)
+    constexpr int BUF = 2 * TBM * PS;   // bf16 elements per LDS buffer: A hi and lo planes of one K tile (20 480 B)
+    int row_tile, col_tile;
+    if ((size_t)N * K > (size_t)512 * 1024 && !(gridDim.x & 1)) xcd_tile_split(row_tile, col_tile);
+    else xcd_tile(row_tile, col_tile);
+    if (row_tile * TBM >= M) return;
+    extern __shared__ __attribute__((aligned(16))) char smem3p[];
+    __bf16 *lds = reinterpret_cast<__bf16 *>(smem3p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m_blk = row_tile * TBM, n_blk = col_tile * BN + wave * 32 * NB;
+    const int T = K / PK, KK = K / 16;
+#ifdef G3P_ROTATE
+    const int rot = (row_tile * 5) % T; // workgroups of an XCD walk K from different tiles: they stream the same W rows
+#else
+    const int rot = 0;
+#endif
+    auto phys = [&](int tile) { const int x = tile + rot; return x >= T ? x - T : x; };
+
+    f32x16 acc[MI][NB];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // A staging: 8 lanes cover one 128-byte row segment, 32 rows per pass, 4 passes
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const float *ap[4], *gp[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const size_t o = (size_t)min(m_blk + arow + 32 * p, M - 1) * lda + acol; // surplus rows repeat row M-1: computed, never stored
+        ap[p] = A + o;
+        gp[p] = GATE ? Agate + o : nullptr;
+    }
+    // W fragment sets / staged A tiles in flight (prefetch depth in K tiles).  4 / 2 measured the same as 2 / 1 (2.16 ms on the
+    // q|k|v shape either way): the loop is not waiting for latency, so the smaller register footprint stays
+    constexpr int WD = 2, AD = 1;
+    f32x4 sa[AD][4], sg[GATE ? AD : 1][4];
+    bf16x8 fah[2][MI], fal[2][MI];   // [k-step][block] hi / lo fragments of A
+    bf16x8 fwh[WD][2][NB], fwl[WD][2][NB]; // [tile % WD][k-step][block] hi / lo fragments of W
+    auto load_a = [&](int set, int p, int tile) {
+        if (KO & 8) return;
+        sa[set][p] = *reinterpret_cast<const f32x4 *>(ap[p] + phys(tile) * PK);
+        if (GATE) sg[GATE ? set : 0][p] = *reinterpret_cast<const f32x4 *>(gp[p] + phys(tile) * PK); // the select happens at the conversion
+    };
+    auto stage_a = [&](int set, int p, int b) { // convert pass p of a staged tile into buffer b
+        __bf16 *Ah = lds + b * BUF, *Al = Ah + TBM * PS;
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = GATE ? (sg[GATE ? set : 0][p][q] > 0.0f ? sa[set][p][q] : 0.0f) : sa[set][p][q];
+            hi[q] = (__bf16)a;
+            lo[q] = (__bf16)(a - (float)hi[q]);
+        }
+        *reinterpret_cast<bf16x4 *>(&Ah[(arow + 32 * p) * PS + acol]) = hi;
+        *reinterpret_cast<bf16x4 *>(&Al[(arow + 32 * p) * PS + acol]) = lo;
+    };
+    const int a_off = l31 * PS + half * 8;
+    auto read_a = [&](int ks, int s, int b) { // one of the 8 A fragment reads of a k-step
+        const __bf16 *Ah = lds + b * BUF + ks * 16 + a_off, *Al = Ah + TBM * PS;
+        if (s < 4) fah[ks][s] = *reinterpret_cast<const bf16x8 *>(&Ah[s * 32 * PS]);
+        else fal[ks][s - 4] = *reinterpret_cast<const bf16x8 *>(&Al[(s - 4) * 32 * PS]);
+    };
+    const size_t w_base = ((size_t)(n_blk >> 5) * KK * 64 + lane) * 8; // fragment (cb, kk) starts at ((cb * KK + kk) * 64 + lane) * 8
+    auto load_w = [&](int par, int ks, int j, int tile) {
+        if (KO & 8) return;
+        const size_t o = w_base + ((size_t)j * KK + phys(tile) * 2 + ks) * 512;
+        fwh[par][ks][j] = *reinterpret_cast<const bf16x8 *>(Whi + o);
+        fwl[par][ks][j] = *reinterpret_cast<const bf16x8 *>(Wlo + o);
+    };
+    // one MFMA of a k-step: term-major order (lo*hi, hi*lo, hi*hi; consecutive MFMAs hit different accumulators)
+    auto mfma_one = [&](int par, int ks, int s) {
+        const int t = s / (MI * NB), i = (s % (MI * NB)) / NB, j = s % NB;
+        if (KO & 4) { acc[i][j][0] += (float)fal[ks][i][t] * (float)fwh[par][ks][j][0] + (float)fah[ks][i][1] * (float)fwl[par][ks][j][t]; return; }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? fal[ks][i] : fah[ks][i], t == 1 ? fwl[par][ks][j] : fwh[par][ks][j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int G = MI * NB, RPG = 8 / G, SPG = G / 4; // groups of three MFMAs per k-step; A fragment reads per group; groups per staging pass
+
+    // prologue: A tile 0 in LDS buffer 0, tiles 1 .. AD staged in registers; W fragments of tiles 0 .. WD-1 requested
+#pragma unroll
+    for (int p = 0; p < 4; ++p) load_a(0, p, 0);
+#pragma unroll
+    for (int u = 0; u < WD; ++u)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { load_w(u, 0, j, min(u, T - 1)); load_w(u, 1, j, min(u, T - 1)); }
+    if (AD > 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) load_a(1 % AD, p, min(1, T - 1));
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { stage_a(0, p, 0); load_a(0, p, min(AD, T - 1)); }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) read_a(0, s, 0);
+    // T % WD == 0 (K % 64 == 0): WD tiles per trip so that register sets are compile-time indices
+    for (int t = 0; t < T; t += WD) {
+#pragma unroll
+        for (int u = 0; u < WD; ++u) {
+            const int cur = u & 1;      // tile t + u lives in LDS buffer (t + u) & 1
+            const int nset = (u + 1) % AD; // the staged copy of tile t + u + 1
+            // Branch-free body (the last tiles stage / read / load once more than needed: the last K tile again, into the
+            // buffer nobody reads again).  Fenced groups of three MFMAs keep the side work spread out under them.
+            const int ta = min(t + u + 1 + AD, T - 1), tw = min(t + u + WD, T - 1);
+            // ---- phase A: k-step 0 | A fragments of k-step 1; the staged A tile (t+u+1) converted into the other buffer and the
+            //      tile AD further on requested ----
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                mfma_one(u, 0, 3 * g);
+#pragma unroll
+                for (int r = 0; r < RPG; ++r) read_a(1, g * RPG + r, cur);
+                mfma_one(u, 0, 3 * g + 1);
+                if (g % SPG == 0) { stage_a(nset, g / SPG, cur ^ 1); load_a(nset, g / SPG, ta); }
+                mfma_one(u, 0, 3 * g + 2);
+                // the k-step-1 W registers of the PREVIOUS tile's set are free since its phase B: the tile WD further on goes
+                // there, one fragment per group (in the very first trip this re-requests what the prologue put there)
+                if (g >= G - NB) load_w((u + WD - 1) % WD, 1, g - (G - NB), min(t + u - 1 + WD, T - 1));
+#ifndef G3P_NO_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            __syncthreads(); // A tile t+u+1 is complete, the buffer of tile t+u is free
+            // ---- phase B: k-step 1 | A fragments (k-step 0) of tile t+u+1 ----
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                mfma_one(u, 1, 3 * g);
+#pragma unroll
+                for (int r = 0; r < RPG; ++r) read_a(0, g * RPG + r, cur ^ 1);
+                mfma_one(u, 1, 3 * g + 1);
+                if (g < NB) load_w(u, 0, g, tw); // this set's k-step-0 registers are free since phase A
+                mfma_one(u, 1, 3 * g + 2);
+#ifndef G3P_NO_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+    }
+    // Epilogue.  The bias is fetched and waited for ONCE, and a workgroup whose 128 rows are all inside M stores without per-row
+    // predicates: with the predicate, every store sat in its own basic block behind an s_waitcnt vmcnt(0) (the compiler cannot
+    // tell there that the bias load has landed), i.e. every store waited for the previous one to complete.
+    float bv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = bias ? bias[n_blk + j * 32 + l31] : 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto store_all = [&](auto guard) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float *cp = C + (size_t)(m_blk + i * 32 + 4 * half) * ldc + n_blk + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bv[j];
+                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if ((KO & 1) && v != 12345.678f) continue;
+                    if (guard(m_blk + i * 32 + 4 * half + ro)) __builtin_nontemporal_store(v, cp + (size_t)ro * ldc); // streaming result: keep A / W in the L2
+                }
+            }
+    };
+    if (m_blk + TBM <= M) store_all([](int) { return true; });
+    else store_all([&](int row) { return row < M; });
+}
+
+template <int ACT, int KO = 0>
+static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
+                         hipStream_t st, const float *Agate)
+{
+    CN_REQUIRE(N % 128 == 0 && K % 64 == 0 && lda % 4 == 0, "gemm3p: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    if (M == 0) return CN_OK;
+    constexpr size_t lds = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16); // 40 960 B
+    const unsigned gy = (unsigned)((((M + 127) / 128) + 7) & ~7);
+    if (N % 256 == 0) {
+        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, true, KO>), dim3(N / 256, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        else hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, false, KO>), dim3(N / 256, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+    } else {
+        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, true, KO>), dim3(N / 128, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        else hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, false, KO>), dim3(N / 128, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+    }
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+} // namespace

@@ -4,7 +4,7 @@
 // (rl/networks/selfAttn_srnn_temp_node.py:63-91,408) executed under autograd by PPO.update (rl/ppo.py:60-95:
 // evaluate_actions -> loss.backward()).
 #include "common.h"
-#include "gemm3.h"
+#include "gemm3p.h"
 
 namespace {
 
@@ -302,10 +302,12 @@ extern "C" int cn_split_bf16(const float *w, int rows, int cols, int transpose, 
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(w && hi && lo && rows > 0 && cols > 0, "cn_split_bf16: bad argument");
     hipStream_t st = (hipStream_t)stream;
+    // W' = w (transpose = 0) or w^T: [Nw, Kw]; stored in the MFMA fragment order gemm3p_nt_kernel loads (gemm3p.h)
+    const int Nw = transpose ? cols : rows, Kw = transpose ? rows : cols;
+    CN_REQUIRE(Nw % 32 == 0 && Kw % 16 == 0, "cn_split_bf16: the weight seen by the product must be [32 a, 16 b], got [%d, %d]", Nw, Kw);
     const size_t n = (size_t)rows * cols;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    if (transpose) hipLaunchKernelGGL(split_bf16_t_kernel, dim3(blocks), dim3(256), 0, st, rows, cols, w, (__bf16 *)hi, (__bf16 *)lo);
-    else hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, st, n, w, (__bf16 *)hi, (__bf16 *)lo);
+    hipLaunchKernelGGL(split_bf16_frag_kernel, dim3(blocks), dim3(256), 0, st, Nw, Kw, transpose, w, (__bf16 *)hi, (__bf16 *)lo);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -318,8 +320,17 @@ extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const
     CN_REQUIRE(act == 0 || act == 1, "cn_linear_fwd: act must be 0 (none) or 1 (relu)");
     CN_REQUIRE(ldx >= K && ldy >= N, "cn_linear_fwd: leading dimension smaller than the row length");
     hipStream_t st = (hipStream_t)stream;
-    if (act == 1) return launch_gemm3<128, ACT_RELU>(M, N, K, X, ldx, (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Y, ldy, st, nullptr, relu_gate);
-    return launch_gemm3<128, ACT_NONE>(M, N, K, X, ldx, (const __bf16 *)Whi, (const __bf16 *)Wlo, bias, Y, ldy, st, nullptr, relu_gate);
+    const __bf16 *wh = (const __bf16 *)Whi, *wl = (const __bf16 *)Wlo;
+#ifdef CN_G3_KNOCKOUT
+    static const int ko = getenv("CN_G3KO") ? atoi(getenv("CN_G3KO")) : 0;
+    if (ko && act == 0 && !relu_gate) {
+#define KOV(k) if (ko == k) return launch_gemm3p<ACT_NONE, k>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, nullptr);
+        KOV(1) KOV(4) KOV(5) KOV(8) KOV(9) KOV(12)
+#undef KOV
+    }
+#endif
+    return act == 1 ? launch_gemm3p<ACT_RELU>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, relu_gate)
+                    : launch_gemm3p<ACT_NONE>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, relu_gate);
 }
 
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)

@@ -290,7 +290,9 @@ int cn_gru_seq_bwd(int T, int N, const float *gates, const float *hms, const flo
  * Replace torch.nn.Linear forward/backward of embedding_layer.2, the folded (q|k|v)_linear∘in_proj and the folded
  * out_proj∘spatial_linear (rl/networks/selfAttn_srnn_temp_node.py:63-91,408) as autograd runs them inside PPO.update
  * (rl/ppo.py:60-95).  All pointers are device pointers; hi/lo are bf16 planes (uint16 storage) of the weight.
- * cn_split_bf16:   w [rows,cols] fp32 -> hi, lo (bf16) of w (transpose = 0) or of w^T [cols,rows] (transpose = 1).
+ * cn_split_bf16:   w [rows,cols] fp32 -> hi, lo (bf16) of w (transpose = 0) or of w^T [cols,rows] (transpose = 1), stored in
+ *                  the fragment order cn_linear_fwd loads (opaque: only cn_linear_fwd reads these planes).  The weight as
+ *                  the product sees it must be [32 a, 16 b].
  * cn_linear_fwd:   Y[M,N] = act(X[M,K] W^T + bias), W given as hi/lo [N,K]; act 0 = none, 1 = ReLU; bias may be NULL.
  *                  With the transposed split of W [N,K] passed as a [K,N] weight it computes dX = dY W (no bias).
  *                  relu_gate (optional, same shape and leading dimension as X): X is replaced by X * [relu_gate > 0] while it
