@@ -142,24 +142,32 @@ __global__ __launch_bounds__(256, (GATE && G3_OCC > 2) ? G3_OCC - 1 : G3_OCC) vo
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+    // Epilogue.  The bias is fetched and waited for once, and a tile that lies inside M stores without per-row predicates: with
+    // the predicate every store sits in its own basic block behind an s_waitcnt vmcnt(0) (the compiler cannot tell there that
+    // the bias load has landed), i.e. every store waits for the previous one to complete (see gemm3p.h).
+    float bv[NB];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NB; ++j) bv[j] = bias ? bias[n_blk + wn * (BN / 2) + j * 32 + l31] : 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto store_all = [&](auto guard) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
-            const float b = bias ? bias[col] : 0.0f;
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m_blk + wm * (TBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M) {
-                    float v = acc[i][j][r] + b;
+            for (int j = 0; j < NB; ++j) {
+                const int col = n_blk + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m_blk + wm * (TBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bv[j];
                     if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
                     if (ACT == ACT_TANH) v = tanhf(v);
                     // streaming result (150 MB for q|k|v, far beyond any L2): non-temporal stores keep A / W resident in the L2
-                    __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
+                    if (guard(row)) __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
                 }
             }
-        }
+    };
+    if (m_blk + TBM <= M) store_all([](int) { return true; });
+    else store_all([&](int row) { return row < M; });
 }
 
 // split a fp32 weight matrix into bf16 hi / lo parts

@@ -225,4 +225,156 @@ static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __b
     return CN_OK;
 }
 
+// ---- weight gradient: P[s][n][k] = sum_{m in split s} dY[m][n] X[m][k] (see gemm3_tn_kernel in gemm3.h for the contract) ----
+// Same division of labour as gemm3p_nt_kernel: the 128 dY columns of the tile are shared by the four wavefronts and go through
+// the LDS (transposed on the way in: a thread loads 8 consecutive m of ONE column with 8 coalesced dword loads and stores them as
+// one 16-byte fragment word per plane), the X columns belong to exactly one wavefront each (32 NB of them) and go straight from
+// global memory into fragment registers: lane (l31, half) of block j loads X[m0 + 8 half + e][k0 + 32 j + l31], e = 0..7 -- eight
+// dword loads of two full 128-byte lines each.  One barrier per 32 rows of m; no LDS traffic for X at all.
+template <int NB, bool GATE>
+__global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ Ygate,
+                                                           const float *__restrict__ X, int ldx, int rows_per_split, float *__restrict__ partials,
+                                                           float *__restrict__ db_part)
+{
+    constexpr int MI = 4, PS = 40, BUF = 2 * 128 * PS;
+    extern __shared__ __attribute__((aligned(16))) char smem3p[];
+    __bf16 *lds = reinterpret_cast<__bf16 *>(smem3p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n_blk = blockIdx.x * 128, k_blk = blockIdx.y * (128 * NB) + wave * 32 * NB, split = blockIdx.z;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    const int T = (m_end - m_begin + 31) / 32;
+    const bool want_db = db_part != nullptr && blockIdx.y == 0;
+
+    f32x16 acc[MI][NB];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // dY staging: thread (column c, half-tile g0) owns m groups g0 and g0 + 2 (8 rows each) of the 32-row tile
+    const int c = tid & 127, g0 = tid >> 7;
+    const float *yp = dY + n_blk + c, *gp = GATE ? Ygate + n_blk + c : nullptr;
+    float sy[2][8], sg[GATE ? 2 : 1][8];
+    // X: raw rows of this lane's fragments, [k-step][block][e]
+    const float *xp = X + k_blk + l31;
+    float rx[2][NB][8];
+    bf16x8 fah[2][MI], fal[2][MI], fwh[2][NB], fwl[2][NB];
+    float colsum = 0.0f;
+    // rows at or past m_end read row m_end - 1 (valid memory) and are zeroed at the conversion
+    auto load_y = [&](int q, int tile) {
+        const int m0 = m_begin + tile * 32 + (g0 + 2 * q) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const size_t o = (size_t)min(m0 + e, m_end - 1) * ldy;
+            sy[q][e] = yp[o];
+            if (GATE) sg[GATE ? q : 0][e] = gp[o];
+        }
+    };
+    auto stage_y = [&](int q, int tile, int b) {
+        const int m0 = m_begin + tile * 32 + (g0 + 2 * q) * 8;
+        __bf16 *Ah = lds + b * BUF, *Al = Ah + 128 * PS;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = sy[q][e];
+            if (GATE) a = sg[GATE ? q : 0][e] > 0.0f ? a : 0.0f;
+            a = m0 + e < m_end ? a : 0.0f;
+            colsum += a;
+            const __bf16 h = (__bf16)a;
+            hi[e] = h;
+            lo[e] = (__bf16)(a - (float)h);
+        }
+        *reinterpret_cast<bf16x8 *>(&Ah[c * PS + (g0 + 2 * q) * 8]) = hi;
+        *reinterpret_cast<bf16x8 *>(&Al[c * PS + (g0 + 2 * q) * 8]) = lo;
+    };
+    auto load_x = [&](int ks, int j, int tile) {
+        const int m0 = m_begin + tile * 32 + ks * 16 + half * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rx[ks][j][e] = xp[(size_t)min(m0 + e, m_end - 1) * ldx + 32 * j];
+    };
+    auto convert_x = [&](int ks, int j, int tile) {
+        const int m0 = m_begin + tile * 32 + ks * 16 + half * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = m0 + e < m_end ? rx[ks][j][e] : 0.0f;
+            const __bf16 h = (__bf16)a;
+            fwh[ks][j][e] = h;
+            fwl[ks][j][e] = (__bf16)(a - (float)h);
+        }
+    };
+    const int a_off = l31 * PS + half * 8;
+    auto read_a = [&](int ks, int s, int b) {
+        const __bf16 *Ah = lds + b * BUF + ks * 16 + a_off, *Al = Ah + 128 * PS;
+        if (s < 4) fah[ks][s] = *reinterpret_cast<const bf16x8 *>(&Ah[s * 32 * PS]);
+        else fal[ks][s - 4] = *reinterpret_cast<const bf16x8 *>(&Al[(s - 4) * 32 * PS]);
+    };
+    auto mfma_one = [&](int ks, int s) {
+        const int t = s / (MI * NB), i = (s % (MI * NB)) / NB, j = s % NB;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? fal[ks][i] : fah[ks][i], t == 1 ? fwl[ks][j] : fwh[ks][j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int G = MI * NB, RPG = 8 / G; // groups of three MFMAs per k-step; dY fragment reads per group
+
+    // prologue: dY tile 0 in LDS buffer 0, tile 1 staged; X tile 0 converted (k-step 0) / raw (k-step 1), tile 1 k-step 0 requested
+    load_y(0, 0); load_y(1, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { load_x(0, j, 0); load_x(1, j, 0); }
+    stage_y(0, 0, 0); stage_y(1, 0, 0);
+    load_y(0, 1); load_y(1, 1);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { convert_x(0, j, 0); load_x(0, j, 1); }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) read_a(0, s, 0);
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        // Branch-free body; tiles past the end of the split read its last row and contribute zeros.
+        // ---- phase A: k-step 0 | dY fragments of k-step 1; dY tile t+1 into the other buffer, tile t+2 requested; X k-step 1 of
+        //      tile t converted, of tile t+1 requested ----
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            mfma_one(0, 3 * g);
+#pragma unroll
+            for (int r = 0; r < RPG; ++r) read_a(1, g * RPG + r, cur);
+            mfma_one(0, 3 * g + 1);
+            if (g == 0 || g == G / 2) { const int q = g ? 1 : 0; stage_y(q, t + 1, cur ^ 1); load_y(q, t + 2); }
+            if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(1, j, t); load_x(1, j, t + 1); }
+            mfma_one(0, 3 * g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads(); // dY tile t+1 is complete, the buffer of tile t is free
+        // ---- phase B: k-step 1 | dY fragments (k-step 0) of tile t+1; X k-step 0 of tile t+1 converted, of tile t+2 requested ----
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            mfma_one(1, 3 * g);
+#pragma unroll
+            for (int r = 0; r < RPG; ++r) read_a(0, g * RPG + r, cur ^ 1);
+            mfma_one(1, 3 * g + 1);
+            if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(0, j, t + 1); load_x(0, j, t + 2); }
+            mfma_one(1, 3 * g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+    }
+    float *P = partials + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            float *pp = P + (size_t)(n_blk + i * 32 + 4 * half) * K + k_blk + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pp[(size_t)((r & 3) + 8 * (r >> 2)) * K] = acc[i][j][r];
+        }
+    if (want_db) { // uniform per block
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem3p);
+        red[tid] = colsum;
+        __syncthreads();
+        if (tid < 128) db_part[(size_t)split * N + n_blk + tid] = red[tid] + red[tid + 128];
+    }
+}
+
 } // namespace

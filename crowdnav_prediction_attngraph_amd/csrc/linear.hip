@@ -333,9 +333,20 @@ extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const
                     : launch_gemm3p<ACT_NONE>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, relu_gate);
 }
 
+// shapes the pipelined TN kernel takes: whole 128-column tiles of dY, enough rows to fill the machine
+static bool wgrad_pipelined(int M, int N, int K) { return N % 128 == 0 && K % 128 == 0 && M >= 65536; }
+
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 128) return 0;
+    if (wgrad_pipelined(M, N, K)) { // gemm3p_tn_kernel: one workgroup per CU, tiles of 128 x 256 (128 x 128 when K is not a multiple of 256)
+        const long long tiles = (long long)(N / 128) * (K / (K % 256 ? 128 : 256));
+        long long s = 512 / tiles;                       // at most two full rounds of one workgroup per CU (never a few stragglers in a third)
+        if (s > 64) s = 64;
+        const long long chunks = ((long long)M + 31) / 32;
+        if (s > chunks) s = chunks;
+        return (int)(s < 1 ? 1 : s);
+    }
     const long long tiles = (long long)((N + 127) / 128) * (K / 128);
     long long s = (768 + tiles - 1) / tiles;             // 1.5 resident rounds of blocks on 256 CUs (shorter blocks, small tail) ...
     if (s > 64) s = 64;                                  // ... but bounded: every split costs an [N,K] partial to write and re-read
@@ -354,8 +365,19 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
     CN_REQUIRE(ldy >= N && ldx >= K, "cn_linear_wgrad: leading dimension smaller than the row length");
     hipStream_t st = (hipStream_t)stream;
     int rows = (M + splits - 1) / splits;
-    rows = (rows + BK3 - 1) / BK3 * BK3;
+    rows = (rows + 31) / 32 * 32;
     const int used = (M + rows - 1) / rows; // <= splits, every split non-empty
+    if (wgrad_pipelined(M, N, K)) {
+        constexpr size_t lds2 = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16);
+        if (K % 256 == 0) {
+            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<2, true>), dim3(N / 128, K / 256, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
+            else hipLaunchKernelGGL((gemm3p_tn_kernel<2, false>), dim3(N / 128, K / 256, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
+        } else {
+            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<1, true>), dim3(N / 128, K / 128, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
+            else hipLaunchKernelGGL((gemm3p_tn_kernel<1, false>), dim3(N / 128, K / 128, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
+        }
+        CN_CHECK_LAUNCH();
+    } else {
     constexpr size_t lds = (size_t)(2 * BM + 2 * 128) * L3_STRIDE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -366,6 +388,7 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
     if (relu_gate) hipLaunchKernelGGL(gemm3_tn_kernel<true>, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
     else hipLaunchKernelGGL(gemm3_tn_kernel<false>, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
     CN_CHECK_LAUNCH();
+    }
     const size_t nk = (size_t)N * K;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, nk, used, partials, dW);
     CN_CHECK_LAUNCH();
