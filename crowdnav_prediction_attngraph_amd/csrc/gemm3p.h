@@ -233,19 +233,27 @@ static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __b
 // dword loads of two full 128-byte lines each.  One barrier per 32 rows of m; no LDS traffic for X at all.
 template <int NB, bool GATE>
 __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ Ygate,
-                                                           const float *__restrict__ X, int ldx, int rows_per_split, float *__restrict__ partials,
-                                                           float *__restrict__ db_part)
+                                                           const float *__restrict__ X, int ldx, int rows_per_split, int nsplit,
+                                                           float *__restrict__ partials, float *__restrict__ db_part)
 {
     constexpr int MI = 4, PS = 40, BUF = 2 * 128 * PS;
     extern __shared__ __attribute__((aligned(16))) char smem3p[];
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem3p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int n_blk = blockIdx.x * 128, k_blk = blockIdx.y * (128 * NB) + wave * 32 * NB, split = blockIdx.z;
+    // XCD-aware 1-D grid: workgroup L runs on XCD L % 8 (round-robin dispatch); all tiles of one split go to ONE XCD, so the rows
+    // of dY and X that the split owns stream through one L2 once (the tiles advance over m together) instead of through up to 8 of
+    // them (with x-fastest 3-D indexing every tile of a split sat on a different XCD: 14.7 GB of L2 misses for 3.3 GB of operands)
+    const int L = blockIdx.x, NX = N / 128, tiles = NX * (K / (128 * NB));
+    const int split = (L & 7) + 8 * ((L >> 3) / tiles), tile = (L >> 3) % tiles;
+    if (split >= nsplit) return;
+    const int n_blk = (tile % NX) * 128, k_blk = (tile / NX) * (128 * NB) + wave * 32 * NB;
+    // M and rows_per_split are multiples of 32 here (the launcher hands the last M % 32 rows to gemm3_tn_kernel): no row predicates,
+    // and every row offset below is wave-uniform, i.e. scalar address arithmetic (one SALU add per load instead of a 64-bit VALU chain)
     const int m_begin = split * rows_per_split;
     const int m_end = min(M, m_begin + rows_per_split);
-    const int T = (m_end - m_begin + 31) / 32;
-    const bool want_db = db_part != nullptr && blockIdx.y == 0;
+    const int T = (m_end - m_begin) / 32;
+    const bool want_db = db_part != nullptr && tile / NX == 0;
 
     f32x16 acc[MI][NB];
 #pragma unroll
@@ -256,34 +264,34 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // dY staging: thread (column c, half-tile g0) owns m groups g0 and g0 + 2 (8 rows each) of the 32-row tile
-    const int c = tid & 127, g0 = tid >> 7;
-    const float *yp = dY + n_blk + c, *gp = GATE ? Ygate + n_blk + c : nullptr;
+    const int c = tid & 127, g0 = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const float *yp = dY + n_blk, *gp = GATE ? Ygate + n_blk : nullptr;
     float sy[2][8], sg[GATE ? 2 : 1][8];
     // X: raw rows of this lane's fragments, [k-step][block][e]
-    const float *xp = X + k_blk + l31;
+    const float *xp = X + k_blk;
+    const int x_lane = half * 8 * ldx + l31; // the lane's part of the address: its 8 rows start 8 * half below the k-step's first row
     float rx[2][NB][8];
     bf16x8 fah[2][MI], fal[2][MI], fwh[2][NB], fwl[2][NB];
     float colsum = 0.0f;
-    // rows at or past m_end read row m_end - 1 (valid memory) and are zeroed at the conversion
+    // tiles past the end of the split (the pipeline runs two ahead) read its last tile again; what they stage is never multiplied
     auto load_y = [&](int q, int tile) {
-        const int m0 = m_begin + tile * 32 + (g0 + 2 * q) * 8;
+        const int m0 = m_begin + min(tile, T - 1) * 32 + (g0 + 2 * q) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const size_t o = (size_t)min(m0 + e, m_end - 1) * ldy;
-            sy[q][e] = yp[o];
-            if (GATE) sg[GATE ? q : 0][e] = gp[o];
+            const size_t o = (size_t)(m0 + e) * ldy;
+            sy[q][e] = (yp + o)[c];
+            if (GATE) sg[GATE ? q : 0][e] = (gp + o)[c];
         }
     };
     auto stage_y = [&](int q, int tile, int b) {
-        const int m0 = m_begin + tile * 32 + (g0 + 2 * q) * 8;
+        const float cm = tile < T ? 1.0f : 0.0f; // the column sums count every row once
         __bf16 *Ah = lds + b * BUF, *Al = Ah + 128 * PS;
         bf16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float a = sy[q][e];
             if (GATE) a = sg[GATE ? q : 0][e] > 0.0f ? a : 0.0f;
-            a = m0 + e < m_end ? a : 0.0f;
-            colsum += a;
+            colsum = fmaf(cm, a, colsum);
             const __bf16 h = (__bf16)a;
             hi[e] = h;
             lo[e] = (__bf16)(a - (float)h);
@@ -292,15 +300,14 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
         *reinterpret_cast<bf16x8 *>(&Al[c * PS + (g0 + 2 * q) * 8]) = lo;
     };
     auto load_x = [&](int ks, int j, int tile) {
-        const int m0 = m_begin + tile * 32 + ks * 16 + half * 8;
+        const int m0 = m_begin + min(tile, T - 1) * 32 + ks * 16;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rx[ks][j][e] = xp[(size_t)min(m0 + e, m_end - 1) * ldx + 32 * j];
+        for (int e = 0; e < 8; ++e) rx[ks][j][e] = (xp + (size_t)(m0 + e) * ldx + 32 * j)[x_lane];
     };
-    auto convert_x = [&](int ks, int j, int tile) {
-        const int m0 = m_begin + tile * 32 + ks * 16 + half * 8;
+    auto convert_x = [&](int ks, int j) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float a = m0 + e < m_end ? rx[ks][j][e] : 0.0f;
+            const float a = rx[ks][j][e];
             const __bf16 h = (__bf16)a;
             fwh[ks][j][e] = h;
             fwl[ks][j][e] = (__bf16)(a - (float)h);
@@ -325,13 +332,13 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
     stage_y(0, 0, 0); stage_y(1, 0, 0);
     load_y(0, 1); load_y(1, 1);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { convert_x(0, j, 0); load_x(0, j, 1); }
+    for (int j = 0; j < NB; ++j) { convert_x(0, j); load_x(0, j, 1); }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 8; ++s) read_a(0, s, 0);
     int cur = 0;
     for (int t = 0; t < T; ++t) {
-        // Branch-free body; tiles past the end of the split read its last row and contribute zeros.
+        // Branch-free body.
         // ---- phase A: k-step 0 | dY fragments of k-step 1; dY tile t+1 into the other buffer, tile t+2 requested; X k-step 1 of
         //      tile t converted, of tile t+1 requested ----
 #pragma unroll
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
             for (int r = 0; r < RPG; ++r) read_a(1, g * RPG + r, cur);
             mfma_one(0, 3 * g + 1);
             if (g == 0 || g == G / 2) { const int q = g ? 1 : 0; stage_y(q, t + 1, cur ^ 1); load_y(q, t + 2); }
-            if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(1, j, t); load_x(1, j, t + 1); }
+            if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(1, j); load_x(1, j, t + 1); }
             mfma_one(0, 3 * g + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
 #pragma unroll
             for (int r = 0; r < RPG; ++r) read_a(0, g * RPG + r, cur ^ 1);
             mfma_one(1, 3 * g + 1);
-            if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(0, j, t + 1); load_x(0, j, t + 2); }
+            if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(0, j); load_x(0, j, t + 2); }
             mfma_one(1, 3 * g + 2);
             __builtin_amdgcn_sched_barrier(0);
         }

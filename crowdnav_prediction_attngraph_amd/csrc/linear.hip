@@ -340,12 +340,15 @@ extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 128) return 0;
     if (wgrad_pipelined(M, N, K)) { // gemm3p_tn_kernel: one workgroup per CU, tiles of 128 x 256 (128 x 128 when K is not a multiple of 256)
+        // every XCD (32 CUs, one workgroup each) takes whole splits: s = 8 a with a * tiles a multiple of 32 fills the XCDs in
+        // whole rounds; prefer the smallest such s with at least two rounds of work, bounded by 64 partials
         const long long tiles = (long long)(N / 128) * (K / (K % 256 ? 128 : 256));
-        long long s = 512 / tiles;                       // at most two full rounds of one workgroup per CU (never a few stragglers in a third)
-        if (s > 64) s = 64;
-        const long long chunks = ((long long)M + 31) / 32;
+        long long s = 64;
+        for (long long a = 1; a <= 8; ++a)
+            if ((a * tiles) % 32 == 0 && a * tiles >= 64) { s = 8 * a; break; }
+        const long long chunks = (long long)M / 32;
         if (s > chunks) s = chunks;
-        return (int)(s < 1 ? 1 : s);
+        return (int)(s < 1 ? 1 : s) + (M % 32 ? 1 : 0); // + one partial for the last M % 32 rows (gemm3_tn_kernel takes those)
     }
     const long long tiles = (long long)((N + 127) / 128) * (K / 128);
     long long s = (768 + tiles - 1) / tiles;             // 1.5 resident rounds of blocks on 256 CUs (shorter blocks, small tail) ...
@@ -364,20 +367,6 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
     CN_REQUIRE((db == nullptr) == (db_partials == nullptr), "cn_linear_wgrad: db and db_partials go together");
     CN_REQUIRE(ldy >= N && ldx >= K, "cn_linear_wgrad: leading dimension smaller than the row length");
     hipStream_t st = (hipStream_t)stream;
-    int rows = (M + splits - 1) / splits;
-    rows = (rows + 31) / 32 * 32;
-    const int used = (M + rows - 1) / rows; // <= splits, every split non-empty
-    if (wgrad_pipelined(M, N, K)) {
-        constexpr size_t lds2 = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16);
-        if (K % 256 == 0) {
-            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<2, true>), dim3(N / 128, K / 256, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
-            else hipLaunchKernelGGL((gemm3p_tn_kernel<2, false>), dim3(N / 128, K / 256, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
-        } else {
-            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<1, true>), dim3(N / 128, K / 128, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
-            else hipLaunchKernelGGL((gemm3p_tn_kernel<1, false>), dim3(N / 128, K / 128, used), dim3(256), lds2, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
-        }
-        CN_CHECK_LAUNCH();
-    } else {
     constexpr size_t lds = (size_t)(2 * BM + 2 * 128) * L3_STRIDE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -385,9 +374,41 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (relu_gate) hipLaunchKernelGGL(gemm3_tn_kernel<true>, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
-    else hipLaunchKernelGGL(gemm3_tn_kernel<false>, dim3((N + 127) / 128, K / 128, used), dim3(256), lds, st, M, N, K, dY, ldy, relu_gate, X, ldx, rows, partials, db_partials);
-    CN_CHECK_LAUNCH();
+    auto launch_tn = [&](int m, const float *dy, const float *gate, const float *x, int rows_per, int nsplit, float *part, float *dbp) {
+        if (gate) hipLaunchKernelGGL(gemm3_tn_kernel<true>, dim3((N + 127) / 128, K / 128, nsplit), dim3(256), lds, st, m, N, K, dy, ldy, gate, x, ldx, rows_per, part, dbp);
+        else hipLaunchKernelGGL(gemm3_tn_kernel<false>, dim3((N + 127) / 128, K / 128, nsplit), dim3(256), lds, st, m, N, K, dy, ldy, gate, x, ldx, rows_per, part, dbp);
+    };
+    int used;
+    if (wgrad_pipelined(M, N, K)) {
+        // whole tiles of 32 rows on the pipelined kernel, the last M % 32 rows as one more split on the two-barrier kernel
+        const int M32 = M / 32 * 32, tail = M - M32, main_splits = splits - (tail ? 1 : 0);
+        CN_REQUIRE(main_splits >= 1, "cn_linear_wgrad: splits=%d leaves no room for the row tail (use cn_linear_wgrad_splits)", splits);
+        int rows = (M32 + main_splits - 1) / main_splits;
+        rows = (rows + 31) / 32 * 32;
+        used = (M32 + rows - 1) / rows;
+        constexpr size_t lds2 = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16);
+        const int tiles = (N / 128) * (K / (K % 256 ? 128 : 256));
+        const dim3 grid(8 * ((used + 7) / 8) * tiles); // XCD-aware 1-D grid, see the kernel
+        if (K % 256 == 0) {
+            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<2, true>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
+            else hipLaunchKernelGGL((gemm3p_tn_kernel<2, false>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
+        } else {
+            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<1, true>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
+            else hipLaunchKernelGGL((gemm3p_tn_kernel<1, false>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
+        }
+        CN_CHECK_LAUNCH();
+        if (tail) {
+            launch_tn(tail, dY + (size_t)M32 * ldy, relu_gate ? relu_gate + (size_t)M32 * ldy : nullptr, X + (size_t)M32 * ldx, 32, 1,
+                      partials + (size_t)used * N * K, db_partials ? db_partials + (size_t)used * N : nullptr);
+            CN_CHECK_LAUNCH();
+            ++used;
+        }
+    } else {
+        int rows = (M + splits - 1) / splits;
+        rows = (rows + BK3 - 1) / BK3 * BK3;
+        used = (M + rows - 1) / rows; // <= splits, every split non-empty
+        launch_tn(M, dY, relu_gate, X, rows, used, partials, db_partials);
+        CN_CHECK_LAUNCH();
     }
     const size_t nk = (size_t)N * K;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, nk, used, partials, dW);
