@@ -53,12 +53,8 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
     const int half = lane >> 5, l31 = lane & 31;
     const int m_blk = row_tile * TBM, n_blk = col_tile * BN + wave * 32 * NB;
     const int T = K / PK, KK = K / 16;
-#ifdef G3P_ROTATE
-    const int rot = (row_tile * 5) % T; // workgroups of an XCD walk K from different tiles: they stream the same W rows
-#else
-    const int rot = 0;
-#endif
-    auto phys = [&](int tile) { const int x = tile + rot; return x >= T ? x - T : x; };
+    // (starting the K walk of each workgroup at a different tile -- the workgroups of an XCD stream the same W rows -- changed
+    // nothing: 2.10 vs 2.15 ms; L2 channel hot-spotting is not the bound here)
 
     f32x16 acc[MI][NB];
 #pragma unroll
@@ -85,8 +81,8 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
     bf16x8 fwh[WD][2][NB], fwl[WD][2][NB]; // [tile % WD][k-step][block] hi / lo fragments of W
     auto load_a = [&](int set, int p, int tile) {
         if (KO & 8) return;
-        sa[set][p] = *reinterpret_cast<const f32x4 *>(ap[p] + phys(tile) * PK);
-        if (GATE) sg[GATE ? set : 0][p] = *reinterpret_cast<const f32x4 *>(gp[p] + phys(tile) * PK); // the select happens at the conversion
+        sa[set][p] = *reinterpret_cast<const f32x4 *>(ap[p] + tile * PK);
+        if (GATE) sg[GATE ? set : 0][p] = *reinterpret_cast<const f32x4 *>(gp[p] + tile * PK); // the select happens at the conversion
     };
     auto stage_a = [&](int set, int p, int b) { // convert pass p of a staged tile into buffer b
         __bf16 *Ah = lds + b * BUF, *Al = Ah + TBM * PS;
@@ -109,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
     const size_t w_base = ((size_t)(n_blk >> 5) * KK * 64 + lane) * 8; // fragment (cb, kk) starts at ((cb * KK + kk) * 64 + lane) * 8
     auto load_w = [&](int par, int ks, int j, int tile) {
         if (KO & 8) return;
-        const size_t o = w_base + ((size_t)j * KK + phys(tile) * 2 + ks) * 512;
+        const size_t o = w_base + ((size_t)j * KK + tile * 2 + ks) * 512;
         fwh[par][ks][j] = *reinterpret_cast<const bf16x8 *>(Whi + o);
         fwl[par][ks][j] = *reinterpret_cast<const bf16x8 *>(Wlo + o);
     };
@@ -159,9 +155,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
                 // the k-step-1 W registers of the PREVIOUS tile's set are free since its phase B: the tile WD further on goes
                 // there, one fragment per group (in the very first trip this re-requests what the prologue put there)
                 if (g >= G - NB) load_w((u + WD - 1) % WD, 1, g - (G - NB), min(t + u - 1 + WD, T - 1));
-#ifndef G3P_NO_SCHED
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             }
             __syncthreads(); // A tile t+u+1 is complete, the buffer of tile t+u is free
             // ---- phase B: k-step 1 | A fragments (k-step 0) of tile t+u+1 ----
@@ -173,9 +167,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
                 mfma_one(u, 1, 3 * g + 1);
                 if (g < NB) load_w(u, 0, g, tw); // this set's k-step-0 registers are free since phase A
                 mfma_one(u, 1, 3 * g + 2);
-#ifndef G3P_NO_SCHED
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         }
     }

@@ -130,6 +130,18 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
+        // this step's inputs do not depend on the state: request them before the MFMAs, unpredicated (surplus rows of the last
+        // workgroup read row N-1).  Loaded inside the per-row `if (row < N)` blocks below, every row paid its own memory round
+        // trip behind an s_waitcnt vmcnt(0): 16 of them in series per step (24 us per step, ~5 of them MFMA).
+        float gir[16], giz[16], gin[16], mk[16];
+        const int tn = min(t + 1, T - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, N - 1);
+            const float *gip = gi + ((size_t)t * N + rowc) * 384 + u;
+            gir[r] = gip[0]; giz[r] = gip[128]; gin[r] = gip[256];
+            mk[r] = m[(size_t)tn * N + rowc];
+        }
         f32x16 acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -146,22 +158,18 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + rl;
-            float next = 0.0f;
-            if (row < N) {
+            const float hn = acc[2][r] + bias[2];
+            const float rg = sigmoidf_(gir[r] + acc[0][r] + bias[0]);
+            const float zg = sigmoidf_(giz[r] + acc[1][r] + bias[1]);
+            const float ng = tanhf(gin[r] + rg * hn);
+            const float hnew = (1.0f - zg) * ng + zg * hm[cur][rl * GHS + u];
+            const float next = row < N ? hnew * mk[r] : 0.0f;
+            if (row < N) { // stores only: nothing in here waits for memory
                 const size_t tr = (size_t)t * N + row;
-                const float *gip = gi + tr * 384;
-                const float hn = acc[2][r] + bias[2];
-                const float rg = sigmoidf_(gip[u] + acc[0][r] + bias[0]);
-                const float zg = sigmoidf_(gip[128 + u] + acc[1][r] + bias[1]);
-                const float ng = tanhf(gip[256 + u] + rg * hn);
-                const float hnew = (1.0f - zg) * ng + zg * hm[cur][rl * GHS + u];
                 hs[tr * 128 + u] = hnew;
                 float *gp = gates + tr * 512;
                 gp[u] = rg; gp[128 + u] = zg; gp[256 + u] = ng; gp[384 + u] = hn;
-                if (t + 1 < T) {
-                    next = hnew * m[(size_t)(t + 1) * N + row];
-                    hms[(tr + N) * 128 + u] = next;
-                }
+                if (t + 1 < T) hms[(tr + N) * 128 + u] = next;
             }
             if (t + 1 < T) hm[cur ^ 1][rl * GHS + u] = next;
         }
@@ -185,31 +193,47 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const fl
     f32x16 carry;
 #pragma unroll
     for (int r = 0; r < 16; ++r) carry[r] = 0.0f;
+    // The saved gates / states / incoming gradients of a step do not depend on the carried gradient: they are requested one step
+    // ahead, unpredicated (surplus rows read row N-1), right behind the barrier that ends their last use -- the 192 MFMAs of the
+    // current step hide the round trip.  Loaded inside the per-row `if (row < N)` blocks they cost 16 serial round trips per step.
+    float s_rg[16], s_zg[16], s_ng[16], s_hn[16], s_h[16], s_d[16], s_m[16];
+    auto preload = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, N - 1);
+            const size_t tr = (size_t)t * N + rowc;
+            const float *gp = gates + tr * 512 + u;
+            s_rg[r] = gp[0]; s_zg[r] = gp[128]; s_ng[r] = gp[256]; s_hn[r] = gp[384];
+            s_h[r] = hms[tr * 128 + u];
+            s_d[r] = d_hs[tr * 128 + u];
+            s_m[r] = m[tr];
+        }
+    };
+    preload(T - 1);
     for (int t = T - 1; t >= 0; --t) {
-        float direct[16];
+        float direct[16], mt[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + rl;
-            float dr = 0.0f, dz = 0.0f, dn = 0.0f;
-            direct[r] = 0.0f;
-            if (row < N) {
+            const bool ok = row < N;
+            const float rg = s_rg[r], zg = s_zg[r], ng = s_ng[r], hn = s_hn[r], h = s_h[r];
+            const float d = s_d[r] + carry[r];
+            const float din = d * (1.0f - zg) * (1.0f - ng * ng);
+            const float dr = ok ? din * hn * rg * (1.0f - rg) : 0.0f;
+            const float dz = ok ? d * (h - ng) * zg * (1.0f - zg) : 0.0f;
+            const float dn = ok ? din * rg : 0.0f;
+            direct[r] = ok ? d * zg : 0.0f;
+            mt[r] = s_m[r];
+            if (ok) { // stores only
                 const size_t tr = (size_t)t * N + row;
-                const float *gp = gates + tr * 512;
-                const float rg = gp[u], zg = gp[128 + u], ng = gp[256 + u], hn = gp[384 + u];
-                const float h = hms[tr * 128 + u];
-                const float d = d_hs[tr * 128 + u] + carry[r];
-                const float din = d * (1.0f - zg) * (1.0f - ng * ng);
-                dr = din * hn * rg * (1.0f - rg);
-                dz = d * (h - ng) * zg * (1.0f - zg);
-                dn = din * rg;
                 float *a = dgi + tr * 384, *b = dgh + tr * 384;
                 a[u] = dr; a[128 + u] = dz; a[256 + u] = din;
                 b[u] = dr; b[128 + u] = dz; b[256 + u] = dn;
-                direct[r] = d * zg;
             }
             dg[rl * GDS + u] = dr; dg[rl * GDS + 128 + u] = dz; dg[rl * GDS + 256 + u] = dn;
         }
         __syncthreads();
+        preload(t > 0 ? t - 1 : 0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -222,7 +246,7 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            carry[r] = row < N ? (direct[r] + acc[r]) * m[(size_t)t * N + row] : 0.0f;
+            carry[r] = row < N ? (direct[r] + acc[r]) * mt[r] : 0.0f;
         }
         __syncthreads(); // the next (earlier) step overwrites dg
     }
