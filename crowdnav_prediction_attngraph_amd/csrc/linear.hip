@@ -73,13 +73,25 @@ __global__ __launch_bounds__(128) void embed0_bwd_kernel(int R, int D, const flo
     float acc[17];
 #pragma unroll
     for (int d = 0; d < 17; ++d) acc[d] = 0.0f;
-    for (int r = blockIdx.x; r < R; r += gridDim.x) {
-        const float g = y[(size_t)r * 128 + n] > 0.0f ? dy[(size_t)r * 128 + n] : 0.0f;
-        const float *xr = x + (size_t)r * D;
+    // eight rows per trip, all their loads requested before the first use (one row per trip = one memory round trip per row)
+    for (int r0 = blockIdx.x; r0 < R; r0 += 8 * gridDim.x) {
+        float yv[8], dv[8];
 #pragma unroll
-        for (int d = 0; d < 16; ++d)
-            if (d < D) acc[d] += g * xr[d];
-        acc[16] += g;
+        for (int k = 0; k < 8; ++k) {
+            const int r = min(r0 + k * (int)gridDim.x, R - 1);
+            yv[k] = y[(size_t)r * 128 + n];
+            dv[k] = dy[(size_t)r * 128 + n];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + k * (int)gridDim.x;
+            const float g = (r < R && yv[k] > 0.0f) ? dv[k] : 0.0f;
+            const float *xr = x + (size_t)min(r, R - 1) * D;
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d < D) acc[d] += g * xr[d];
+            acc[16] += g;
+        }
     }
     float *p = part + ((size_t)blockIdx.x * 128 + n) * (D + 1); // [block][n][D weights | bias]
 #pragma unroll

@@ -262,16 +262,56 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
     float *Qs = smem + (size_t)wave * (4 * CAP * RS + 2 * CAP * CAP);
     float *Ks = Qs + CAP * RS, *Vs = Ks + CAP * RS, *Gs = Vs + CAP * RS; // Gs = dO rows
     float *P = Gs + CAP * RS, *dS = P + CAP * CAP;
-    for (int unit = blockIdx.x * wpb + wave; unit < n_units; unit += gridDim.x * wpb) {
-        const int b = cls_list ? cls_list[unit >> 3] : unit >> 3, head = unit & 7;
-        const int r0 = row_off[b], nd = row_off[b + 1] - r0;
-        if (nd > CAP) continue; // (only without a class list: another launch handles it)
-        const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
-        const float *gbase = d_out + (size_t)r0 * 512 + head * 64 + lane;
+    // A wavefront walks ~240 units, and a unit starts with three DEPENDENT memory round trips (class list -> row offsets -> rows)
+    // before any arithmetic.  For the small classes (4 CAP registers) the walk is a three-stage pipeline instead: while unit u is
+    // computed, the rows of unit u+1, the row offsets of unit u+2 and the sample id of unit u+3 are in flight.
+    constexpr bool PIPE = CAP <= 16;
+    float pq[PIPE ? CAP : 1], pk[PIPE ? CAP : 1], pv[PIPE ? CAP : 1], pg[PIPE ? CAP : 1];
+    const int stride = gridDim.x * wpb;
+    int unit = blockIdx.x * wpb + wave;
+    auto sample_of = [&](int u) { return u < n_units ? (cls_list ? cls_list[u >> 3] : u >> 3) : 0; };
+    auto request_rows = [&](int r0n, int ndn, int head) {
+        const float *base = qkv + (size_t)r0n * 1536 + head * 64 + lane;
+        const float *gbase = d_out + (size_t)r0n * 512 + head * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < (PIPE ? CAP : 0); ++j)
+            if (j < ndn) { // wave-uniform
+                pq[j] = base[(size_t)j * 1536]; pk[j] = base[(size_t)j * 1536 + 512]; pv[j] = base[(size_t)j * 1536 + 1024];
+                pg[j] = gbase[(size_t)j * 512];
+            }
+    };
+    int c_r0 = 0, c_nd = 0, n_lo = 0, n_hi = 0, b2 = 0; // rows in flight belong to (c_r0, c_nd); raw offsets of the unit after it; sample after that
+    if (PIPE && unit < n_units) {
+        const int b0 = sample_of(unit), b1 = sample_of(unit + stride);
+        b2 = sample_of(unit + 2 * stride);
+        c_r0 = row_off[b0]; c_nd = row_off[b0 + 1] - c_r0;
+        n_lo = row_off[b1]; n_hi = row_off[b1 + 1];
+        request_rows(c_r0, c_nd, unit & 7);
+    }
+    for (; unit < n_units; unit += stride) {
+        const int head = unit & 7;
+        int r0, nd;
+        if (PIPE) {
+            r0 = c_r0; nd = c_nd;
+#pragma unroll
+            for (int j = 0; j < (PIPE ? CAP : 0); ++j)
+                if (j < nd && nd <= CAP) { Qs[j * RS + lane] = pq[j]; Ks[j * RS + lane] = pk[j]; Vs[j * RS + lane] = pv[j]; Gs[j * RS + lane] = pg[j]; }
+            c_r0 = n_lo; c_nd = n_hi - n_lo;
+            request_rows(c_r0, c_nd, (unit + stride) & 7);        // (past the end: sample 0 again, never used)
+            n_lo = row_off[b2]; n_hi = row_off[b2 + 1];
+            b2 = sample_of(unit + 3 * stride);
+            if (nd > CAP) continue; // (only without a class list: another launch handles it)
+        } else {
+            const int b = cls_list ? cls_list[unit >> 3] : unit >> 3;
+            r0 = row_off[b]; nd = row_off[b + 1] - r0;
+            if (nd > CAP) continue; // (only without a class list: another launch handles it)
+            const float *base = qkv + (size_t)r0 * 1536 + head * 64 + lane;
+            const float *gbase = d_out + (size_t)r0 * 512 + head * 64 + lane;
 #pragma unroll 4
-        for (int j = 0; j < nd; ++j) {
-            const float q = base[(size_t)j * 1536], k = base[(size_t)j * 1536 + 512], v = base[(size_t)j * 1536 + 1024], g = gbase[(size_t)j * 512];
-            Qs[j * RS + lane] = q; Ks[j * RS + lane] = k; Vs[j * RS + lane] = v; Gs[j * RS + lane] = g;
+            for (int j = 0; j < nd; ++j) {
+                const float q = base[(size_t)j * 1536], k = base[(size_t)j * 1536 + 512], v = base[(size_t)j * 1536 + 1024], g = gbase[(size_t)j * 512];
+                Qs[j * RS + lane] = q; Ks[j * RS + lane] = k; Vs[j * RS + lane] = v; Gs[j * RS + lane] = g;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
