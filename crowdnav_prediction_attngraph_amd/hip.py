@@ -414,7 +414,7 @@ class Embed0(torch.autograd.Function):
         R, D = x.shape
         if R == 0:
             return None, x.new_zeros(128, D), x.new_zeros(128)
-        blocks = min(R, 1024)
+        blocks = min(R, 4096)   # 16 resident blocks of 128 threads per CU: each walks its rows 8 at a time (one round trip per trip)
         part = torch.empty(blocks, 128, D + 1, device=x.device)
         dwb = torch.empty(128, D + 1, device=x.device)
         A.check(A.lib().cn_embed0_bwd(R, D, A.ptr(x), A.ptr(y), A.ptr(dy.contiguous()), blocks, A.ptr(part), A.ptr(dwb), A.stream_ptr()), "cn_embed0_bwd")
