@@ -364,4 +364,25 @@ __global__ void reduce_partials_kernel(size_t n, int splits, const float *__rest
     }
 }
 
+// The same sum for MANY partials of a SMALL output (embed0's 128 x (D + 1) gradient from thousands of blocks, a bias gradient from
+// 64 splits): one output per wavefront instead of per thread -- lane l adds partials l, l + 64, ... (ascending), then the 64 lane
+// sums are combined in a fixed butterfly order: deterministic, and the serial chain is splits / 64 long instead of splits.
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(size_t n, int splits, const float *__restrict__ part, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float acc = 0.0f;
+    for (int s = lane; s < splits; s += 64) acc += part[(size_t)s * n + i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[i] = acc;
+}
+
+static void launch_reduce_partials(size_t n, int splits, const float *part, float *out, hipStream_t st)
+{
+    if (splits >= 48 && n <= 16384) hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, splits, part, out);
+    else hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, splits, part, out);
+}
+
 } // namespace

@@ -290,7 +290,7 @@ extern "C" int cn_embed0_bwd(int R, int D, const float *x, const float *y, const
     hipLaunchKernelGGL(embed0_bwd_kernel, dim3(blocks), dim3(128), 0, st, R, D, x, y, dy, partials);
     CN_CHECK_LAUNCH();
     const size_t n = (size_t)128 * (D + 1);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, blocks, partials, dWb);
+    launch_reduce_partials(n, blocks, partials, dWb, st);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -447,10 +447,10 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         CN_CHECK_LAUNCH();
     }
     const size_t nk = (size_t)N * K;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, nk, used, partials, dW);
+    launch_reduce_partials(nk, used, partials, dW, st);
     CN_CHECK_LAUNCH();
     if (db) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (size_t)N, used, db_partials, db);
+        launch_reduce_partials((size_t)N, used, db_partials, db, st);
         CN_CHECK_LAUNCH();
     }
     return CN_OK;
