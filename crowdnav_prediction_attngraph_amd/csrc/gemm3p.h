@@ -43,16 +43,28 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
     constexpr int TBM = 128, MI = 4, BN = 128 * NB;
     constexpr int PK = 32, PS = 40;     // K tile (two k-steps), LDS row stride in bf16 (80 B: conflict-free 16-byte fragment reads)
     constexpr int BUF = 2 * TBM * PS;   // bf16 elements per LDS buffer: A hi and lo planes of one K tile (20 480 B)
-    int row_tile, col_tile;
-    if ((size_t)N * K > (size_t)512 * 1024 && !(gridDim.x & 1)) xcd_tile_split(row_tile, col_tile);
-    else xcd_tile(row_tile, col_tile);
-    if (row_tile * TBM >= M) return;
+    // PERSISTENT workgroups: one per CU, grid = 8 x slots.  Workgroup L runs on XCD L % 8 (round-robin dispatch) and walks the tiles
+    // q = slot, slot + slots, ... of that XCD in the order of xcd_tile / xcd_tile_split (gemm.h: the column tiles of a row tile are
+    // consecutive, so the ~32 tiles in flight on an XCD share five or six A row tiles), WITHOUT draining the pipeline in between:
+    // the last K tiles of one output tile already request / stage the first K tiles of the next.  Per-tile overhead (two exposed
+    // memory round trips of the prologue, the store drain, the dispatch) was 8 us of the 29 us a q|k|v tile takes.
+    const int nbx = N / BN, gy = (((M + TBM - 1) / TBM) + 7) & ~7, Qx = nbx * gy / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const bool wide = (size_t)N * K > (size_t)512 * 1024 && !(nbx & 1); // W planes > 2 MB: halve the per-L2 W set (xcd_tile_split)
+    auto tile_of = [&](int q, int &row_tile, int &col_tile) {
+        if (wide) { const int ch = nbx >> 1; col_tile = (xcd >> 2) * ch + q % ch; row_tile = (q / ch) * 4 + (xcd & 3); }
+        else { col_tile = q % nbx; row_tile = (q / nbx) * 8 + xcd; }
+    };
     extern __shared__ __attribute__((aligned(16))) char smem3p[];
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem3p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int m_blk = row_tile * TBM, n_blk = col_tile * BN + wave * 32 * NB;
     const int T = K / PK, KK = K / 16;
+    int q = slot, row_tile, col_tile;
+    if (q >= Qx) return;
+    tile_of(q, row_tile, col_tile);
+    if (row_tile * TBM >= M) return; // (row tiles grow with q: nothing further on either)
+    int m_blk = row_tile * TBM, n_blk = col_tile * BN + wave * 32 * NB;
     // (starting the K walk of each workgroup at a different tile -- the workgroups of an XCD stream the same W rows -- changed
     // nothing: 2.10 vs 2.15 ms; L2 channel hot-spotting is not the bound here)
 
@@ -66,23 +78,38 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
 
     // A staging: 8 lanes cover one 128-byte row segment, 32 rows per pass, 4 passes
     const int arow = tid >> 3, acol = (tid & 7) * 4;
-    const float *ap[4], *gp[4];
+    int ao[4], ao_n[4];      // element offsets of this thread's four A rows (+ column) in this output tile / the next one (M lda < 2^31)
+    int w_base, w_base_n;    // fragment (cb, kk) starts at element ((cb * KK + kk) * 64 + lane) * 8 of a W plane
+    int m_blk_n, n_blk_n;
+    bool more;
+    auto point_at = [&](int mb, int nb, int (&a)[4], int &wb) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const size_t o = (size_t)min(m_blk + arow + 32 * p, M - 1) * lda + acol; // surplus rows repeat row M-1: computed, never stored
-        ap[p] = A + o;
-        gp[p] = GATE ? Agate + o : nullptr;
-    }
+        for (int p = 0; p < 4; ++p) a[p] = min(mb + arow + 32 * p, M - 1) * lda + acol; // surplus rows repeat row M-1: computed, never stored
+        wb = ((nb >> 5) * KK * 64 + lane) * 8;
+    };
+    auto look_ahead = [&]() { // the tile after (m_blk, n_blk); without one the "next" tile is this one again (its loads are never used)
+        int rt, ct;
+        more = q + slots < Qx;
+        if (more) { tile_of(q + slots, rt, ct); more = rt * TBM < M; }
+        m_blk_n = more ? rt * TBM : m_blk;
+        n_blk_n = more ? ct * BN + wave * 32 * NB : n_blk;
+        point_at(m_blk_n, n_blk_n, ao_n, w_base_n);
+    };
+    point_at(m_blk, n_blk, ao, w_base);
+    look_ahead();
     // W fragment sets / staged A tiles in flight (prefetch depth in K tiles).  4 / 2 measured the same as 2 / 1 (2.16 ms on the
     // q|k|v shape either way): the loop is not waiting for latency, so the smaller register footprint stays
     constexpr int WD = 2, AD = 1;
     f32x4 sa[AD][4], sg[GATE ? AD : 1][4];
     bf16x8 fah[2][MI], fal[2][MI];   // [k-step][block] hi / lo fragments of A
     bf16x8 fwh[WD][2][NB], fwl[WD][2][NB]; // [tile % WD][k-step][block] hi / lo fragments of W
+    // K tile indices T, T + 1, ... are K tiles 0, 1, ... of the next output tile
     auto load_a = [&](int set, int p, int tile) {
         if (KO & 8) return;
-        sa[set][p] = *reinterpret_cast<const f32x4 *>(ap[p] + tile * PK);
-        if (GATE) sg[GATE ? set : 0][p] = *reinterpret_cast<const f32x4 *>(gp[p] + tile * PK); // the select happens at the conversion
+        const bool nx = tile >= T;
+        const size_t o = (size_t)((nx ? ao_n[p] : ao[p]) + (nx ? tile - T : tile) * PK);
+        sa[set][p] = *reinterpret_cast<const f32x4 *>(A + o);
+        if (GATE) sg[GATE ? set : 0][p] = *reinterpret_cast<const f32x4 *>(Agate + o); // the select happens at the conversion
     };
     auto stage_a = [&](int set, int p, int b) { // convert pass p of a staged tile into buffer b
         __bf16 *Ah = lds + b * BUF, *Al = Ah + TBM * PS;
@@ -102,10 +129,10 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
         if (s < 4) fah[ks][s] = *reinterpret_cast<const bf16x8 *>(&Ah[s * 32 * PS]);
         else fal[ks][s - 4] = *reinterpret_cast<const bf16x8 *>(&Al[(s - 4) * 32 * PS]);
     };
-    const size_t w_base = ((size_t)(n_blk >> 5) * KK * 64 + lane) * 8; // fragment (cb, kk) starts at ((cb * KK + kk) * 64 + lane) * 8
     auto load_w = [&](int par, int ks, int j, int tile) {
         if (KO & 8) return;
-        const size_t o = w_base + ((size_t)j * KK + tile * 2 + ks) * 512;
+        const bool nx = tile >= T;
+        const size_t o = (size_t)((nx ? w_base_n : w_base) + (j * KK + (nx ? tile - T : tile) * 2 + ks) * 512);
         fwh[par][ks][j] = *reinterpret_cast<const bf16x8 *>(Whi + o);
         fwl[par][ks][j] = *reinterpret_cast<const bf16x8 *>(Wlo + o);
     };
@@ -123,25 +150,28 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
 #pragma unroll
     for (int u = 0; u < WD; ++u)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { load_w(u, 0, j, min(u, T - 1)); load_w(u, 1, j, min(u, T - 1)); }
+        for (int j = 0; j < NB; ++j) { load_w(u, 0, j, u); load_w(u, 1, j, u); }
     if (AD > 1) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) load_a(1 % AD, p, min(1, T - 1));
+        for (int p = 0; p < 4; ++p) load_a(1 % AD, p, 1);
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { stage_a(0, p, 0); load_a(0, p, min(AD, T - 1)); }
+    for (int p = 0; p < 4; ++p) { stage_a(0, p, 0); load_a(0, p, AD); }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 8; ++s) read_a(0, s, 0);
+    float bv[NB]; // this output tile's bias (requested a whole tile ahead of its use)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = bias ? bias[n_blk + j * 32 + l31] : 0.0f;
+    for (;;) {
     // T % WD == 0 (K % 64 == 0): WD tiles per trip so that register sets are compile-time indices
     for (int t = 0; t < T; t += WD) {
 #pragma unroll
         for (int u = 0; u < WD; ++u) {
             const int cur = u & 1;      // tile t + u lives in LDS buffer (t + u) & 1
             const int nset = (u + 1) % AD; // the staged copy of tile t + u + 1
-            // Branch-free body (the last tiles stage / read / load once more than needed: the last K tile again, into the
-            // buffer nobody reads again).  Fenced groups of three MFMAs keep the side work spread out under them.
-            const int ta = min(t + u + 1 + AD, T - 1), tw = min(t + u + WD, T - 1);
+            // Branch-free body.  Fenced groups of three MFMAs keep the side work spread out under them.
+            const int ta = t + u + 1 + AD, tw = t + u + WD;
             // ---- phase A: k-step 0 | A fragments of k-step 1; the staged A tile (t+u+1) converted into the other buffer and the
             //      tile AD further on requested ----
 #pragma unroll
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
                 mfma_one(u, 0, 3 * g + 2);
                 // the k-step-1 W registers of the PREVIOUS tile's set are free since its phase B: the tile WD further on goes
                 // there, one fragment per group (in the very first trip this re-requests what the prologue put there)
-                if (g >= G - NB) load_w((u + WD - 1) % WD, 1, g - (G - NB), min(t + u - 1 + WD, T - 1));
+                if (g >= G - NB) load_w((u + WD - 1) % WD, 1, g - (G - NB), t + u - 1 + WD);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads(); // A tile t+u+1 is complete, the buffer of tile t+u is free
@@ -171,13 +201,10 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
             }
         }
     }
-    // Epilogue.  The bias is fetched and waited for ONCE, and a workgroup whose 128 rows are all inside M stores without per-row
-    // predicates: with the predicate, every store sat in its own basic block behind an s_waitcnt vmcnt(0) (the compiler cannot
-    // tell there that the bias load has landed), i.e. every store waited for the previous one to complete.
-    float bv[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) bv[j] = bias ? bias[n_blk + j * 32 + l31] : 0.0f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Epilogue of this output tile (the pipeline already holds the first K tiles of the next one).  A workgroup whose 128 rows are
+    // all inside M stores without per-row predicates: with the predicate, every store sat in its own basic block behind an
+    // s_waitcnt vmcnt(0) (the compiler cannot tell there that the bias load has landed), i.e. every store waited for the previous
+    // one to complete.
     auto store_all = [&](auto guard) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -189,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
                     const int ro = (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bv[j];
                     if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    acc[i][j][r] = 0.0f;
                     if ((KO & 1) && v != 12345.678f) continue;
                     if (guard(m_blk + i * 32 + 4 * half + ro)) __builtin_nontemporal_store(v, cp + (size_t)ro * ldc); // streaming result: keep A / W in the L2
                 }
@@ -196,6 +224,16 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
     };
     if (m_blk + TBM <= M) store_all([](int) { return true; });
     else store_all([&](int row) { return row < M; });
+    if (!more) break;
+    // the next output tile becomes the current one
+    q += slots;
+    m_blk = m_blk_n; n_blk = n_blk_n; w_base = w_base_n;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ao[p] = ao_n[p];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = bias ? bias[n_blk + j * 32 + l31] : 0.0f;
+    look_ahead();
+    }
 }
 
 template <int ACT, int KO = 0>
@@ -203,15 +241,19 @@ static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __b
                          hipStream_t st, const float *Agate)
 {
     CN_REQUIRE(N % 128 == 0 && K % 64 == 0 && lda % 4 == 0, "gemm3p: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
+    CN_REQUIRE((long long)M * lda < (1LL << 31) && (long long)N * K < (1LL << 31), "gemm3p: operand too large for 32-bit element offsets (M=%d lda=%d)", M, lda);
     if (M == 0) return CN_OK;
     constexpr size_t lds = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16); // 40 960 B
-    const unsigned gy = (unsigned)((((M + 127) / 128) + 7) & ~7);
-    if (N % 256 == 0) {
-        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, true, KO>), dim3(N / 256, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
-        else hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, false, KO>), dim3(N / 256, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+    const int gy = (((M + 127) / 128) + 7) & ~7;
+    const int nb = N % 256 == 0 ? 2 : 1;
+    const int per_xcd = N / (128 * nb) * gy / 8;                 // output tiles per XCD
+    const dim3 grid(8 * (per_xcd < 32 ? per_xcd : 32));          // persistent: one workgroup per CU, 32 CUs per XCD
+    if (nb == 2) {
+        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, true, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        else hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, false, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
     } else {
-        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, true, KO>), dim3(N / 128, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
-        else hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, false, KO>), dim3(N / 128, gy), dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, true, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        else hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, false, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
     }
     CN_CHECK_LAUNCH();
     return CN_OK;
