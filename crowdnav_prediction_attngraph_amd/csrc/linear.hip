@@ -370,7 +370,7 @@ extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const
 }
 
 // shapes the pipelined TN kernel takes: whole 128-column tiles of dY, enough rows to fill the machine
-static bool wgrad_pipelined(int M, int N, int K) { return N % 128 == 0 && K % 128 == 0 && M >= 65536; }
+static bool wgrad_pipelined(int M, int N, int K) { return N % 128 == 0 && K % 128 == 0 && M >= 32768; }
 
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {

@@ -167,6 +167,8 @@ class AttnGraphBase(nn.Module):
         matrix) goes to the split-K TN kernel, everything else stays a library product."""
         if x.is_cuda and self.train_gemm_mode == "bf16x3":
             from . import hip
+            if hip.linear_supported(x, w) and x.shape[0] >= 16384:
+                return hip.HipLinear.apply(x, w, b, False)   # [128 a, 128 b] weights: forward, dX and dW on the pipelined bf16x3 kernels
             if hip.wgrad_supported(x, w):
                 return hip.WgradLinear.apply(x, w, b)
         return F.linear(x, w, b)
