@@ -183,14 +183,26 @@ __global__ __launch_bounds__(256) void hh_attention_kernel(int E, int cap_lo, co
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     if (lane < nd) {
+        // whole row in registers (16-byte reads, all issued before the first use): as loops over the run-time nd, every LDS read
+        // waited for the one before it.  Entries past nd hold stale scores of earlier units: masked here, stored as zeros.
         float *row = S + lane * CAP;
+        float p[CAP];
+#pragma unroll
+        for (int j4 = 0; j4 < CAP / 4; ++j4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(row + 4 * j4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[4 * j4 + u] = a[u];
+        }
         float mx = -INFINITY;
-        for (int j = 0; j < nd; ++j) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) mx = j < nd ? fmaxf(mx, p[j]) : mx;
         float sum = 0.0f;
-        for (int j = 0; j < nd; ++j) { const float p = expf(row[j] - mx); row[j] = p; sum += p; }
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) { p[j] = j < nd ? expf(p[j] - mx) : 0.0f; sum += p[j]; }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < nd; ++j) row[j] *= inv;
-        for (int j = nd; j < CAP; ++j) row[j] = 0.0f;
+#pragma unroll
+        for (int j4 = 0; j4 < CAP / 4; ++j4)
+            *reinterpret_cast<f32x4 *>(row + 4 * j4) = f32x4{p[4 * j4] * inv, p[4 * j4 + 1] * inv, p[4 * j4 + 2] * inv, p[4 * j4 + 3] * inv};
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -259,9 +271,14 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int n_units = (cls_list ? *cls_cnt : B) * 8;
-    float *Qs = smem + (size_t)wave * (4 * CAP * RS + 2 * CAP * CAP);
+    constexpr bool REG = CAP <= 32; // softmax rows and the K / Q / dO columns in registers, see below
+    float *Qs = smem + (size_t)wave * (4 * CAP * RS + (REG ? 4 : 2) * CAP * CAP);
     float *Ks = Qs + CAP * RS, *Vs = Ks + CAP * RS, *Gs = Vs + CAP * RS; // Gs = dO rows
     float *P = Gs + CAP * RS, *dS = P + CAP * CAP;
+    float *PT = dS + CAP * CAP, *dST = PT + CAP * CAP; // (REG only) transposed copies: dK and dV walk columns of dS and P
+    if (REG) { // rows at or past nd are read (with zero weights) by the unrolled loops below: they must hold finite numbers
+        for (int x = lane; x < 4 * CAP * RS; x += 64) Qs[x] = 0.0f;
+    }
     // A wavefront walks ~240 units, and a unit starts with three DEPENDENT memory round trips (class list -> row offsets -> rows)
     // before any arithmetic.  For the small classes (4 CAP registers) the walk is a three-stage pipeline instead: while unit u is
     // computed, the rows of unit u+1, the row offsets of unit u+2 and the sample id of unit u+3 are in flight.
@@ -313,6 +330,10 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
                 Qs[j * RS + lane] = q; Ks[j * RS + lane] = k; Vs[j * RS + lane] = v; Gs[j * RS + lane] = g;
             }
         }
+        if (REG) { // entries outside nd x nd stay zero for this unit
+#pragma unroll
+            for (int x = 0; x < 4 * CAP * CAP; x += 64) P[x + lane] = 0.0f;
+        }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int npairs = nd * nd;
@@ -332,6 +353,54 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        float *ob = d_qkv + (size_t)r0 * 1536 + head * 64 + lane;
+        if (REG) {
+            // The loops over nd below have run-time bounds: left as loops, every LDS read waits for the one before it (a (sample,
+            // head) unit cost ~nd^2 serial LDS round trips).  Here they run to the compile-time CAP on whole rows in registers
+            // (16-byte reads, all issued before the first use); entries past nd are zeros, so they add nothing.
+            if (lane < nd) {
+                float p[CAP], d[CAP];
+#pragma unroll
+                for (int j4 = 0; j4 < CAP / 4; ++j4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(P + lane * CAP + 4 * j4), b = *reinterpret_cast<const f32x4 *>(dS + lane * CAP + 4 * j4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { p[4 * j4 + u] = a[u]; d[4 * j4 + u] = b[u]; }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) mx = j < nd ? fmaxf(mx, p[j]) : mx;
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) { p[j] = j < nd ? expf(p[j] - mx) : 0.0f; sum += p[j]; }
+                const float inv = 1.0f / sum;
+                float rd = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) { p[j] *= inv; rd += d[j] * p[j]; }
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) d[j] = scale * p[j] * (d[j] - rd);
+#pragma unroll
+                for (int j4 = 0; j4 < CAP / 4; ++j4)
+                    *reinterpret_cast<f32x4 *>(dS + lane * CAP + 4 * j4) = f32x4{d[4 * j4], d[4 * j4 + 1], d[4 * j4 + 2], d[4 * j4 + 3]};
+#pragma unroll
+                for (int j = 0; j < CAP; ++j) { PT[j * CAP + lane] = p[j]; dST[j * CAP + lane] = d[j]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            float kr[CAP], qr[CAP], gr[CAP]; // column `lane` of K, Q, dO
+#pragma unroll
+            for (int i = 0; i < CAP; ++i) { kr[i] = Ks[i * RS + lane]; qr[i] = Qs[i * RS + lane]; gr[i] = Gs[i * RS + lane]; }
+            for (int j = 0; j < nd; ++j) {
+                float dq = 0.0f, dk = 0.0f, dv = 0.0f; // row j of dQ, dK, dV, column `lane`
+#pragma unroll
+                for (int i4 = 0; i4 < CAP / 4; ++i4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(dS + j * CAP + 4 * i4), b = *reinterpret_cast<const f32x4 *>(dST + j * CAP + 4 * i4);
+                    const f32x4 c = *reinterpret_cast<const f32x4 *>(PT + j * CAP + 4 * i4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { dq += a[u] * kr[4 * i4 + u]; dk += b[u] * qr[4 * i4 + u]; dv += c[u] * gr[4 * i4 + u]; }
+                }
+                ob[(size_t)j * 1536] = dq; ob[(size_t)j * 1536 + 512] = dk; ob[(size_t)j * 1536 + 1024] = dv;
+            }
+        } else {
         if (lane < nd) {
             float *prow = P + lane * CAP, *drow = dS + lane * CAP;
             float mx = -INFINITY;
@@ -345,7 +414,6 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        float *ob = d_qkv + (size_t)r0 * 1536 + head * 64 + lane;
         for (int j = 0; j < nd; ++j) {
             float dq = 0.0f, dk = 0.0f, dv = 0.0f; // row j of dQ, dK, dV, column `lane`
             for (int i = 0; i < nd; ++i) {
@@ -355,6 +423,7 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
             }
             ob[(size_t)j * 1536] = dq; ob[(size_t)j * 1536 + 512] = dk; ob[(size_t)j * 1536 + 1024] = dv;
         }
+        }
         __builtin_amdgcn_wave_barrier(); // the next unit reuses this wavefront's LDS slices
     }
 }
@@ -363,7 +432,7 @@ template <int CAP>
 static int launch_hh_attention_bwd(int B, const float *qkv, const int *row_off, const int *cls, int c, const float *d_out, float *d_qkv, float scale,
                                    hipStream_t st)
 {
-    const size_t per_wave = (size_t)(4 * CAP * 68 + 2 * CAP * CAP) * sizeof(float);
+    const size_t per_wave = (size_t)(4 * CAP * 68 + (CAP <= 32 ? 4 : 2) * CAP * CAP) * sizeof(float);
     int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
     int per_cu = (int)((160 * 1024) / (per_wave * wpb)); per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     int blocks = (B * 8 + wpb - 1) / wpb;
