@@ -374,8 +374,10 @@ class GRUSequence(torch.autograd.Function):
         dh0 = torch.empty(N, 128, device=hms.device)
         A.check(A.lib().cn_gru_seq_bwd(T, N, A.ptr(gates), A.ptr(hms), A.ptr(m), A.ptr(w), A.ptr(d_hs), A.ptr(dgi), A.ptr(dgh), A.ptr(dh0), A.stream_ptr()),
                 "cn_gru_seq_bwd")
-        dgh2 = dgh.view(T * N, 384)
-        return dgi, dh0, None, dgh2.t() @ hms.view(T * N, 128), dgh2.sum(0)
+        # d(W_hh) = d(gh)^T hms and d(b_hh) = column sums of d(gh): a reduction over all T*N rows into a 384 x 128 matrix, which the
+        # library product leaves on a dozen workgroups (287 us) -- the split-K weight-gradient kernel does both in one pass
+        dw, db = wgrad(dgh.view(T * N, 384), hms.view(T * N, 128))
+        return dgi, dh0, None, dw, db
 
 
 def split_bf16(w, transpose=False):
@@ -419,6 +421,40 @@ class Embed0(torch.autograd.Function):
         dwb = torch.empty(128, D + 1, device=x.device)
         A.check(A.lib().cn_embed0_bwd(R, D, A.ptr(x), A.ptr(y), A.ptr(dy.contiguous()), blocks, A.ptr(part), A.ptr(dwb), A.stream_ptr()), "cn_embed0_bwd")
         return None, dwb[:, :D].contiguous(), dwb[:, D].contiguous()
+
+
+def wgrad(dy, x):
+    """(dy^T x [N,K], column sums of dy [N]) over all M rows on the split-K TN kernel (cn_linear_wgrad); N % 64 == 0, K % 128 == 0."""
+    dy, x = dy.contiguous(), x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    splits = A.lib().cn_linear_wgrad_splits(M, N, K)
+    if splits <= 0:
+        return dy.t() @ x, dy.sum(0)
+    part = torch.empty(splits, N, K, device=x.device)
+    dbp = torch.empty(splits, N, device=x.device)
+    dw = torch.empty(N, K, device=x.device)
+    db = torch.empty(N, device=x.device)
+    A.check(A.lib().cn_linear_wgrad(M, N, K, A.ptr(dy), N, None, A.ptr(x), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()),
+            "cn_linear_wgrad")
+    return dw, db
+
+
+class RightMatmul(torch.autograd.Function):
+    """t @ w for a tall t [M,N] and a small w [N,K]: the weight gradient t^T d(out) (a reduction over all M rows) on the split-K
+    TN kernel; forward and d(t) are ordinary library products."""
+
+    @staticmethod
+    def forward(ctx, t, w):
+        ctx.save_for_backward(t, w)
+        return t @ w
+
+    @staticmethod
+    def backward(ctx, du):
+        t, w = ctx.saved_tensors
+        dt = du @ w.t() if ctx.needs_input_grad[0] else None
+        dw = wgrad(t, du)[0] if ctx.needs_input_grad[1] else None
+        return dt, dw
 
 
 def wgrad_supported(x, w):

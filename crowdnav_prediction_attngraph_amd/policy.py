@@ -54,6 +54,15 @@ def _arg(args, name, default):
     return getattr(args, name, default)
 
 
+def _skinny_linear(x, w, b):
+    """nn.Linear with one or two output columns over tens of thousands of rows (critic_linear, dist.fc_mean in the update).  On the GPU
+    the library runs these skinny products, and above all their weight gradients, on a handful of workgroups (0.1-0.2 ms each); as
+    row-wise multiply + reduce they are memory-bound passes over x, and autograd's backward of them is too."""
+    if x.is_cuda and x.dim() == 2 and w.shape[0] <= 4 and x.shape[0] >= 4096:
+        return torch.stack([(x * w[n]).sum(-1) for n in range(w.shape[0])], -1) + b
+    return F.linear(x, w, b)
+
+
 def _ortho(module, gain=1.0):
     nn.init.orthogonal_(module.weight.data, gain=gain)
     nn.init.constant_(module.bias.data, 0)
@@ -264,7 +273,9 @@ class AttnGraphBase(nn.Module):
             from .hip import HRAttention
             sl = self.attn.spatial_edge_layer[0]
             tl = self.attn.temporal_edge_layer[0]
-            u = self._lin(robot_states, tl.weight, tl.bias) @ sl.weight + 0.0 * sl.bias.sum()
+            from .hip import RightMatmul
+            t_emb = self._lin(robot_states, tl.weight, tl.bias)
+            u = (RightMatmul.apply(t_emb, sl.weight) if t_emb.shape[0] >= 4096 else t_emb @ sl.weight) + 0.0 * sl.bias.sum()
             hr = HRAttention.apply(u, out_sp, valid, self.human_num)
         else:
             hr, _ = self._hr_attention(robot_states, out_sp, valid)
@@ -285,7 +296,7 @@ class AttnGraphBase(nn.Module):
                 hs.append(h)
             hs_all = torch.stack(hs, 0)
         out = self._lin(hs_all.view(B, -1), rnn.output_linear.weight, rnn.output_linear.bias)
-        value = self.critic_linear(self._mlp2(self.critic, out))
+        value = _skinny_linear(self._mlp2(self.critic, out), self.critic_linear.weight, self.critic_linear.bias)
         return value, self._mlp2(self.actor, out), h
 
 
@@ -387,7 +398,7 @@ class Policy(nn.Module):
         N = rnn_hxs["human_node_rnn"].shape[0]
         T = B // N
         value, feat, h = self.base.forward_sequence(inputs, rnn_hxs["human_node_rnn"], masks, T, N)
-        mean = self.dist.fc_mean(feat)
+        mean = _skinny_linear(feat, self.dist.fc_mean.weight, self.dist.fc_mean.bias)
         logstd = self.dist.logstd(torch.zeros_like(mean))
         logp = self._log_prob(mean, logstd.exp(), action)
         entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).mean()   # FixedNormal.entropy().mean(): over batch and dims
