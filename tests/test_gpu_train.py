@@ -311,3 +311,41 @@ def test_gru_sequence_kernels_match_torch_autograd(T, N):
                             (w_g.grad, w_r.grad, "d_Whh"), (b_g.grad, b_r.grad, "d_bhh")):
         err = float((got.cpu().double() - want).abs().max())
         assert err <= 2e-5 * max(float(want.abs().max()), 1.0), (what, err, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+def test_skinny_products_of_the_update_match_fp64():
+    """The update's replacements for library products that reduce tens of thousands of rows into a tiny matrix: RightMatmul (t @ w with
+    the weight gradient on the split-K kernel) and _skinny_linear (one / two output columns as multiply + reduce), values and gradients
+    against fp64."""
+    from crowdnav_prediction_attngraph_amd import hip, policy
+    g = torch.Generator().manual_seed(5)
+    M = 5000
+    t, w, du = torch.randn(M, 64, generator=g), torch.randn(64, 256, generator=g) * 0.1, torch.randn(M, 256, generator=g)
+    tg, wg = t.cuda().requires_grad_(), w.cuda().requires_grad_()
+    u = hip.RightMatmul.apply(tg, wg)
+    u.backward(du.cuda())
+    tr, wr = t.double().requires_grad_(), w.double().requires_grad_()
+    (tr @ wr).backward(du.double())
+
+    def close(a, ref, what, tol=1e-4):
+        ref = ref.float()
+        err = float((a.detach().cpu() - ref).abs().max())
+        assert err <= tol * max(float(ref.abs().max()), 1e-3), (what, err, float(ref.abs().max()))
+
+    close(u, (tr @ wr).detach(), "u")
+    close(tg.grad, tr.grad, "dt")
+    close(wg.grad, wr.grad, "dw")
+    for n_out in (1, 2):
+        x, w2, b2, dy = torch.randn(M, 256, generator=g), torch.randn(n_out, 256, generator=g) * 0.1, torch.randn(n_out, generator=g), torch.randn(M, n_out, generator=g)
+        xg, w2g, b2g = x.cuda().requires_grad_(), w2.cuda().requires_grad_(), b2.cuda().requires_grad_()
+        y = policy._skinny_linear(xg, w2g, b2g)
+        assert y.shape == (M, n_out)
+        y.backward(dy.cuda())
+        xr, w2r, b2r = x.double().requires_grad_(), w2.double().requires_grad_(), b2.double().requires_grad_()
+        yr = torch.nn.functional.linear(xr, w2r, b2r)
+        yr.backward(dy.double())
+        close(y, yr.detach(), "y%d" % n_out, 1e-5)
+        close(xg.grad, xr.grad, "dx%d" % n_out, 1e-5)
+        close(w2g.grad, w2r.grad, "dw%d" % n_out, 1e-5)
+        close(b2g.grad, b2r.grad, "db%d" % n_out, 1e-5)
