@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path of BASELINE.json on MI355X: env-steps/s of (policy forward -> crowd_sim step) at 20 humans.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E]        (N > 1 without a launcher: re-executes itself under
+                                                                            torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the whole batch: the attention-graph policy's forward on the current
@@ -138,14 +139,26 @@ def main():
                          "as separate launches (round-1 path); 'fp32' = exact fp32 MFMA, separate launches")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) under torch.distributed.run on this node
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the line would not describe the run" % (args.gpus, world))
+    if not args.same_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d device(s) visible (one rank per GPU; --same-gpu is a plumbing test only)" % (world, torch.cuda.device_count()))
     dev_index = 0 if args.same_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
@@ -232,7 +245,15 @@ def main():
     elapsed = time.perf_counter() - t0
     pol.set_profiling(False)
     prof_ms, prof_n = pol.get_profile()
-    it += args.steps + (args.steps & 1)
+    it += args.steps            # the hxs / masks ping-pong follows the step index: advance by exactly the steps taken
+    per_rank = None
+    if dist is not None:
+        tdev0 = "cuda" if args.dist_backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed], device=tdev0, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [round(E * args.steps / float(x.item()), 1) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)    # max over ranks
     worst = None
     if not args.no_worst_case and rank == 0:
         force_all_detected[0] = True
@@ -249,10 +270,6 @@ def main():
         worst = {"value": round(E * args.steps / tw, 1), "unit": "env-steps/s (this rank)", "ms_per_step": round(tw / args.steps * 1e3, 4), "mean_detected_humans": float(H),
                  "note": "second timed window, same steps: every env reports all %d humans detected (%d live rows instead of the natural count) -- "
                          "the upper bound of the state-dependent human-human work" % (H, E * H)}
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda" if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     # second half of BASELINE.json's metric: PPO samples/sec = T * E_total / wall time of (rollout + GAE + update), the
     # reference's train.py loop (rl/ppo.py defaults: T = 30, 5 epochs x 2 recurrent minibatches); every rank runs it,
     # gradients are all-reduced once per optimiser step (one flat bucket), time = max over ranks of the last update
@@ -312,14 +329,25 @@ def main():
     kname = ("hh_fused_kernel (v_mfma_f32_16x16x32_bf16, 3 passes hi*hi+hi*lo+lo*hi): embedding -> q|k|v -> attention -> out_proj∘spatial_linear in one launch" if fused else
              "gemm3_nt_kernel<128,NONE> (v_mfma_f32_32x32x16_bf16, 3 passes hi*hi+hi*lo+lo*hi): folded q|k|v projection" if split
              else "gemm_nt_kernel<128,NONE> (v_mfma_f32_32x32x2_f32): folded q|k|v projection")
-    # HBM traffic of the dominant kernel comes from the committed PMC passes (bench.py cannot run rocprofv3 on itself)
+    # HBM traffic of the dominant kernel: bench.py cannot run rocprofv3 on itself, so the number comes from the committed PMC passes of
+    # the same command (tools/profile_step.sh -> tools/mk_traffic.py) -- but only while their stamp (sha256 of csrc/hh_fused.hip at the
+    # time of the measurement) matches the kernel source of this build; a stale constant is reported as null with the reason
     traffic = None
     traffic_note = None
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if fused else "r01_pmc_traffic.json")
-    if args.gemm in ("fused", "bf16x3") and (args.env_name, E, H, args.randomized) == ("CrowdSimVarNum-v0", 4096, 20, False) and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        traffic = tj["hbm_bytes_per_launch_corrected"]
-        traffic_note = "traffic is NOT measured in this run: it is the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE result of the same command (%s)" % os.path.basename(tpath)
+    if fused and (args.env_name, E, H, args.randomized) == ("CrowdSimVarNum-v0", 4096, 20, False):
+        import glob
+        import hashlib
+        src = os.path.join(ROOT, "crowdnav_prediction_attngraph_amd", "csrc", "hh_fused.hip")
+        stamp = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] if os.path.exists(src) else None
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        tj = json.load(open(cands[-1])) if cands else None
+        if tj is not None and stamp is not None and tj.get("kernel_source_sha16") == stamp:
+            traffic = tj["hbm_bytes_per_launch_corrected"]
+            traffic_note = ("not measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same command on the same kernel "
+                            "source (%s, stamp %s; %.2fx the algorithmic bytes)" % (os.path.basename(cands[-1]), stamp, tj["ratio"]))
+        else:
+            traffic_note = ("null: the newest committed PMC result (%s) was measured on a different hh_fused.hip (stamp %s, this build %s)"
+                            % (os.path.basename(cands[-1]) if cands else "none", tj.get("kernel_source_sha16") if tj else None, stamp))
     line = {
         "metric": "env-steps/sec (sim+policy fwd) at %d humans" % H, "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -344,6 +372,8 @@ def main():
                                             "(padded humans are not computed and affine pairs are folded)"}},
     }
     line["config"]["dephase_steps"] = args.dephase
+    if per_rank is not None:
+        line["per_rank_env_steps_per_s"] = per_rank     # each rank's own clock over the same K steps (value uses the slowest)
     if worst is not None:
         line["worst_case_all_detected"] = worst
     if ppo is not None:

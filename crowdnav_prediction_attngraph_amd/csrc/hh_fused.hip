@@ -28,21 +28,25 @@
 //     registers, and S^T (keys in the C layout rows) is exactly the P fragment of the same product.
 //   * LDS holds fragments in fragment-major order [plane][k-step][row block][lane][16 B]: every ds_read_b128 / ds_write_b64 /
 //     ds_write_b128 is lane-linear, hence bank-conflict free by construction.
+//
+// Two kernels share this file:
+//   hh_fused_kernel       (crowds of <= 48 humans, the default): 8 wavefronts = TWO TEAMS of four, two wavefronts per SIMD.  The tile is
+//       48 rows (X = 96 KB) which leaves room for one 24 KB scratch region PER TEAM; after the embedding phases the teams walk
+//       ALTERNATE HEADS on their own (team-local barriers on LDS counters, s_barrier only between tile phases), so that on every
+//       SIMD the barrier / LDS / softmax phases of one head sit beside the q.k.v MFMA loop of another head instead of running with
+//       nothing to overlap.  The teams' partial out_sp accumulators are exchanged through the (dead) X region at the end of the tile.
+//   hh_fused_wide_kernel  (crowds of 49..64 humans: an env must fit one tile): the round-2 schedule, 4 wavefronts, 64-row tiles.
 #include "hh_fused.h"
 
 #include <climits>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int FR = 64;                  // rows per tile (4 row blocks of 16)
-constexpr int LDS_X = 0;                // [plane 2][kx 16][rb 4][lane 64][16 B]  = 128 KB
-constexpr int LDS_S = 131072;           // scratch: two halves of 16 KB, [plane 2][ks 2][rb 4][lane 64][16 B] each
-constexpr int LDS_H0 = LDS_S, LDS_H1 = LDS_S + 16384;
-constexpr int LDS_BYTES = 163840;
 
 // weight fragments are read once per tile by exactly one wavefront: stream them past the vector L1
 __device__ __forceinline__ bf16x8 ldw(const char *p)
@@ -54,6 +58,12 @@ __device__ __forceinline__ bf16x8 ldw(const char *p)
 #endif
 }
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): an unrolled loop whose index is a constant expression
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct Split8 { bf16x8 hi, lo; };
 __device__ __forceinline__ void split1(float x, __bf16 &hi, __bf16 &lo)
@@ -115,6 +125,14 @@ struct TileCtx {
     int my_env, my_start;       // lane l <-> row l of the tile: env index inside the tile (-1 beyond nrows), its first row
     int tile_ord;
 };
+
+// ===================================================== wide kernel: 4 wavefronts, 64-row tiles (49..64 humans) ====================
+namespace wide {
+constexpr int FR = 64;                  // rows per tile (4 row blocks of 16)
+constexpr int LDS_X = 0;                // [plane 2][kx 16][rb 4][lane 64][16 B]  = 128 KB
+constexpr int LDS_S = 131072;           // scratch: two halves of 16 KB, [plane 2][ks 2][rb 4][lane 64][16 B] each
+constexpr int LDS_H0 = LDS_S, LDS_H1 = LDS_S + 16384;
+constexpr int LDS_BYTES = 163840;
 
 template <int NRB>
 __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const float *__restrict__ se, const HhFusedWeights &W,
@@ -532,47 +550,94 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     }
 #endif
 }
+} // namespace wide
 
-__global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
-                                                          int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
+// Row compaction fused into the launch: row_off[e] = sum_{e' < e} clamp(detected_human_num[e'], 1, H).  EVERY workgroup
+// computes the whole prefix sum (E values: a few microseconds next to ~150) and writes the whole array -- all workgroups
+// write identical values, so nobody has to wait for anybody, and the separate 16 us single-wavefront launch (plus its
+// launch gap) is gone from the critical path.  The robot-node kernel behind this one reads the same array.
+template <int NT> // threads of the workgroup
+__device__ __forceinline__ void row_offsets_prologue(int E, int H, const float *__restrict__ det, int *row_off, unsigned long long *live_total, char *lds)
+{
+    constexpr int NW = NT / 64;
+    int *part = reinterpret_cast<int *>(lds);
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    const int chunk = (E + NT - 1) / NT;
+    const int lo = tid * chunk < E ? tid * chunk : E, hi = lo + chunk < E ? lo + chunk : E;
+    int sum = 0;
+    for (int e = lo; e < hi; ++e) { int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd); sum += nd; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (ln >= o) incl += v;
+    }
+    if (ln == 63) part[wv] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wv; ++w) run += part[w];
+    for (int e = lo; e < hi; ++e) {
+        row_off[e] = run;
+        int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
+        run += nd;
+    }
+    if (tid == NT - 1) {
+        row_off[E] = run;
+        if (live_total && blockIdx.x == 0) *live_total += (unsigned long long)run; // measurement aid: live rows over the profiled launches
+    }
+    (void)NW;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The next tile of a workgroup's chunk [e, e_end): whole envs, at most FR rows (every env has 1..H <= FR rows); the rows left in the
+// chunk are split evenly over the tiles they need, because a tile's cost is dominated by terms that do not shrink with its row count
+// (weight stream, barriers).  Wave-uniform; every lane of the calling wavefront must be active.
+template <int FR>
+__device__ __forceinline__ TileCtx next_tile(const int *row_off, int e, int e_end, int chunk_end_row, int tile_ord, int lane)
+{
+    TileCtx t;
+    t.tile_ord = tile_ord;
+    t.e_lo = e;
+    t.r0 = ld_ro(row_off + e);
+    const int probe = e + 1 + lane;
+    const int v = probe <= e_end ? ld_ro(row_off + probe) : INT_MAX;
+    const int left = chunk_end_row - t.r0;
+    const int ntile = (left + FR - 1) / FR;
+    int want = (left + ntile - 1) / ntile + 2; // small slack: prefer closing a tile just after the even split
+    want = want > FR ? FR : want;
+    // ... but never so early that the rest no longer fits the remaining ntile - 1 tiles: an extra tile for a handful of rows costs a
+    // whole pass over the weights, and the launch lasts as long as its slowest workgroup (measured: one such workgroup in most
+    // launches, +15 % on the kernel).  If the even split falls short of `lo` rows, one env more is taken when it still fits.
+    const int lo = left - FR * (ntile - 1);
+    const int n1 = __popcll(__ballot(v <= t.r0 + want));
+    const int p1 = n1 >= 1 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 - 1, 64)) - t.r0 : 0;
+    const int v2 = n1 < 64 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 < 64 ? n1 : 63, 64)) : INT_MAX; // INT_MAX beyond the chunk
+    int n_env = n1;
+    if ((n1 < 1 || p1 < lo) && v2 != INT_MAX && v2 - t.r0 <= FR) n_env = n1 + 1;
+    n_env = n_env < 1 ? 1 : n_env;             // one env always fits (H <= FR)
+    t.n_env = n_env;
+    t.nrows = __builtin_amdgcn_readfirstlane(__shfl(v, n_env - 1, 64)) - t.r0;
+    // row -> env map: lane k < n_env knows the start of env k, lane l then counts the starts <= l
+    // (the shuffle must run with every lane active: as part of the conditional below the compiler executes it under the
+    // narrowed EXEC mask and a ds_bpermute from an inactive lane returns 0)
+    const int prev_end = __shfl(v, lane >= 1 ? lane - 1 : 0, 64);
+    const int st = lane >= n_env ? INT_MAX : (lane == 0 ? 0 : prev_end - t.r0);
+    int cnt = 0;
+    for (int k = 0; k < n_env; ++k) cnt += lane >= __builtin_amdgcn_readlane(st, k) ? 1 : 0;
+    t.my_env = lane < t.nrows ? cnt - 1 : -1;
+    t.my_start = __shfl(st, cnt - 1 >= 0 ? cnt - 1 : 0, 64);
+    return t;
+}
+
+__global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
+                                                               int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (det) {
-        // Row compaction fused into this launch: row_off[e] = sum_{e' < e} clamp(detected_human_num[e'], 1, H).  EVERY workgroup
-        // computes the whole prefix sum (E values: a few microseconds next to ~200) and writes the whole array -- all workgroups
-        // write identical values, so nobody has to wait for anybody, and the separate 16 us single-wavefront launch (plus its
-        // launch gap) is gone from the critical path.  The robot-node kernel behind this one reads the same array.
-        int *part = reinterpret_cast<int *>(lds);
-        const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
-        const int chunk = (E + 255) >> 8;
-        const int lo = tid * chunk < E ? tid * chunk : E, hi = lo + chunk < E ? lo + chunk : E;
-        int sum = 0;
-        for (int e = lo; e < hi; ++e) { int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd); sum += nd; }
-        int incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (ln >= o) incl += v;
-        }
-        if (ln == 63) part[wv] = incl;
-        __syncthreads();
-        int run = incl - sum;
-        for (int w = 0; w < wv; ++w) run += part[w];
-        for (int e = lo; e < hi; ++e) {
-            row_off[e] = run;
-            int nd = (int)det[e]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
-            run += nd;
-        }
-        if (tid == 255) {
-            row_off[E] = run;
-            if (live_total && blockIdx.x == 0) *live_total += (unsigned long long)run; // measurement aid: live rows over the profiled launches
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
+    if (det) row_offsets_prologue<256>(E, H, det, row_off, live_total, lds);
     // this kernel is the critical path of the step; the simulator's ORCA wavefronts of the side stream share the SIMDs with it and
-    // are latency tolerant (81 920 short wavefronts): win the issue arbitration against them
+    // are latency tolerant: win the issue arbitration against them
     if (W.prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total = ld_ro(row_off + E);
@@ -587,47 +652,601 @@ __global__ __launch_bounds__(256, 1) void hh_fused_kernel(int E, int H, int D, c
     int tile_ord = 0;
     const int chunk_end_row = ld_ro(row_off + e_end);
     while (e < e_end) {
-        TileCtx t;
-        t.tile_ord = tile_ord++;
-        t.e_lo = e;
-        t.r0 = ld_ro(row_off + e);
-        // whole envs, at most FR rows (every env has 1..H <= 64 rows); the rows left in the chunk are split evenly over the tiles
-        // they need, because a tile's cost is dominated by terms that do not shrink with its row count (weight stream, barriers)
-        const int probe = e + 1 + lane;
-        const int v = probe <= e_end ? ld_ro(row_off + probe) : INT_MAX;
-        const int left = chunk_end_row - t.r0;
-        const int ntile = (left + FR - 1) / FR;
-        int want = (left + ntile - 1) / ntile + 2; // small slack: prefer closing a tile just after the even split
-        want = want > FR ? FR : want;
-        // ... but never so early that the rest no longer fits the remaining ntile - 1 tiles: an extra tile for a handful of rows costs a
-        // whole pass over the weights, and the launch lasts as long as its slowest workgroup (measured: one such workgroup in most
-        // launches, +15 % on the kernel).  If the even split falls short of `lo` rows, one env more is taken when it still fits.
-        const int lo = left - FR * (ntile - 1);
-        const int n1 = __popcll(__ballot(v <= t.r0 + want));
-        const int p1 = n1 >= 1 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 - 1, 64)) - t.r0 : 0;
-        const int v2 = n1 < 64 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 < 64 ? n1 : 63, 64)) : INT_MAX; // INT_MAX beyond the chunk
-        int n_env = n1;
-        if ((n1 < 1 || p1 < lo) && v2 != INT_MAX && v2 - t.r0 <= FR) n_env = n1 + 1;
-        n_env = n_env < 1 ? 1 : n_env;             // one env always fits (H <= FR)
-        t.n_env = n_env;
-        t.nrows = __builtin_amdgcn_readfirstlane(__shfl(v, n_env - 1, 64)) - t.r0;
-        // row -> env map: lane k < n_env knows the start of env k, lane l then counts the starts <= l
-        // (the shuffle must run with every lane active: as part of the conditional below the compiler executes it under the
-        // narrowed EXEC mask and a ds_bpermute from an inactive lane returns 0)
-        const int prev_end = __shfl(v, lane >= 1 ? lane - 1 : 0, 64);
-        const int st = lane >= n_env ? INT_MAX : (lane == 0 ? 0 : prev_end - t.r0);
-        int cnt = 0;
-        for (int k = 0; k < n_env; ++k) cnt += lane >= __builtin_amdgcn_readlane(st, k) ? 1 : 0;
-        t.my_env = lane < t.nrows ? cnt - 1 : -1;
-        t.my_start = __shfl(st, cnt - 1 >= 0 ? cnt - 1 : 0, 64);
+        const TileCtx t = next_tile<wide::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
         const int nrb = (t.nrows + 15) >> 4;
         switch (nrb) {
-        case 1: tile_body<1>(t, H, D, se, W, out_sp, lds, lane, wave); break;
-        case 2: tile_body<2>(t, H, D, se, W, out_sp, lds, lane, wave); break;
-        case 3: tile_body<3>(t, H, D, se, W, out_sp, lds, lane, wave); break;
-        default: tile_body<4>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        case 1: wide::tile_body<1>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        case 2: wide::tile_body<2>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        case 3: wide::tile_body<3>(t, H, D, se, W, out_sp, lds, lane, wave); break;
+        default: wide::tile_body<4>(t, H, D, se, W, out_sp, lds, lane, wave); break;
         }
-        e += n_env;
+        e += t.n_env;
+    }
+}
+
+// ===================================================== two-team kernel: 8 wavefronts, 63-row tiles (<= 48 humans) =====================
+#ifndef HH_SPIN_SLEEP
+#define HH_SPIN_SLEEP 1
+#endif
+#ifndef HH_PRIO_QKV
+#define HH_PRIO_QKV 1
+#endif
+namespace team {
+
+constexpr int FR = 63;                       // rows per tile: 4 row blocks of 16, the last row of the last block is never live (see LDS_CTR)
+constexpr int RB = 4;                        // row-block stride of every LDS image
+constexpr int X_PLANE = 16 * RB * 1024;      // X: [plane 2][kx 16][rb 4][lane 64][16 B] = 128 KB
+constexpr int LDS_X = 0;
+constexpr int LDS_S = 2 * X_PLANE;           // ONE scratch region of 32 KB, used by the teams in turns (and by the e0 fragments of a tile):
+constexpr int H_PLANE = 2 * RB * 1024;       //   H0 (Q, then P) and H1 (K, then O), [plane 2][ks 2][rb 4][lane 64][16 B] = 16 KB each
+constexpr int H_BYTES = 2 * H_PLANE;
+constexpr int E0_PLANE = 4 * RB * 1024;      // e0: [plane 2][ks 4][rb 4][lane 64][16 B] = 32 KB
+constexpr int LDS_BYTES = LDS_S + 2 * H_BYTES; // = 163840: all of the CU's LDS
+constexpr int XCH_TEAM = 4 * 2 * RB * 1024;  // accumulator exchange at the end of a tile: [wave 4][jj 2][rb 4][lane 64][16 B] = 32 KB per team, over X
+// The synchronisation counters need 12 bytes and the images above fill the LDS to the last byte.  They live in the fragment slot of the
+// one (row, k) position that can never matter: plane lo, X k-step 15, row block 3, lane 63 = row 63 of the tile, k 24..31 -- a tile holds
+// at most 63 rows, so row 63 is always padding.  Nobody else writes the slot (the X epilogue skips it); whoever reads it as an X fragment
+// sees small integers = tiny finite bf16 values, which only ever reach the (discarded) outputs of the padded row.
+constexpr int LDS_CTR = LDS_X + X_PLANE + (15 * RB + 3) * 1024 + 63 * 16; // +0 / +4: team barrier counters, +8: finished scratch turns x 4
+static_assert(LDS_BYTES == 163840, "the layout is sized for the whole LDS");
+
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+// Weight fragments come in through buffer loads: (resource in SGPRs) + (wave-uniform byte offset in an SGPR) + (lane offset, ONE VGPR
+// for every stream of the kernel).  With flat addressing the compiler hoists a 64-bit VGPR address pair per fragment out of the tile
+// loop and spills them at 256 registers.  One resource spans the three fragment images (they are carved from one allocation).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct WeightBuf {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned emb2, qkv, os; // byte offsets of the three images inside the resource
+};
+__device__ __forceinline__ WeightBuf make_weight_buf(const HhFusedWeights &W)
+{
+    const char *a = (const char *)W.emb2_frag, *b = (const char *)W.qkv_frag, *c = (const char *)W.os_frag;
+    const char *lo = a < b ? a : b; lo = lo < c ? lo : c;
+    WeightBuf wb;
+    wb.rs = __builtin_amdgcn_make_buffer_rsrc((void *)lo, 0, 0x7fffffff, 0x00020000);
+    wb.emb2 = (unsigned)(a - lo); wb.qkv = (unsigned)(b - lo); wb.os = (unsigned)(c - lo);
+    return wb;
+}
+__device__ __forceinline__ bf16x8 ldb(const WeightBuf &wb, unsigned soff, unsigned voff)
+{
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wb.rs, voff, soff, 0));
+}
+
+// Barrier among the four wavefronts of ONE team (gfx950 has a single s_barrier per workgroup, which would couple the teams): a
+// monotonic LDS counter, every wavefront adds 1 and spins until the count reaches 4 x (barriers so far).  LDS operations of one
+// wavefront complete in order and lgkmcnt(0) has been waited for before the add, so whoever sees the count sees the data (and the
+// adder's own earlier LDS reads have returned: the write-after-read side).  The asm statements are compiler barriers as well.
+__device__ __forceinline__ void team_barrier(char *lds, int bar_off, unsigned &target, int lane)
+{
+    lds_u32 *ctr = (lds_u32 *)(lds + bar_off);
+    target += 4;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - target) < 0)
+        __builtin_amdgcn_s_sleep(HH_SPIN_SLEEP);
+    asm volatile("" ::: "memory");
+}
+
+// The scratch region is used in TURNS: turn n belongs to team n & 1 (heads alternate between the teams).  A wavefront may touch the scratch
+// in turn n once all 4 wavefronts of turn n - 1 have finished with it (which also covers its own team's turn n - 2: it replaces the
+// barrier before the Q / K exchange).  `done` counts finished (turn, wavefront) pairs.
+__device__ __forceinline__ void wait_turn(char *lds, unsigned turn)
+{
+    lds_u32 *done = (lds_u32 *)(lds + LDS_CTR + 8);
+    const unsigned need = 4u * turn;
+    while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - need) < 0)
+        __builtin_amdgcn_s_sleep(HH_SPIN_SLEEP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void finish_turn(char *lds, int lane)
+{
+    lds_u32 *done = (lds_u32 *)(lds + LDS_CTR + 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's last reads of the scratch have returned
+    if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// out_sp rows of feature blocks 4*wave + J0, 4*wave + J0 + 1: own partial sum + the other team's (from LDS) + bias, ReLU, streamed to HBM
+template <int NRB, int J0>
+__device__ __forceinline__ void finish_rows(const TileCtx &t, const f32x4 (&acc)[4][NRB], const char *xch, const HhFusedWeights &W,
+                                            float *__restrict__ out_sp, int lane, int wave)
+{
+    const int i = lane & 15, g = lane >> 4, loff = lane * 16;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int f0 = (4 * wave + J0 + jj) * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(W.os_b + f0);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const f32x4 other = *reinterpret_cast<const f32x4 *>(xch + ((wave * 2 + jj) * RB + rb) * 1024 + loff);
+            const int row = rb * 16 + i;
+            if (row < t.nrows) {
+                f32x4 v = acc[J0 + jj][rb] + other + b;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
+                // streamed past this XCD's L2: the reader (rn_fused) runs on other XCDs anyway, and the 24 MB of rows would push
+                // the 3.9 MB weight image, which every tile of every workgroup on the XCD re-reads, out of the 4 MB L2
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out_sp + (size_t)(t.r0 + row) * 256 + f0));
+            }
+        }
+    }
+}
+
+template <int NRB, int PF, bool XDB>
+__device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const float *__restrict__ se, const HhFusedWeights &W, const WeightBuf &WB,
+                                          float *__restrict__ out_sp, char *lds, int lane_in, int wave, int tm, unsigned &bar_target, unsigned turn_base)
+{
+    // Everything derived from the lane index is recomputed per tile: visible as loop invariant, the compiler hoists a few dozen
+    // per-lane addresses out of the tile loop and keeps them alive (spilled) across the whole kernel.
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+    const int loff = lane * 16;
+    const unsigned uoff = (unsigned)loff;
+    constexpr int NKS = (NRB + 1) / 2; // key k-steps of 32 rows
+    const int w8 = 4 * tm + wave;
+#ifdef HH_TIMING
+    long long tacc[16] = {0}, tlast = clock64();
+#endif
+
+    // ---------------- e0: relu(x W0^T + b0) for feature k-step `wave` (natural k order); team tm takes the row blocks of its parity ----------------
+    {
+        const int c0 = 32 * wave + 8 * g;
+#pragma unroll
+        for (int rr = 0; rr < (NRB + 1) / 2; ++rr) {
+            const int rb = 2 * rr + tm;
+            if (rb < NRB) {
+                int row = rb * 16 + i;
+                row = row < t.nrows ? row : t.nrows - 1; // padded rows repeat the last live row: finite values, masked later
+                const int env = __shfl(t.my_env, row, 64), st = __shfl(t.my_start, row, 64);
+                const float *xp = se + ((size_t)(t.e_lo + env) * H + (row - st)) * D;
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = W.emb0_b[c0 + u];
+                for (int d = 0; d < D; ++d) {
+                    const float xd = xp[d];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += xd * W.emb0_w[(c0 + u) * D + d];
+                }
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { __bf16 h, l; split1(fmaxf(v[u], 0.0f), h, l); hi[u] = h; lo[u] = l; }
+                *reinterpret_cast<bf16x8 *>(lds + LDS_S + (wave * RB + rb) * 1024 + loff) = hi;
+                *reinterpret_cast<bf16x8 *>(lds + LDS_S + E0_PLANE + (wave * RB + rb) * 1024 + loff) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    HH_T(0);
+    // ---------------- X = relu(e0 W2^T + b2): wavefront w8 of the 8 produces feature blocks 4*w8..4*w8+3 (X k-steps 2*w8, 2*w8+1) ----------------
+    {
+        const int wv = w8 >> 1, half = w8 & 1; // position in the baked image: [wave 4][ks 4][j 8 = half 2 x 4][plane 2]
+        const unsigned wp = WB.emb2 + (unsigned)wv * 4 * 16 * 1024;
+        f32x4 acc[4][NRB];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 wq[2][8]; // [slot][j*2 + plane]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wq[0][2 * j] = ldb(WB, wp + ((0 * 8 + half * 4 + j) * 2 + 0) * 1024, uoff);
+            wq[0][2 * j + 1] = ldb(WB, wp + ((0 * 8 + half * 4 + j) * 2 + 1) * 1024, uoff);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wq[(ks + 1) & 1][2 * j] = ldb(WB, wp + (((ks + 1) * 8 + half * 4 + j) * 2 + 0) * 1024, uoff);
+                    wq[(ks + 1) & 1][2 * j + 1] = ldb(WB, wp + (((ks + 1) * 8 + half * 4 + j) * 2 + 1) * 1024, uoff);
+                }
+            }
+            bf16x8 xh[NRB], xl[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                xh[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_S + (ks * RB + rb) * 1024 + loff);
+                xl[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_S + E0_PLANE + (ks * RB + rb) * 1024 + loff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 *w = wq[ks & 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = mfma(w[2 * j + 1], xh[rb], acc[j][rb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = mfma(w[2 * j], xl[rb], acc[j][rb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = mfma(w[2 * j], xh[rb], acc[j][rb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int fb0 = 4 * w8 + 2 * p;
+            const f32x4 ba = *reinterpret_cast<const f32x4 *>(W.emb2_b + fb0 * 16 + 4 * g);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(W.emb2_b + (fb0 + 1) * 16 + 4 * g);
+            const int kx = 2 * w8 + p;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                f32x4 a = acc[2 * p][rb] + ba, b = acc[2 * p + 1][rb] + bb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.0f); b[q] = fmaxf(b[q], 0.0f); }
+                const Split8 s = split8(a, b);
+                *reinterpret_cast<bf16x8 *>(lds + LDS_X + (kx * RB + rb) * 1024 + loff) = s.hi;
+                if (!(rb == 3 && kx == 15 && lane == 63)) // the synchronisation counters live in this slot (LDS_CTR)
+                    *reinterpret_cast<bf16x8 *>(lds + LDS_X + X_PLANE + (kx * RB + rb) * 1024 + loff) = s.lo;
+            }
+        }
+    }
+    __syncthreads(); // X complete; the e0 fragments (team 0's scratch) are dead
+    HH_T(1);
+
+    // env block mask of this lane's S^T entries: query = 16*wave + i, keys 16*jb + 4*g + r
+    unsigned vmask = 0;
+    {
+        const int q = 16 * wave + i;
+        const int eq = __shfl(t.my_env, q, 64);
+#pragma unroll
+        for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ek = __shfl(t.my_env, 16 * jb + 4 * g + r, 64);
+                if (ek == eq && eq >= 0) vmask |= 1u << (jb * 4 + r);
+            }
+    }
+
+    f32x4 acc_os[4][NRB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    char *const H0 = lds + LDS_S, *const H1 = H0 + H_BYTES;
+    const int bar = LDS_CTR + 4 * tm;
+    // Head order: team tm takes every second head; the starting head is staggered over the workgroups of an XCD (32 simultaneous
+    // readers of one weight line serialise on its L2 channel).  The sum over the heads is order independent up to fp32 rounding.
+    const int h0 = ((int)blockIdx.x >> 3) & 7;
+#pragma unroll 1
+    for (int hh = 0; hh < 4; ++hh) {
+        const int h = (h0 + 2 * hh + tm) & 7;
+        // ---------------- q|k|v feature block `wave` of head h for every row block: 16 k-steps over X ----------------
+        f32x4 aq[NRB], ak[NRB], av[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) { aq[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[rb] = aq[rb]; av[rb] = aq[rb]; }
+        const unsigned wp = WB.qkv + (unsigned)((h * 4 + wave) * 16) * 6 * 1024;
+        bf16x8 wf[PF][6]; // weight prefetch ring: steps ks .. ks+PF-1
+#pragma unroll
+        for (int p = 0; p < PF - 1; ++p)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) wf[p][c] = ldb(WB, wp + (p * 6 + c) * 1024, uoff);
+        constexpr int NXB = XDB ? 2 : 1;
+        bf16x8 xh[NXB][NRB], xl[NXB][NRB];
+        if (XDB) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                xh[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + rb * 1024 + loff);
+                xl[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + rb * 1024 + loff);
+            }
+        }
+        static_assert(16 % PF == 0, "the ring position must be compile-time inside the unrolled group");
+        // a group of PF k-steps; the last group is a separate instance whose prefetches end at compile time (a run-time test would
+        // cut the k-step into basic blocks and the loads could no longer be interleaved with the MFMAs)
+        auto group = [&](const int k4, auto tail_c) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        static_for<PF>([&](auto ku_c) __attribute__((always_inline)) {
+            constexpr int ku = decltype(ku_c)::value;
+            const int ks = k4 + ku;
+            {
+                // prefetch k-step ks + PF - 1 into the ring slot consumed last iteration.  The scheduling barrier pins the issue point:
+                // left alone, the scheduler sinks these loads next to their use.
+                if (!TAIL || ku == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) wf[(ku + PF - 1) % PF][c] = ldb(WB, wp + ((ks + PF - 1) * 6 + c) * 1024, uoff);
+                }
+                if (XDB) {
+                    if (!TAIL || ku + 1 < PF) {
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) {
+                            xh[(ku + 1) & (NXB - 1)][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + ((ks + 1) * RB + rb) * 1024 + loff);
+                            xl[(ku + 1) & (NXB - 1)][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + ((ks + 1) * RB + rb) * 1024 + loff);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        xh[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + (ks * RB + rb) * 1024 + loff);
+                        xl[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + (ks * RB + rb) * 1024 + loff);
+                    }
+                }
+                if (!XDB) __builtin_amdgcn_sched_barrier(0); // this step's own X fragments: nothing to interleave them with
+            }
+            const bf16x8 *w6 = wf[ku]; // q hi, q lo, k hi, k lo, v hi, v lo
+            const bf16x8 *xhc = xh[ku & (NXB - 1)], *xlc = xl[ku & (NXB - 1)];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] = mfma(w6[1], xhc[rb], aq[rb]);
+                ak[rb] = mfma(w6[3], xhc[rb], ak[rb]);
+                av[rb] = mfma(xhc[rb], w6[5], av[rb]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] = mfma(w6[0], xlc[rb], aq[rb]);
+                ak[rb] = mfma(w6[2], xlc[rb], ak[rb]);
+                av[rb] = mfma(xlc[rb], w6[4], av[rb]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] = mfma(w6[0], xhc[rb], aq[rb]);
+                ak[rb] = mfma(w6[2], xhc[rb], ak[rb]);
+                av[rb] = mfma(xhc[rb], w6[4], av[rb]);
+            }
+            // Issue order inside the k-step: one memory instruction after every few MFMAs, so that it issues in the shadow of a running
+            // MFMA.  Issued as one burst at the top of the step (the plain sched_barrier version) the 6 + 2*NRB memory instructions
+            // cost ~170 cycles per step during which this wavefront keeps the matrix pipe empty.
+            {
+                constexpr int NM = 9 * NRB, ND = XDB && (!TAIL || ku + 1 < PF) ? 2 * NRB : 0, NV = !TAIL || ku == 0 ? 6 : 0;
+                constexpr int A = NM >= 12 + ND ? 2 : 1;                 // MFMAs in front of each weight load
+                constexpr int B = ND ? (NM - NV * A) / ND : 0;           // MFMAs in front of each X fragment read
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, A, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, B, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NM - NV * A - ND * B, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        };
+#pragma unroll 1
+        for (int k4 = 0; k4 < 16 - PF; k4 += PF) group(k4, std::false_type{});
+        group(16 - PF, std::true_type{});
+        HH_T(2);
+        // the attention chain is short, latency bound and holds the shared scratch: let it win the issue arbitration against the
+        // partner wavefront's q.k.v loop on this SIMD (which fills whatever is left)
+        __builtin_amdgcn_s_setprio(3);
+        {
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(W.qkv_b + h * 64 + 16 * wave + 4 * g);
+            const f32x4 bk = *reinterpret_cast<const f32x4 *>(W.qkv_b + 512 + h * 64 + 16 * wave + 4 * g);
+            const float bv = W.qkv_b[1024 + h * 64 + 16 * wave + i];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                aq[rb] += bq; ak[rb] += bk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[rb][q] += bv;
+            }
+        }
+        wait_turn(lds, turn_base + 2 * hh + tm); // A: the scratch is ours once every wavefront of the previous turn has finished with it
+        HH_T(3);
+        // Q -> H0, K -> H1: this wavefront holds head features 16w + 4g + r = half (w&1) of the fragment entries of k-step w>>1
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            bf16x4 qh, ql, kh, kl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __bf16 a, b;
+                split1(aq[rb][q], a, b); qh[q] = a; ql[q] = b;
+                split1(ak[rb][q], a, b); kh[q] = a; kl[q] = b;
+            }
+            const int o = ((wave >> 1) * RB + rb) * 1024 + loff + 8 * (wave & 1);
+            *reinterpret_cast<bf16x4 *>(H0 + o) = qh;
+            *reinterpret_cast<bf16x4 *>(H0 + H_PLANE + o) = ql;
+            *reinterpret_cast<bf16x4 *>(H1 + o) = kh;
+            *reinterpret_cast<bf16x4 *>(H1 + H_PLANE + o) = kl;
+        }
+        team_barrier(lds, bar, bar_target, lane); // B
+        HH_T(4);
+        // this head's out_proj∘spatial_linear fragments: in flight during the attention phases, consumed after barrier E
+        bf16x8 wos[2][4][2];
+        {
+            const unsigned op = WB.os + (unsigned)((h * 4 + wave) * 2) * 8 * 1024;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wos[ks][j][0] = ldb(WB, op + ((ks * 4 + j) * 2 + 0) * 1024, uoff);
+                    wos[ks][j][1] = ldb(WB, op + ((ks * 4 + j) * 2 + 1) * 1024, uoff);
+                }
+        }
+        // ---------------- S^T = K Q^T for query block `wave`, masked softmax over the keys of the query's env ----------------
+        float p[2 * NKS][4]; // [jb][r]
+#pragma unroll
+        for (int jb = 0; jb < 2 * NKS; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[jb][r] = 0.0f;
+        if (wave < NRB) {
+            f32x4 s[NRB];
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb) s[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 qh = *reinterpret_cast<const bf16x8 *>(H0 + (ks * RB + wave) * 1024 + loff);
+                const bf16x8 ql = *reinterpret_cast<const bf16x8 *>(H0 + H_PLANE + (ks * RB + wave) * 1024 + loff);
+#pragma unroll
+                for (int jb = 0; jb < NRB; ++jb) {
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(H1 + (ks * RB + jb) * 1024 + loff);
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(H1 + H_PLANE + (ks * RB + jb) * 1024 + loff);
+                    s[jb] = mfma(kl, qh, s[jb]);
+                    s[jb] = mfma(kh, ql, s[jb]);
+                    s[jb] = mfma(kh, qh, s[jb]);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((vmask >> (jb * 4 + r)) & 1u) mx = fmaxf(mx, s[jb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = ((vmask >> (jb * 4 + r)) & 1u) ? __builtin_amdgcn_exp2f((s[jb][r] - mx) * 1.44269504088896340736f) : 0.0f;
+                    p[jb][r] = e; sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+#pragma unroll
+            for (int jb = 0; jb < NRB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[jb][r] *= inv;
+        }
+        HH_T(5);
+        team_barrier(lds, bar, bar_target, lane); // C: Q (H0) is dead, P may overwrite it
+        HH_T(6);
+        if (wave < NRB) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const Split8 sp = split8(f32x4{p[2 * ks][0], p[2 * ks][1], p[2 * ks][2], p[2 * ks][3]},
+                                         f32x4{p[2 * ks + 1][0], p[2 * ks + 1][1], p[2 * ks + 1][2], p[2 * ks + 1][3]});
+                *reinterpret_cast<bf16x8 *>(H0 + (ks * RB + wave) * 1024 + loff) = sp.hi;
+                *reinterpret_cast<bf16x8 *>(H0 + H_PLANE + (ks * RB + wave) * 1024 + loff) = sp.lo;
+            }
+        }
+        team_barrier(lds, bar, bar_target, lane); // D
+        HH_T(7);
+        // ---------------- O^T = V^T P^T: value features 16w..16w+15 of the head for every query block ----------------
+        f32x4 o[NRB];
+#pragma unroll
+        for (int ib = 0; ib < NRB; ++ib) o[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const Split8 vf = split8(av[2 * ks], 2 * ks + 1 < NRB ? av[2 * ks + 1 < NRB ? 2 * ks + 1 : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int ib = 0; ib < NRB; ++ib) {
+                const bf16x8 ph = *reinterpret_cast<const bf16x8 *>(H0 + (ks * RB + ib) * 1024 + loff);
+                const bf16x8 pl = *reinterpret_cast<const bf16x8 *>(H0 + H_PLANE + (ks * RB + ib) * 1024 + loff);
+                o[ib] = mfma(vf.lo, ph, o[ib]);
+                o[ib] = mfma(vf.hi, pl, o[ib]);
+                o[ib] = mfma(vf.hi, ph, o[ib]);
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < NRB; ++ib) {
+            bf16x4 oh, ol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { __bf16 a, b; split1(o[ib][q], a, b); oh[q] = a; ol[q] = b; }
+            const int off = ((wave >> 1) * RB + ib) * 1024 + loff + 8 * (wave & 1);
+            *reinterpret_cast<bf16x4 *>(H1 + off) = oh;
+            *reinterpret_cast<bf16x4 *>(H1 + H_PLANE + off) = ol;
+        }
+        HH_T(8);
+        team_barrier(lds, bar, bar_target, lane); // E
+        HH_T(9);
+        // ---------------- out += O Wos[:, head h]^T: feature blocks 4w..4w+3 ----------------
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 oh[NRB], ol[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                oh[rb] = *reinterpret_cast<const bf16x8 *>(H1 + (ks * RB + rb) * 1024 + loff);
+                ol[rb] = *reinterpret_cast<const bf16x8 *>(H1 + H_PLANE + (ks * RB + rb) * 1024 + loff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][1], oh[rb], acc_os[j][rb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][0], ol[rb], acc_os[j][rb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][0], oh[rb], acc_os[j][rb]);
+            if (ks == 1) finish_turn(lds, lane); // the O fragments are in registers: the scratch may go to the other team
+        }
+        __builtin_amdgcn_s_setprio(HH_PRIO_QKV);
+        HH_T(10);
+    }
+    // ---------------- out_sp = relu(out_team0 + out_team1 + b): each team finishes two of its four feature blocks ----------------
+    __syncthreads(); // both teams are through their heads: X and the scratch regions are dead
+    HH_T(11);
+    {
+        char *const xch = lds + LDS_X;
+        if (tm == 0) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) *reinterpret_cast<f32x4 *>(xch + ((wave * 2 + jj) * RB + rb) * 1024 + loff) = acc_os[2 + jj][rb];
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) *reinterpret_cast<f32x4 *>(xch + XCH_TEAM + ((wave * 2 + jj) * RB + rb) * 1024 + loff) = acc_os[jj][rb];
+        }
+        __syncthreads();
+        if (tm == 0) finish_rows<NRB, 0>(t, acc_os, xch + XCH_TEAM, W, out_sp, lane, wave);
+        else finish_rows<NRB, 2>(t, acc_os, xch, W, out_sp, lane, wave);
+    }
+    HH_T(12);
+#ifdef HH_TIMING
+    if (g_hh_tim && wave == 0 && lane == 0) {
+        long long *d = g_hh_tim + ((size_t)blockIdx.x * 2 + tm) * 20;
+        for (int k = 0; k < 16; ++k) d[k] += tacc[k];
+        d[16] += 1; d[17] += t.nrows; d[18] += NRB;
+    }
+#endif
+    // no barrier here: the next tile's e0 fragments go to team 0's scratch (dead since the barrier above), and X is rewritten
+    // only behind the next tile's first __syncthreads()
+}
+
+} // namespace team
+
+#ifndef HH_TEAM_PF4
+#define HH_TEAM_PF4 2   // prefetch depth of the 4-row-block body (register budget: 256)
+#endif
+#ifndef HH_TEAM_XDB4
+#define HH_TEAM_XDB4 1
+#endif
+
+__global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
+                                                          int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (det) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
+    if (threadIdx.x < 4) *reinterpret_cast<unsigned *>(lds + team::LDS_CTR + 4 * threadIdx.x) = 0u; // counters + the slot's unused word
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(HH_PRIO_QKV); // above the simulator's side-stream wavefronts; the attention chains go to 3 (tile_body)
+    const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = w8 & 3, tm = w8 >> 2;
+    const int total = ld_ro(row_off + E);
+    // chunk of this workgroup: rows [c*Q, (c+1)*Q) snapped to env starts
+    int Q = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    Q = Q < 16 ? 16 : Q;
+    const long long lo_row = (long long)blockIdx.x * Q;
+    if (lo_row >= total) return;
+    const long long hi_row = lo_row + Q;
+    int e = lower_bound_wave(row_off, E, (int)lo_row, lane);
+    const int e_end = hi_row >= total ? E : lower_bound_wave(row_off, E, (int)hi_row, lane);
+    int tile_ord = 0;
+    unsigned bar_target = 0, turn_base = 0;
+    const team::WeightBuf WB = team::make_weight_buf(W);
+    const int chunk_end_row = ld_ro(row_off + e_end);
+    while (e < e_end) {
+        const TileCtx t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
+        const int nrb = (t.nrows + 15) >> 4;
+        switch (nrb) {
+        case 1: team::tile_body<1, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
+        case 2: team::tile_body<2, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
+        case 3: team::tile_body<3, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
+        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
+        }
+        turn_base += 8;
+        e += t.n_env;
     }
 }
 
@@ -708,14 +1327,21 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const floa
     int dev = 0;
     CN_HIP(hipGetDevice(&dev));
     if (dev != attr_dev) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::LDS_BYTES));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES));
         attr_dev = dev;
     }
     // one workgroup per CU (the LDS footprint admits exactly one); small batches get fewer so that a chunk is >= one row block
     long long max_rows = (long long)E * H;
     int grid = (int)((max_rows + 15) / 16);
     grid = grid > 256 ? 256 : (grid < 1 ? 1 : grid);
-    hipLaunchKernelGGL(hh_fused_kernel, dim3(grid), dim3(256), LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+    // an env must fit one tile: the two-team kernel holds 48 rows, the wide one 64 (CN_HH_WIDE=1 forces the latter: A/B measurements)
+    static int force_wide = -1;
+    if (force_wide < 0) { const char *v = getenv("CN_HH_WIDE"); force_wide = v ? atoi(v) : 0; }
+    if (H > team::FR || force_wide)
+        hipLaunchKernelGGL(hh_fused_wide_kernel, dim3(grid), dim3(256), wide::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+    else
+        hipLaunchKernelGGL(hh_fused_kernel, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
