@@ -110,6 +110,20 @@ __device__ __forceinline__ int lower_bound_wave(const int *a, int n, int target,
     return __builtin_amdgcn_readfirstlane(lo);
 }
 
+// Chunk boundary c of n: the env start NEAREST to row c * total / n (both neighbours of a boundary compute the same env, so the
+// chunks tile the batch exactly).  Nearest instead of "first at or behind" halves the spread of the chunk sizes: a chunk of more than
+// ~104 rows may not split into a 3-block and a 4-block tile, and one such workgroup sets the duration of the launch.
+__device__ __forceinline__ int chunk_boundary(const int *row_off, int E, int total, int c, int n, int lane)
+{
+    if (c <= 0) return 0;
+    if (c >= n) return E;
+    const int target = (int)((long long)c * total / n);
+    const int e1 = lower_bound_wave(row_off, E, target, lane); // first env with start >= target (E if none)
+    if (e1 == 0) return 0;
+    const int above = ld_ro(row_off + e1) - target, below = target - ld_ro(row_off + e1 - 1);
+    return below < above ? e1 - 1 : e1;
+}
+
 #ifdef HH_DEBUG
 __device__ int *g_hh_dbg = nullptr;
 #endif
@@ -591,9 +605,11 @@ __device__ __forceinline__ void row_offsets_prologue(int E, int H, const float *
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// The next tile of a workgroup's chunk [e, e_end): whole envs, at most FR rows (every env has 1..H <= FR rows); the rows left in the
-// chunk are split evenly over the tiles they need, because a tile's cost is dominated by terms that do not shrink with its row count
-// (weight stream, barriers).  Wave-uniform; every lane of the calling wavefront must be active.
+// The next tile of a workgroup's chunk [e, e_end): whole envs, at most FR rows (every env has 1..H <= FR rows), in the fewest tiles
+// (a tile costs a pass over the 3.9 MB weight stream whatever its size).  Among the env boundaries that keep that tile count, the one
+// that minimises the 16-row blocks of this tile plus those of the rest is taken: the MFMA time of a tile is proportional to its row
+// blocks, so 100 rows are cut 48 + 52 (3 + 4 blocks), not 50 + 50 (4 + 4) -- measured per workgroup: 27 k cycles per row block on top
+// of 42 k per tile, and the launch lasts as long as its slowest workgroup.  Wave-uniform; every lane of the calling wavefront active.
 template <int FR>
 __device__ __forceinline__ TileCtx next_tile(const int *row_off, int e, int e_end, int chunk_end_row, int tile_ord, int lane)
 {
@@ -602,21 +618,26 @@ __device__ __forceinline__ TileCtx next_tile(const int *row_off, int e, int e_en
     t.e_lo = e;
     t.r0 = ld_ro(row_off + e);
     const int probe = e + 1 + lane;
-    const int v = probe <= e_end ? ld_ro(row_off + probe) : INT_MAX;
+    const int v = probe <= e_end ? ld_ro(row_off + probe) : INT_MAX; // end row of env e + lane
     const int left = chunk_end_row - t.r0;
     const int ntile = (left + FR - 1) / FR;
-    int want = (left + ntile - 1) / ntile + 2; // small slack: prefer closing a tile just after the even split
-    want = want > FR ? FR : want;
-    // ... but never so early that the rest no longer fits the remaining ntile - 1 tiles: an extra tile for a handful of rows costs a
-    // whole pass over the weights, and the launch lasts as long as its slowest workgroup (measured: one such workgroup in most
-    // launches, +15 % on the kernel).  If the even split falls short of `lo` rows, one env more is taken when it still fits.
-    const int lo = left - FR * (ntile - 1);
-    const int n1 = __popcll(__ballot(v <= t.r0 + want));
-    const int p1 = n1 >= 1 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 - 1, 64)) - t.r0 : 0;
-    const int v2 = n1 < 64 ? __builtin_amdgcn_readfirstlane(__shfl(v, n1 < 64 ? n1 : 63, 64)) : INT_MAX; // INT_MAX beyond the chunk
-    int n_env = n1;
-    if ((n1 < 1 || p1 < lo) && v2 != INT_MAX && v2 - t.r0 <= FR) n_env = n1 + 1;
-    n_env = n_env < 1 ? 1 : n_env;             // one env always fits (H <= FR)
+    // candidate: the tile ends behind env e + lane
+    const int rows = v == INT_MAX ? INT_MAX : v - t.r0;
+    const bool ok = rows <= FR && left - rows <= FR * (ntile - 1);
+    const int rest = left - rows;
+    // cost: row blocks (this tile + lower bound for the rest); ties: the larger tile (the rest may then round down a block later)
+    int key = ok ? ((((rows + 15) >> 4) + ((rest + 15) >> 4)) << 8) + (FR - rows) : INT_MAX;
+    int best = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(best, o, 64); best = x < best ? x : best; }
+    int n_env;
+    if (best == INT_MAX) {
+        // no boundary keeps the minimal tile count (env sizes make FR-row tiles impossible to fill): take as many envs as fit
+        n_env = __popcll(__ballot(rows <= FR));
+        n_env = n_env < 1 ? 1 : n_env; // one env always fits (H <= FR)
+    } else {
+        n_env = __ffsll(__ballot(key == best)); // first lane holding the minimum: lane index + 1 = number of envs
+    }
     t.n_env = n_env;
     t.nrows = __builtin_amdgcn_readfirstlane(__shfl(v, n_env - 1, 64)) - t.r0;
     // row -> env map: lane k < n_env knows the start of env k, lane l then counts the starts <= l
@@ -641,14 +662,10 @@ __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int
     if (W.prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total = ld_ro(row_off + E);
-    // chunk of this workgroup: rows [c*Q, (c+1)*Q) snapped to env starts
-    int Q = (total + (int)gridDim.x - 1) / (int)gridDim.x;
-    Q = Q < 16 ? 16 : Q;
-    const long long lo_row = (long long)blockIdx.x * Q;
-    if (lo_row >= total) return;
-    const long long hi_row = lo_row + Q;
-    int e = lower_bound_wave(row_off, E, (int)lo_row, lane);
-    const int e_end = hi_row >= total ? E : lower_bound_wave(row_off, E, (int)hi_row, lane);
+    // chunk of this workgroup: envs [boundary(c), boundary(c + 1))
+    int e = chunk_boundary(row_off, E, total, (int)blockIdx.x, (int)gridDim.x, lane);
+    const int e_end = chunk_boundary(row_off, E, total, (int)blockIdx.x + 1, (int)gridDim.x, lane);
+    if (e >= e_end) return;
     int tile_ord = 0;
     const int chunk_end_row = ld_ro(row_off + e_end);
     while (e < e_end) {
@@ -671,24 +688,38 @@ __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int
 #ifndef HH_PRIO_QKV
 #define HH_PRIO_QKV 1
 #endif
+#ifndef HH_PRIO_ALT
+#define HH_PRIO_ALT 0
+#endif
 namespace team {
 
-constexpr int FR = 63;                       // rows per tile: 4 row blocks of 16, the last row of the last block is never live (see LDS_CTR)
-constexpr int RB = 4;                        // row-block stride of every LDS image
-constexpr int X_PLANE = 16 * RB * 1024;      // X: [plane 2][kx 16][rb 4][lane 64][16 B] = 128 KB
-constexpr int LDS_X = 0;
-constexpr int LDS_S = 2 * X_PLANE;           // ONE scratch region of 32 KB, used by the teams in turns (and by the e0 fragments of a tile):
-constexpr int H_PLANE = 2 * RB * 1024;       //   H0 (Q, then P) and H1 (K, then O), [plane 2][ks 2][rb 4][lane 64][16 B] = 16 KB each
-constexpr int H_BYTES = 2 * H_PLANE;
-constexpr int E0_PLANE = 4 * RB * 1024;      // e0: [plane 2][ks 4][rb 4][lane 64][16 B] = 32 KB
-constexpr int LDS_BYTES = LDS_S + 2 * H_BYTES; // = 163840: all of the CU's LDS
-constexpr int XCH_TEAM = 4 * 2 * RB * 1024;  // accumulator exchange at the end of a tile: [wave 4][jj 2][rb 4][lane 64][16 B] = 32 KB per team, over X
-// The synchronisation counters need 12 bytes and the images above fill the LDS to the last byte.  They live in the fragment slot of the
-// one (row, k) position that can never matter: plane lo, X k-step 15, row block 3, lane 63 = row 63 of the tile, k 24..31 -- a tile holds
-// at most 63 rows, so row 63 is always padding.  Nobody else writes the slot (the X epilogue skips it); whoever reads it as an X fragment
-// sees small integers = tiny finite bf16 values, which only ever reach the (discarded) outputs of the padded row.
-constexpr int LDS_CTR = LDS_X + X_PLANE + (15 * RB + 3) * 1024 + 63 * 16; // +0 / +4: team barrier counters, +8: finished scratch turns x 4
-static_assert(LDS_BYTES == 163840, "the layout is sized for the whole LDS");
+constexpr int FR = 63;                       // rows per tile: at most 4 row blocks of 16; the last row of a fourth block is never live (see CTR)
+constexpr int LDS_BYTES = 163840;            // all of the CU's LDS
+// The LDS layout depends on the row blocks of the tile:
+//   <= 3 row blocks (<= 48 rows, the common case at 4096 envs): X takes 96 KB and each team has its OWN 24 KB scratch region -- the
+//       attention chains of the two teams run independently of each other;
+//   4 row blocks (49..63 rows): X takes 128 KB and the teams share ONE 32 KB scratch region in turns.
+template <int RB_>
+struct Layout {
+    static constexpr int RB = RB_;                     // row-block stride of every LDS image
+    static constexpr bool TURNS = RB_ == 4;            // one shared scratch region, used in turns
+    static constexpr int X_PLANE = 16 * RB * 1024;     // X: [plane 2][kx 16][rb RB][lane 64][16 B]
+    static constexpr int LDS_X = 0;
+    static constexpr int LDS_S = 2 * X_PLANE;          // scratch: H0 (Q, then P) and H1 (K, then O), [plane 2][ks 2][rb RB][lane 64][16 B] each
+    static constexpr int H_PLANE = 2 * RB * 1024;
+    static constexpr int H_BYTES = 2 * H_PLANE;
+    static constexpr int TEAM_S = TURNS ? 0 : 2 * H_BYTES; // offset of team 1's scratch region
+    static constexpr int E0_PLANE = 4 * RB * 1024;     // e0: [plane 2][ks 4][rb RB][lane 64][16 B] = one scratch region
+    static constexpr int XCH_TEAM = 4 * 2 * RB * 1024; // accumulator exchange at the end of a tile: [wave 4][jj 2][rb RB][lane 64][16 B] per team, over X
+    // Synchronisation counters (+0 / +4: team barriers, +8: finished scratch turns x 4; zeroed at the start of every tile).  With 3 row
+    // blocks there is room behind the scratch regions.  With 4 the images fill the LDS to the last byte and the counters live in the
+    // fragment slot of the one (row, k) position that can never matter: plane lo, X k-step 15, row block 3, lane 63 = row 63 of the
+    // tile, k 24..31 -- a tile holds at most 63 rows, so row 63 is always padding.  Nobody else writes the slot (the X epilogue skips
+    // it); whoever reads it as an X fragment sees small integers = tiny finite bf16 values, which only ever reach the (discarded)
+    // outputs of the padded row.
+    static constexpr int CTR = TURNS ? LDS_X + X_PLANE + (15 * RB + 3) * 1024 + 63 * 16 : LDS_S + 4 * H_BYTES;
+    static_assert(LDS_S + (TURNS ? 2 : 4) * H_BYTES + (TURNS ? 0 : 16) <= LDS_BYTES, "layout exceeds the LDS");
+};
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
@@ -732,23 +763,23 @@ __device__ __forceinline__ void team_barrier(char *lds, int bar_off, unsigned &t
 // The scratch region is used in TURNS: turn n belongs to team n & 1 (heads alternate between the teams).  A wavefront may touch the scratch
 // in turn n once all 4 wavefronts of turn n - 1 have finished with it (which also covers its own team's turn n - 2: it replaces the
 // barrier before the Q / K exchange).  `done` counts finished (turn, wavefront) pairs.
-__device__ __forceinline__ void wait_turn(char *lds, unsigned turn)
+__device__ __forceinline__ void wait_turn(char *lds, int ctr_off, unsigned turn)
 {
-    lds_u32 *done = (lds_u32 *)(lds + LDS_CTR + 8);
+    lds_u32 *done = (lds_u32 *)(lds + ctr_off + 8);
     const unsigned need = 4u * turn;
     while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - need) < 0)
         __builtin_amdgcn_s_sleep(HH_SPIN_SLEEP);
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void finish_turn(char *lds, int lane)
+__device__ __forceinline__ void finish_turn(char *lds, int ctr_off, int lane)
 {
-    lds_u32 *done = (lds_u32 *)(lds + LDS_CTR + 8);
+    lds_u32 *done = (lds_u32 *)(lds + ctr_off + 8);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's last reads of the scratch have returned
     if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // out_sp rows of feature blocks 4*wave + J0, 4*wave + J0 + 1: own partial sum + the other team's (from LDS) + bias, ReLU, streamed to HBM
-template <int NRB, int J0>
+template <int NRB, int J0, int RB>
 __device__ __forceinline__ void finish_rows(const TileCtx &t, const f32x4 (&acc)[4][NRB], const char *xch, const HhFusedWeights &W,
                                             float *__restrict__ out_sp, int lane, int wave)
 {
@@ -775,10 +806,13 @@ __device__ __forceinline__ void finish_rows(const TileCtx &t, const f32x4 (&acc)
 
 template <int NRB, int PF, bool XDB>
 __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const float *__restrict__ se, const HhFusedWeights &W, const WeightBuf &WB,
-                                          float *__restrict__ out_sp, char *lds, int lane_in, int wave, int tm, unsigned &bar_target, unsigned turn_base)
+                                          float *__restrict__ out_sp, char *lds, int lane_in, int wave, int tm)
 {
     // Everything derived from the lane index is recomputed per tile: visible as loop invariant, the compiler hoists a few dozen
     // per-lane addresses out of the tile loop and keeps them alive (spilled) across the whole kernel.
+    using L = Layout<(NRB <= 3 ? 3 : 4)>;
+    constexpr int RB = L::RB, X_PLANE = L::X_PLANE, LDS_X = L::LDS_X, LDS_S = L::LDS_S, H_PLANE = L::H_PLANE, H_BYTES = L::H_BYTES,
+                  E0_PLANE = L::E0_PLANE, XCH_TEAM = L::XCH_TEAM, LDS_CTR = L::CTR;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int i = lane & 15, g = lane >> 4;
@@ -790,6 +824,10 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     long long tacc[16] = {0}, tlast = clock64();
 #endif
 
+    // the synchronisation counters of this tile's layout start at zero (every wavefront is past the previous tile's last team barrier
+    // when it gets here, and nobody touches them before the second __syncthreads below)
+    if (w8 == 0 && lane < 4) *reinterpret_cast<unsigned *>(lds + LDS_CTR + 4 * lane) = 0u;
+    unsigned bar_target = 0;
     // ---------------- e0: relu(x W0^T + b0) for feature k-step `wave` (natural k order); team tm takes the row blocks of its parity ----------------
     {
         const int c0 = 32 * wave + 8 * g;
@@ -878,7 +916,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.0f); b[q] = fmaxf(b[q], 0.0f); }
                 const Split8 s = split8(a, b);
                 *reinterpret_cast<bf16x8 *>(lds + LDS_X + (kx * RB + rb) * 1024 + loff) = s.hi;
-                if (!(rb == 3 && kx == 15 && lane == 63)) // the synchronisation counters live in this slot (LDS_CTR)
+                if (!(L::TURNS && rb == 3 && kx == 15 && lane == 63)) // the synchronisation counters live in this slot (Layout::CTR)
                     *reinterpret_cast<bf16x8 *>(lds + LDS_X + X_PLANE + (kx * RB + rb) * 1024 + loff) = s.lo;
             }
         }
@@ -906,7 +944,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    char *const H0 = lds + LDS_S, *const H1 = H0 + H_BYTES;
+    char *const H0 = lds + LDS_S + tm * L::TEAM_S, *const H1 = H0 + H_BYTES;
     const int bar = LDS_CTR + 4 * tm;
     // Head order: team tm takes every second head; the starting head is staggered over the workgroups of an XCD (32 simultaneous
     // readers of one weight line serialise on its L2 channel).  The sum over the heads is order independent up to fp32 rounding.
@@ -1025,7 +1063,10 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int q = 0; q < 4; ++q) av[rb][q] += bv;
             }
         }
-        wait_turn(lds, turn_base + 2 * hh + tm); // A: the scratch is ours once every wavefront of the previous turn has finished with it
+        // A: the scratch may be rewritten -- shared region: once every wavefront of the previous turn has finished with it; own region:
+        // once the team's previous head's P (H0) and O (H1) fragments have been consumed
+        if (L::TURNS) wait_turn(lds, LDS_CTR, 2 * hh + tm);
+        else team_barrier(lds, bar, bar_target, lane);
         HH_T(3);
         // Q -> H0, K -> H1: this wavefront holds head features 16w + 4g + r = half (w&1) of the fragment entries of k-step w>>1
 #pragma unroll
@@ -1167,9 +1208,15 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][0], oh[rb], acc_os[j][rb]);
-            if (ks == 1) finish_turn(lds, lane); // the O fragments are in registers: the scratch may go to the other team
+            if (L::TURNS && ks == 1) finish_turn(lds, LDS_CTR, lane); // the O fragments are in registers: the scratch may go to the other team
         }
+#if HH_PRIO_ALT
+        // q.k.v loops: with equal priorities the older wavefronts (team 0) win every arbitration and team 1 trails by a fifth; the
+        // preference alternates from head to head instead
+        if ((hh + tm) & 1) __builtin_amdgcn_s_setprio(HH_PRIO_QKV); else __builtin_amdgcn_s_setprio(HH_PRIO_QKV + 1);
+#else
         __builtin_amdgcn_s_setprio(HH_PRIO_QKV);
+#endif
         HH_T(10);
     }
     // ---------------- out_sp = relu(out_team0 + out_team1 + b): each team finishes two of its four feature blocks ----------------
@@ -1189,8 +1236,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int rb = 0; rb < NRB; ++rb) *reinterpret_cast<f32x4 *>(xch + XCH_TEAM + ((wave * 2 + jj) * RB + rb) * 1024 + loff) = acc_os[jj][rb];
         }
         __syncthreads();
-        if (tm == 0) finish_rows<NRB, 0>(t, acc_os, xch + XCH_TEAM, W, out_sp, lane, wave);
-        else finish_rows<NRB, 2>(t, acc_os, xch, W, out_sp, lane, wave);
+        if (tm == 0) finish_rows<NRB, 0, RB>(t, acc_os, xch + XCH_TEAM, W, out_sp, lane, wave);
+        else finish_rows<NRB, 2, RB>(t, acc_os, xch, W, out_sp, lane, wave);
     }
     HH_T(12);
 #ifdef HH_TIMING
@@ -1218,34 +1265,26 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (det) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
-    if (threadIdx.x < 4) *reinterpret_cast<unsigned *>(lds + team::LDS_CTR + 4 * threadIdx.x) = 0u; // counters + the slot's unused word
-    __syncthreads();
     __builtin_amdgcn_s_setprio(HH_PRIO_QKV); // above the simulator's side-stream wavefronts; the attention chains go to 3 (tile_body)
     const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = w8 & 3, tm = w8 >> 2;
     const int total = ld_ro(row_off + E);
-    // chunk of this workgroup: rows [c*Q, (c+1)*Q) snapped to env starts
-    int Q = (total + (int)gridDim.x - 1) / (int)gridDim.x;
-    Q = Q < 16 ? 16 : Q;
-    const long long lo_row = (long long)blockIdx.x * Q;
-    if (lo_row >= total) return;
-    const long long hi_row = lo_row + Q;
-    int e = lower_bound_wave(row_off, E, (int)lo_row, lane);
-    const int e_end = hi_row >= total ? E : lower_bound_wave(row_off, E, (int)hi_row, lane);
+    // chunk of this workgroup: envs [boundary(c), boundary(c + 1))
+    int e = chunk_boundary(row_off, E, total, (int)blockIdx.x, (int)gridDim.x, lane);
+    const int e_end = chunk_boundary(row_off, E, total, (int)blockIdx.x + 1, (int)gridDim.x, lane);
+    if (e >= e_end) return;
     int tile_ord = 0;
-    unsigned bar_target = 0, turn_base = 0;
     const team::WeightBuf WB = team::make_weight_buf(W);
     const int chunk_end_row = ld_ro(row_off + e_end);
     while (e < e_end) {
         const TileCtx t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
         const int nrb = (t.nrows + 15) >> 4;
         switch (nrb) {
-        case 1: team::tile_body<1, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
-        case 2: team::tile_body<2, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
-        case 3: team::tile_body<3, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
-        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm, bar_target, turn_base); break;
+        case 1: team::tile_body<1, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 2: team::tile_body<2, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 3: team::tile_body<3, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
         }
-        turn_base += 8;
         e += t.n_env;
     }
 }
