@@ -8,7 +8,12 @@ as an independent cross-check of the kernels.  Same state-dict keys as the shipp
   gst_updated/scripts/wrapper/crowd_nav_interface_parallel.py:45-114
   rl/vec_env/vec_pretext_normalize.py:85-191
 """
+import argparse
+import glob
+import json
 import os
+import pickle
+import re
 
 import torch
 import torch.nn as nn
@@ -187,7 +192,40 @@ def load_predictor(config, device):
     model_dir = getattr(getattr(config, "pred", None), "model_dir", None)
     if model_dir is None:
         raise ValueError("config.pred.model_dir is required for CrowdSimPredRealGST-v0 with the prediction wrapper")
-    path = os.path.join(model_dir, "checkpoint", "epoch_100.pt")
-    if not os.path.exists(path):
-        raise FileNotFoundError("GST checkpoint not found: %s (config.pred.model_dir must point at the reference's gst_updated/results/.../sj)" % path)
-    return GSTPredictor.from_checkpoint(path, device)
+    return GSTPredictor.from_checkpoint(find_checkpoint(model_dir), device)
+
+
+class _NamespaceOnlyUnpickler(pickle.Unpickler):
+    """args.pickle holds an argparse.Namespace of plain values (gst_updated/scripts/experiments/train.py:88-89); nothing else may load."""
+
+    def find_class(self, module, name):
+        if (module, name) == ("argparse", "Namespace"):
+            return argparse.Namespace
+        raise pickle.UnpicklingError("args.pickle may only contain an argparse.Namespace of plain values, found %s.%s" % (module, name))
+
+
+def find_checkpoint(model_dir):
+    """<model_dir>/checkpoint/epoch_<num_epochs>.pt, num_epochs as the run recorded it -- the rule of the reference's loader
+    (crowd_nav_interface_multi_env_parallel.py:21-28: args.pickle -> 'epoch_' + str(args.num_epochs) + '.pt').  args.json (written by
+    gst_train.train) is preferred, then args.pickle through an unpickler restricted to argparse.Namespace, then the highest epoch_*.pt
+    present (the shipped gst_updated/results/*/sj directories: epoch_100.pt)."""
+    ckpt_dir = os.path.join(model_dir, "checkpoint")
+    num_epochs = None
+    if os.path.exists(os.path.join(ckpt_dir, "args.json")):
+        with open(os.path.join(ckpt_dir, "args.json")) as f:
+            num_epochs = json.load(f).get("num_epochs")
+    elif os.path.exists(os.path.join(ckpt_dir, "args.pickle")):
+        try:
+            with open(os.path.join(ckpt_dir, "args.pickle"), "rb") as f:
+                num_epochs = getattr(_NamespaceOnlyUnpickler(f).load(), "num_epochs", None)
+        except Exception:
+            num_epochs = None            # e.g. a Namespace holding numpy scalars: fall through to the directory listing
+    if num_epochs is not None:
+        path = os.path.join(ckpt_dir, "epoch_%d.pt" % int(num_epochs))
+        if os.path.exists(path):
+            return path
+    found = sorted(glob.glob(os.path.join(ckpt_dir, "epoch_*.pt")), key=lambda p: int(re.sub(r"\D", "", os.path.basename(p)) or 0))
+    if not found:
+        raise FileNotFoundError("no GST checkpoint under %s (config.pred.model_dir must point at a gst_updated/results/.../sj style "
+                                "directory or at the out_dir of gst_train.train)" % ckpt_dir)
+    return found[-1]

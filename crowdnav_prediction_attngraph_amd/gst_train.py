@@ -12,9 +12,11 @@ which are NOT part of the reference checkout (only the shell wrappers that call 
 TrajectoriesDataset items directly -- one sequence (all pedestrians of a 10-frame window) per optimiser step, which is what a
 BatchTrajectoriesDataset item of one sequence is.
 """
+import argparse
 import json
 import math
 import os
+import pickle
 import time
 
 import numpy as np
@@ -276,7 +278,8 @@ def train(data_dir, out_dir, num_epochs=100, temp_epochs=100, lr=1e-3, clip_grad
           random_seed=1000, device=None, num_workers=0, log=print):
     """gst_updated/scripts/experiments/train.py:49-195 for the shipped configuration.  data_dir holds the text files of collect.py /
     collect_data.py; the first 80 % of every file's windows train, the rest validate (TrajectoriesDataset modes).  Writes
-    <out_dir>/checkpoint/epoch_<n>.pt in the reference's format (loadable by GSTPredictor.from_checkpoint and by the reference)."""
+    <out_dir>/checkpoint/{epoch_<n>.pt, args.pickle, train_hist.pickle} in the reference's format (+ args.json / train_hist.json): the
+    directory is a valid config.pred.model_dir for load_predictor here and for the reference's CrowdNavPredInterfaceMultiEnv."""
     torch.manual_seed(random_seed)
     np.random.seed(random_seed)
     device = torch.device(device if device is not None else ("cuda:0" if torch.cuda.is_available() else "cpu"))
@@ -289,10 +292,18 @@ def train(data_dir, out_dir, num_epochs=100, temp_epochs=100, lr=1e-3, clip_grad
     scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=max(int(temp_epochs / 4), 1), gamma=0.3)
     ckpt_dir = os.path.join(out_dir, "checkpoint")
     os.makedirs(ckpt_dir, exist_ok=True)
+    run_args = dict(spatial="gumbel_social_transformer", temporal="faster_lstm", output_dim=5, embedding_size=64, spatial_num_heads=8,
+                    spatial_num_heads_edges=0, spatial_num_layers=1, ghost=False, lstm_hidden_size=64, lstm_num_layers=1, decode_style="recursive",
+                    detach_sample=False, motion_dim=2, only_observe_full_period=False, dataset="sj", obs_seq_len=5, pred_seq_len=5, batch_size=1,
+                    lr=lr, clip_grad=clip_grad, rotation_pattern=rotation_pattern, num_epochs=num_epochs, temp_epochs=temp_epochs,
+                    save_epochs=save_epochs, init_temp=init_temp, random_seed=random_seed, deterministic=False, resume_training=False,
+                    resume_epoch=None)
     with open(os.path.join(ckpt_dir, "args.json"), "w") as f:
-        json.dump(dict(spatial="gumbel_social_transformer", temporal="faster_lstm", embedding_size=64, spatial_num_heads=8, spatial_num_heads_edges=0,
-                       spatial_num_layers=1, ghost=False, lstm_hidden_size=64, obs_seq_len=5, pred_seq_len=5, lr=lr, clip_grad=clip_grad,
-                       rotation_pattern=rotation_pattern, num_epochs=num_epochs, temp_epochs=temp_epochs, init_temp=init_temp, random_seed=random_seed), f)
+        json.dump(run_args, f)
+    # the reference's loaders (crowd_nav_interface_multi_env_parallel.py:21-28, scripts/experiments/eval.py:30) unpickle an
+    # argparse.Namespace from args.pickle and open 'epoch_<args.num_epochs>.pt': write that too (train.py:88-89)
+    with open(os.path.join(ckpt_dir, "args.pickle"), "wb") as f:
+        pickle.dump(argparse.Namespace(**run_args), f)
     hist = {"epoch": 0, "train_loss_task": [], "val_loss_task": [], "train_aoe_task": [], "val_aoe_task": [], "train_foe_task": [], "val_foe_task": []}
     for epoch in range(1, num_epochs + 1):
         model.train()
@@ -331,5 +342,7 @@ def train(data_dir, out_dir, num_epochs=100, temp_epochs=100, lr=1e-3, clip_grad
                         "val_aoe_epoch": va[1], "train_foe_epoch": tr[2], "val_foe_epoch": va[2]}, os.path.join(ckpt_dir, "epoch_%d.pt" % epoch))
             with open(os.path.join(ckpt_dir, "train_hist.json"), "w") as f:
                 json.dump(hist, f)
+            with open(os.path.join(ckpt_dir, "train_hist.pickle"), "wb") as f:      # train.py:189-190 (resume reads it back)
+                pickle.dump(hist, f)
     model.eval()
     return model, hist

@@ -157,6 +157,11 @@ def rollout_case(tag, env_name, E, H, D, T, nmb):
             out["obs%d_%s" % (s, k)] = v
     for k, v in checks.items():
         out["chk_" + k] = v
+    # every post-update tensor at <= 256 evenly spaced flat positions (np.linspace(0, n - 1, min(n, 256)).astype(int64)): the checksums
+    # above average over millions of entries, these pin individual weights of EVERY layer
+    for k, v in sd_after.items():
+        flat = v.reshape(-1)
+        out["smp_" + k] = flat[np.linspace(0, flat.size - 1, min(flat.size, 256)).astype(np.int64)].copy()
     # full post-update tensors for two small layers (tight check of Adam + clipping)
     out["after_dist.fc_mean.weight"] = sd_after["dist.fc_mean.weight"]
     out["after_base.critic_linear.weight"] = sd_after["base.critic_linear.weight"]
@@ -186,6 +191,10 @@ def init_case():
 
 def main():
     R.install()
+    if "--rollouts-only" in sys.argv:
+        rollout_case("varnum_e4_h5_t6", "CrowdSimVarNum-v0", 4, 5, 2, 6, 2)
+        rollout_case("pred_e4_h20_t5", "CrowdSimPred-v0", 4, 20, 12, 5, 2)
+        return
     init_case()
     policy_case("varnum_e4_h20", "CrowdSimVarNum-v0", 4, 20, 2)
     policy_case("varnum_e1_h5", "CrowdSimVarNum-v0", 1, 5, 2)

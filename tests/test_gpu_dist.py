@@ -1,0 +1,126 @@
+"""Two ranks on ONE MI355X (gloo process group, CUDA tensors): the branch of PPO.update() that RCCL ranks execute.
+
+* flat gradient bucket -> ONE all-reduce per optimiser step -> cn_adam_clip_step(grad_scale = 1 / world) on every rank
+  (ppo.py, `on_gpu` branch), global advantage statistics through cn_adv_stats partial sums + all-reduce;
+  result == the single-process update over the union of the two env shards, and both ranks hold identical weights;
+* env shards through make_vec_envs: rank r owns global env indices [r * E, (r + 1) * E) (seed + global index), so the union
+  of the shards reproduces the single-process batch bit for bit.
+
+The reference is single process (train.py:112 discards DataParallel); BASELINE north_star asks for env shards + one
+gradient all-reduce.  gloo stands in for RCCL because both ranks share one device here; the code path above the
+collective is the same.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+H, D, T = 5, 2, 6
+E_TOTAL = 8
+
+
+def _build(lo, hi, dev):
+    """Seeded policy on the GPU + rollout storage holding envs [lo, hi) of a deterministic synthetic rollout of E_TOTAL envs."""
+    sys.path.insert(0, ROOT)
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from crowdnav_prediction_attngraph_amd.storage import RolloutStorage
+    from tests import policy_util as PU
+    ob_space, act_space = make_spaces(H, D)
+    torch.manual_seed(7)
+    E = hi - lo
+    pol = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn",
+                 base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E, num_mini_batch=1, seq_length=T)).to(dev)
+    ro = RolloutStorage(T, E, ob_space.spaces, act_space, 128, 256)
+    rs = np.random.RandomState(3)
+    full = dict(rewards=rs.uniform(-1, 1, (T, E_TOTAL, 1)), values=rs.uniform(-1, 1, (T + 1, E_TOTAL, 1)),
+                returns=rs.uniform(-1, 1, (T + 1, E_TOTAL, 1)), logp=rs.uniform(-3, -1, (T, E_TOTAL, 1)),
+                actions=rs.uniform(-1, 1, (T, E_TOTAL, 2)), masks=(rs.uniform(size=(T + 1, E_TOTAL, 1)) > 0.2).astype(np.float64),
+                hx=rs.uniform(-1, 1, (E_TOTAL, 1, 128)))
+    obs = [PU.synth_obs(E_TOTAL, H, D, seed=50 + s) for s in range(T + 1)]
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, lo:hi]).astype(np.float32))  # noqa: E731
+    for s in range(T + 1):
+        for k, v in obs[s].items():
+            ro.obs[k][s].copy_(torch.from_numpy(v[lo:hi]))
+    ro.rewards.copy_(f32(full["rewards"])); ro.value_preds.copy_(f32(full["values"])); ro.returns.copy_(f32(full["returns"]))
+    ro.action_log_probs.copy_(f32(full["logp"])); ro.actions.copy_(f32(full["actions"])); ro.masks.copy_(f32(full["masks"]))
+    ro.recurrent_hidden_states["human_node_rnn"][0].copy_(torch.from_numpy(full["hx"][lo:hi].astype(np.float32)))
+    ro.to(dev)
+    return pol, ro
+
+
+def _update(pol, ro):
+    from crowdnav_prediction_attngraph_amd.ppo import PPO
+    agent = PPO(pol, 0.2, 2, 1, 0.5, 0.0, lr=1e-3, eps=1e-5, max_grad_norm=0.5)
+    torch.manual_seed(11)
+    losses = agent.update(ro)
+    assert agent._flat is not None, "the GPU update must run on the flat buckets"
+    flat = agent._flat["p"].detach().clone()
+    return losses, flat, agent
+
+
+def _env_trace(E, dev, steps=12):
+    """A short rollout of this process's env shard under fixed actions (a function of the GLOBAL env index)."""
+    from crowdnav_prediction_attngraph_amd import config as CFG
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    envs = make_vec_envs("CrowdSimVarNum-v0", 425, E, 0.99, None, dev, False, config=CFG.non_randomized(**{"sim.human_num": H}))
+    obs = envs.reset()
+    gidx = torch.arange(rank * E, (rank + 1) * E, device=dev, dtype=torch.float32)
+    tr = [torch.cat([obs["robot_node"].reshape(E, -1), obs["spatial_edges"].reshape(E, -1)], 1).clone()]
+    for s in range(steps):
+        a = torch.stack([torch.cos(0.3 * gidx + 0.1 * s), torch.sin(0.2 * gidx - 0.05 * s)], 1) * 0.7
+        obs, rew, done, infos = envs.step(a)
+        tr.append(torch.cat([obs["robot_node"].reshape(E, -1), obs["spatial_edges"].reshape(E, -1), rew.to(dev).reshape(E, 1)], 1).clone())
+    envs.close()
+    return [t.cpu() for t in tr]
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = E_TOTAL // world
+    pol, ro = _build(rank * per, (rank + 1) * per, dev)
+    losses, flat, agent = _update(pol, ro)
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    trace = _env_trace(per, dev)
+    torch.save(dict(losses=losses, flat=flat.cpu(), same=all(torch.equal(gathered[0], g) for g in gathered), trace=trace,
+                    allreduce_ms=agent.last_allreduce_ms), out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_bucket_update_and_env_shards_equal_the_single_process_union(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rank.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = [torch.load(out + ".%d" % r, weights_only=False) for r in range(2)]
+    assert got[0]["same"], "ranks diverged after the all-reduced update"
+    assert got[0]["allreduce_ms"] is not None and got[0]["allreduce_ms"] > 0, "the flat-bucket branch must have all-reduced the gradients"
+    dev = torch.device("cuda", 0)
+    pol, ro = _build(0, E_TOTAL, dev)
+    losses, flat, _ = _update(pol, ro)
+    # the three reported losses are averages over ranks of per-rank minibatch means == the union's mean (equal shard sizes)
+    np.testing.assert_allclose(got[0]["losses"], losses, rtol=2e-5, atol=2e-6)
+    # same weights as one process that saw all 8 envs: the summation order of the weight-gradient products differs (two partial
+    # products + all-reduce vs one product), hence the tolerance; lr 1e-3 x 2 steps
+    np.testing.assert_allclose(got[0]["flat"].numpy(), flat.cpu().numpy(), rtol=0, atol=5e-6)
+    # env shards: rank r's envs are the union's envs r*4 .. r*4+3, bit for bit
+    per = E_TOTAL // 2
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    union = _env_trace(E_TOTAL, dev)
+    for step, u in enumerate(union):
+        for r in range(2):
+            assert torch.equal(got[r]["trace"][step], u[r * per:(r + 1) * per]), "env shard %d differs from the union at step %d" % (r, step)

@@ -23,18 +23,18 @@ def _scripted(robot_node, t):
     return a.contiguous()
 
 
-@pytest.mark.parametrize("kw,T", [(dict(human_num=20), 120), (dict(human_num=50, randomize_attributes=1, random_goal_changing=1), 40),
-                                  (dict(human_num=20, env_kind=1), 70)],     # BASELINE configs[1], [4] (per-GPU share) and [2] (CrowdSimPred-v0)
-                         ids=["varnum_h20", "varnum_h50_rand", "pred_h20_constvel"])
-def test_full_batch_sample_matches_oracle_and_properties_hold(kw, T):
+@pytest.mark.parametrize("kw,T,E", [(dict(human_num=20), 120, 4096), (dict(human_num=50, randomize_attributes=1, random_goal_changing=1), 40, 8192),
+                                    (dict(human_num=20, env_kind=1), 70, 4096)],   # BASELINE configs[1], [4] (its 8192-env per-GPU share) and [2] (CrowdSimPred-v0)
+                         ids=["varnum_h20", "varnum_h50_rand_8192", "pred_h20_constvel"])
+def test_full_batch_sample_matches_oracle_and_properties_hold(kw, T, E):
     from crowdnav_prediction_attngraph_amd import _abi as A
     from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch
     from oracle import oracle as O
-    E, seed = 4096, 425
+    seed = 425
     H = kw["human_num"]
     ccfg, ocfg = A.default_env_config(nenv=E, **kw), O.default_config(nenv=E, **kw)
     env = HipEnvBatch(ccfg, E, seed)
-    sample = [0, 1, 63, 64, 1000, 2047, 2048, 4095]
+    sample = [0, 1, 63, 64, 1000, 2047, 2048, E - 1]
     oenvs = {i: O.OracleEnv(ocfg, seed + i) for i in sample}
     obs = env.reset()
     for i, oe in oenvs.items():
@@ -211,5 +211,5 @@ def test_full_batch_predrealgst_wrapper_kernels_equal_torch_expression():
         act = _scripted(obs["robot_node"].view(E, 7), t)
         obs, rew_env, done, info, _, _ = env.step(act)
         n_done += int(done.sum())
-    assert worst > 0.0 or True
+    assert n_done > 0, "the 30-step window must contain auto-resets (the wrapper's buffers restart with the episode)"
     env.close()

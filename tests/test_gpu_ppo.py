@@ -103,7 +103,14 @@ def test_ppo_update_reference_golden_through_the_hip_path(path, mode):
         np.testing.assert_allclose(sd[k].numpy(), z["after_" + k], rtol=1e-5, atol=2e-6, err_msg=k)
     for k, t in sd.items():
         a = t.numpy().astype(np.float64)
-        np.testing.assert_allclose([a.sum(), np.abs(a).sum()], z["chk_" + k], rtol=1e-5, atol=2e-4, err_msg=k)
+        # every tensor: 256 individual post-update weights at 1e-5 relative (atol: fp32 resolution of the Adam step lr x 4 = 1.6e-4 on
+        # weights that are exactly zero in the reference, e.g. biases initialised to 0)
+        flat = t.numpy().reshape(-1)
+        idx = np.linspace(0, flat.size - 1, min(flat.size, 256)).astype(np.int64)
+        np.testing.assert_allclose(flat[idx], z["smp_" + k], rtol=1e-5, atol=2e-6, err_msg="sampled weights of " + k)
+        # ... and the sums over the whole tensor, 1e-5 relative to sum |w| (the plain sum cancels)
+        np.testing.assert_allclose(np.abs(a).sum(), z["chk_" + k][1], rtol=1e-5, atol=0, err_msg=k)
+        np.testing.assert_allclose(a.sum(), z["chk_" + k][0], rtol=0, atol=1e-5 * float(z["chk_" + k][1]) + 1e-12, err_msg=k)
     # the torch optimiser object still owns a faithful state (checkpointing): step count and moments of a touched parameter
     st = agent.optimizer.state[pol.dist.fc_mean.weight]
     assert float(st["step"]) == meta["ppo_epoch"] * nmb and float(st["exp_avg"].abs().sum()) > 0

@@ -30,7 +30,7 @@ def _check(device, use_hip=False):
         out, mask = m(torch.from_numpy(z["in_traj_" + case]).to(device), torch.from_numpy(z["in_mask_" + case]).to(device))
         np.testing.assert_array_equal(mask.cpu().numpy(), z["out_mask_" + case])
         valid = z["out_mask_" + case][..., 0] > 0
-        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=0, atol=1e-4)
         assert np.all(out.cpu().numpy()[~valid][..., :2] == -999.0)
     E, H, T = meta["E"], meta["H"], meta["T"]
     w = PretextProcessor(m, E, H, 5, 0.3, 0.3, -20.0, torch.device(device), use_hip=use_hip)
@@ -38,7 +38,7 @@ def _check(device, use_hip=False):
         obs = {"robot_node": torch.from_numpy(z["w_in_robot_node_%d" % t]).to(device), "spatial_edges": torch.from_numpy(z["w_in_spatial_edges_%d" % t]).to(device),
                "visible_masks": torch.from_numpy(z["w_in_visible_masks_%d" % t]).to(device)}
         se, rews = w.process(obs, torch.from_numpy(z["w_in_rews_%d" % t]).to(device))
-        np.testing.assert_allclose(se.cpu().numpy(), z["w_out_spatial_edges_%d" % t], rtol=1e-4, atol=1e-4, err_msg="edges @%d" % t)
+        np.testing.assert_allclose(se.cpu().numpy(), z["w_out_spatial_edges_%d" % t], rtol=0, atol=1e-4, err_msg="edges @%d" % t)
         np.testing.assert_allclose(rews.cpu().numpy().reshape(E, 1), z["w_out_rews_%d" % t], atol=1e-5, err_msg="rews @%d" % t)
 
 
@@ -77,7 +77,7 @@ def test_hip_gst_predict_matches_reference_golden_and_torch_path():
         out, mask = g.predict(torch.from_numpy(z["in_traj_" + case]).cuda(), torch.from_numpy(z["in_mask_" + case]).cuda())
         np.testing.assert_array_equal(mask.cpu().numpy(), z["out_mask_" + case])
         valid = z["out_mask_" + case][..., 0] > 0
-        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=0, atol=1e-4)
         assert np.all(out.cpu().numpy()[~valid][..., :2] == -999.0)
     # larger ragged batch against the torch expression of the same model
     sys.path.insert(0, GOLDEN)
@@ -88,7 +88,7 @@ def test_hip_gst_predict_matches_reference_golden_and_torch_path():
     out, om = g.predict(t_d, m_d)
     assert torch.equal(om, ref_mask)
     v = ref_mask[..., 0] > 0
-    assert torch.allclose(out[v], ref_out[v], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(out[v], ref_out[v], rtol=0, atol=1e-4)
 
 
 @pytest.mark.gpu
@@ -117,7 +117,7 @@ def test_hip_gst_kernels_match_torch_expression_for_other_crowd_sizes(H, E):
     out, om = g.predict(t_d, m_d)
     assert torch.equal(om, ref_mask)
     v = ref_mask[..., 0] > 0
-    assert int(v.sum()) > 0 and torch.allclose(out[v], ref_out[v], rtol=1e-4, atol=1e-4)
+    assert int(v.sum()) > 0 and torch.allclose(out[v], ref_out[v], rtol=0, atol=1e-4)
     assert bool((out[~v][..., :2] == -999.0).all())
 
 
@@ -166,7 +166,7 @@ def test_predictor_with_the_shipped_weights_matches_reference_cpu():
         out, mask = m(torch.from_numpy(z["in_traj_" + case]), torch.from_numpy(z["in_mask_" + case]))
         np.testing.assert_array_equal(mask.numpy(), z["out_mask_" + case])
         valid = z["out_mask_" + case][..., 0] > 0
-        np.testing.assert_allclose(out.detach().numpy()[valid], z["out_traj_" + case][valid], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out.detach().numpy()[valid], z["out_traj_" + case][valid], rtol=0, atol=1e-4)
 
 
 @pytest.mark.gpu
@@ -180,4 +180,4 @@ def test_hip_gst_predict_with_the_shipped_weights_matches_reference_golden():
         out, mask = g.predict(torch.from_numpy(z["in_traj_" + case]).cuda(), torch.from_numpy(z["in_mask_" + case]).cuda())
         np.testing.assert_array_equal(mask.cpu().numpy(), z["out_mask_" + case])
         valid = z["out_mask_" + case][..., 0] > 0
-        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=0, atol=1e-4)

@@ -98,3 +98,41 @@ def test_train_loop_learns_and_writes_a_loadable_checkpoint(gold, tmp_path):
     m2 = GSTPredictor.from_checkpoint(str(tmp_path / "run" / "checkpoint" / "epoch_3.pt"), "cpu")
     for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_trained_run_directory_is_a_valid_model_dir(gold, tmp_path):
+    """A run of gst_train.train() with num_epochs != 100 plugs back in as config.pred.model_dir: load_predictor picks
+    'epoch_<num_epochs>.pt' from the run's own args (the reference loader's rule, crowd_nav_interface_multi_env_parallel.py:21-28),
+    and the args.pickle / train_hist.pickle the reference's loaders open are there and hold plain argparse / dict objects."""
+    import argparse
+    import pickle
+    import shutil
+    from types import SimpleNamespace
+    from crowdnav_prediction_attngraph_amd import gst_train as T
+    from crowdnav_prediction_attngraph_amd.gst import find_checkpoint, load_predictor
+    d = tmp_path / "data"
+    d.mkdir()
+    with open(str(d / "0.txt"), "w") as f:
+        f.write(str(gold["file_lines"]) + "\n")
+    run = tmp_path / "run"
+    model, _ = T.train(str(d), str(run), num_epochs=5, temp_epochs=4, save_epochs=2, device="cpu", log=lambda s: None)
+    ck = run / "checkpoint"
+    assert sorted(p.name for p in ck.iterdir()) == ["args.json", "args.pickle", "epoch_2.pt", "epoch_4.pt", "epoch_5.pt", "train_hist.json", "train_hist.pickle"]
+    with open(str(ck / "args.pickle"), "rb") as f:
+        args = pickle.load(f)
+    assert isinstance(args, argparse.Namespace) and args.num_epochs == 5 and args.spatial == "gumbel_social_transformer" and args.temporal == "faster_lstm"
+    assert (args.embedding_size, args.spatial_num_heads, args.spatial_num_layers, args.spatial_num_heads_edges, args.lstm_hidden_size,
+            args.obs_seq_len, args.pred_seq_len, args.output_dim, args.ghost) == (64, 8, 1, 0, 64, 5, 5, 5, False)
+    with open(str(ck / "train_hist.pickle"), "rb") as f:
+        assert pickle.load(f)["epoch"] == 5
+    cfg = SimpleNamespace(pred=SimpleNamespace(model_dir=str(run)))
+    assert find_checkpoint(str(run)).endswith("epoch_5.pt")
+    loaded = load_predictor(cfg, "cpu")
+    for (k, a), (_, b) in zip(model.state_dict().items(), loaded.state_dict().items()):
+        assert torch.equal(a, b), k
+    # reference-style directory (args.pickle only) and a bare directory of checkpoints
+    (ck / "args.json").unlink()
+    assert find_checkpoint(str(run)).endswith("epoch_5.pt")
+    (ck / "args.pickle").unlink()
+    shutil.copy(str(ck / "epoch_5.pt"), str(ck / "epoch_100.pt"))
+    assert find_checkpoint(str(run)).endswith("epoch_100.pt")
