@@ -293,6 +293,7 @@ def main():
             err = "%s: %s" % (type(exc).__name__, exc)
         tdev = "cuda" if (dist is None or args.dist_backend == "nccl") else "cpu"
         tt = torch.tensor([last["rollout_s"] if last else 0.0, last["update_s"] if last else 0.0, 1.0 if err else 0.0], device=tdev, dtype=torch.float64)
+        rows_local = float(last["live_rows"]) if last else 0.0
         if dist is not None:
             try:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -305,6 +306,14 @@ def main():
             ppo = {"samples_per_s": round(30 * E * world / (r_s + u_s), 1), "rollout_s": round(r_s, 5), "update_s": round(u_s, 5),
                    "config": "T=30 steps x %d envs per GPU, ppo_epoch 5, num_mini_batch 2, Adam; 3 updates run, the last one timed" % E,
                    "value_loss": round(last["value_loss"], 6)}
+            # roofline of the update on THIS rank (every rank does the same work on its own shard; the time is the max over ranks):
+            # algorithmic FLOPs of forward + backward over ppo_epoch passes / update_s, against the bf16x3 MFMA peak
+            from crowdnav_prediction_attngraph_amd.trainer import update_flops
+            uf = update_flops(rows_local, 30 * E, 5)
+            ppo["roofline"] = {"bound": "mfma", "achieved": round(uf / u_s / 1e12, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
+                               "frac": round(uf / u_s / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4), "live_rows": int(rows_local),
+                               "note": "3 (fwd + dX + dW) x ppo_epoch 5 x [live rows x 1.966 MFLOP (the three dense layers of the human-human block) + "
+                                       "30 x %d samples x 0.79 MFLOP (robot-node layers)] / update_s; peak = 2500 TFLOP/s dense bf16 / 3 split passes" % E}
             if last.get("allreduce_ms") is not None:   # N > 1: one flat 10 MB gradient all-reduce per optimiser step (this rank's mean)
                 ppo["grad_allreduce_ms_per_step"] = round(float(last["allreduce_ms"]), 4)
     if rank != 0:

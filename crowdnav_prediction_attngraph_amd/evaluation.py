@@ -66,7 +66,11 @@ def _evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging
     if num_processes != 1 or eval_envs.num_envs != 1:
         raise NotImplementedError("the reference evaluates with ONE env (test.py:136); use evaluate_batched for the parallel form")
     if visualize:
-        raise NotImplementedError("rendering is out of scope of the accelerated path")
+        # rl/evaluation.py:84-85 draws every step.  Rendering is out of scope here, but the reference's test.py cannot switch it off (its
+        # --visualize flag is `default=True, action='store_true'`, test.py:25), so the request is acknowledged instead of refused: the
+        # episodes run, nothing is drawn, the metrics are the same.
+        import warnings
+        warnings.warn("evaluate(visualize=True): rendering is not implemented on the accelerated path; running the episodes without drawing")
     scripted = actor_critic is None          # robot.policy in ('orca', ...): the env drives the robot itself (test.py:152-153)
     if scripted and int(eval_envs.cfg.robot_policy) == 0:
         raise ValueError("actor_critic is None but the env was not configured with robot.policy = 'orca'")

@@ -61,8 +61,11 @@ class PPO():
         if self._bound(params):
             return
         dev = params[0].device
-        n = sum(p.numel() for p in params)
-        # 16-byte aligned starts for every parameter would waste nothing useful here: the kernels index the bucket as a whole
+        # every parameter starts on a 16-byte boundary of the bucket: its .data pointer is handed to kernels that load rows as float4
+        # (cn_split_bf16, cn_embed0_*, cn_gru_seq_*, bias vectors ...); the 1- and 2-element tensors (critic_linear.bias, fc_mean.bias,
+        # logstd) would otherwise leave everything behind them 4-byte aligned.  The padding stays zero in all four buckets: no
+        # gradient, no moment, no update, nothing added to the gradient norm.
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)
         flat = {k: torch.zeros(n, dtype=torch.float32, device=dev) for k in ("p", "g", "m", "v")}
         views, off, step = [], 0, 0
         for p in params:
@@ -77,7 +80,7 @@ class PPO():
             p.grad = gv
             self.optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": mv, "exp_avg_sq": vv}
             views.append((pv, gv, mv, vv))
-            off += k
+            off += (k + 3) // 4 * 4
         flat["views"] = views
         flat["ws"] = torch.empty(hip.A.lib().cn_adam_workspace_doubles(), dtype=torch.float64, device=dev)
         self._flat = flat

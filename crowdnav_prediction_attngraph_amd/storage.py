@@ -102,14 +102,17 @@ class RolloutStorage(object):
         assert num_processes >= num_mini_batch, (
             "PPO requires the number of processes ({}) to be greater than or equal to the number of PPO mini batches ({}).".format(
                 num_processes, num_mini_batch))
-        if num_processes % num_mini_batch != 0:
-            # the reference's per-env loop indexes perm[start + offset] and raises IndexError here (storage.py:198-203)
-            raise IndexError("num_processes ({}) must be divisible by num_mini_batch ({})".format(num_processes, num_mini_batch))
+        # storage.py:190-192: groups of num_processes // num_mini_batch envs, as many as range(0, num_processes, npb) gives -- 6 envs
+        # with 4 mini-batches run as 6 groups of one env, 8 with 3 as 4 groups of two
         npb = num_processes // num_mini_batch
         perm = torch.randperm(num_processes)
         T = self.num_steps
         dev = self.rewards.device
         for start in range(0, num_processes, npb):
+            if start + npb > num_processes:
+                # a last, incomplete group: the reference's per-env loop reads perm[start + offset] past the end here and raises
+                # IndexError in the middle of the epoch, after the complete groups have been yielded (storage.py:209-210)
+                raise IndexError("index {} is out of bounds for dimension 0 with size {}".format(num_processes, num_processes))
             idx = perm[start:start + npb].to(dev)
             N = idx.numel()
 

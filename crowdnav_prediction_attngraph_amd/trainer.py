@@ -128,6 +128,18 @@ def load_checkpoint(policy_path, resume_path, actor_critic, agent, envs, rollout
     return int(ck["update"]) + 1
 
 
+def update_flops(live_rows, samples, ppo_epoch):
+    """Algorithmic FLOPs of one PPO.update(): ppo_epoch passes over all samples, forward + backward (dX and dW: 2 x forward) of
+      * the three dense layers of the human-human block on the live rows (embedding_layer.2 128->512, folded q|k|v 512->1536, folded
+        out_proj∘spatial_linear 512->256: 1.966 MFLOP per row, the figure bench.py prices the rollout kernel with), and
+      * the per-sample robot-node layers (robot_linear 9->256, [u | enc] 256->320, edge embed 256->64, GRU 2 x 128->384, folded
+        output_linear∘(actor.0 | critic.0) 128->512, actor.2 / critic.2 256->256, heads): 0.79 MFLOP per sample.
+    The attention cores, the D->128 input layer and all pointwise work are left out (< 3 %)."""
+    hh = 2.0 * (128 * 512 + 512 * 1536 + 512 * 256)
+    rn = 2.0 * (9 * 256 + 256 * 320 + 256 * 64 + 2 * 128 * 384 + 128 * 512 + 2 * 256 * 256 + 256 + 512)
+    return 3.0 * ppo_epoch * (live_rows * hh + samples * rn)
+
+
 def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_updates=10, seed=425, config=None, ppo_epoch=5,
           num_mini_batch=2, lr=4e-5, eps=1e-5, clip_param=0.2, value_loss_coef=0.5, entropy_coef=0.0, max_grad_norm=0.5, gamma=0.99,
           gae_lambda=0.95, log=print, device=None, save_dir=None, save_interval=0, resume=None):
@@ -164,12 +176,14 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
         rollouts.compute_returns(next_value, True, gamma, gae_lambda, False)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
+        # live (env, human) rows of the T x E samples the update trains on: the human-human block runs on these (see update_flops)
+        live_rows = rollouts.obs["detected_human_num"][:num_steps].clamp(1, envs.human_num).sum()
         value_loss, action_loss, dist_entropy = agent.update(rollouts)
         rollouts.after_update()
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
         rec = dict(update=j, value_loss=value_loss, action_loss=action_loss, entropy=dist_entropy, rollout_s=t1 - t0, update_s=t2 - t1,
-                   allreduce_ms=getattr(agent, "last_allreduce_ms", None),
+                   allreduce_ms=getattr(agent, "last_allreduce_ms", None), live_rows=int(live_rows.item()),
                    samples_per_s=num_steps * num_processes / (t2 - t0), **stats.pop())
         history.append(rec)
         if log:

@@ -164,3 +164,92 @@ def test_reference_collect_data_py_runs_unchanged_and_writes_the_collector_s_fil
     for i in range(3):
         got = open(str(tmp_path / "ds" / "test" / ("%d.txt" % i))).read().split("\n")
         assert got[-1] == "" and got[:-1] == want[i] and len(want[i]) > 100
+
+
+def test_reference_train_py_then_test_py_run_unchanged_on_baseline_config0(tmp_path, monkeypatch):
+    """BASELINE configs[0] literally -- CrowdSimVarNum-v0, 5 ORCA humans, predict_method 'none', 1 env (`--num-processes 1
+    --num-mini-batch 1 --no-cuda`, which makes the env phase 'test', rl/networks/envs.py:55-58) -- through the reference's own workflow:
+    edit config.py / arguments.py, run train.py, run test.py on the directory it wrote.  Both scripts are EXECUTED where they lie,
+    unmodified, against a working copy of dropin/ carrying the user's edits; the only substitution is the simulator behind
+    make_vec_envs (C oracle on the CPU).  test.py takes no flags that arguments.get_args() would accept (test.py:20-33 are edited by
+    hand upstream), so it runs with its built-in defaults: model_dir 'trained_models/GST_predictor_rand', weights '41665.pt',
+    visualize on.  Its log line must equal what the mirror's evaluate() returns for the same policy and envs."""
+    import re
+    import shutil
+    work = tmp_path / "work"
+    shutil.copytree(DROPIN, str(work), ignore=shutil.ignore_patterns("__pycache__"))
+    # --- the edits a user of the reference makes by hand before training (config.py:43, :22; arguments.py defaults) ---
+    cfg_py = work / "crowd_nav" / "configs" / "config.py"
+    cfg_py.write_text(cfg_py.read_text() + "        self.sim.human_num = 5\n        self.env.test_size = 4\n")
+    arg_py = work / "arguments.py"
+    txt = arg_py.read_text()
+    for a, b in (('("--env-name", dict(default="CrowdSimPredRealGST-v0"))', '("--env-name", dict(default="CrowdSimVarNum-v0"))'),
+                 ('("--no-cuda", dict(action="store_true", default=False))', '("--no-cuda", dict(action="store_true", default=True))'),
+                 ('("--num-processes", dict(type=int, default=16))', '("--num-processes", dict(type=int, default=1))'),
+                 ('("--num-mini-batch", dict(type=int, default=2))', '("--num-mini-batch", dict(type=int, default=1))'),
+                 ('("--num-steps", dict(type=int, default=30))', '("--num-steps", dict(type=int, default=6))'),
+                 ('("--seq_length", dict(type=int, default=30))', '("--seq_length", dict(type=int, default=6))'),
+                 ('("--ppo-epoch", dict(type=int, default=5))', '("--ppo-epoch", dict(type=int, default=2))'),
+                 ('("--num-env-steps", dict(type=float, default=20e6))', '("--num-env-steps", dict(type=float, default=6))'),
+                 ('("--output_dir", dict(type=str, default="trained_models/my_model"))', '("--output_dir", dict(type=str, default="trained_models/GST_predictor_rand"))')):
+        assert a in txt, a
+        txt = txt.replace(a, b)
+    arg_py.write_text(txt)
+    saved_path, saved_mods = list(sys.path), set(sys.modules)
+    sys.path.insert(0, str(work))
+    monkeypatch.chdir(str(work))
+    monkeypatch.setenv("MPLBACKEND", "Agg")
+    nthreads = torch.get_num_threads()
+    try:
+        import matplotlib
+        matplotlib.use("Agg", force=True)
+        import rl.networks.envs as shim_envs
+        from tests import oracle_vec_env
+        assert os.path.abspath(shim_envs.__file__).startswith(str(work))
+        monkeypatch.setattr(shim_envs, "make_vec_envs", oracle_vec_env.make_vec_envs)   # the ONLY substitution: simulator -> CPU oracle
+        # ---- train.py: one PPO update of 6 steps on one env ----
+        monkeypatch.setattr(sys, "argv", ["train.py"])
+        runpy.run_path(os.path.join(REF, "train.py"), run_name="__main__")
+        model_dir = work / "trained_models" / "GST_predictor_rand"
+        assert (model_dir / "checkpoints" / "00000.pt").is_file() and (model_dir / "configs" / "config.py").is_file() and (model_dir / "arguments.py").is_file()
+        os.rename(str(model_dir / "checkpoints" / "00000.pt"), str(model_dir / "checkpoints" / "41665.pt"))   # test.py:29 default weight file
+        for d in ("trained_models", "trained_models/GST_predictor_rand", "trained_models/GST_predictor_rand/configs"):
+            init = work / d / "__init__.py"           # test.py:41-60 imports <model_dir>.arguments / .configs.config as packages
+            if not init.exists():
+                init.write_text("")
+        # ---- test.py: 4 test episodes with the checkpoint train.py wrote ----
+        monkeypatch.setattr(sys, "argv", ["test.py"])
+        import logging
+        monkeypatch.setattr(logging.root, "handlers", [])     # test.py:80-82 logging.basicConfig is a no-op while pytest's capture handlers sit on the root logger
+        with pytest.warns(UserWarning, match="rendering is not implemented"):
+            runpy.run_path(os.path.join(REF, "test.py"), run_name="__main__")
+        log = (model_dir / "test" / "test_visual.log").read_text()
+        m = re.search(r"Testing success rate: ([\d.]+), collision rate: ([\d.]+), timeout rate: ([\d.]+), nav time: ([\d.]+), path length: ([\d.]+), "
+                      r"average intrusion ratio: ([\d.]+)%, average minimal distance during intrusions: ([\d.naif]+)", log)
+        assert m, log
+        # ---- the same evaluation through the mirror's API ----
+        from arguments import get_args
+        from crowd_nav.configs.config import Config
+        from rl.evaluation import evaluate
+        from rl.networks.model import Policy
+        args, config = get_args([]), None
+        monkeypatch.setattr(sys, "argv", ["x"])
+        config = Config()
+        assert (args.env_name, args.num_processes, config.sim.human_num, config.sim.predict_method, config.env.test_size) == ("CrowdSimVarNum-v0", 1, 5, "none", 4)
+        envs = oracle_vec_env.make_vec_envs(args.env_name, args.seed, 1, args.gamma, None, torch.device("cpu"), True, config=config)
+        assert envs.cfg.phase == 2 and envs.cfg.human_num == 5            # phase 'test' (one env), five humans
+        pol = Policy(envs.observation_space.spaces, envs.action_space, base_kwargs=args, base=config.robot.policy)
+        pol.load_state_dict(torch.load(str(model_dir / "checkpoints" / "41665.pt"), map_location="cpu"))
+        pol.base.nenv = 1
+        got = evaluate(pol, envs, 1, torch.device("cpu"), config.env.test_size, None, config, args, False)
+        want = [float(x) if x not in ("nan",) else float("nan") for x in m.groups()]
+        have = [got["success_rate"], got["collision_rate"], got["timeout_rate"], got["nav_time"], got["path_length"], got["intrusion_ratio"], got["min_intrusion_dist"]]
+        for w, h in zip(want, have):
+            assert (w != w and h != h) or abs(w - float("%.2f" % h)) < 1e-9, (want, have)
+        assert got["episodes"] == 4
+    finally:
+        torch.set_num_threads(nthreads)
+        sys.path[:] = saved_path
+        for mname in set(sys.modules) - saved_mods:
+            if mname.split(".")[0] in ("rl", "crowd_sim", "crowd_nav", "arguments", "trained_models"):
+                del sys.modules[mname]

@@ -259,5 +259,9 @@ def test_recurrent_generator_on_the_gpu_matches_reference_layout():
         assert hx_b["human_human_edge_rnn"].shape == (npb, H + 1, 256) and obs_b["spatial_edges"].is_cuda
         n += 1
     assert n == nmb
+    # 5 envs in 2 mini-batches: two complete groups of two, then the reference's IndexError on the incomplete third (storage.py:209-210)
+    got = []
     with pytest.raises(IndexError):
-        next(iter(RolloutStorage(T, 5, ob_space.spaces, act_space, 128, 256).recurrent_generator(torch.zeros(T, 5, 1), 2)))
+        for batch in RolloutStorage(T, 5, ob_space.spaces, act_space, 128, 256).recurrent_generator(torch.zeros(T, 5, 1), 2):
+            got.append(batch[2].shape[0])
+    assert got == [2 * T, 2 * T]

@@ -111,6 +111,8 @@ def test_ppo_update_reference_golden_through_the_hip_path(path, mode):
         # ... and the sums over the whole tensor, 1e-5 relative to sum |w| (the plain sum cancels)
         np.testing.assert_allclose(np.abs(a).sum(), z["chk_" + k][1], rtol=1e-5, atol=0, err_msg=k)
         np.testing.assert_allclose(a.sum(), z["chk_" + k][0], rtol=0, atol=1e-5 * float(z["chk_" + k][1]) + 1e-12, err_msg=k)
+    # every parameter (view into the flat bucket) starts on a 16-byte boundary: their raw pointers feed float4 loads in the kernels
+    assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in pol.parameters())
     # the torch optimiser object still owns a faithful state (checkpointing): step count and moments of a touched parameter
     st = agent.optimizer.state[pol.dist.fc_mean.weight]
     assert float(st["step"]) == meta["ppo_epoch"] * nmb and float(st["exp_avg"].abs().sum()) > 0

@@ -142,3 +142,14 @@ def test_recurrent_generator_layout_matches_reference_semantics():
     assert sorted(seen) == list(range(E))
     with pytest.raises(AssertionError):
         list(ro.recurrent_generator(adv, E + 1))
+    # the group size is num_processes // num_mini_batch and range(0, num_processes, size) decides how many groups there are
+    # (storage.py:190-192): 6 envs with 4 mini-batches -> 6 groups of one env; an incomplete last group raises IndexError only
+    # after the complete ones were yielded (storage.py:209-210)
+    assert [b[2].shape[0] for b in ro.recurrent_generator(adv, 4)] == [T] * 6
+    ro8 = RolloutStorage(T, 8, ob_space.spaces, act_space, 128, 256)
+    assert [b[2].shape[0] for b in ro8.recurrent_generator(torch.zeros(T, 8, 1), 3)] == [2 * T] * 4
+    ro7, got = RolloutStorage(T, 7, ob_space.spaces, act_space, 128, 256), []
+    with pytest.raises(IndexError):
+        for b in ro7.recurrent_generator(torch.zeros(T, 7, 1), 2):
+            got.append(b[2].shape[0])
+    assert got == [3 * T, 3 * T]
