@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--dephase", type=int, default=240,
                     help="untimed pre-roll steps before the warm-up so that the envs are spread over their episodes (all envs start an episode "
                          "together at reset; SURVEY 8d asks for a de-phased steady-state window)")
+    ap.add_argument("--kernel-events-every", type=int, default=4,
+                    help="the dominant kernel is timed live with a pair of HIP events on its stream around every n-th launch of the timed "
+                         "window (an event record on the critical stream costs a few microseconds of dispatch gap: 1 = every launch)")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -234,7 +237,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    pol.set_profiling(True)
+    pol.set_profiling(args.kernel_events_every)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):

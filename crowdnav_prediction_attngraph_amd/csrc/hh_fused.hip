@@ -828,6 +828,21 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     // when it gets here, and nobody touches them before the second __syncthreads below)
     if (w8 == 0 && lane < 4) *reinterpret_cast<unsigned *>(lds + LDS_CTR + 4 * lane) = 0u;
     unsigned bar_target = 0;
+    // The embedding_layer.2 weights of this wavefront (4 k-steps x 8 fragments, 32 KB) are requested before anything else: in the
+    // X phase below all eight wavefronts are in the same phase, nothing hides its 256 KB weight stream (6 k cycles at the L2 rate,
+    // the longest item of the tile prologue) -- here it runs under the latency-bound e0 phase.
+    bf16x8 wq[4][8]; // [k-step][j*2 + plane]
+    {
+        const int wv = w8 >> 1, half = w8 & 1; // position in the baked image: [wave 4][ks 4][j 8 = half 2 x 4][plane 2]
+        const unsigned wp = WB.emb2 + (unsigned)wv * 4 * 16 * 1024;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wq[ks][2 * j] = ldb(WB, wp + ((ks * 8 + half * 4 + j) * 2 + 0) * 1024, uoff);
+                wq[ks][2 * j + 1] = ldb(WB, wp + ((ks * 8 + half * 4 + j) * 2 + 1) * 1024, uoff);
+            }
+    }
     // ---------------- e0: relu(x W0^T + b0) for feature k-step `wave` (natural k order); team tm takes the row blocks of its parity ----------------
     {
         const int c0 = 32 * wave + 8 * g;
@@ -859,28 +874,13 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     HH_T(0);
     // ---------------- X = relu(e0 W2^T + b2): wavefront w8 of the 8 produces feature blocks 4*w8..4*w8+3 (X k-steps 2*w8, 2*w8+1) ----------------
     {
-        const int wv = w8 >> 1, half = w8 & 1; // position in the baked image: [wave 4][ks 4][j 8 = half 2 x 4][plane 2]
-        const unsigned wp = WB.emb2 + (unsigned)wv * 4 * 16 * 1024;
         f32x4 acc[4][NRB];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) acc[j][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 wq[2][8]; // [slot][j*2 + plane]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wq[0][2 * j] = ldb(WB, wp + ((0 * 8 + half * 4 + j) * 2 + 0) * 1024, uoff);
-            wq[0][2 * j + 1] = ldb(WB, wp + ((0 * 8 + half * 4 + j) * 2 + 1) * 1024, uoff);
-        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    wq[(ks + 1) & 1][2 * j] = ldb(WB, wp + (((ks + 1) * 8 + half * 4 + j) * 2 + 0) * 1024, uoff);
-                    wq[(ks + 1) & 1][2 * j + 1] = ldb(WB, wp + (((ks + 1) * 8 + half * 4 + j) * 2 + 1) * 1024, uoff);
-                }
-            }
             bf16x8 xh[NRB], xl[NRB];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -888,7 +888,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 xl[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_S + E0_PLANE + (ks * RB + rb) * 1024 + loff);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 *w = wq[ks & 1];
+            const bf16x8 *w = wq[ks];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -949,6 +949,18 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     // Head order: team tm takes every second head; the starting head is staggered over the workgroups of an XCD (32 simultaneous
     // readers of one weight line serialise on its L2 channel).  The sum over the heads is order independent up to fp32 rounding.
     const int h0 = ((int)blockIdx.x >> 3) & 7;
+    // weight prefetch ring of the q.k.v loop: steps ks .. ks+PF-1.  The first PF-1 steps of a head are requested BEFORE the previous
+    // head's attention chain (and, for the first head, before the X epilogue above), so that every loop starts on a warm ring instead
+    // of a cold L2 round trip.
+    bf16x8 wf[PF][6];
+    auto ring_prologue = [&](const int hh_) __attribute__((always_inline)) {
+        const unsigned wp_ = WB.qkv + (unsigned)((((h0 + 2 * hh_ + tm) & 7) * 4 + wave) * 16) * 6 * 1024;
+#pragma unroll
+        for (int p = 0; p < PF - 1; ++p)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) wf[p][c] = ldb(WB, wp_ + (p * 6 + c) * 1024, uoff);
+    };
+    ring_prologue(0);
 #pragma unroll 1
     for (int hh = 0; hh < 4; ++hh) {
         const int h = (h0 + 2 * hh + tm) & 7;
@@ -957,11 +969,6 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { aq[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[rb] = aq[rb]; av[rb] = aq[rb]; }
         const unsigned wp = WB.qkv + (unsigned)((h * 4 + wave) * 16) * 6 * 1024;
-        bf16x8 wf[PF][6]; // weight prefetch ring: steps ks .. ks+PF-1
-#pragma unroll
-        for (int p = 0; p < PF - 1; ++p)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) wf[p][c] = ldb(WB, wp + (p * 6 + c) * 1024, uoff);
         constexpr int NXB = XDB ? 2 : 1;
         bf16x8 xh[NXB][NRB], xl[NXB][NRB];
         if (XDB) {
@@ -1048,6 +1055,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll 1
         for (int k4 = 0; k4 < 16 - PF; k4 += PF) group(k4, std::false_type{});
         group(16 - PF, std::true_type{});
+        if (hh + 1 < 4) ring_prologue(hh + 1); // in flight during this head's attention chain
         HH_T(2);
         // the attention chain is short, latency bound and holds the shared scratch: let it win the issue arbitration against the
         // partner wavefront's q.k.v loop on this SIMD (which fills whatever is left)
@@ -1253,6 +1261,9 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 
 } // namespace team
 
+#ifndef HH_TEAM_PF3
+#define HH_TEAM_PF3 2   // prefetch depth (k-steps) of the bodies of <= 3 row blocks (4 measured the same; 2 leaves registers for the cross-head prefetch)
+#endif
 #ifndef HH_TEAM_PF4
 #define HH_TEAM_PF4 2   // prefetch depth of the 4-row-block body (register budget: 256)
 #endif
@@ -1280,9 +1291,9 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
         const TileCtx t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
         const int nrb = (t.nrows + 15) >> 4;
         switch (nrb) {
-        case 1: team::tile_body<1, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        case 2: team::tile_body<2, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        case 3: team::tile_body<3, 4, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 1: team::tile_body<1, HH_TEAM_PF3, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 2: team::tile_body<2, HH_TEAM_PF3, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 3: team::tile_body<3, HH_TEAM_PF3, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
         default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
         }
         e += t.n_env;

@@ -662,8 +662,11 @@ struct cn_policy {
     // robot-side launches that do not depend on the human-human block run on this stream, beside the big GEMMs
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
-    // profiling of the dominant kernel (QKV projection)
-    bool profiling;
+    // profiling of the dominant kernel: every prof_every-th forward is bracketed by a pair of events (an event record on the
+    // critical stream costs a few microseconds of dispatch gap, so the bracket is sampled, not put around every launch)
+    bool profiling;       // THIS forward is bracketed
+    int prof_every;       // 0 = off
+    long long prof_tick;
     static constexpr int PROF_RING = 64;
     hipEvent_t ev[PROF_RING][2]; // ring of (start, stop) pairs around the QKV projection launch
     int ev_head, ev_tail;        // [tail, head) are recorded but not yet harvested
@@ -750,7 +753,7 @@ extern "C" int cn_policy_create(int human_num, int edge_width, int max_envs, cn_
     p->gemm_mode = 2;
     p->te_w = F(o_tew); p->te_b = F(o_teb); p->ac0f_w = F(o_acfw); p->ac0f_b = F(o_acfb); p->z = F(o_z);
     p->weights_set = false;
-    p->profiling = false;
+    p->profiling = false; p->prof_every = 0; p->prof_tick = 0;
     p->ev_head = p->ev_tail = 0;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest); // side work yields to the caller's stream (critical path)
@@ -878,6 +881,7 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_REQUIRE(hxs_in && masks && value, "policy: null pointer");
     const int H = p->H, D = p->D, M = E * H;
     int rc;
+    p->profiling = p->prof_every > 0 && (p->prof_tick++ % p->prof_every) == 0;
     if (p->gemm_mode == 2) {
         // fused mode: two launches -- the human-human kernel (which also builds the row offsets) and the robot-node kernel
         if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
@@ -1010,8 +1014,8 @@ extern "C" int cn_policy_set_taps(cn_policy *p, int enabled)
 
 extern "C" int cn_policy_set_profiling(cn_policy *p, int enabled)
 {
-    CN_REQUIRE(p, "cn_policy_set_profiling: null handle");
-    p->profiling = enabled != 0;
+    CN_REQUIRE(p && enabled >= 0, "cn_policy_set_profiling: null handle or negative stride");
+    p->prof_every = enabled; p->prof_tick = 0; p->profiling = false;
     return CN_OK;
 }
 

@@ -218,8 +218,9 @@ class HipPolicy:
         """Fused mode: keep / drop the test taps (robot_emb, hr_attn, hr_out, actor_feat) the robot-node kernel writes per forward."""
         A.check(A.lib().cn_policy_set_taps(self._h, int(bool(enabled))), "cn_policy_set_taps")
 
-    def set_profiling(self, enabled):
-        A.check(A.lib().cn_policy_set_profiling(self._h, int(bool(enabled))), "cn_policy_set_profiling")
+    def set_profiling(self, every):
+        """0 / False: off; n >= 1 (True = 1): every n-th forward's dominant kernel is timed with a pair of events on its stream."""
+        A.check(A.lib().cn_policy_set_profiling(self._h, int(every)), "cn_policy_set_profiling")
 
     def get_profile(self):
         ms = (C.c_double * 8)()

@@ -229,9 +229,11 @@ int cn_policy_set_taps(cn_policy *p, int enabled);
  *   0           = exact fp32 on v_mfma_f32_32x32x2_f32, separate launches.
  * Everything outside the three large GEMMs always runs in exact fp32. */
 int cn_policy_set_gemm_mode(cn_policy *p, int mode);
-/* Dominant-kernel timing support for bench.py: number of HH-block launches so far and accumulated device time of the
- * QKV projection kernel measured with hipEvents on `stream` when profiling is enabled. */
-int cn_policy_set_profiling(cn_policy *p, int enabled);
+/* Dominant-kernel timing support for bench.py: `every` = 0 switches it off, n >= 1 brackets every n-th forward's dominant kernel
+ * (the fused human-human kernel, or the QKV projection of the separate-launch modes) with a pair of hipEvents on `stream`;
+ * cn_policy_get_profile returns the accumulated device time [0], the bracketed launches [0] and their live rows [1].  An event
+ * record costs a few microseconds of dispatch gap on the stream it sits on, hence the stride. */
+int cn_policy_set_profiling(cn_policy *p, int every);
 int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launches_out /*[8]*/);
 
 /* ---- human-human attention core, stand-alone (training path) ----
