@@ -4,11 +4,11 @@
 // on the compacted live rows.  Nothing between the observation and out_sp [rows,256] touches HBM: the activations live in
 // LDS / registers, the weights stream from L2 straight into MFMA operand registers.
 //
-// Work split.  One workgroup (4 wavefronts, one per SIMD, 160 KB of LDS) per CU owns a contiguous chunk of ~rows/256 live rows
-// (whole envs) and walks it in tiles of <= 64 rows = <= 4 row blocks of 16.  Per tile:
+// Work split.  One workgroup per CU (all 160 KB of its LDS) owns a contiguous chunk of ~rows/256 live rows (whole envs) and walks it
+// in tiles of <= 63 rows = <= 4 row blocks of 16.  Per tile:
 //   e0   = relu(x W0^T + b0)                     VALU, written as bf16 hi/lo MFMA fragments into LDS
-//   X    = relu(e0 W2^T + b2)        [64,512]    MFMA; stays in LDS for the whole tile as hi/lo fragments (128 KB)
-//   for each head h:  q|k|v = X Wh^T + bh        [64,192]   MFMA (16 k-steps, the dominant loop)
+//   X    = relu(e0 W2^T + b2)        [rows,512]  MFMA; stays in LDS for the whole tile as hi/lo fragments (2 KB per row)
+//   for each head h:  q|k|v = X Wh^T + bh        [rows,192]  MFMA (16 k-steps, the dominant loop)
 //                     S^T = K Q^T, P = softmax over the keys of the query's env     MFMA + VALU (env block mask)
 //                     O^T = V^T P^T              MFMA, V straight from the accumulators
 //                     out += O Wos[:, h]^T       MFMA, accumulators persist over the heads
@@ -17,25 +17,27 @@
 // the same arithmetic as gemm3.h; softmax in fp32.
 //
 // Layout tricks that keep the chain on chip:
-//   * wavefront w owns OUTPUT FEATURES (q/k/v feature block w of the head, X k-steps 4w..4w+3, out_sp feature blocks 4w..4w+3), never
-//     rows: a weight fragment is needed by exactly one wavefront, so it goes global -> VGPR with one coalesced 1 KB load (the
-//     fragments are stored in streaming order by hh_fused_bake) and is reused by every row block; only activations use LDS.
+//   * a wavefront owns OUTPUT FEATURES (q/k/v feature block w of the head, out_sp feature blocks 4w..4w+3), never rows: a weight
+//     fragment is needed by exactly one wavefront, so it goes L2 -> VGPR with one coalesced 1 KB load (the fragments are stored in
+//     streaming order by hh_fused_bake) and is reused by every row block; only activations use LDS.
 //   * products are issued "transposed" (A operand = weight fragment, B operand = activation fragment): the C layout then has
 //     4 consecutive output features of ONE row in a lane, i.e. half of the next product's activation fragment -- a pair of
 //     feature blocks is one 16-byte fragment entry.  The contraction index of every consumer is permuted accordingly
 //     (perm32: element u of lane group g <-> offset 16*(u>>2) + 4*g + (u&3)); weights are baked with the same permutation.
 //   * V is produced in normal form (rows in the C layout) so that it is the A operand of O^T = V^T P^T without leaving the
 //     registers, and S^T (keys in the C layout rows) is exactly the P fragment of the same product.
-//   * LDS holds fragments in fragment-major order [plane][k-step][row block][lane][16 B]: every ds_read_b128 / ds_write_b64 /
-//     ds_write_b128 is lane-linear, hence bank-conflict free by construction.
+//   * LDS holds fragments in fragment-major order [plane][k-step][row block][lane][16 B]: every ds_read_b128 / ds_write_b128 is
+//     lane-linear (the 8-byte half-fragment stores of Q / K / O are 2-way: two wavefronts share a 16-byte entry).
 //
 // Two kernels share this file:
-//   hh_fused_kernel       (crowds of <= 48 humans, the default): 8 wavefronts = TWO TEAMS of four, two wavefronts per SIMD.  The tile is
-//       48 rows (X = 96 KB) which leaves room for one 24 KB scratch region PER TEAM; after the embedding phases the teams walk
-//       ALTERNATE HEADS on their own (team-local barriers on LDS counters, s_barrier only between tile phases), so that on every
-//       SIMD the barrier / LDS / softmax phases of one head sit beside the q.k.v MFMA loop of another head instead of running with
-//       nothing to overlap.  The teams' partial out_sp accumulators are exchanged through the (dead) X region at the end of the tile.
-//   hh_fused_wide_kernel  (crowds of 49..64 humans: an env must fit one tile): the round-2 schedule, 4 wavefronts, 64-row tiles.
+//   hh_fused_kernel       (crowds of <= 48 humans, the default): 8 wavefronts = TWO TEAMS of four, two wavefronts per SIMD, 256
+//       registers each.  After the embedding phases the teams walk ALTERNATE HEADS on their own (team barriers on LDS counters,
+//       s_barrier only between tile phases), so that on every SIMD the barrier / LDS / softmax chain of one head sits beside the
+//       q.k.v MFMA loop of another head.  Tiles of <= 48 rows give each team its own scratch region; tiles of 49..63 rows fill the
+//       LDS with X and share one scratch region in turns (namespace team, struct Layout).  The teams' partial out_sp accumulators
+//       are exchanged through the (dead) X region at the end of the tile.  DESIGN.md section 4 has the measurements behind each choice.
+//   hh_fused_wide_kernel  (crowds of 49..64 humans: an env must fit one tile): the round-2 schedule, 4 wavefronts (one per SIMD),
+//       64-row tiles.
 #include "hh_fused.h"
 
 #include <climits>
