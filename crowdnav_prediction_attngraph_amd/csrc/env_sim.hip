@@ -1816,6 +1816,13 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     return prefetch_orca(env, st); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
 }
 
+extern "C" int cn_env_join(cn_env_batch *env, void *stream)
+{
+    CN_REQUIRE(env, "cn_env_join: null handle");
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent((hipStream_t)stream, env->ev_orca, 0));
+    return CN_OK;
+}
+
 extern "C" int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream)
 {
     CN_REQUIRE(env, "cn_env_get_state: null handle");

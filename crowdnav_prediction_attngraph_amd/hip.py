@@ -73,6 +73,12 @@ class HipEnvBatch:
                                         A.ptr(self.ep_return), A.ptr(self.ep_len), A.ptr(not_done), A.stream_ptr()), "cn_env_step")
         return obs, reward, self.done, self.info, self.ep_return, self.ep_len
 
+    def join(self):
+        """Order the library's side-stream work (ORCA of the current state, episode pre-generation) before what the caller enqueues next
+        on the current stream: needed to close a graph capture of a block of steps."""
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_join(self._h, A.stream_ptr()), "cn_env_join")
+
     def get_state(self):
         humans = torch.zeros(self.E, self.H, 8, dtype=torch.float64, device=self.device)
         robot = torch.zeros(self.E, 8, dtype=torch.float64, device=self.device)

@@ -145,6 +145,10 @@ int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);
  * Envs that finish are reset in the same launch and `obs` holds the reset observation for them (shmem_vec_env.py:139-142). */
 int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done, uint8_t *info,
                 double *ep_return, int32_t *ep_len, float *not_done, void *stream);
+/* Orders everything the library has in flight on its internal side stream (ORCA of the current state, next-episode pre-generation)
+ * before whatever is enqueued on `stream` next.  cn_env_step does this itself; a caller needs it to close a hipGraph capture of a block
+ * of steps (a capture may not end with unjoined work on a forked stream) -- see trainer.GraphedRollout / bench.py --graph. */
+int cn_env_join(cn_env_batch *env, void *stream);
 /* Debug/test access to the simulator state: copies humans [E,H,8] (px,py,vx,vy,gx,gy,radius,v_pref) and robot [E,8]
  * (px,py,vx,vy,gx,gy,theta,potential) as float64 into caller DEVICE buffers (either may be NULL). */
 int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream);
