@@ -160,10 +160,13 @@ class PPO():
                     flat = self._flat
                     flat["g"].zero_()                         # optimizer.zero_grad(): the views stay bound
                     total_loss.backward()
-                    for p, (_, gv, _, _) in zip(self._params(), flat["views"]):
-                        if p.grad is not gv and p.grad.data_ptr() != gv.data_ptr():
-                            gv.copy_(p.grad)                  # something replaced .grad instead of accumulating into the bucket
-                            p.grad = gv
+                    if num_steps == 0:
+                        # autograd accumulates into the bound views; checked once per update() (not per optimiser step: the walk is
+                        # O(parameters) of Python) in case something replaced a .grad instead of accumulating into the bucket
+                        for p, (_, gv, _, _) in zip(self._params(), flat["views"]):
+                            if p.grad is not gv and p.grad.data_ptr() != gv.data_ptr():
+                                gv.copy_(p.grad)
+                                p.grad = gv
                     scale = 1.0
                     if d is not None:
                         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
