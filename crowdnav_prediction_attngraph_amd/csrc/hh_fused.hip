@@ -684,15 +684,6 @@ __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int
 }
 
 // ===================================================== two-team kernel: 8 wavefronts, 63-row tiles (<= 48 humans) =====================
-#ifndef HH_SPIN_SLEEP
-#define HH_SPIN_SLEEP 1
-#endif
-#ifndef HH_PRIO_QKV
-#define HH_PRIO_QKV 1
-#endif
-#ifndef HH_PRIO_ALT
-#define HH_PRIO_ALT 0
-#endif
 namespace team {
 
 constexpr int FR = 63;                       // rows per tile: at most 4 row blocks of 16; the last row of a fourth block is never live (see CTR)
@@ -758,7 +749,7 @@ __device__ __forceinline__ void team_barrier(char *lds, int bar_off, unsigned &t
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - target) < 0)
-        __builtin_amdgcn_s_sleep(HH_SPIN_SLEEP);
+        __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
 
@@ -770,7 +761,7 @@ __device__ __forceinline__ void wait_turn(char *lds, int ctr_off, unsigned turn)
     lds_u32 *done = (lds_u32 *)(lds + ctr_off + 8);
     const unsigned need = 4u * turn;
     while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - need) < 0)
-        __builtin_amdgcn_s_sleep(HH_SPIN_SLEEP);
+        __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void finish_turn(char *lds, int ctr_off, int lane)
@@ -1038,7 +1029,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
             {
                 constexpr int NM = 9 * NRB, ND = XDB && (!TAIL || ku + 1 < PF) ? 2 * NRB : 0, NV = !TAIL || ku == 0 ? 6 : 0;
                 constexpr int A = NM >= 12 + ND ? 2 : 1;                 // MFMAs in front of each weight load
-                constexpr int B = ND ? (NM - NV * A) / ND : 0;           // MFMAs in front of each X fragment read
+                constexpr int B = (NM - NV * A) / (ND ? ND : 1);         // MFMAs in front of each X fragment read (unused when ND == 0)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     __builtin_amdgcn_sched_group_barrier(0x008, A, 0);
@@ -1220,13 +1211,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int rb = 0; rb < NRB; ++rb) acc_os[j][rb] = mfma(wos[ks][j][0], oh[rb], acc_os[j][rb]);
             if (L::TURNS && ks == 1) finish_turn(lds, LDS_CTR, lane); // the O fragments are in registers: the scratch may go to the other team
         }
-#if HH_PRIO_ALT
-        // q.k.v loops: with equal priorities the older wavefronts (team 0) win every arbitration and team 1 trails by a fifth; the
-        // preference alternates from head to head instead
-        if ((hh + tm) & 1) __builtin_amdgcn_s_setprio(HH_PRIO_QKV); else __builtin_amdgcn_s_setprio(HH_PRIO_QKV + 1);
-#else
-        __builtin_amdgcn_s_setprio(HH_PRIO_QKV);
-#endif
+        __builtin_amdgcn_s_setprio(1); // back to the loop priority (0 / 2 and alternating the preference between the teams measured the same)
         HH_T(10);
     }
     // ---------------- out_sp = relu(out_team0 + out_team1 + b): each team finishes two of its four feature blocks ----------------
@@ -1278,7 +1263,7 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (det) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
-    __builtin_amdgcn_s_setprio(HH_PRIO_QKV); // above the simulator's side-stream wavefronts; the attention chains go to 3 (tile_body)
+    __builtin_amdgcn_s_setprio(1); // above the simulator's side-stream wavefronts; the attention chains go to 3 (tile_body)
     const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = w8 & 3, tm = w8 >> 2;
     const int total = ld_ro(row_off + E);
