@@ -105,7 +105,7 @@ ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
     "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
-    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
+    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
@@ -152,6 +152,9 @@ def lib():
         L.cn_policy_set_gemm_mode.argtypes = [vp, i32]
         L.cn_policy_set_taps.argtypes = [vp, i32]
         L.cn_policy_get_profile.argtypes = [vp, C.POINTER(f64), C.POINTER(i64)]
+        L.cn_hh_block_workspace_bytes.restype = C.c_int64
+        L.cn_hh_block_workspace_bytes.argtypes = []
+        L.cn_hh_block_fwd.argtypes = [i32, i32, i32] + [vp] * 10 + [f32] + [vp] * 7
         L.cn_hh_attention_workspace_ints.restype = C.c_int64
         L.cn_hh_attention_workspace_ints.argtypes = [i32]
         L.cn_hh_attention_fwd.argtypes = [i32, i32, vp, vp, f32, vp, vp, vp]

@@ -9,6 +9,12 @@ struct HhFusedWeights {
     const void *os_frag;   // [head 8][wave 4][ks 2][j 4][plane 2][64][8]               512 KB
     const float *emb0_w, *emb0_b, *emb2_b, *qkv_b, *os_b;
     int prio; // raise the wavefront priority (s_setprio 3) against co-resident side-stream work
+    // training forward (cn_hh_block_fwd): the activations the backward kernels need, written out while they pass through the registers
+    // (all NULL in the rollout): e0 [rows,128] = relu(x W0^T + b0), x [rows,512] = relu(e0 W2^T + b2), qkv [rows,1536] (q NOT scaled),
+    // attn [rows,512] = the attention output before out_proj.  qscale multiplies the scores (1 when the 1/sqrt(64) is folded into the
+    // q weights, as cn_policy_set_weights does; 0.125 for the training weights, which are folded without it).
+    float qscale;
+    float *e0_out, *x_out, *qkv_out, *attn_out;
 };
 
 constexpr size_t HH_EMB2_FRAG_BYTES = (size_t)512 * 128 * 4;

@@ -738,6 +738,24 @@ __device__ __forceinline__ bf16x8 ldb(const WeightBuf &wb, unsigned soff, unsign
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wb.rs, voff, soff, 0));
 }
 
+// Training outputs go out through buffer stores whose resource covers exactly the live rows of the tile: a padded row's store is out of
+// range and the hardware drops it -- no per-row predication (EXEC juggling, one SGPR pair per condition) in the hot loops.
+struct RowBuf { __amdgpu_buffer_rsrc_t rs; };
+__device__ __forceinline__ RowBuf make_row_buf(float *base, int r0, int nrows, int width)
+{
+    RowBuf rb;
+    rb.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)r0 * width), 0, nrows * width * 4, 0x00020000);
+    return rb;
+}
+__device__ __forceinline__ void st4(const RowBuf &b, int float_off, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.rs, float_off * 4, 0, 0);
+}
+__device__ __forceinline__ void st1(const RowBuf &b, int float_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.rs, float_off * 4, 0, 0);
+}
+
 // Barrier among the four wavefronts of ONE team (gfx950 has a single s_barrier per workgroup, which would couple the teams): a
 // monotonic LDS counter, every wavefront adds 1 and spins until the count reaches 4 x (barriers so far).  LDS operations of one
 // wavefront complete in order and lgkmcnt(0) has been waited for before the add, so whoever sees the count sees the data (and the
@@ -797,7 +815,7 @@ __device__ __forceinline__ void finish_rows(const TileCtx &t, const f32x4 (&acc)
     }
 }
 
-template <int NRB, int PF, bool XDB>
+template <int NRB, int PF, bool XDB, bool TRAIN>
 __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const float *__restrict__ se, const HhFusedWeights &W, const WeightBuf &WB,
                                           float *__restrict__ out_sp, char *lds, int lane_in, int wave, int tm)
 {
@@ -811,6 +829,11 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     const int i = lane & 15, g = lane >> 4;
     const int loff = lane * 16;
     const unsigned uoff = (unsigned)loff;
+    RowBuf o_e0{}, o_x{}, o_qkv{}, o_attn{};
+    if (TRAIN) {
+        o_e0 = make_row_buf(W.e0_out, t.r0, t.nrows, 128); o_x = make_row_buf(W.x_out, t.r0, t.nrows, 512);
+        o_qkv = make_row_buf(W.qkv_out, t.r0, t.nrows, 1536); o_attn = make_row_buf(W.attn_out, t.r0, t.nrows, 512);
+    }
     constexpr int NKS = (NRB + 1) / 2; // key k-steps of 32 rows
     const int w8 = 4 * tm + wave;
 #ifdef HH_TIMING
@@ -857,7 +880,11 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 }
                 bf16x8 hi, lo;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { __bf16 h, l; split1(fmaxf(v[u], 0.0f), h, l); hi[u] = h; lo[u] = l; }
+                for (int u = 0; u < 8; ++u) { v[u] = fmaxf(v[u], 0.0f); __bf16 h, l; split1(v[u], h, l); hi[u] = h; lo[u] = l; }
+                if (TRAIN) {
+                    st4(o_e0, (rb * 16 + i) * 128 + c0, f32x4{v[0], v[1], v[2], v[3]});
+                    st4(o_e0, (rb * 16 + i) * 128 + c0 + 4, f32x4{v[4], v[5], v[6], v[7]});
+                }
                 *reinterpret_cast<bf16x8 *>(lds + LDS_S + (wave * RB + rb) * 1024 + loff) = hi;
                 *reinterpret_cast<bf16x8 *>(lds + LDS_S + E0_PLANE + (wave * RB + rb) * 1024 + loff) = lo;
             }
@@ -907,6 +934,10 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 f32x4 a = acc[2 * p][rb] + ba, b = acc[2 * p + 1][rb] + bb;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.0f); b[q] = fmaxf(b[q], 0.0f); }
+                if (TRAIN) {
+                    st4(o_x, (rb * 16 + i) * 512 + fb0 * 16 + 4 * g, a);
+                    st4(o_x, (rb * 16 + i) * 512 + fb0 * 16 + 4 * g + 16, b);
+                }
                 const Split8 s = split8(a, b);
                 *reinterpret_cast<bf16x8 *>(lds + LDS_X + (kx * RB + rb) * 1024 + loff) = s.hi;
                 if (!(L::TURNS && rb == 3 && kx == 15 && lane == 63)) // the synchronisation counters live in this slot (Layout::CTR)
@@ -1063,6 +1094,17 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) av[rb][q] += bv;
             }
+            if (TRAIN) {
+                // q, k: lane (i, g) holds features 16w + 4g .. +3 of row 16 rb + i; v (normal form): rows 16 rb + 4g + r of feature 16w + i
+                const int c = h * 64 + 16 * wave;
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    st4(o_qkv, (rb * 16 + i) * 1536 + c + 4 * g, aq[rb]);
+                    st4(o_qkv, (rb * 16 + i) * 1536 + 512 + c + 4 * g, ak[rb]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st1(o_qkv, (rb * 16 + 4 * g + r) * 1536 + 1024 + c + i, av[rb][r]);
+                }
+            }
         }
         // A: the scratch may be rewritten -- shared region: once every wavefront of the previous turn has finished with it; own region:
         // once the team's previous head's P (H0) and O (H1) fragments have been consumed
@@ -1122,6 +1164,10 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                     s[jb] = mfma(kh, qh, s[jb]);
                 }
             }
+            if (TRAIN) { // the rollout folds 1/sqrt(64) into the q weights
+#pragma unroll
+                for (int jb = 0; jb < NRB; ++jb) s[jb] *= W.qscale;
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int jb = 0; jb < NRB; ++jb)
@@ -1178,6 +1224,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
         }
 #pragma unroll
         for (int ib = 0; ib < NRB; ++ib) {
+            if (TRAIN) st4(o_attn, (ib * 16 + i) * 512 + h * 64 + 16 * wave + 4 * g, o[ib]);
             bf16x4 oh, ol;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { __bf16 a, b; split1(o[ib][q], a, b); oh[q] = a; ol[q] = b; }
@@ -1258,6 +1305,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #define HH_TEAM_XDB4 1
 #endif
 
+// TRAIN: also write e0 / x / qkv / attn (HhFusedWeights::*_out) and scale the scores by qscale -- the training forward (cn_hh_block_fwd)
+template <bool TRAIN>
 __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
                                                           int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
 {
@@ -1278,10 +1327,10 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
         const TileCtx t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
         const int nrb = (t.nrows + 15) >> 4;
         switch (nrb) {
-        case 1: team::tile_body<1, HH_TEAM_PF3, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        case 2: team::tile_body<2, HH_TEAM_PF3, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        case 3: team::tile_body<3, HH_TEAM_PF3, true>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 1: team::tile_body<1, HH_TEAM_PF3, true, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 2: team::tile_body<2, HH_TEAM_PF3, true, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 3: team::tile_body<3, HH_TEAM_PF3, true, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
         }
         e += t.n_env;
     }
@@ -1364,7 +1413,8 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const floa
     int dev = 0;
     CN_HIP(hipGetDevice(&dev));
     if (dev != attr_dev) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, team::LDS_BYTES));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, team::LDS_BYTES));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, team::LDS_BYTES));
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_fused_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES));
         attr_dev = dev;
     }
@@ -1375,10 +1425,14 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const floa
     // an env must fit one tile: the two-team kernel holds 48 rows, the wide one 64 (CN_HH_WIDE=1 forces the latter: A/B measurements)
     static int force_wide = -1;
     if (force_wide < 0) { const char *v = getenv("CN_HH_WIDE"); force_wide = v ? atoi(v) : 0; }
-    if (H > team::FR || force_wide)
+    const bool train = w.e0_out != nullptr;
+    if (train) {
+        CN_REQUIRE(H <= 48 && w.x_out && w.qkv_out && w.attn_out, "hh_fused_forward: the training outputs need H <= 48 and all four buffers");
+        hipLaunchKernelGGL(hh_fused_kernel<true>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+    } else if (H > 48 || force_wide)
         hipLaunchKernelGGL(hh_fused_wide_kernel, dim3(grid), dim3(256), wide::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
     else
-        hipLaunchKernelGGL(hh_fused_kernel, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+        hipLaunchKernelGGL(hh_fused_kernel<false>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -887,7 +887,7 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         if (p->profiling) { if ((rc = harvest_profile(p, false))) return rc; CN_HIP(hipEventRecord(p->ev[p->ev_head][0], st)); }
         static int hh_prio = -1;
         if (hh_prio < 0) { const char *v = getenv("CN_HH_PRIO"); hh_prio = v ? atoi(v) : 1; }
-        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b, hh_prio};
+        HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b, hh_prio, 1.0f, nullptr, nullptr, nullptr, nullptr};
         if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, obs->detected_human_num, p->row_off,
                                    p->profiling ? p->live_total : (unsigned long long *)nullptr, fw, p->out_sp, st))) return rc;
         if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
@@ -1028,6 +1028,27 @@ extern "C" int cn_policy_get_profile(cn_policy *p, double *ms_out, int64_t *laun
     p->prof_n[1] = (int64_t)live;                                        // [1] = live (env, human) rows summed over the profiled forwards
     for (int i = 0; i < 8; ++i) { ms_out[i] = p->prof_ms[i]; launches_out[i] = p->prof_n[i]; }
     return CN_OK;
+}
+
+// ---- the human-human block of the TRAINING forward as one launch (the rollout's fused kernel + the activations the backward needs) ----
+extern "C" int64_t cn_hh_block_workspace_bytes(void) { return (int64_t)(HH_EMB2_FRAG_BYTES + HH_QKV_FRAG_BYTES + HH_OS_FRAG_BYTES); }
+
+extern "C" int cn_hh_block_fwd(int B, int H, int D, const float *spatial_edges, const int *row_off, const float *emb0_w, const float *emb0_b,
+                               const float *emb2_w, const float *emb2_b, const float *qkv_w, const float *qkv_b, const float *os_w, const float *os_b,
+                               float q_scale, void *workspace, float *e0, float *x, float *qkv, float *attn, float *out_sp, void *stream)
+{
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= 48 && D >= 1 && D <= 16, "cn_hh_block_fwd: B=%d H=%d D=%d outside B >= 1, 1 <= H <= 48, 1 <= D <= 16", B, H, D);
+    CN_REQUIRE(spatial_edges && row_off && emb0_w && emb0_b && emb2_w && emb2_b && qkv_w && qkv_b && os_w && os_b && workspace && e0 && x && qkv && attn && out_sp,
+               "cn_hh_block_fwd: null pointer");
+    CN_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)emb2_b & 15) == 0 && ((uintptr_t)qkv_b & 15) == 0 && ((uintptr_t)os_b & 15) == 0 &&
+               ((uintptr_t)e0 & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)attn & 15) == 0 && ((uintptr_t)out_sp & 15) == 0,
+               "cn_hh_block_fwd: workspace, bias vectors and outputs must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    void *f_emb2 = ws, *f_qkv = ws + HH_EMB2_FRAG_BYTES, *f_os = ws + HH_EMB2_FRAG_BYTES + HH_QKV_FRAG_BYTES;
+    if (int rc = hh_fused_bake(emb2_w, qkv_w, os_w, f_emb2, f_qkv, f_os, st)) return rc;
+    HhFusedWeights fw{f_emb2, f_qkv, f_os, emb0_w, emb0_b, emb2_b, qkv_b, os_b, 0, q_scale, e0, x, qkv, attn};
+    return hh_fused_forward(B, H, D, spatial_edges, nullptr, const_cast<int *>(row_off), nullptr, fw, out_sp, st);
 }
 
 // ---- stand-alone attention core (training path: autograd Function in the host mirror) ----

@@ -539,6 +539,69 @@ class HipLinear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class HHBlockFused(torch.autograd.Function):
+    """The whole human-human block of evaluate_actions (embedding_layer -> folded q|k|v -> 8-head attention -> folded
+    out_proj∘spatial_linear) on the compacted live rows: forward = ONE launch of the rollout's fused kernel on the training weights
+    (cn_hh_block_fwd), which writes every activation the backward needs exactly once; backward = the per-layer kernels of HipLinear /
+    HHAttention / Embed0 on those activations, in reverse order.  spatial_edges [B,H,D], x_live [R,D] (its live rows, for the input
+    layer's weight gradient), row_off [B+1] int32; weights as the mirror composes them (qkv / os folded, q unscaled)."""
+
+    @staticmethod
+    def forward(ctx, spatial_edges, x_live, row_off, emb0_w, emb0_b, emb2_w, emb2_b, qkv_w, qkv_b, os_w, os_b):
+        B, H, D = spatial_edges.shape
+        R = x_live.shape[0]
+        dev = spatial_edges.device
+        se = spatial_edges.contiguous()
+        ws = torch.empty(int(A.lib().cn_hh_block_workspace_bytes()), dtype=torch.uint8, device=dev)
+        e0, x, qkv = torch.empty(R, 128, device=dev), torch.empty(R, 512, device=dev), torch.empty(R, 1536, device=dev)
+        attn, out = torch.empty(R, 512, device=dev), torch.empty(R, 256, device=dev)
+        ws_w = [t.detach().contiguous() for t in (emb0_w, emb0_b, emb2_w, emb2_b, qkv_w, qkv_b, os_w, os_b)]
+        A.check(A.lib().cn_hh_block_fwd(B, H, D, A.ptr(se), A.ptr(row_off), *[A.ptr(t) for t in ws_w], 0.125, A.ptr(ws), A.ptr(e0), A.ptr(x), A.ptr(qkv),
+                                        A.ptr(attn), A.ptr(out), A.stream_ptr()), "cn_hh_block_fwd")
+        ctx.save_for_backward(x_live, row_off, e0, x, qkv, attn, out, emb2_w, qkv_w, os_w)
+        ctx.meta = (B, H, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x_live, row_off, e0, x, qkv, attn, out, emb2_w, qkv_w, os_w = ctx.saved_tensors
+        B, H, D = ctx.meta
+        R = x_live.shape[0]
+        L = A.lib()
+        dev = d_out.device
+
+        def layer_bwd(dy, gate, w, inp):
+            """Linear (+ReLU when `gate` = its output) backward: dX = (dY * [gate > 0]) W, dW = (dY * [gate > 0])^T X, db = column sums."""
+            M, N = dy.shape
+            K = w.shape[1]
+            g = A.ptr(gate) if gate is not None else None
+            hi_t, lo_t = split_bf16(w.detach(), transpose=True)
+            dx = torch.empty(M, K, device=dev)
+            A.check(L.cn_linear_fwd(M, K, N, A.ptr(dy), N, g, A.ptr(hi_t), A.ptr(lo_t), None, 0, A.ptr(dx), K, A.stream_ptr()), "cn_linear_fwd(dX)")
+            splits = L.cn_linear_wgrad_splits(M, N, K)
+            part, dbp = torch.empty(splits, N, K, device=dev), torch.empty(splits, N, device=dev)
+            dw, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+            A.check(L.cn_linear_wgrad(M, N, K, A.ptr(dy), N, g, A.ptr(inp), K, splits, A.ptr(part), A.ptr(dbp), A.ptr(dw), A.ptr(db), A.stream_ptr()), "cn_linear_wgrad")
+            return dx, dw, db
+
+        d_out = d_out.contiguous()
+        if R == 0:
+            z = lambda t: torch.zeros_like(t)   # noqa: E731
+            return (None, None, None, x_live.new_zeros(128, D), x_live.new_zeros(128), z(emb2_w), x_live.new_zeros(512), z(qkv_w), x_live.new_zeros(1536),
+                    z(os_w), x_live.new_zeros(256))
+        d_attn, d_os_w, d_os_b = layer_bwd(d_out, out, os_w, attn)                       # out = relu(attn Wos^T + b)
+        d_qkv = torch.empty_like(qkv)
+        cls = torch.empty(int(L.cn_hh_attention_workspace_ints(int(B))), dtype=torch.int32, device=dev)
+        A.check(L.cn_hh_attention_bwd(B, H, A.ptr(qkv), A.ptr(row_off), A.ptr(d_attn), 0.125, A.ptr(d_qkv), A.ptr(cls), 0, A.stream_ptr()), "cn_hh_attention_bwd")
+        d_x, d_qkv_w, d_qkv_b = layer_bwd(d_qkv, None, qkv_w, x)                         # qkv = x Wc^T + bc
+        d_e0, d_emb2_w, d_emb2_b = layer_bwd(d_x, x, emb2_w, e0)                         # x = relu(e0 W2^T + b2)
+        blocks = min(R, 4096)
+        part = torch.empty(blocks, 128, D + 1, device=dev)
+        dwb = torch.empty(128, D + 1, device=dev)
+        A.check(L.cn_embed0_bwd(R, D, A.ptr(x_live), A.ptr(e0), A.ptr(d_e0), blocks, A.ptr(part), A.ptr(dwb), A.stream_ptr()), "cn_embed0_bwd")
+        return (None, None, None, dwb[:, :D].contiguous(), dwb[:, D].contiguous(), d_emb2_w, d_emb2_b, d_qkv_w, d_qkv_b, d_os_w, d_os_b)
+
+
 class PPOLoss(torch.autograd.Function):
     """(value_loss, action_loss) of rl/ppo/ppo.py:66-84 as one tensor [2]: forward = cn_ppo_loss_fwd, backward =
     cn_ppo_loss_bwd (gradients w.r.t. `values` and `logp` only -- everything else is rollout data)."""

@@ -162,6 +162,8 @@ class AttnGraphBase(nn.Module):
     # arithmetic of the three large human-human Linear layers in the PPO update on the GPU: 'bf16x3' = split-precision MFMA
     # kernels (forward, dX, dW; same arithmetic as the rollout forward), 'fp32' = torch / rocBLAS fp32
     train_gemm_mode = "bf16x3"
+    # the human-human block of the update's forward as one fused launch (hip.HHBlockFused; crowds of <= 48 humans) instead of five
+    train_fused_hh = True
 
     def _big_linear(self, x, w, b, relu=False):
         if x.is_cuda and self.train_gemm_mode == "bf16x3":
@@ -199,6 +201,20 @@ class AttnGraphBase(nn.Module):
         idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
         emb0, emb2 = sa.embedding_layer[0], sa.embedding_layer[2]
         x_live = spatial_edges.reshape(B * H, D).index_select(0, idx)
+        if x_live.is_cuda and self.train_gemm_mode == "bf16x3" and self.train_fused_hh and H <= 48 and D <= 16 and emb0.weight.shape[0] == 128:
+            # ONE launch for the whole block (the rollout's fused kernel on the training weights, writing the activations the backward
+            # needs); the affine pairs are composed exactly as below, so both factors still receive their exact gradients
+            from .hip import HHBlockFused
+            W, b = sa.multihead_attn.in_proj_weight, sa.multihead_attn.in_proj_bias
+            lins = (sa.q_linear, sa.k_linear, sa.v_linear)
+            Wc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].weight for i in range(3)], 0)
+            bc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].bias + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
+            op, sl = sa.multihead_attn.out_proj, self.spatial_linear[0]
+            nd = det.clamp(max=H).to(torch.int32)
+            row_off = torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
+            o = HHBlockFused.apply(spatial_edges, x_live, row_off, emb0.weight, emb0.bias, emb2.weight, emb2.bias, Wc, bc,
+                                   sl.weight @ op.weight, sl.weight @ op.bias + sl.bias)
+            return o, row_off
         if x_live.is_cuda and D <= 16 and emb0.weight.shape[0] == 128:
             from .hip import Embed0
             e0 = Embed0.apply(x_live, emb0.weight, emb0.bias)

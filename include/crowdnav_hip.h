@@ -240,6 +240,20 @@ int cn_policy_set_gemm_mode(cn_policy *p, int mode);
 int cn_policy_set_profiling(cn_policy *p, int every);
 int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launches_out /*[8]*/);
 
+/* ---- the human-human block of evaluate_actions' forward as ONE launch (training path; crowds of <= 48 humans) ----
+ * rl/networks/selfAttn_srnn_temp_node.py:63-91 + :408 on the compacted live rows, i.e. what cn_embed0_fwd -> cn_linear_fwd (embedding_layer.2,
+ * ReLU) -> cn_linear_fwd (folded q|k|v) -> cn_hh_attention_fwd -> cn_linear_fwd (folded out_proj∘spatial_linear, ReLU) compute in five
+ * launches with every activation passing through HBM twice; here the rollout's fused kernel runs on the training weights and writes each
+ * activation the backward kernels need exactly once: e0 [R,128], x [R,512] (both post-ReLU), qkv [R,1536] (q unscaled; q_scale = 0.125
+ * multiplies the scores), attn [R,512], out_sp [R,256] (post-ReLU).  spatial_edges [B,H,D] dense, row_off [B+1] (exclusive prefix of the
+ * detected humans, R = row_off[B]); weights fp32 row-major ([512,128], [1536,512], [256,512]; biases 16-byte aligned); workspace =
+ * cn_hh_block_workspace_bytes() bytes for the fragment-ordered bf16 hi/lo images, rebuilt on every call (the weights change every
+ * optimiser step).  Same bf16x3 arithmetic as cn_linear_fwd.  The backward is the existing per-layer kernels on these outputs. */
+int64_t cn_hh_block_workspace_bytes(void);
+int cn_hh_block_fwd(int B, int H, int D, const float *spatial_edges, const int *row_off, const float *emb0_w, const float *emb0_b,
+                    const float *emb2_w, const float *emb2_b, const float *qkv_w, const float *qkv_b, const float *os_w, const float *os_b,
+                    float q_scale, void *workspace, float *e0, float *x, float *qkv, float *attn, float *out_sp, void *stream);
+
 /* ---- human-human attention core, stand-alone (training path) ----
  * The (env, head) units of torch.nn.MultiheadAttention's scaled-dot-product core (selfAttn_srnn_temp_node.py:89) on COMPACTED
  * rows: sample b owns rows row_off[b] .. row_off[b+1]-1 (its detected humans); qkv [R,1536] = [q | k | v] (8 heads x 64).

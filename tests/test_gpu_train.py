@@ -349,3 +349,62 @@ def test_skinny_products_of_the_update_match_fp64():
         close(xg.grad, xr.grad, "dx%d" % n_out, 1e-5)
         close(w2g.grad, w2r.grad, "dw%d" % n_out, 1e-5)
         close(b2g.grad, b2r.grad, "db%d" % n_out, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,D", [(3000, 20, 2), (517, 48, 12), (40, 5, 2)])
+def test_fused_hh_block_forward_equals_the_per_layer_kernels(B, H, D):
+    """cn_hh_block_fwd (hip.HHBlockFused: the rollout's fused kernel on the training weights + the activations the backward needs) against
+    the five-launch path (Embed0 -> HipLinear -> HipLinear -> HHAttention -> HipLinear) on ragged crowds: same output rows, same gradient
+    of every parameter of the block (the backward runs the same per-layer kernels on the fused forward's saved activations, so any row the
+    fused kernel failed to write shows up here), and nothing written outside the live rows (guard rows behind every output buffer)."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    torch.manual_seed(3)
+    ob_space, act_space = make_spaces(H, D)
+    env_name = "CrowdSimVarNum-v0" if D == 2 else "CrowdSimPred-v0"
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name=env_name, num_processes=16), base="selfAttn_merge_srnn").cuda()
+    base = net.base
+    g = torch.Generator(device="cuda").manual_seed(B)
+    se = torch.randn(B, H, D, device="cuda", generator=g)
+    det = torch.clamp((torch.rand(B, device="cuda", generator=g) ** 2 * (H + 1)).long(), 1, H)      # most envs see few humans, some all
+    det[::7] = H
+    wgt = torch.randn(int(det.sum()), 256, device="cuda", generator=g)
+    res = {}
+    for fused in (False, True):
+        base.train_fused_hh = fused
+        for p in net.parameters():
+            p.grad = None
+        o, ro = base._hh_block(se, det)
+        (o * wgt).sum().backward()
+        res[fused] = (o.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert int(ro[-1]) == int(det.sum()) and res[True][0].shape == res[False][0].shape
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) >= 14
+    for k, gref in res[False][1].items():
+        # the ReLU masks (e0 > 0, x > 0, out_sp > 0) come from forward values that the two paths round differently (FMA contraction,
+        # summation order): a few of the 10^5..10^6 entries within rounding of zero get the other mask, and ONE flipped entry moves a
+        # weight-gradient entry by a whole |dy x| term.  Entry-wise bars are therefore meaningless here; the Frobenius distance is not
+        # (unwritten activations are caught exactly further down)
+        if k.endswith("k_linear.bias"):
+            continue                     # softmax ignores a key bias: its gradient is rounding noise around an exact zero in both paths
+        err = float((res[True][1][k] - gref).norm()) / (float(gref.norm()) + 1e-6)
+        assert err <= 5e-3, (k, err)
+    # raw ABI call with guard rows: every live row written, nothing behind them touched
+    L = A.lib()
+    nd = det.to(torch.int32)
+    row_off = torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
+    R, G = int(row_off[-1]), 128
+    sa = base.spatial_attn
+    ws = torch.empty(int(L.cn_hh_block_workspace_bytes()), dtype=torch.uint8, device="cuda")
+    w = [sa.embedding_layer[0].weight, sa.embedding_layer[0].bias, sa.embedding_layer[2].weight, sa.embedding_layer[2].bias,
+         torch.randn(1536, 512, device="cuda", generator=g) * 0.05, torch.randn(1536, device="cuda", generator=g),
+         torch.randn(256, 512, device="cuda", generator=g) * 0.05, torch.randn(256, device="cuda", generator=g)]
+    w = [t.detach().contiguous() for t in w]
+    outs = [torch.full((R + G, n), 7777.0, device="cuda") for n in (128, 512, 1536, 512, 256)]
+    A.check(L.cn_hh_block_fwd(B, H, D, A.ptr(se), A.ptr(row_off), *[A.ptr(t) for t in w], 0.125, A.ptr(ws), *[A.ptr(t) for t in outs], A.stream_ptr()),
+            "cn_hh_block_fwd")
+    torch.cuda.synchronize()
+    for name, t in zip(("e0", "x", "qkv", "attn", "out_sp"), outs):
+        assert int((t[R:] != 7777.0).sum()) == 0, "%s: rows behind the live rows were written" % name
+        assert int((t[:R] == 7777.0).sum()) == 0, "%s: live entries left unwritten" % name
