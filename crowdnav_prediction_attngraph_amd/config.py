@@ -57,8 +57,8 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     if not 0 <= hr < hn or hn + hr > 64:
         unsupported.append("sim.human_num_range outside [0, human_num) or human_num + human_num_range > 64")
     rv = bool(g("robot", "visible", False))
-    if rv and (env_name not in ("CrowdSimVarNum-v0", "CrowdSimVarNumCollect-v0") or phase != "train" or hn + hr > 63):
-        unsupported.append("robot.visible=True outside CrowdSimVarNum-v0 / phase train / human_num + human_num_range <= 63")
+    if rv and hn + hr > 63:
+        unsupported.append("robot.visible=True with human_num + human_num_range > 63")
     kin = g("action_space", "kinematics", "holonomic")
     if kin not in ("holonomic", "unicycle"):
         unsupported.append("action_space.kinematics=%r" % kin)
@@ -70,15 +70,14 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     pm = g("sim", "predict_method", "const_vel")
     if env_name == "CrowdSimPred-v0" and pm not in ("const_vel", "truth"):
         unsupported.append("sim.predict_method=%r (CrowdSimPred-v0 runs with 'const_vel' or 'truth')" % pm)
-    if env_name == "CrowdSimPred-v0" and pm == "truth" and rv:
-        unsupported.append("sim.predict_method='truth' with robot.visible=True")
+    if env_name == "CrowdSimPred-v0" and pm == "const_vel" and rv:
+        unsupported.append("CrowdSimPred-v0 with sim.predict_method='const_vel' and robot.visible=True (the reference itself fails there: "
+                           "crowd_sim_var_num.py:174 assigns the H previous human states to H + 1 rows)")
     rp = g("robot", "policy", "selfAttn_merge_srnn")
     if rp not in ("selfAttn_merge_srnn", "srnn", "orca", "social_force"):
         unsupported.append("robot.policy=%r (the network policies, 'orca' and 'social_force' are implemented)" % rp)
-    if hp == "social_force" and (phase != "train" or (env_name == "CrowdSimPred-v0" and pm == "truth")):
-        unsupported.append("humans.policy='social_force' in the test phase or with sim.predict_method='truth'")
-    if kin == "unicycle" and (env_name != "CrowdSimVarNum-v0" or rp in ("orca", "social_force")):
-        unsupported.append("unicycle kinematics outside CrowdSimVarNum-v0 with a network-driven robot")
+    if kin == "unicycle" and (env_name == "CrowdSimVarNumCollect-v0" or rp in ("orca", "social_force")):
+        unsupported.append("unicycle kinematics with an ORCA / social-force robot (those policies return ActionXY) or in CrowdSimVarNumCollect-v0")
     if env_name == "CrowdSimVarNumCollect-v0" and (rp != "orca" or hr != 0 or kin != "holonomic" or phase != "train"):
         unsupported.append("CrowdSimVarNumCollect-v0 outside collect_data.py's set-up (robot.policy='orca', fixed crowd size, holonomic, phase train)")
     if phase not in ("train", "test"):

@@ -88,6 +88,8 @@ struct EnvDev {
     struct Lp3Hdr *lp3_hdr; // [E*H] where linearProgram2 stopped
     float4 *lp3_lines;  // [E*H][32] their ORCA lines (point, direction) in neighbour order
     double *desired_v;  // [E] unicycle robot only: self.desiredVelocity[0] (crowd_sim.py:82: set at construction, never reset)
+    double *wheel;      // [E][4] unicycle robot in CrowdSimPred / PredRealGST: smooth_action's last_left, last_right (crowd_sim.py:84-85, never
+                        // reset) and RandomState's cached normal deviate: value, has_gauss as 0 / 1 (cleared by every np.random.seed)
 };
 
 __device__ __forceinline__ int crowd_size(const EnvDev &s, int e) { return s.nh ? s.nh[e] : s.H; }
@@ -156,6 +158,42 @@ __device__ __forceinline__ double det_exp(double x)
     const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
     const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
     return ldexp(y, k);
+}
+
+// deterministic natural logarithm for normal positive arguments (classic reduction to sqrt(2)/2 < 1 + f < sqrt(2), degree-14 minimax in
+// s = f / (2 + f)); the twin of the oracle's orc_log.  Stands in for log() in RandomState.normal's polar method (arguments in (0, 1)).
+__device__ __forceinline__ double det_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int hx = (int)(bits >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i0 = (hx + 0x95f64) & 0x100000;
+    bits = ((unsigned long long)(unsigned)(hx | (i0 ^ 0x3ff00000)) << 32) | (bits & 0xffffffffull);
+    x = __longlong_as_double((long long)bits);
+    k += i0 >> 20;
+    const double f = x - 1.0;
+    const double dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R0 = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R0 : dk * ln2_hi - ((R0 - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const int i = (hx - 0x6147a) | (0x6b851 - hx);
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -731,6 +769,46 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
     }
 }
 
+// The same roll-outs for humans.policy = 'social_force': act_joint_state -> SOCIAL_FORCE.predict (social_force.py:11-52) on the rolled
+// states, the others being the H - 1 fellow humans with their true radii (no dummy substitution, no robot: crowd_sim_var_num.py:183-190).
+// No solver and no private simulator: one wavefront per env (lane i = human i) walks all P rolls in one launch, the rolled states
+// travel between the lanes by shuffles.  float64, same operation order as the step's own social-force block (env_step_kernel).
+__global__ __launch_bounds__(64) void sf_truth_kernel(EnvDev s)
+{
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int H = s.H, n = crowd_size(s, e);
+    const cn_env_config &c = s.cfg;
+    const double *hum = s.hum + (size_t)e * 8 * H;
+    const bool isH = lane < n;
+    const int lj = isH ? lane : 0;
+    double px = hum[F_PX * H + lj], py = hum[F_PY * H + lj], vx = hum[F_VX * H + lj], vy = hum[F_VY * H + lj];
+    const double rad = hum[F_RAD * H + lj], gx = hum[F_GX * H + lj], gy = hum[F_GY * H + lj], vpref = hum[F_VPREF * H + lj];
+    for (int k = 1; k <= s.P; ++k) {
+        const double dxg = gx - px, dyg = gy - py;
+        const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
+        const double desired_vx = (dxg / dist_to_goal) * vpref, desired_vy = (dyg / dist_to_goal) * vpref;
+        const double curr_dvx = c.sf_KI * (desired_vx - vx), curr_dvy = c.sf_KI * (desired_vy - vy);
+        double ivx = 0.0, ivy = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double ox = __shfl(px, j, 64), oy = __shfl(py, j, 64), orad = __shfl(rad, j, 64);
+            const double dx = px - ox, dy = py - oy;
+            const double d = sqrt(dx * dx + dy * dy);
+            const double f = c.sf_A * det_exp((rad + orad - d) / c.sf_B);
+            if (j != lane) { ivx += f * (dx / d); ivy += f * (dy / d); }
+        }
+        const double nvx = vx + (curr_dvx + ivx) * c.time_step, nvy = vy + (curr_dvy + ivy) * c.time_step;
+        const double act_norm = sqrt(nvx * nvx + nvy * nvy);
+        double ax = nvx, ay = nvy;
+        if (act_norm > vpref) { ax = nvx / act_norm * vpref; ay = nvy / act_norm * vpref; }
+        // one_step_lookahead, agent.py:185-192 (every lane has read the old states: the shuffles above precede these writes)
+        px = px + ax * c.time_step; py = py + ay * c.time_step; vx = ax; vy = ay;
+        if (isH) {
+            double *trk = s.tr + ((size_t)e * (s.P + 1) + k) * 4 * H;
+            trk[0 * H + lane] = px; trk[1 * H + lane] = py; trk[2 * H + lane] = vx; trk[3 * H + lane] = vy;
+        }
+    }
+}
+
 // stand-alone batched solve (cn_orca_solve)
 __global__ __launch_bounds__(256) void orca_solve_kernel(int B, int n_other, const float *self, const float *others, float nd,
                                                          int max_nb, float th, float dt, float *out)
@@ -842,6 +920,25 @@ __device__ __forceinline__ double rng_double(Rng &R, int lane)
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 __device__ __forceinline__ double rng_uniform(Rng &R, int lane, double lo, double hi) { return lo + (hi - lo) * rng_double(R, lane); }
+// np.random.normal(loc, scale) of the legacy RandomState: loc + scale * legacy_gauss (polar Box-Muller, the second deviate of a pair is
+// cached for the next call).  gauss / has_gauss are the caller's copies of the cache (wave-uniform).
+__device__ __forceinline__ double rng_normal(Rng &R, int lane, double loc, double scale, double &gauss, bool &has_gauss)
+{
+    double g;
+    if (has_gauss) { g = gauss; has_gauss = false; gauss = 0.0; }
+    else {
+        double x1, x2, r2;
+        do {
+            x1 = 2.0 * rng_double(R, lane) - 1.0;
+            x2 = 2.0 * rng_double(R, lane) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        const double f = sqrt(-2.0 * det_log(r2) / r2);
+        gauss = f * x1; has_gauss = true;
+        g = f * x2;
+    }
+    return loc + scale * g;
+}
 // legacy RandomState.randint(low, high), default int64 dtype (numpy/random/_bounded_integers: _rand_int64 -> masked rejection on 32-bit
 // words): no draw when the range is a single value
 __device__ __forceinline__ int rng_randint(Rng &R, int lane, int low, int high)
@@ -1087,6 +1184,7 @@ __device__ __forceinline__ void finish_reset(const EnvDev &s, int e, int lane, i
         s.step_counter[e] = 0; s.ep_ret[e] = 0.0; s.ep_cnt[e] = 0;
         if (s.nh) { s.obs_cnt[e] = 0; s.obs_max[e] = -1; } // :327 observed_human_ids = []
         if (s.max_pid) s.max_pid[e] = n; // crowd_sim_var_num_collect.py:79-81
+        if (s.wheel) { s.wheel[(size_t)e * 4 + 2] = 0.0; s.wheel[(size_t)e * 4 + 3] = 0.0; } // np.random.seed -> _legacy_seeding: has_gauss = 0
     }
     if (s.pred_id && lane < s.H) { s.pred_id[(size_t)e * s.H + lane] = lane; s.last_obs[(size_t)e * s.H + lane] = 0; }
     if (with_obs) write_obs(s, e, lane, n, true, rb, h, ob, 0);
@@ -1219,7 +1317,8 @@ __device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e,
             const int i = __ffsll((unsigned long long)reached) - 1;
             reached &= reached - 1;
             // :451-456 respawned (holonomic robot) or given a new goal (unicycle robot)
-            if (c.kinematics == CN_KIN_UNICYCLE) change_goals(s, R, lane, n, rb, h, i);
+            // (crowd_sim_pred.py:208-212 always respawns)
+            if (c.kinematics == CN_KIN_UNICYCLE && c.env_kind == CN_ENV_VARNUM) change_goals(s, R, lane, n, rb, h, i);
             else gen_human(s, R, lane, i, H, rb, h, shared_nd);
         }
     }
@@ -1314,6 +1413,31 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
         uni_v = fmin(fmax(s.desired_v[e] + (double)dv, -c.robot_v_pref), c.robot_v_pref);
         uni_r = (double)ay;
         if (lane == 0) s.desired_v[e] = uni_v;
+        if (s.wheel) {
+            // CrowdSimPred.step (crowd_sim_pred.py:120-131) sends the command through smooth_action (crowd_sim.py:315-358): wheel speeds of
+            // a Turtlebot2i (wheel radius 0.035 m, track 0.23 m) clipped to +-17.5 rad/s, low-pass filtered in the test phase, then
+            // reduced towards zero by a noisy dead band N(1.8, 0.15) per wheel.  Wave-uniform; these are the first draws of the step.
+            double *wh = s.wheel + (size_t)e * 4;
+            const double last_left = wh[0], last_right = wh[1];
+            double gauss = wh[2];
+            bool has_gauss = wh[3] != 0.0;
+            rng_load(R, s, e, lane);
+            const double w = uni_r / c.time_step;
+            double left = (2.0 * uni_v - 0.23 * w) / (2.0 * 0.035), right = (2.0 * uni_v + 0.23 * w) / (2.0 * 0.035);
+            left = fmin(fmax(left, -17.5), 17.5); right = fmin(fmax(right, -17.5), 17.5);
+            if (c.phase == CN_PHASE_TEST) {
+                left = (1. - 0.1) * last_left + 0.1 * left;
+                right = (1. - 0.1) * last_right + 0.1 * right;
+            }
+            const double keep_left = left, keep_right = right;
+            if (left > 0) left = fmax(0., left - rng_normal(R, lane, 1.8, 0.15, gauss, has_gauss));
+            else left = fmin(0., left + rng_normal(R, lane, 1.8, 0.15, gauss, has_gauss));
+            if (right > 0) right = fmax(0., right - rng_normal(R, lane, 1.8, 0.15, gauss, has_gauss));
+            else right = fmin(0., right + rng_normal(R, lane, 1.8, 0.15, gauss, has_gauss));
+            uni_v = 0.035 / 2 * (left + right);
+            uni_r = 0.035 / 0.23 * (right - left) * c.time_step;
+            if (lane == 0) { wh[0] = keep_left; wh[1] = keep_right; wh[2] = gauss; wh[3] = has_gauss ? 1.0 : 0.0; }
+        }
     } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c.robot_v_pref;
@@ -1572,15 +1696,27 @@ struct cn_env_batch {
     bool orca_ready; // hact for the current state has been enqueued on `side`
 };
 
+// calc_human_future_traj(method='truth'): P rolls of every human with its own policy
+static int truth_rollout(cn_env_batch *env, hipStream_t st)
+{
+    if (env->d.cfg.humans_policy == CN_HUMANS_SOCIAL_FORCE) {
+        hipLaunchKernelGGL(sf_truth_kernel, dim3(env->d.E), dim3(64), 0, st, env->d);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
+    const int agents = env->d.E * env->d.H;
+    for (int k = 1; k <= env->d.P; ++k) { // roll k needs all of roll k - 1 of the same env: one launch per roll
+        hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, st, env->d, k);
+        CN_CHECK_LAUNCH();
+    }
+    return CN_OK;
+}
+
 // sim.predict_method = 'truth': roll the humans forward P times from the state the first half of the step (or the reset) left, then
 // write the observation and run the post-observation updates
 static int truth_rollout_and_obs(cn_env_batch *env, const cn_obs *obs, hipStream_t st)
 {
-    const int agents = env->d.E * env->d.H;
-    for (int k = 1; k <= env->d.P; ++k) {
-        hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, st, env->d, k);
-        CN_CHECK_LAUNCH();
-    }
+    if (int rc = truth_rollout(env, st)) return rc;
     hipLaunchKernelGGL(env_obs_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -1625,11 +1761,8 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
             CN_CHECK_LAUNCH();
         }
     }
-    if (env->d.cfg.phase == CN_PHASE_TEST)
-        for (int k = 1; k <= env->d.P; ++k) { // 'truth' roll-out for the next step's Danger decision
-            hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d, k);
-            CN_CHECK_LAUNCH();
-        }
+    if (env->d.cfg.phase == CN_PHASE_TEST) // 'truth' roll-out for the next step's Danger decision
+        if (int rc = truth_rollout(env, env->side)) return rc;
     CN_HIP(hipEventRecord(env->ev_orca, env->side));
     env->orca_ready = true;
     return CN_OK;
@@ -1665,12 +1798,10 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(cfg->human_num_range >= 0 && cfg->human_num_range < cfg->human_num, "cn_env_create: human_num_range must be in [0, human_num)");
     const int HM = cfg->human_num + cfg->human_num_range; // observation rows / lanes per env
     CN_REQUIRE(cfg->human_num >= 1 && HM <= CN_MAX_HUMANS, "cn_env_create: human_num + human_num_range must be in [1,%d]", CN_MAX_HUMANS);
-    CN_REQUIRE(cfg->kinematics == CN_KIN_HOLONOMIC || (cfg->kinematics == CN_KIN_UNICYCLE && cfg->env_kind == CN_ENV_VARNUM && cfg->robot_policy == CN_ROBOT_NETWORK),
-               "cn_env_create: kinematics must be holonomic, or unicycle with CrowdSimVarNum-v0 and a network-driven robot (the only "
-               "combination the reference runs: crowd_sim_var_num.py:78-91, :379-381)");
-    CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA || (cfg->humans_policy == CN_HUMANS_SOCIAL_FORCE && cfg->phase == CN_PHASE_TRAIN && !cfg->predict_truth),
-               "cn_env_create: humans_policy must be ORCA, or social force in the train phase without 'truth' predictions (those roll the "
-               "humans' policies forward, which is only implemented for ORCA humans)");
+    CN_REQUIRE(cfg->kinematics == CN_KIN_HOLONOMIC || (cfg->kinematics == CN_KIN_UNICYCLE && cfg->env_kind != CN_ENV_COLLECT && cfg->robot_policy == CN_ROBOT_NETWORK),
+               "cn_env_create: kinematics must be holonomic, or unicycle with a network-driven robot outside CrowdSimVarNumCollect-v0 (the ORCA / "
+               "social-force robot policies return ActionXY: crowd_sim_var_num.py:78-91, :379-381)");
+    CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA || cfg->humans_policy == CN_HUMANS_SOCIAL_FORCE, "cn_env_create: unknown humans_policy %d", cfg->humans_policy);
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_COLLECT, "cn_env_create: unknown env_kind %d", cfg->env_kind);
     CN_REQUIRE(cfg->env_kind != CN_ENV_COLLECT || (cfg->human_num_range == 0 && cfg->kinematics == CN_KIN_HOLONOMIC && cfg->phase == CN_PHASE_TRAIN &&
@@ -1681,11 +1812,13 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
                "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
     CN_REQUIRE(cfg->robot_policy >= CN_ROBOT_NETWORK && cfg->robot_policy <= CN_ROBOT_SOCIAL_FORCE, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
-    CN_REQUIRE(!cfg->robot_visible || ((cfg->env_kind == CN_ENV_VARNUM || cfg->env_kind == CN_ENV_COLLECT) && cfg->phase == CN_PHASE_TRAIN && HM <= CN_MAX_HUMANS - 1),
-               "cn_env_create: robot_visible needs CrowdSimVarNum-v0, phase train and human_num + human_num_range <= %d (the reference rebuilds every private "
-               "simulator twice per step in the test phase and breaks in CrowdSimPred)", CN_MAX_HUMANS - 1);
-    CN_REQUIRE(!cfg->predict_truth || (cfg->env_kind == CN_ENV_PRED && !cfg->robot_visible),
-               "cn_env_create: predict_truth (sim.predict_method = 'truth') is CrowdSimPred-v0 with an invisible robot");
+    CN_REQUIRE(!cfg->robot_visible || HM <= CN_MAX_HUMANS - 1,
+               "cn_env_create: robot_visible needs human_num + human_num_range <= %d (the robot is one more ORCA neighbour)", CN_MAX_HUMANS - 1);
+    CN_REQUIRE(!cfg->robot_visible || cfg->env_kind != CN_ENV_PRED || cfg->predict_truth,
+               "cn_env_create: robot_visible in CrowdSimPred-v0 needs sim.predict_method = 'truth' (with 'const_vel' the reference itself "
+               "fails: crowd_sim_var_num.py:174 assigns H previous human states to H + 1 rows)");
+    CN_REQUIRE(!cfg->predict_truth || cfg->env_kind == CN_ENV_PRED,
+               "cn_env_create: predict_truth (sim.predict_method = 'truth') is CrowdSimPred-v0");
     CN_REQUIRE(cfg->time_step > 0 && std::fabs(5.0 / cfg->time_step - std::round(5.0 / cfg->time_step)) < 1e-9,
                "cn_env_create: time_step must divide 5 s");
     cn_env_batch *b = new (std::nothrow) cn_env_batch{};
@@ -1714,8 +1847,13 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const bool unicycle = cfg->kinematics == CN_KIN_UNICYCLE;
     const bool var_n = cfg->human_num_range > 0 || unicycle; // a unicycle episode holds randint(1, H + 1) humans
     const size_t o_nh = var_n ? carve(E * 4) : 0, o_nxnh = var_n ? carve(E * 4) : 0, o_oc = var_n ? carve(E * 4) : 0, o_om = var_n ? carve(E * 4) : 0;
-    const size_t o_simn = var_n ? carve(E * H) : 0, o_rsimn = (var_n && rob_orca) ? carve(E) : 0;
+    // agent count each private simulator was built for: the crowd size varies, or (robot.visible with 'truth' roll-outs) the real step
+    // passes H others + the robot while the roll-outs pass the H - 1 fellow humans only -> two rebuilds per step (orca.py:80-82)
+    const bool need_simn = var_n || (cfg->robot_visible && (test_phase || truth_obs));
+    const size_t o_simn = need_simn ? carve(E * H) : 0, o_rsimn = (var_n && rob_orca) ? carve(E) : 0;
     const size_t o_dv = unicycle ? carve(E * 8) : 0;
+    const bool wheel_model = unicycle && cfg->env_kind != CN_ENV_VARNUM; // CrowdSimPred.step's smooth_action
+    const size_t o_wh = wheel_model ? carve(E * 4 * 8) : 0;
     const bool lane_orca = HM + (cfg->robot_visible ? 1 : 0) <= 32 && cfg->humans_policy == CN_HUMANS_ORCA;
     const bool collect = cfg->env_kind == CN_ENV_COLLECT;
     const size_t o_pid = collect ? carve(E * H * 4) : 0, o_mpid = collect ? carve(E * 4) : 0, o_lobs = collect ? carve(E * H) : 0;
@@ -1743,11 +1881,12 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.nh = var_n ? (int32_t *)(base + o_nh) : nullptr; d.nx_nh = var_n ? (int32_t *)(base + o_nxnh) : nullptr;
     d.obs_cnt = var_n ? (int32_t *)(base + o_oc) : nullptr; d.obs_max = var_n ? (int32_t *)(base + o_om) : nullptr;
     d.desired_v = unicycle ? (double *)(base + o_dv) : nullptr;
+    d.wheel = wheel_model ? (double *)(base + o_wh) : nullptr;
     d.pred_id = collect ? (int32_t *)(base + o_pid) : nullptr; d.max_pid = collect ? (int32_t *)(base + o_mpid) : nullptr;
     d.last_obs = collect ? (uint8_t *)(base + o_lobs) : nullptr;
     d.lp3_cnt = (int32_t *)(base + o_l3c);
     d.lp3_hdr = lane_orca ? (Lp3Hdr *)(base + o_l3h) : nullptr; d.lp3_lines = lane_orca ? (float4 *)(base + o_l3l) : nullptr;
-    d.sim_n = var_n ? (uint8_t *)(base + o_simn) : nullptr; d.rob_sim_n = (var_n && rob_orca) ? (uint8_t *)(base + o_rsimn) : nullptr;
+    d.sim_n = need_simn ? (uint8_t *)(base + o_simn) : nullptr; d.rob_sim_n = (var_n && rob_orca) ? (uint8_t *)(base + o_rsimn) : nullptr;
     d.min_dist = (double *)(base + o_md);
     d.rob_sim_valid = rob_orca ? (uint8_t *)(base + o_rsv) : nullptr; d.rob_nd = rob_orca ? (float *)(base + o_rnd) : nullptr;
     d.rob_seen = rob_orca ? (float *)(base + o_rsn) : nullptr;

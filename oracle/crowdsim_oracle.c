@@ -62,6 +62,25 @@ static double env_random(OrcEnv *e)
     return orc_mt_double(&e->rng);
 }
 static double env_uniform(OrcEnv *e, double lo, double hi) { return lo + (hi - lo) * env_random(e); }
+/* np.random.normal(loc, scale) of the legacy RandomState: loc + scale * legacy_gauss (polar Box-Muller; the second deviate of a pair
+ * is cached and returned by the next call; np.random.seed clears the cache) */
+static double env_normal(OrcEnv *e, double loc, double scale)
+{
+    double g;
+    if (e->has_gauss) { g = e->gauss; e->has_gauss = 0; e->gauss = 0.0; }
+    else {
+        double x1, x2, r2;
+        do {
+            x1 = 2.0 * env_random(e) - 1.0;
+            x2 = 2.0 * env_random(e) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        const double f = sqrt(-2.0 * orc_log(r2) / r2);
+        e->gauss = f * x1; e->has_gauss = 1;
+        g = f * x2;
+    }
+    return loc + scale * g;
+}
 
 /* legacy RandomState.randint(low, high) for the default int64 dtype: numpy/random/_bounded_integers (_rand_int64 ->
  * random_bounded_uint64_fill with use_masked = 1): no draw when the range is a single value, else 32-bit words masked to the
@@ -139,6 +158,45 @@ double orc_exp(double x)
     const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
     const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
     return ldexp(y, k);
+}
+
+/* deterministic natural logarithm for normal positive arguments: the classic reduction x = 2^k (1 + f), sqrt(2)/2 < 1 + f < sqrt(2),
+ * log(1 + f) = 2 s + s R(s^2), s = f / (2 + f), with the degree-14 minimax R and the usual hi/lo split of k ln 2; plain +,-,*,/
+ * (no FMA) so the HIP twin is bit-identical.  < 1 ulp.  Stands in for log() inside RandomState.normal's polar method
+ * (numpy/random/src/legacy/legacy-distributions.c legacy_gauss), arguments in (0, 1). */
+double orc_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int32_t hx = (int32_t)(bits >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i0 = (hx + 0x95f64) & 0x100000;
+    bits = ((uint64_t)(uint32_t)(hx | (i0 ^ 0x3ff00000)) << 32) | (bits & 0xffffffffull); /* normalise x or x / 2 */
+    memcpy(&x, &bits, 8);
+    k += i0 >> 20;
+    const double f = x - 1.0;
+    const double dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) { /* |f| < 2^-20 */
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R0 = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R0 : dk * ln2_hi - ((R0 - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const int32_t i = (hx - 0x6147a) | (0x6b851 - hx);
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -567,6 +625,7 @@ void orc_env_reset(OrcEnv *e, OrcObs *obs)
     const uint64_t seed = offset[ph] + e->case_counter[ph] + (uint64_t)e->this_seed;
     orc_mt_seed(&e->rng, (uint32_t)seed);
     e->rng_draws = 0;
+    e->has_gauss = 0; e->gauss = 0.0; /* _legacy_seeding */
     e->step_counter = 0;
     double px, py, gx, gy;
     e->observed_count = 0; e->observed_max = -1; /* :327 */
@@ -721,6 +780,30 @@ static void truth_future_traj(OrcEnv *e)
     for (int k = 1; k <= P; ++k) {
         for (int i = 0; i < H; ++i) {
             const OrcHuman *me = &e->humans[i];
+            if (c->humans_policy == ORC_HUMANS_SOCIAL_FORCE) {
+                /* humans.policy = 'social_force': act_joint_state -> SOCIAL_FORCE.predict (social_force.py:11-52) on the rolled states;
+                 * the others are the H - 1 fellow humans with their true radii (no dummy substitution, no robot: :183-190), float64 */
+                const double dxg = me->gx - cur[i][0], dyg = me->gy - cur[i][1];
+                const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
+                const double desired_vx = (dxg / dist_to_goal) * me->v_pref, desired_vy = (dyg / dist_to_goal) * me->v_pref;
+                const double curr_dvx = c->sf_KI * (desired_vx - cur[i][2]), curr_dvy = c->sf_KI * (desired_vy - cur[i][3]);
+                double ivx = 0.0, ivy = 0.0;
+                for (int j = 0; j < H; ++j) {
+                    if (j == i) continue;
+                    const double dx = cur[i][0] - cur[j][0], dy = cur[i][1] - cur[j][1];
+                    const double d = sqrt(dx * dx + dy * dy);
+                    const double f = c->sf_A * orc_exp((me->radius + e->humans[j].radius - d) / c->sf_B);
+                    ivx += f * (dx / d);
+                    ivy += f * (dy / d);
+                }
+                const double nvx = cur[i][2] + (curr_dvx + ivx) * c->time_step, nvy = cur[i][3] + (curr_dvy + ivy) * c->time_step;
+                const double act_norm = sqrt(nvx * nvx + nvy * nvy);
+                double ax = nvx, ay = nvy;
+                if (act_norm > me->v_pref) { ax = nvx / act_norm * me->v_pref; ay = nvy / act_norm * me->v_pref; }
+                nxt[i][0] = cur[i][0] + ax * c->time_step; nxt[i][1] = cur[i][1] + ay * c->time_step;
+                nxt[i][2] = ax; nxt[i][3] = ay;
+                continue;
+            }
             float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
             int n = 0;
             ensure_human_sim(e, i, H); /* only new at reset (predict_method 'truth'): act_joint_state builds it like ORCA.predict */
@@ -847,6 +930,23 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         ay = fminf(fmaxf(ay, (float)-0.06), (float)0.06);
         e->desired_v = fmin(fmax(e->desired_v + (double)dv, -c->robot_v_pref), c->robot_v_pref);
         uni_v = e->desired_v; uni_r = (double)ay;
+        if (c->env_kind != ORC_ENV_VARNUM) {
+            /* CrowdSimPred.step (crowd_sim_pred.py:120-131; CrowdSimPredRealGST steps through it) sends the command through
+             * smooth_action (crowd_sim.py:315-358): the wheel speeds of a Turtlebot2i (wheel radius 0.035 m, track 0.23 m), clipped to
+             * +-17.5 rad/s, low-pass filtered in the test phase, then reduced towards zero by a noisy dead band N(1.8, 0.15) per wheel */
+            const double w = uni_r / c->time_step;
+            double left = (2.0 * uni_v - 0.23 * w) / (2.0 * 0.035), right = (2.0 * uni_v + 0.23 * w) / (2.0 * 0.035);
+            left = fmin(fmax(left, -17.5), 17.5); right = fmin(fmax(right, -17.5), 17.5);
+            if (c->phase == ORC_PHASE_TEST) {
+                left = (1. - 0.1) * e->last_left + 0.1 * left;
+                right = (1. - 0.1) * e->last_right + 0.1 * right;
+            }
+            e->last_left = left; e->last_right = right;
+            if (left > 0) left = fmax(0., left - env_normal(e, 1.8, 0.15)); else left = fmin(0., left + env_normal(e, 1.8, 0.15));
+            if (right > 0) right = fmax(0., right - env_normal(e, 1.8, 0.15)); else right = fmin(0., right + env_normal(e, 1.8, 0.15));
+            uni_v = 0.035 / 2 * (left + right);
+            uni_r = 0.035 / 0.23 * (right - left) * c->time_step;
+        }
     } else {
         const float act_norm = sqrtf(ax * ax + ay * ay);
         const float vp = (float)c->robot_v_pref;
@@ -1011,7 +1111,8 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
         for (int i = 0; i < n; ++i) {
             const OrcHuman *h = &e->humans[i];
             if (norm2(h->gx - h->px, h->gy - h->py) < h->radius) {
-                if (c->kinematics == ORC_KIN_UNICYCLE) update_human_goals_randomly(e, i);
+                /* crowd_sim_var_num.py:453-458 gives the humans of a unicycle robot a new goal; crowd_sim_pred.py:208-212 always respawns */
+                if (c->kinematics == ORC_KIN_UNICYCLE && c->env_kind == ORC_ENV_VARNUM) update_human_goals_randomly(e, i);
                 else gen_circle_crossing_human(e, i, n);
             }
         }

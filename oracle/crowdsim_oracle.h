@@ -128,6 +128,8 @@ typedef struct OrcEnv {
     int32_t n_humans;              /* len(self.humans): == cfg.human_num unless human_num_range > 0 or the robot is a unicycle */
     int32_t observed_count, observed_max; /* self.observed_human_ids of the last generate_ob (crowd_sim_var_num.py:275) */
     double desired_v;              /* self.desiredVelocity[0] (crowd_sim.py:82: set once at construction, never reset) */
+    double last_left, last_right;  /* smooth_action's wheel speeds (crowd_sim.py:84-85, :333-334: set at construction, never reset) */
+    int32_t has_gauss; double gauss; /* RandomState's cached second normal deviate (cleared by np.random.seed) */
     /* per-observer ORCA simulator state (orca.py:80-89: sim built lazily, radii frozen at addAgent) */
     int32_t sim_valid[ORC_MAX_HUMANS];
     int32_t sim_n[ORC_MAX_HUMANS];      /* getNumAgents() of that simulator: a different crowd size rebuilds it (orca.py:80-82) */
@@ -172,6 +174,7 @@ double orc_mt_double(OrcMT *mt);
 /* ---- deterministic sin/cos on [0, 2*pi) (shared algorithm with the HIP path) ---- */
 void orc_sincos(double x, double *s, double *c);
 double orc_exp(double x);
+double orc_log(double x);
 
 /* ---- ORCA (RVO2 v2.0.2 semantics, fp32) ----
  * Computes agent 0's new velocity given n_other other agents (already in the observer's order).

@@ -84,6 +84,8 @@ def lib():
         L.orc_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_exp.restype = C.c_double
         L.orc_exp.argtypes = [C.c_double]
+        L.orc_log.restype = C.c_double
+        L.orc_log.argtypes = [C.c_double]
         fp = C.POINTER(C.c_float)
         L.orc_orca_velocity.restype = C.c_int
         L.orc_orca_velocity.argtypes = [C.c_float] * 9 + [C.c_int, C.c_float, C.c_float, C.c_int, fp, fp, fp, fp, fp,
@@ -106,12 +108,15 @@ def default_config(**over):
         setattr(cfg, k, v)
     if cfg.human_num + cfg.human_num_range > MAX_HUMANS or cfg.human_num_range >= max(cfg.human_num, 1):
         raise ValueError("human_num + human_num_range must be <= %d and human_num > human_num_range (crowd_sim.py:158)" % MAX_HUMANS)
-    if cfg.predict_truth and (cfg.env_kind != ENV_PRED or cfg.robot_visible or cfg.humans_policy != 0):
-        raise NotImplementedError("predict_method='truth': CrowdSimPred-v0 with ORCA humans and an invisible robot")
+    if cfg.predict_truth and cfg.env_kind != ENV_PRED:
+        raise NotImplementedError("predict_method='truth': CrowdSimPred-v0 only")
+    if cfg.robot_visible and cfg.env_kind == ENV_PRED and not cfg.predict_truth:
+        raise ValueError("robot.visible with sim.predict_method='const_vel': the reference itself fails there (crowd_sim_var_num.py:174 "
+                         "assigns the H previous human states to H + 1 rows)")
     if cfg.env_kind == ENV_COLLECT and (cfg.human_num_range or cfg.kinematics or cfg.phase != 0 or cfg.robot_policy != 1):
         raise NotImplementedError("CrowdSimVarNumCollect-v0: fixed crowd size, holonomic ORCA-driven robot, phase train (what collect_data.py runs)")
-    if cfg.kinematics == 1 and cfg.env_kind != ENV_VARNUM:
-        raise NotImplementedError("unicycle robot: CrowdSimVarNum-v0 only (CrowdSimPred.step adds the noisy wheel model)")
+    if cfg.kinematics == 1 and cfg.env_kind == ENV_COLLECT:
+        raise NotImplementedError("unicycle robot: not with CrowdSimVarNumCollect-v0")
     if cfg.kinematics == 1 and cfg.robot_policy != 0:
         raise NotImplementedError("unicycle robot: the ORCA / social-force robot policies return ActionXY (holonomic only)")
     return cfg

@@ -225,6 +225,43 @@ def env_goldens():
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 6, "sim.human_num_range": 5, "action_space.kinematics": "unicycle"}),
           425, 1, 4, 500, "varnum_h6_rand_unicycle_r1")
 
+    # ---- round 3: settings that used to raise NotImplementedError --------------------------------------------------------------
+    # robot.visible in the TEST phase: the 'truth' roll-outs pass each human its H - 1 fellow humans only (crowd_sim_var_num.py:183-190),
+    # the real step passes them plus the robot (crowd_sim.py:695-699) -> every private rvo2 simulator is rebuilt twice per step
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 10, "robot.visible": True}), 425, 0, 1, 300, "varnum_h10_robotvisible_test_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 8, "robot.visible": True}), 425, 0, 1, 300, "varnum_h8_rand_robotvisible_test_r0")
+    # ... and with 'truth' as the observation predictor of CrowdSimPred-v0 (train and test phase)
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 10, "robot.visible": True, "sim.predict_method": "truth"}), 425, 1, 4, 260,
+          "pred_h10_truthobs_robotvisible_r1")
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 7, "robot.visible": True, "sim.predict_method": "truth"}), 425, 0, 1, 240,
+          "pred_h7_rand_truthobs_robotvisible_test_r0")
+    trace("CrowdSimPredRealGST-v0", dict(NON_RAND, **{"sim.human_num": 8, "robot.visible": True, "sim.predict_method": "inferred"}), 425, 1, 4, 200,
+          "predgst_h8_robotvisible_r1")
+    trace("CrowdSimPredRealGST-v0", dict(RAND, **{"sim.human_num": 8, "robot.visible": True, "sim.predict_method": "inferred"}), 425, 0, 1, 200,
+          "predgst_h8_rand_robotvisible_test_r0")
+    # humans.policy = 'social_force' with 'truth' roll-outs (test phase; observation predictor): the roll-outs roll the humans' OWN policy
+    # (act_joint_state -> SOCIAL_FORCE.predict on the rolled states, crowd_sim_var_num.py:180-198) -- no rvo2 anywhere in these traces
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 10, "humans.policy": "social_force"}), 425, 0, 1, 300, "varnum_h10_sfhumans_test_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 8, "humans.policy": "social_force", "robot.visible": True}), 425, 0, 1, 300,
+          "varnum_h8_rand_sfhumans_robotvisible_test_r0")
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 10, "humans.policy": "social_force", "sim.predict_method": "truth"}), 425, 1, 4, 260,
+          "pred_h10_sfhumans_truthobs_r1")
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 9, "sim.human_num_range": 3, "humans.policy": "social_force", "sim.predict_method": "const_vel"}),
+          425, 0, 1, 260, "pred_h9_rand_range3_sfhumans_test_r0")
+    trace("CrowdSimPredRealGST-v0", dict(NON_RAND, **{"sim.human_num": 8, "humans.policy": "social_force", "sim.predict_method": "inferred"}), 425, 0, 1, 200,
+          "predgst_h8_sfhumans_test_r0")
+    # action_space.kinematics = 'unicycle' in CrowdSimPred-v0 / CrowdSimPredRealGST-v0: CrowdSimPred.step sends the command through
+    # smooth_action (the Turtlebot wheel model with np.random.normal dead-band noise; low-pass filtered in the test phase) and always
+    # respawns the humans that reached their goal (crowd_sim_pred.py:120-131, :208-212)
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 3, "sim.human_num_range": 2, "action_space.kinematics": "unicycle",
+                                               "sim.predict_method": "const_vel"}), 425, 0, 4, 700, "pred_h3_unicycle_r0")
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 6, "sim.human_num_range": 5, "action_space.kinematics": "unicycle",
+                                           "sim.predict_method": "const_vel"}), 425, 0, 1, 500, "pred_h6_rand_unicycle_test_r0")
+    trace("CrowdSimPredRealGST-v0", dict(NON_RAND, **{"sim.human_num": 4, "sim.human_num_range": 3, "action_space.kinematics": "unicycle",
+                                                      "sim.predict_method": "inferred"}), 425, 1, 4, 500, "predgst_h4_unicycle_r1")
+
+
+
 if __name__ == "__main__":
     what = _ARGV or ["env"]
     if "env" in what:

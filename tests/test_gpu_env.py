@@ -91,6 +91,26 @@ CASES = {
     "varnum_h10_rand_sfrobot_test": dict(human_num=10, robot_policy=2, phase=2, randomize_attributes=1, random_goal_changing=1),
     "varnum_h10_sfrobot_sfhumans": dict(human_num=10, robot_policy=2, humans_policy=1),
     "varnum_h63_rand_robotvisible": dict(human_num=63, robot_visible=1, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
+    # robot.visible with 'truth' roll-outs (test phase / observation predictor): the real step hands every human its H - 1 fellows plus
+    # the robot, the roll-outs only the fellows -> each private simulator is rebuilt twice per step (orca.py:80-82)
+    "varnum_h10_robotvisible_test": dict(human_num=10, robot_visible=1, phase=2),
+    "varnum_h8_rand_robotvisible_test": dict(human_num=8, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h40_rand_robotvisible_test": dict(human_num=40, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1, circle_radius=16.0),
+    "pred_h10_truthobs_robotvisible": dict(human_num=10, env_kind=1, predict_truth=1, robot_visible=1),
+    "pred_h8_rand_truthobs_robotvisible_test": dict(human_num=8, env_kind=1, predict_truth=1, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "predgst_h8_rand_robotvisible_test": dict(human_num=8, env_kind=2, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    # social-force humans with 'truth' roll-outs: the roll-outs roll SOCIAL_FORCE.predict (sf_truth_kernel)
+    "varnum_h10_sfhumans_test": dict(human_num=10, humans_policy=1, phase=2),
+    "varnum_h8_rand_sfhumans_robotvisible_test": dict(human_num=8, humans_policy=1, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "pred_h10_sfhumans_truthobs": dict(human_num=10, env_kind=1, predict_truth=1, humans_policy=1),
+    "pred_h9_rand_range3_sfhumans_truthobs_test": dict(human_num=9, human_num_range=3, env_kind=1, predict_truth=1, humans_policy=1, phase=2,
+                                                       randomize_attributes=1, random_goal_changing=1),
+    # unicycle robot in CrowdSimPred-v0 / CrowdSimPredRealGST-v0: the Turtlebot wheel model with np.random.normal dead-band noise (legacy
+    # polar Gaussian on the env's MT19937 stream), low-pass filtered in the test phase; humans at their goal are respawned
+    "pred_h5_unicycle": dict(human_num=5, env_kind=1, kinematics=1),
+    "pred_h6_rand_range5_unicycle_test": dict(human_num=6, human_num_range=5, env_kind=1, kinematics=1, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "predgst_h4_range3_unicycle": dict(human_num=4, human_num_range=3, env_kind=2, kinematics=1),
+    "pred_h6_rand_unicycle_truthobs": dict(human_num=6, env_kind=1, kinematics=1, predict_truth=1, randomize_attributes=1, random_goal_changing=1),
 }
 
 
