@@ -38,6 +38,7 @@ class EnvConfig(C.Structure):
         ("orca_neighbor_dist", C.c_double), ("orca_safety_space", C.c_double),
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
         ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
+        ("robot_fov", C.c_double), ("human_fov", C.c_double),
     ]
 
 

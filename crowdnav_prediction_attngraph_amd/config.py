@@ -65,8 +65,9 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     hp = g("humans", "policy", "orca")
     if hp not in ("orca", "social_force"):
         unsupported.append("humans.policy=%r" % hp)
-    if float(g("humans", "FOV", 2.)) != 2.0 or float(g("robot", "FOV", 2)) != 2.0:
-        unsupported.append("FOV != 2*pi")
+    hfov, rfov = float(g("humans", "FOV", 2.)), float(g("robot", "FOV", 2))
+    if hfov <= 0.0 or rfov <= 0.0:
+        unsupported.append("FOV <= 0")
     pm = g("sim", "predict_method", "const_vel")
     if env_name == "CrowdSimPred-v0" and pm not in ("const_vel", "truth"):
         unsupported.append("sim.predict_method=%r (CrowdSimPred-v0 runs with 'const_vel' or 'truth')" % pm)
@@ -80,8 +81,9 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         unsupported.append("unicycle kinematics with an ORCA / social-force robot (those policies return ActionXY) or in CrowdSimVarNumCollect-v0")
     if env_name == "CrowdSimVarNumCollect-v0" and (rp != "orca" or hr != 0 or kin != "holonomic" or phase != "train"):
         unsupported.append("CrowdSimVarNumCollect-v0 outside collect_data.py's set-up (robot.policy='orca', fixed crowd size, holonomic, phase train)")
-    if phase not in ("train", "test"):
-        unsupported.append("phase=%r (train.py / test.py only use 'train' and 'test')" % phase)
+    if phase not in ("train", "val", "test") or (phase == "val" and env_name != "CrowdSimPred-v0"):
+        unsupported.append("phase=%r (phase 'val' only runs in CrowdSimPred-v0: the other env classes fail at crowd_sim_var_num.py:501, "
+                           "self.human_future_traj is only assigned in their test phase)" % phase)
     if float(g("env", "time_step", 0.25)) != float(g("data", "pred_timestep", 0.25)):
         unsupported.append("data.pred_timestep != env.time_step")
     if unsupported:
@@ -93,8 +95,8 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
         sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
         predict_truth=int(env_name == "CrowdSimPred-v0" and pm == "truth"),
-        phase={"train": 0, "test": 2}[phase], nenv=int(nenv_total), robot_policy={"orca": 1, "social_force": 2}.get(rp, 0), humans_policy=int(hp == "social_force"),
-        sf_A=float(g("sf", "A", 2.)), sf_B=float(g("sf", "B", 1.)), sf_KI=float(g("sf", "KI", 1.)), robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
+        phase={"train": 0, "val": 1, "test": 2}[phase], nenv=int(nenv_total), robot_policy={"orca": 1, "social_force": 2}.get(rp, 0), humans_policy=int(hp == "social_force"),
+        sf_A=float(g("sf", "A", 2.)), sf_B=float(g("sf", "B", 1.)), sf_KI=float(g("sf", "KI", 1.)), robot_fov=rfov, human_fov=hfov, robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
         time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),
         success_reward=float(g("reward", "success_reward", 10)), collision_penalty=float(g("reward", "collision_penalty", -20)),
         discomfort_dist=float(g("reward", "discomfort_dist", 0.25)),

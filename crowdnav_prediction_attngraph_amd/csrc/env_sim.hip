@@ -196,6 +196,27 @@ __device__ __forceinline__ double det_log(double x)
     return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
+// The field-of-view half of detect_visible (crowd_sim.py:513-537): agent 2 inside agent 1's cone of fov * pi radians around agent 1's
+// heading -- the direction of its velocity when the robot is holonomic (at rest: +x, or -x for vx = -0.0, as np.arctan2 has it), its theta
+// otherwise.  Decision-equivalent form of arccos(clip(v_fov . v_12)) <= fov / 2 (see the oracle's in_fov for why); coincident agents
+// give NaN and are not visible.
+__device__ __forceinline__ bool in_fov(const cn_env_config &c, double fov, double px1, double py1, double vx1, double vy1, double theta1,
+                                       double px2, double py2)
+{
+    double fx, fy;
+    if (c.kinematics == CN_KIN_UNICYCLE) det_sincos(theta1, fy, fx);
+    else if (vx1 == 0.0 && vy1 == 0.0) { fx = __double_as_longlong(vx1) < 0 ? -1.0 : 1.0; fy = 0.0; }
+    else { const double nv = sqrt(vx1 * vx1 + vy1 * vy1); fx = vx1 / nv; fy = vy1 / nv; }
+    const double dx = px2 - px1, dy = py2 - py1;
+    const double n12 = sqrt(dx * dx + dy * dy);
+    double d = fx * (dx / n12) + fy * (dy / n12);
+    d = d < -1.0 ? -1.0 : (d > 1.0 ? 1.0 : d); // keeps NaN, like np.clip
+    const double half = M_PI * fov / 2.0;
+    double thr = -1.0;
+    if (half < M_PI) { double sn; det_sincos(half, sn, thr); }
+    return d >= thr;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Wave-cooperative RVO2 linear programs.  Lane k holds line k = (point, direction); `valid` marks live lines
 // (bit k).  All scalars (result, t bounds, ...) are wave-uniform: every lane computes them identically.
@@ -400,11 +421,20 @@ __device__ __forceinline__ void orca_agent(const EnvDev &s, int agent, int lane)
     float nd, self_r, self_ms, seen_r;
     const bool rv = s.cfg.robot_visible != 0;
     const int n_agents = n + (rv ? 1 : 0);
+    // other humans as seen by i (human FOV = 2*pi: always the true state unless coincident, otherwise the ones inside i's cone; the rest
+    // are the dummy (7,7,0,0)); with robot.visible the robot is appended as the last neighbour on lane n (crowd_sim.py:695-699), same
+    // visibility rule
+    const bool isR = rv && lane == n;
+    const double *rob = s.rob + (size_t)e * 8;
+    const double qx = isR ? rob[R_PX] : px, qy = isR ? rob[R_PY] : py, qvx = isR ? rob[R_VX] : vx, qvy = isR ? rob[R_VY] : vy;
+    const bool coincident = s.cfg.human_fov < 2.0 ? !in_fov(s.cfg, s.cfg.human_fov, spx, spy, svx, svy, 0.0, qx, qy) : (qx == spx) && (qy == spy);
     if (!s.sim_valid[ei] || (s.sim_n && s.sim_n[ei] != n_agents)) {
         nd = (float)s.shared_nd[e];
         self_r = (float)(srad + 0.01 + safety);
         self_ms = (float)svpref;
-        seen_r = (float)(rad + 0.01 + safety);
+        // addAgent takes the radius of the state it is handed: a human outside i's field of view right now is the dummy human with the
+        // config radius, and keeps that size in this simulator
+        seen_r = (float)((coincident ? s.cfg.human_radius : rad) + 0.01 + safety);
         if (s.sim_seen && isH) s.sim_seen[ei * H + lane] = seen_r;
         if (lane == 0) {
             s.sim_nd[ei] = nd; s.sim_self_radius[ei] = self_r; s.sim_self_maxspeed[ei] = self_ms; s.sim_valid[ei] = 1;
@@ -414,14 +444,8 @@ __device__ __forceinline__ void orca_agent(const EnvDev &s, int agent, int lane)
         nd = s.sim_nd[ei]; self_r = s.sim_self_radius[ei]; self_ms = s.sim_self_maxspeed[ei];
         seen_r = s.sim_seen ? s.sim_seen[ei * H + lj] : (float)(rad + 0.01 + safety);
     }
-    // other humans as seen by i (human FOV = 2*pi: always the true state unless coincident -> dummy (7,7,0,0)); with
-    // robot.visible the robot is appended as the last neighbour on lane n (crowd_sim.py:695-699), same visibility rule
-    const bool isR = rv && lane == n;
-    const double *rob = s.rob + (size_t)e * 8;
-    const double qx = isR ? rob[R_PX] : px, qy = isR ? rob[R_PY] : py, qvx = isR ? rob[R_VX] : vx, qvy = isR ? rob[R_VY] : vy;
     if (isR) seen_r = (float)(s.cfg.robot_radius + 0.01 + safety); // fixed for the whole run
     const bool cand = (isH && lane != i) || isR;
-    const bool coincident = (qx == spx) && (qy == spy);
     const float opx = coincident ? 7.0f : (float)qx, opy = coincident ? 7.0f : (float)qy;
     const float ovx = coincident ? 0.0f : (float)qvx, ovy = coincident ? 0.0f : (float)qvy;
     // preferred velocity: orca.py:97-100
@@ -1037,9 +1061,11 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int 
     const cn_env_config &c = s.cfg;
     const int H = s.H, D = s.D, P = s.P; // H observation rows (crowd_sim_var_num.py:249, crowd_sim_pred.py:78), n humans present
     const bool isH = lane < n, isRow = lane < H;
-    // robot FOV = 2*pi: visible iff not coincident and within sensor range (detect_visible, crowd_sim.py:513-552)
+    // detect_visible(robot, human, robot1=True), crowd_sim.py:513-552: inside the robot's field of view (FOV = 2*pi: iff not coincident) and
+    // within sensor range
     const double dx = rb.px - h.px, dy = rb.py - h.py;
-    const bool vis = isH && !(dx == 0.0 && dy == 0.0) && (norm2(dx, dy) - c.robot_radius - h.rad <= c.sensor_range);
+    bool vis = isH && !(dx == 0.0 && dy == 0.0) && (norm2(dx, dy) - c.robot_radius - h.rad <= c.sensor_range);
+    if (c.robot_fov < 2.0) vis = vis && in_fov(c, c.robot_fov, rb.px, rb.py, rb.vx, rb.vy, rb.theta, h.px, h.py);
     const uint64_t vmask = __ballot(vis);
     const int num_visible = __popcll(vmask);
     if (s.vis && isRow) s.vis[(size_t)e * H + lane] = vis ? 1 : 0; // human_visibility, read by the next step's 'truth' blanking
@@ -1458,7 +1484,8 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
             const int src = j < n ? j : 0; // the shuffles stay outside any conditional (they read inactive lanes as 0 otherwise)
             const double jx = __shfl(h.px, src, 64), jy = __shfl(h.py, src, 64), jr = __shfl(h.rad, src, 64);
             double ox = j < n ? jx : rb.px, oy = j < n ? jy : rb.py, orad = j < n ? jr : c.robot_radius;
-            if (ox == h.px && oy == h.py) { ox = 7.0; oy = 7.0; if (j < n) orad = c.human_radius; }
+            const bool hidden = c.human_fov < 2.0 ? !in_fov(c, c.human_fov, h.px, h.py, h.vx, h.vy, 0.0, ox, oy) : (ox == h.px && oy == h.py);
+            if (hidden) { ox = 7.0; oy = 7.0; if (j < n) orad = c.human_radius; }
             const double dx = h.px - ox, dy = h.py - oy;
             const double d = sqrt(dx * dx + dy * dy);
             const double f = c.sf_A * det_exp((h.rad + orad - d) / c.sf_B);
@@ -1500,6 +1527,20 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
                 }
             }
         }
+        best = wv_min(best);
+        danger_cond = best < INFINITY;
+        min_danger = danger_cond ? best : 0.0;
+    } else if (c.phase == CN_PHASE_VAL) {
+        // phase 'val' (CrowdSimPred-v0): the same test on what the previous observation left in self.human_future_traj -- its const_vel /
+        // truth predictions, unseen humans already blanked (ftraj)
+        const double *ft = s.ftraj + (size_t)e * s.P * 2 * H;
+        double best = INFINITY;
+        for (int k = 1; k <= s.P; ++k)
+            if (isH) {
+                const double fx = ft[((k - 1) * 2 + 0) * H + lane] - rb.px, fy = ft[((k - 1) * 2 + 1) * H + lane] - rb.py;
+                const double d = sqrt(fx * fx + fy * fy);
+                if (d < c.robot_radius + c.human_radius) best = fmin(best, d);
+            }
         best = wv_min(best);
         danger_cond = best < INFINITY;
         min_danger = danger_cond ? best : 0.0;
@@ -1728,7 +1769,8 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
     const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0); // candidate neighbours per agent (self included)
     static int coop = -1; // CN_ORCA_COOP=1 forces the one-wavefront-per-agent kernel (A/B measurements)
     if (coop < 0) { const char *v = getenv("CN_ORCA_COOP"); coop = v ? atoi(v) : 0; }
-    const bool lane_path = env->d.cfg.humans_policy == CN_HUMANS_ORCA && slots <= 32 && !coop;
+    // (a narrowed human field of view goes through the cooperative kernel: the lane kernel has no visibility test in its inner loops)
+    const bool lane_path = env->d.cfg.humans_policy == CN_HUMANS_ORCA && slots <= 32 && !coop && env->d.cfg.human_fov >= 2.0;
     // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial
     // fp64 work per such env).  It only depends on the step that just ran, needs a little LDS, and is light: it runs beside the lane
     // kernel, before the policy kernels take the whole LDS of every CU
@@ -1779,6 +1821,7 @@ extern "C" void cn_env_config_default(cn_env_config *c)
     c->success_reward = 10.0; c->collision_penalty = -20.0; c->discomfort_dist = 0.25; c->discomfort_penalty_factor = 10.0;
     c->circle_radius = 6.0 * std::sqrt(2.0); c->arena_size = 6.0;
     c->human_radius = 0.3; c->human_v_pref = 1.0; c->robot_radius = 0.3; c->robot_v_pref = 1.0; c->sensor_range = 5.0;
+    c->robot_fov = 2.0; c->human_fov = 2.0;
     c->goal_change_chance = 0.5; c->end_goal_change_chance = 1.0;
     c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0; c->orca_time_horizon_obst = 5.0;
     c->sf_A = 2.0; c->sf_B = 1.0; c->sf_KI = 1.0; // config.py:126-128
@@ -1802,14 +1845,16 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
                "cn_env_create: kinematics must be holonomic, or unicycle with a network-driven robot outside CrowdSimVarNumCollect-v0 (the ORCA / "
                "social-force robot policies return ActionXY: crowd_sim_var_num.py:78-91, :379-381)");
     CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA || cfg->humans_policy == CN_HUMANS_SOCIAL_FORCE, "cn_env_create: unknown humans_policy %d", cfg->humans_policy);
+    CN_REQUIRE(cfg->robot_fov > 0.0 && cfg->human_fov > 0.0, "cn_env_create: robot_fov / human_fov are in units of pi and must be positive (2 = all round)");
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_COLLECT, "cn_env_create: unknown env_kind %d", cfg->env_kind);
     CN_REQUIRE(cfg->env_kind != CN_ENV_COLLECT || (cfg->human_num_range == 0 && cfg->kinematics == CN_KIN_HOLONOMIC && cfg->phase == CN_PHASE_TRAIN &&
                                                    cfg->robot_policy == CN_ROBOT_ORCA && !cfg->predict_truth),
                "cn_env_create: CrowdSimVarNumCollect-v0 runs with a fixed crowd size, a holonomic ORCA-driven robot and phase train "
                "(what collect_data.py sets up; the reference's pred_info needs human_num_range == 0)");
-    CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST,
-               "cn_env_create: phase must be train or test (the reference never runs phase 'val' on this path)");
+    CN_REQUIRE(cfg->phase == CN_PHASE_TRAIN || cfg->phase == CN_PHASE_TEST || (cfg->phase == CN_PHASE_VAL && cfg->env_kind == CN_ENV_PRED),
+               "cn_env_create: phase must be train or test, or val with CrowdSimPred-v0 (the other env classes fail in phase 'val': "
+               "crowd_sim_var_num.py:501 reads self.human_future_traj, which they only assign in the test phase)");
     CN_REQUIRE(cfg->nenv >= 1, "cn_env_create: nenv (total env count) must be >= 1");
     CN_REQUIRE(cfg->robot_policy >= CN_ROBOT_NETWORK && cfg->robot_policy <= CN_ROBOT_SOCIAL_FORCE, "cn_env_create: unknown robot_policy %d", cfg->robot_policy);
     CN_REQUIRE(!cfg->robot_visible || HM <= CN_MAX_HUMANS - 1,
@@ -1854,7 +1899,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_dv = unicycle ? carve(E * 8) : 0;
     const bool wheel_model = unicycle && cfg->env_kind != CN_ENV_VARNUM; // CrowdSimPred.step's smooth_action
     const size_t o_wh = wheel_model ? carve(E * 4 * 8) : 0;
-    const bool lane_orca = HM + (cfg->robot_visible ? 1 : 0) <= 32 && cfg->humans_policy == CN_HUMANS_ORCA;
+    const bool lane_orca = HM + (cfg->robot_visible ? 1 : 0) <= 32 && cfg->humans_policy == CN_HUMANS_ORCA && cfg->human_fov >= 2.0;
     const bool collect = cfg->env_kind == CN_ENV_COLLECT;
     const size_t o_pid = collect ? carve(E * H * 4) : 0, o_mpid = collect ? carve(E * 4) : 0, o_lobs = collect ? carve(E * H) : 0;
     const size_t state_bytes = off; // everything below is per-step scratch of the ORCA pass: not part of a snapshot

@@ -104,7 +104,7 @@ class _SingleCrowdSim(object):
         a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, 2)).to(self._env.device)
         obs, reward, done, info, _, _ = self._env.step(a)
         code = int(info.cpu()[0])
-        if code == 4 and self._env.cfg.phase == 2:
+        if code == 4 and self._env.cfg.phase in (1, 2):
             inf = I.from_code(code, float(self._env.get_danger_min_dist().cpu()[0]))
         else:
             inf = I.from_code(code)

@@ -102,7 +102,7 @@ class BatchedCrowdSim(object):
         # one D2H transfer for everything the reference returns on the host (VecPyTorch.step_wait, envs.py:216-224)
         reward_h, done_h, info_h, ret_h, len_h = (reward.cpu(), done.cpu().numpy().astype(bool), info.cpu().numpy(),
                                                   ep_ret.cpu().numpy(), ep_len.cpu().numpy())
-        if self.cfg.phase == 2 and (info_h == 4).any():      # test phase: Danger carries the min distance to an intruded future position
+        if self.cfg.phase in (1, 2) and (info_h == 4).any():  # val / test phase: Danger carries the min distance to an intruded future position
             md = self._env.get_danger_min_dist().cpu().numpy()
             infos = [{"info": I.from_code(int(c), float(md[i]))} for i, c in enumerate(info_h)]
         else:

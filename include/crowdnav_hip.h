@@ -109,6 +109,7 @@ typedef struct {
     double goal_change_chance, end_goal_change_chance;
     double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
     double sf_A, sf_B, sf_KI;     /* config.sf.* (crowd_nav/policy/social_force.py) */
+    double robot_fov, human_fov;  /* robot.FOV, humans.FOV in units of pi (crowd_sim.py:122-123, detect_visible :513-552); 2 = all round */
 } cn_env_config;
 
 /* CN_ENV_COLLECT (crowd_sim/envs/crowd_sim_var_num_collect.py, driven by collect_data.py): the dataset generator of the GST predictor.

@@ -404,6 +404,7 @@ void orc_config_default(OrcConfig *c)
     c->sf_A = 2.0; c->sf_B = 1.0; c->sf_KI = 1.0;
     c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0;
     c->orca_time_horizon_obst = 5.0;
+    c->robot_fov = 2.0; c->human_fov = 2.0;
 }
 
 int orc_obs_width(const OrcConfig *cfg)
@@ -465,12 +466,36 @@ static void gen_circle_crossing_human(OrcEnv *e, int slot, int n_existing)
     e->sim_valid[slot] = 0; /* new Human -> new ORCA policy object with sim None */
 }
 
-/* crowd_sim.py:513-552 detect_visible(robot, human, robot1=True) with robot FOV = 2*pi:
- * the arccos test is always true unless the two agents coincide (0/0 -> NaN -> False). */
+/* The field-of-view half of detect_visible (crowd_sim.py:513-537): agent 2 is inside agent 1's cone of `fov` * pi radians around
+ * agent 1's heading -- the direction of its velocity when the ROBOT is holonomic (np.arctan2(vy, vx); at rest that is +x, or -x for
+ * vx = -0.0), its theta otherwise (the robot's heading; 0 for every human, human.set(..., theta = 0)).
+ * Restated in a decision-equivalent form: arccos(clip(v_fov . v_12)) <= fov / 2  <=>  clip(v_fov . v_12) >= cos(fov / 2), and
+ * (cos, sin)(arctan2(vy, vx)) = v / |v|; the reference's own evaluation goes through BLAS dot / nrm2, whose last-bit rounding is
+ * build dependent, so its offset angle is not reproducible to the bit either -- only the decision is.  Coincident agents give
+ * 0 / 0 = NaN and are not visible, as in the reference (np.abs(nan) <= x is False). */
+static int in_fov(const OrcConfig *c, double fov, double px1, double py1, double vx1, double vy1, double theta1, double px2, double py2)
+{
+    double fx, fy;
+    if (c->kinematics == ORC_KIN_UNICYCLE) orc_sincos(theta1, &fy, &fx);
+    else if (vx1 == 0.0 && vy1 == 0.0) { fx = signbit(vx1) ? -1.0 : 1.0; fy = 0.0; }
+    else { const double nv = sqrt(vx1 * vx1 + vy1 * vy1); fx = vx1 / nv; fy = vy1 / nv; }
+    const double dx = px2 - px1, dy = py2 - py1;
+    const double n12 = sqrt(dx * dx + dy * dy);
+    double d = fx * (dx / n12) + fy * (dy / n12);
+    d = d < -1.0 ? -1.0 : (d > 1.0 ? 1.0 : d); /* np.clip keeps NaN */
+    const double half = M_PI * fov / 2.0;
+    double thr = -1.0;
+    if (half < M_PI) { double sn; orc_sincos(half, &sn, &thr); }
+    return d >= thr;
+}
+
+/* crowd_sim.py:513-552 detect_visible(robot, human, robot1=True).  With robot FOV = 2*pi the arccos test is always true unless the two
+ * agents coincide (0/0 -> NaN -> False). */
 static int robot_sees(const OrcEnv *e, const OrcHuman *h)
 {
     const double dx = e->rpx - h->px, dy = e->rpy - h->py;
     if (dx == 0.0 && dy == 0.0) return 0;
+    if (e->cfg.robot_fov < 2.0 && !in_fov(&e->cfg, e->cfg.robot_fov, e->rpx, e->rpy, e->rvx, e->rvy, e->rtheta, h->px, h->py)) return 0;
     const double dist = norm2(dx, dy) - e->cfg.robot_radius - h->radius;
     return dist <= e->cfg.sensor_range;
 }
@@ -671,7 +696,7 @@ void orc_env_reset(OrcEnv *e, OrcObs *obs)
 }
 
 /* human i's private rvo2 simulator, orca.py:80-89: rebuilt when the agent count differs, parameters frozen at creation */
-static void ensure_human_sim(OrcEnv *e, int i, int n_agents)
+static void ensure_human_sim(OrcEnv *e, int i, int n_agents, const int *sees /* NULL: every other human as it is */)
 {
     const OrcConfig *c = &e->cfg;
     const int H = e->n_humans;
@@ -682,10 +707,19 @@ static void ensure_human_sim(OrcEnv *e, int i, int n_agents)
         e->sim_nd[i] = (float)e->shared_neighbor_dist;
         e->sim_self_radius[i] = (float)(me->radius + 0.01 + c->orca_safety_space);
         e->sim_self_maxspeed[i] = (float)me->v_pref;
+        /* addAgent takes the radius of the state it is handed: a human outside i's field of view at this moment is the dummy human with
+         * the config radius (crowd_sim.py:688-693) -- and stays that size in this simulator */
         for (int j = 0; j < H; ++j)
-            if (j != i) e->sim_seen_radius[i][j] = (float)(e->humans[j].radius + 0.01 + c->orca_safety_space);
+            if (j != i) e->sim_seen_radius[i][j] = (float)((sees && !sees[j] ? c->human_radius : e->humans[j].radius) + 0.01 + c->orca_safety_space);
         e->sim_valid[i] = 1;
     }
+}
+
+/* detect_visible(human i, other agent) of get_human_actions (crowd_sim.py:686-699): no sensor range for humans, only the field of view */
+static int human_sees(const OrcEnv *e, const OrcHuman *me, double ox, double oy)
+{
+    if (e->cfg.human_fov >= 2.0) return !(ox == me->px && oy == me->py);
+    return in_fov(&e->cfg, e->cfg.human_fov, me->px, me->py, me->vx, me->vy, 0.0, ox, oy);
 }
 
 /* ORCA.predict for human i, orca.py:64-117 */
@@ -694,14 +728,16 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
     const OrcConfig *c = &e->cfg;
     const int H = e->n_humans;
     const OrcHuman *me = &e->humans[i];
-    ensure_human_sim(e, i, H + (c->robot_visible ? 1 : 0)); /* self + the others (+ the robot) */
+    int sees[ORC_MAX_HUMANS];
+    for (int j = 0; j < H; ++j) sees[j] = j != i && human_sees(e, me, e->humans[j].px, e->humans[j].py);
+    ensure_human_sim(e, i, H + (c->robot_visible ? 1 : 0), sees); /* self + the others (+ the robot) */
     float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
     int n = 0;
     for (int j = 0; j < H; ++j) {
         if (j == i) continue;
         const OrcHuman *o = &e->humans[j];
         /* get_human_actions, crowd_sim.py:686-693: human FOV = 2*pi -> visible unless coincident, else dummy (7,7,0,0) */
-        if (o->px == me->px && o->py == me->py) {
+        if (!sees[j]) {
             opx[n] = 7.0f; opy[n] = 7.0f; ovx[n] = 0.0f; ovy[n] = 0.0f;
         } else {
             opx[n] = (float)o->px; opy[n] = (float)o->py; ovx[n] = (float)o->vx; ovy[n] = (float)o->vy;
@@ -712,7 +748,7 @@ static void human_orca_action(OrcEnv *e, int i, float *avx, float *avy)
     if (c->robot_visible) {
         /* crowd_sim.py:695-699: the robot is appended as the last neighbour; FOV = 2*pi -> visible unless coincident, else the
          * dummy robot parked at (7,7).  Its rvo2 radius was fixed when human i's simulator was created. */
-        if (e->rpx == me->px && e->rpy == me->py) { opx[n] = 7.0f; opy[n] = 7.0f; ovx[n] = 0.0f; ovy[n] = 0.0f; }
+        if (!human_sees(e, me, e->rpx, e->rpy)) { opx[n] = 7.0f; opy[n] = 7.0f; ovx[n] = 0.0f; ovy[n] = 0.0f; }
         else { opx[n] = (float)e->rpx; opy[n] = (float)e->rpy; ovx[n] = (float)e->rvx; ovy[n] = (float)e->rvy; }
         orad[n] = (float)(c->robot_radius + 0.01 + c->orca_safety_space);
         ++n;
@@ -744,11 +780,11 @@ static void human_sf_action(const OrcEnv *e, int i, double *avx, double *avy)
         if (j == i) continue;
         if (j < H) {
             const OrcHuman *o = &e->humans[j];
-            if (o->px == me->px && o->py == me->py) { ox = 7.0; oy = 7.0; orad = c->human_radius; } /* dummy_human: config radius */
+            if (!human_sees(e, me, o->px, o->py)) { ox = 7.0; oy = 7.0; orad = c->human_radius; } /* dummy_human: config radius */
             else { ox = o->px; oy = o->py; orad = o->radius; }
         } else {
             if (!c->robot_visible) continue;
-            if (e->rpx == me->px && e->rpy == me->py) { ox = 7.0; oy = 7.0; } else { ox = e->rpx; oy = e->rpy; }
+            if (!human_sees(e, me, e->rpx, e->rpy)) { ox = 7.0; oy = 7.0; } else { ox = e->rpx; oy = e->rpy; }
             orad = c->robot_radius;
         }
         const double dx = me->px - ox, dy = me->py - oy;
@@ -806,7 +842,7 @@ static void truth_future_traj(OrcEnv *e)
             }
             float opx[ORC_MAX_HUMANS], opy[ORC_MAX_HUMANS], ovx[ORC_MAX_HUMANS], ovy[ORC_MAX_HUMANS], orad[ORC_MAX_HUMANS];
             int n = 0;
-            ensure_human_sim(e, i, H); /* only new at reset (predict_method 'truth'): act_joint_state builds it like ORCA.predict */
+            ensure_human_sim(e, i, H, NULL); /* only new at reset (predict_method 'truth'): act_joint_state builds it like ORCA.predict */
             for (int j = 0; j < H; ++j) {
                 if (j == i) continue;
                 opx[n] = (float)cur[j][0]; opy[n] = (float)cur[j][1]; ovx[n] = (float)cur[j][2]; ovy[n] = (float)cur[j][3];
@@ -981,7 +1017,10 @@ int orc_env_step(OrcEnv *e, const float action_in[2], OrcObs *obs, double *rewar
     const double global_time = (double)e->step_counter * c->time_step;
     double reward; int done, info; double mind = 0.0;
     int danger_cond = dmin < c->discomfort_dist; /* :496-498 */
-    if (c->phase == ORC_PHASE_TEST) { /* :499-511 intrusion into the humans' future positions (np.amin over the hits) */
+    /* :499-511 intrusion into the humans' future positions (np.amin over the hits).  Test phase: the 'truth' roll-out just made.  Phase 'val'
+     * (CrowdSimPred-v0 only -- the other two env classes never assign self.human_future_traj outside the test phase and fail at :501):
+     * whatever the previous observation left there, i.e. its const_vel / truth predictions with the unseen humans blanked. */
+    if (c->phase == ORC_PHASE_TEST || c->phase == ORC_PHASE_VAL) {
         danger_cond = 0;
         for (int k = 1; k <= c->predict_steps; ++k)
             for (int i = 0; i < H; ++i) {

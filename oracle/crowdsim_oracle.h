@@ -105,6 +105,7 @@ typedef struct {
                                      only: CrowdSimPred.step adds the Turtlebot wheel model with Gaussian noise); oracle only so far */
     int32_t predict_truth;        /* CrowdSimPred-v0 only: config.sim.predict_method == 'truth' -- the observation carries the humans' true
                                      future positions (their own ORCA rolled forward) instead of the constant-velocity ones; oracle only so far */
+    double robot_fov, human_fov;  /* config.robot.FOV, config.humans.FOV in units of pi (crowd_sim.py:122-123); 2 = all round (the default) */
 } OrcConfig;
 
 typedef struct {

@@ -44,6 +44,7 @@ class OrcConfig(C.Structure):
         ("orca_time_horizon", C.c_double), ("orca_time_horizon_obst", C.c_double),
         ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
         ("humans_policy", C.c_int32), ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("predict_truth", C.c_int32),
+        ("robot_fov", C.c_double), ("human_fov", C.c_double),
     ]
 
 
@@ -115,6 +116,9 @@ def default_config(**over):
                          "assigns the H previous human states to H + 1 rows)")
     if cfg.env_kind == ENV_COLLECT and (cfg.human_num_range or cfg.kinematics or cfg.phase != 0 or cfg.robot_policy != 1):
         raise NotImplementedError("CrowdSimVarNumCollect-v0: fixed crowd size, holonomic ORCA-driven robot, phase train (what collect_data.py runs)")
+    if cfg.phase == PHASE_VAL and cfg.env_kind != ENV_PRED:
+        raise ValueError("phase 'val': CrowdSimPred-v0 only (the other env classes fail at crowd_sim_var_num.py:501: self.human_future_traj "
+                         "is only ever assigned by calc_human_future_traj, which they call in the test phase only)")
     if cfg.kinematics == 1 and cfg.env_kind == ENV_COLLECT:
         raise NotImplementedError("unicycle robot: not with CrowdSimVarNumCollect-v0")
     if cfg.kinematics == 1 and cfg.robot_policy != 0:

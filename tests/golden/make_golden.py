@@ -104,10 +104,12 @@ def action_for(env, t, ep, rank):
     return a.astype(np.float32)
 
 
-def trace(env_name, over, seed, rank, nenv, steps, tag):
+def trace(env_name, over, seed, rank, nenv, steps, tag, phase=None):
     cfg = R.make_config(**over)
     cfg.args.env_name = env_name
     env = make_env(env_name, cfg, seed, rank, nenv)
+    if phase is not None:   # make_env follows rl/networks/envs.py (train / test by env count); 'val' is only reachable by setting it
+        env.phase = phase
     if cfg.action_space.kinematics == "unicycle":
         widen_unicycle_actions(env)
     H = cfg.sim.human_num + cfg.sim.human_num_range   # rows of every observation; len(env.humans) may be smaller
@@ -161,8 +163,10 @@ def trace(env_name, over, seed, rank, nenv, steps, tag):
         out["reset_" + k] = v
     out["init_humans"] = init_humans
     out["init_robot"] = init_robot
-    out["meta"] = np.array(json.dumps(dict(env_name=env_name, over=over, seed=seed, rank=rank, nenv=nenv, steps=steps,
-                                           sort_humans=bool(cfg.args.sort_humans))))
+    meta = dict(env_name=env_name, over=over, seed=seed, rank=rank, nenv=nenv, steps=steps, sort_humans=bool(cfg.args.sort_humans))
+    if phase is not None:
+        meta["phase"] = phase
+    out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(HERE, "env_%s.npz" % tag)
     np.savez_compressed(path, **out)
     dn = int(np.sum(out["done"]))
@@ -259,6 +263,23 @@ def env_goldens():
                                            "sim.predict_method": "const_vel"}), 425, 0, 1, 500, "pred_h6_rand_unicycle_test_r0")
     trace("CrowdSimPredRealGST-v0", dict(NON_RAND, **{"sim.human_num": 4, "sim.human_num_range": 3, "action_space.kinematics": "unicycle",
                                                       "sim.predict_method": "inferred"}), 425, 1, 4, 500, "predgst_h4_unicycle_r1")
+    # phase 'val' (CrowdSimPred-v0; the other env classes fail there): seeds 0 + case, case counter modulo env.val_size, Danger decided by
+    # the predictions the PREVIOUS observation left in self.human_future_traj
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 12, "sim.predict_method": "const_vel"}), 425, 1, 4, 300, "pred_h12_constvel_val_r1", phase="val")
+    trace("CrowdSimPred-v0", dict(RAND, **{"sim.human_num": 8, "sim.human_num_range": 2, "sim.predict_method": "truth", "env.val_size": 3}), 425, 0, 2, 300,
+          "pred_h8_rand_range2_truthobs_val_r0", phase="val")
+    # robot.FOV / humans.FOV below 2 (x pi): the robot only detects humans inside the cone around its heading (the direction of its velocity
+    # for a holonomic robot), a human's ORCA / social force gets the dummy at (7, 7) for every agent outside its own cone (crowd_sim.py:513-552)
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 10, "robot.FOV": 1.0}), 425, 0, 4, 300, "varnum_h10_robotfov_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 8, "humans.FOV": 1.2, "robot.visible": True}), 425, 1, 4, 300, "varnum_h8_rand_humanfov_robotvisible_r1")
+    trace("CrowdSimPred-v0", dict(NON_RAND, **{"sim.human_num": 10, "robot.FOV": 0.8, "humans.FOV": 1.5, "sim.predict_method": "const_vel"}), 425, 0, 1, 260,
+          "pred_h10_fov_test_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 6, "humans.policy": "social_force", "humans.FOV": 1.0, "robot.FOV": 1.5}), 425, 0, 4, 300,
+          "varnum_h6_rand_sfhumans_fov_r0")
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **{"sim.human_num": 3, "sim.human_num_range": 2, "action_space.kinematics": "unicycle", "robot.FOV": 1.0,
+                                                 "humans.FOV": 1.0}), 425, 0, 4, 500, "varnum_h3_unicycle_fov_r0")
+    trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 8, "robot.FOV": 1.0, "humans.FOV": 1.0, "robot.visible": True}), 425, 0, 1, 300,
+          "varnum_h8_rand_fov_robotvisible_test_r0")
 
 
 
@@ -270,16 +291,16 @@ if __name__ == "__main__":
     if only:                # python make_golden.py only:<substring of the tag>
         _all2 = trace
 
-        def trace(env_name, over, seed, rank, nenv, steps, tag):  # noqa: F811
+        def trace(env_name, over, seed, rank, nenv, steps, tag, phase=None):  # noqa: F811
             if any(o in tag for o in only):
-                _all2(env_name, over, seed, rank, nenv, steps, tag)
+                _all2(env_name, over, seed, rank, nenv, steps, tag, phase)
         env_goldens()
     if "env-test" in what:  # only the test-phase traces (the train-phase fixtures stay byte-identical)
         _all = trace
 
-        def trace(env_name, over, seed, rank, nenv, steps, tag):  # noqa: F811
+        def trace(env_name, over, seed, rank, nenv, steps, tag, phase=None):  # noqa: F811
             if nenv == 1:
-                _all(env_name, over, seed, rank, nenv, steps, tag)
+                _all(env_name, over, seed, rank, nenv, steps, tag, phase)
         env_goldens()
     if "policy" in what:
         import make_golden_policy

@@ -37,6 +37,12 @@ def sim_kwargs(meta, oracle=False):
         extra["predict_truth"] = 1
     if over.get("action_space.kinematics", "holonomic") == "unicycle":
         extra["kinematics"] = 1
+    if "robot.FOV" in over:
+        extra["robot_fov"] = float(over["robot.FOV"])
+    if "humans.FOV" in over:
+        extra["human_fov"] = float(over["humans.FOV"])
+    if "env.val_size" in over:
+        extra["val_size"] = int(over["env.val_size"])
     return dict(extra,
         human_num=int(over.get("sim.human_num", 20)),
         env_kind=ENV_KIND[meta["env_name"]],
@@ -45,7 +51,7 @@ def sim_kwargs(meta, oracle=False):
         end_goal_changing=int(bool(over.get("humans.end_goal_changing", True))),
         sort_humans=int(bool(meta.get("sort_humans", True))),
         nenv=int(meta["nenv"]),
-        phase=0 if meta["nenv"] > 1 else 2,
+        phase={"train": 0, "val": 1, "test": 2}[meta["phase"]] if meta.get("phase") else (0 if meta["nenv"] > 1 else 2),
         robot_policy={"orca": 1, "social_force": 2}.get(over.get("robot.policy", "selfAttn_merge_srnn"), 0),
         robot_visible=int(bool(over.get("robot.visible", False))),
     )

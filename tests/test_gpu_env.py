@@ -110,6 +110,18 @@ CASES = {
     "pred_h5_unicycle": dict(human_num=5, env_kind=1, kinematics=1),
     "pred_h6_rand_range5_unicycle_test": dict(human_num=6, human_num_range=5, env_kind=1, kinematics=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     "predgst_h4_range3_unicycle": dict(human_num=4, human_num_range=3, env_kind=2, kinematics=1),
+    # phase 'val' (CrowdSimPred-v0): seeds 0 + case modulo val_size, Danger from the predictions of the previous observation
+    "pred_h12_constvel_val": dict(human_num=12, env_kind=1, phase=1),
+    "pred_h8_rand_range2_truthobs_val": dict(human_num=8, human_num_range=2, env_kind=1, predict_truth=1, phase=1, val_size=5, randomize_attributes=1,
+                                             random_goal_changing=1),
+    # robot.FOV / humans.FOV < 2 (x pi): cone around the heading; what a human does not see is the dummy at (7, 7), with the config radius
+    # frozen into its private simulator if that is what it was built from
+    "varnum_h10_robotfov": dict(human_num=10, robot_fov=1.0),
+    "varnum_h8_rand_humanfov_robotvisible": dict(human_num=8, human_fov=1.2, robot_visible=1, randomize_attributes=1, random_goal_changing=1),
+    "pred_h10_fov_test": dict(human_num=10, env_kind=1, robot_fov=0.8, human_fov=1.5, phase=2),
+    "varnum_h6_rand_sfhumans_fov": dict(human_num=6, humans_policy=1, human_fov=1.0, robot_fov=1.5, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h3_range2_unicycle_fov": dict(human_num=3, human_num_range=2, kinematics=1, robot_fov=1.0, human_fov=1.0),
+    "varnum_h8_rand_fov_robotvisible_test": dict(human_num=8, robot_fov=1.0, human_fov=1.0, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     "pred_h6_rand_unicycle_truthobs": dict(human_num=6, env_kind=1, kinematics=1, predict_truth=1, randomize_attributes=1, random_goal_changing=1),
 }
 
