@@ -77,14 +77,15 @@ typedef struct {
     int32_t random_goal_changing; /* humans.random_goal_changing */
     int32_t end_goal_changing;    /* humans.end_goal_changing */
     int32_t sort_humans;          /* args.sort_humans */
-    int32_t phase;                /* CN_PHASE_TRAIN or CN_PHASE_TEST (test: seeds 1000 + case, 'truth' roll-out, future-zone Danger) */
+    int32_t phase;                /* CN_PHASE_TRAIN, CN_PHASE_TEST (seeds 1000 + case, 'truth' roll-out, future-zone Danger) or, CrowdSimPred-v0 only,
+                                   * CN_PHASE_VAL (seeds 0 + case, Danger from the previous observation's predictions) */
     int32_t nenv;                 /* TOTAL number of envs across all GPUs: the case_counter stride (crowd_sim_var_num.py:348) */
     uint32_t val_size, test_size;
     int32_t robot_policy;         /* CN_ROBOT_NETWORK: cn_env_step's action drives the robot; CN_ROBOT_ORCA: robot.policy = 'orca'
                                    * (crowd_sim_var_num.py:371-375), ORCA on the robot's beliefs, the action argument is ignored;
                                    * CN_ROBOT_SOCIAL_FORCE: robot.policy = 'social_force' (crowd_nav/policy/social_force.py), likewise */
-    int32_t robot_visible;        /* robot.visible: every human's ORCA sees the robot as one more neighbour (crowd_sim.py:695-699);
-                                   * CrowdSimVarNum-v0, train phase, human_num <= 63 */
+    int32_t robot_visible;        /* robot.visible: every human's ORCA / social force sees the robot as one more neighbour (crowd_sim.py:695-699);
+                                   * human_num + human_num_range <= 63; not with CrowdSimPred-v0 + const_vel predictions (the reference fails there) */
     int32_t auto_reset;           /* 1 (default): vec-env semantics, a finished env is reset inside cn_env_step and `obs` holds the
                                    * reset observation (shmem_vec_env.py:139-142); 0: single gym env semantics
                                    * (crowd_sim_var_num.py:366-460 alone): the terminal observation is returned, cn_env_reset restarts */
@@ -98,8 +99,9 @@ typedef struct {
     int32_t human_num_range;      /* sim.human_num_range: the crowd holds human_num - range .. human_num + range humans (drawn at reset,
                                    * changed every 5 s: crowd_sim_var_num.py:103-104, :404-437, crowd_sim_pred.py:165-190); observations
                                    * always have human_num + human_num_range rows, which must be <= CN_MAX_HUMANS */
-    int32_t kinematics;           /* CN_KIN_* (action_space.kinematics) */
-    int32_t humans_policy;        /* CN_HUMANS_* (humans.policy); social force: train phase, no 'truth' predictions */
+    int32_t kinematics;           /* CN_KIN_* (action_space.kinematics); unicycle: network-driven robot; in CrowdSimPred-v0 / PredRealGST-v0 the command
+                                   * passes through smooth_action's noisy wheel model (crowd_sim.py:315-358) */
+    int32_t humans_policy;        /* CN_HUMANS_* (humans.policy) */
     int32_t reserved0;
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;

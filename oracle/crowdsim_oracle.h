@@ -97,14 +97,14 @@ typedef struct {
     double goal_change_chance, end_goal_change_chance;
     double orca_neighbor_dist, orca_safety_space, orca_time_horizon, orca_time_horizon_obst;
     double sf_A, sf_B, sf_KI;     /* config.sf.* (social-force robot / humans, crowd_nav/policy/social_force.py) */
-    int32_t humans_policy;        /* ORC_HUMANS_ORCA (default) or ORC_HUMANS_SOCIAL_FORCE (config.humans.policy; oracle only) */
+    int32_t humans_policy;        /* ORC_HUMANS_ORCA (default) or ORC_HUMANS_SOCIAL_FORCE (config.humans.policy) */
     int32_t human_num_range;      /* config.sim.human_num_range: the crowd size varies in [human_num - range, human_num + range]
                                      (drawn at reset, humans removed / added every 5 s: crowd_sim_var_num.py:103-104,404-437,
-                                     crowd_sim_pred.py:165-190); oracle only so far */
-    int32_t kinematics;           /* ORC_KIN_HOLONOMIC (default) or ORC_KIN_UNICYCLE (config.action_space.kinematics; CrowdSimVarNum-v0
-                                     only: CrowdSimPred.step adds the Turtlebot wheel model with Gaussian noise); oracle only so far */
+                                     crowd_sim_pred.py:165-190) */
+    int32_t kinematics;           /* ORC_KIN_HOLONOMIC (default) or ORC_KIN_UNICYCLE (config.action_space.kinematics; CrowdSimPred.step
+                                     adds the Turtlebot wheel model with Gaussian noise) */
     int32_t predict_truth;        /* CrowdSimPred-v0 only: config.sim.predict_method == 'truth' -- the observation carries the humans' true
-                                     future positions (their own ORCA rolled forward) instead of the constant-velocity ones; oracle only so far */
+                                     future positions (their own ORCA rolled forward) instead of the constant-velocity ones */
     double robot_fov, human_fov;  /* config.robot.FOV, config.humans.FOV in units of pi (crowd_sim.py:122-123); 2 = all round (the default) */
 } OrcConfig;
 
