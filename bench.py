@@ -219,7 +219,10 @@ def main():
         if noise_i[0] % NOISE_BLOCK == 0:
             eps.normal_(generator=gen)
         out["hxs"] = hxs[(i + 1) & 1]
-        pol.act(pol_obs, hxs[i & 1], masks2[i & 1], eps=eps[noise_i[0] % NOISE_BLOCK], out=out)
+        # the simulator's row plan belongs to the observation env.step() just wrote: not to the GST-wrapped one, nor to one whose
+        # detected_human_num was overwritten for the worst-case leg (the kernel then cuts the envs in order itself)
+        plan = env.row_plan if (gst is None and not force_all_detected[0]) else None
+        pol.act(pol_obs, hxs[i & 1], masks2[i & 1], eps=eps[noise_i[0] % NOISE_BLOCK], out=out, row_plan=plan)
         noise_i[0] += 1
         _, reward, done, _, _, _ = env.step(out["action"], not_done=masks2[(i + 1) & 1])   # done mask for the next forward
         if gst is not None:

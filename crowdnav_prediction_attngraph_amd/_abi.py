@@ -44,7 +44,7 @@ class EnvConfig(C.Structure):
 
 class Obs(C.Structure):
     _fields_ = [("robot_node", C.c_void_p), ("temporal_edges", C.c_void_p), ("spatial_edges", C.c_void_p),
-                ("detected_human_num", C.c_void_p), ("visible_masks", C.c_void_p)]
+                ("detected_human_num", C.c_void_p), ("visible_masks", C.c_void_p), ("row_plan", C.c_void_p)]
 
 
 # order == field order of cn_policy_weights; values == reference state_dict keys
@@ -104,7 +104,7 @@ class PolicyWeights(C.Structure):
 # every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
-    "cn_env_obs_width", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
+    "cn_env_obs_width", "cn_row_plan_words", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
@@ -133,6 +133,8 @@ def lib():
         L.cn_env_reset.argtypes = [vp, C.POINTER(Obs), vp]
         L.cn_env_step.argtypes = [vp, vp, C.POINTER(Obs), vp, vp, vp, vp, vp, vp, vp]
         L.cn_env_join.argtypes = [vp, vp]
+        L.cn_row_plan_words.restype = C.c_int64
+        L.cn_row_plan_words.argtypes = [C.c_int]
         L.cn_env_get_state.argtypes = [vp, vp, vp, vp]
         L.cn_env_get_danger_min_dist.argtypes = [vp, vp, vp]
         L.cn_env_set_case_counters.argtypes = [vp, vp, vp]
@@ -222,8 +224,18 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def obs_struct(obs):
+def torch_int32():
+    import torch
+    return torch.int32
+
+
+def obs_struct(obs, row_plan=None):
+    """cn_obs over the tensors of an observation dict.  row_plan: optional int32 tensor of cn_row_plan_words(E) elements -- an OUTPUT of
+    cn_env_reset / cn_env_step beside the observation and an INPUT of cn_policy_act with that same observation (csrc/row_plan.h)."""
     o = Obs()
+    if row_plan is not None and (row_plan.dtype != torch_int32() or not row_plan.is_cuda or not row_plan.is_contiguous()):
+        raise CnError("row_plan must be a contiguous int32 tensor on the GPU")
+    o.row_plan = ptr(row_plan)
     o.robot_node = ptr(obs["robot_node"])
     o.temporal_edges = ptr(obs["temporal_edges"])
     o.spatial_edges = ptr(obs["spatial_edges"])

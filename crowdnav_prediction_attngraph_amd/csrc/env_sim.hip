@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
 // Same arithmetic, same operation order as orca_wave / the oracle: results are bit-identical.
 // ------------------------------------------------------------------------------------------------------------------
 #include "orca_sortnet.inc"
+#include "row_plan.h"
 
 template <int W> struct LaneVec;
 template <> struct LaneVec<8> { typedef float f __attribute__((ext_vector_type(8))); };
@@ -493,8 +494,12 @@ template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(
 // a uniform register index (s_set_gpr_idx), not by 20-32 unrolled copies -- fully unrolled the kernel was 85 KB of straight-line
 // code that every wavefront fetched exactly once (instruction-fetch bound, slower than the cooperative kernel).
 template <int NB, int VW>
-__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s)
+__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan)
 {
+    // one extra workgroup (the last) builds the row plan of the policy's human-human kernel for the observation that was just written
+    // (row_plan.h): it only needs the detected-human counts, and this kernel is on the step's critical path anyway
+    __shared__ rowplan::Lds rp_lds;
+    if (plan && blockIdx.x == gridDim.x - 1) { rowplan::build(s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds); return; }
     typedef typename LaneVec<VW>::f vec;
     const int agent = blockIdx.x * 64 + threadIdx.x;
     const int H = s.H;
@@ -1735,6 +1740,7 @@ struct cn_env_batch {
     hipStream_t side;
     hipEvent_t ev_state, ev_orca, ev_pre;
     bool orca_ready; // hact for the current state has been enqueued on `side`
+    bool plan_ok;      // this configuration's step builds the row plan (lane kernel, crowds of <= 48: what the consumer takes)
 };
 
 // calc_human_future_traj(method='truth'): P rolls of every human with its own policy
@@ -1763,8 +1769,10 @@ static int truth_rollout_and_obs(cn_env_batch *env, const cn_obs *obs, hipStream
     return CN_OK;
 }
 
-static int prefetch_orca(cn_env_batch *env, hipStream_t main)
+static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
 {
+    const float *plan_det = obs ? obs->detected_human_num : nullptr;
+    int32_t *row_plan = obs ? obs->row_plan : nullptr;
     const int agents = env->d.E * env->d.H;
     const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0); // candidate neighbours per agent (self included)
     static int coop = -1; // CN_ORCA_COOP=1 forces the one-wavefront-per-agent kernel (A/B measurements)
@@ -1781,12 +1789,16 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main)
     if (lane_path) {
         // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
         // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
-        const dim3 grid((agents + 63) / 64), blk(64);
-        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, env->d);
-        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, env->d);
-        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, env->d);
+        int32_t *plan = (plan_det && env->plan_ok) ? row_plan : nullptr;
+        if (plan) row_plan = nullptr; // built below
+        const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, env->d, plan_det, plan);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, env->d, plan_det, plan);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, env->d, plan_det, plan);
         CN_CHECK_LAUNCH();
     }
+    // a caller's plan buffer that this step does not fill must not keep the previous observation's plan
+    if (row_plan) CN_HIP(hipMemsetAsync(row_plan, 0, 4, main));
     CN_HIP(hipEventRecord(env->ev_state, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
@@ -1943,9 +1955,14 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
         hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_pre, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(base); delete b; cn_set_error("cn_env_create: stream/event creation failed"); return CN_ERR_HIP;
     }
+    // the row plan is built by the lane kernel's extra workgroup: only configs that run that kernel have one (and the consumer, the
+    // two-team human-human kernel, takes crowds of <= 48 humans)
+    b->plan_ok = lane_orca && HM <= RP_HMAX && num_envs <= RP_EMAX;
     *out = b;
     return CN_OK;
 }
+
+extern "C" int64_t cn_row_plan_words(int num_envs) { return num_envs > 0 ? (int64_t)rp_words(num_envs) : 0; }
 
 extern "C" int cn_env_destroy(cn_env_batch *env)
 {
@@ -1976,7 +1993,7 @@ extern "C" int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream)
     CN_CHECK_LAUNCH();
     if (split) { if (int rc = truth_rollout_and_obs(env, obs, st)) return rc; }
     env->reset_done = true;
-    return prefetch_orca(env, st);
+    return prefetch_orca(env, st, obs);
 }
 
 extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done,
@@ -1987,7 +2004,7 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     if (int rc = check_obs(obs)) return rc;
     CN_REQUIRE(actions && reward && done && info && ep_return && ep_len, "cn_env_step: null output/input pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (!env->orca_ready) { if (int rc = prefetch_orca(env, st)) return rc; }
+    if (!env->orca_ready) { if (int rc = prefetch_orca(env, st, nullptr)) return rc; }
     CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // human velocities for the current state (computed on the side stream)
     if (env->d.cfg.predict_truth) {
         hipLaunchKernelGGL(env_step_kernel<true>, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
@@ -1997,7 +2014,7 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
         hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         CN_CHECK_LAUNCH();
     }
-    return prefetch_orca(env, st); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
+    return prefetch_orca(env, st, obs); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
 }
 
 extern "C" int cn_env_join(cn_env_batch *env, void *stream)

@@ -27,5 +27,7 @@ int hh_fused_bake(const float *emb2_w, const float *qkv_w, const float *os_w, vo
 // out_sp [row_off[E], 256] = relu(spatial_linear(out_proj(attention(...)))) on the compacted live rows.  det != NULL: the kernel first
 // builds row_off [E+1] (exclusive prefix of clamp(detected_human_num, 1, H)) itself and leaves it behind for the caller's next kernels
 // (live_total, optional, accumulates row_off[E]); det == NULL: row_off is an input.
+// row_plan: cn_obs.row_plan of the observation (or NULL): when valid for this batch the kernel takes its row offsets and tile packing
+// (row_plan.h) instead of scanning det and cutting consecutive envs (row_off still receives the offsets)
 int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const float *det, int *row_off, unsigned long long *live_total,
-                     const HhFusedWeights &w, float *out_sp, hipStream_t st);
+                     const HhFusedWeights &w, float *out_sp, hipStream_t st, const int32_t *row_plan = nullptr);

@@ -39,6 +39,7 @@
 //   hh_fused_wide_kernel  (crowds of 49..64 humans: an env must fit one tile): the round-2 schedule, 4 wavefronts (one per SIMD),
 //       64-row tiles.
 #include "hh_fused.h"
+#include "row_plan.h"
 
 #include <climits>
 #include <type_traits>
@@ -137,8 +138,9 @@ __device__ long long *g_hh_tim = nullptr; // [block][16] phase cycle sums of wav
 #endif
 
 struct TileCtx {
-    int e_lo, n_env, r0, nrows; // envs [e_lo, e_lo + n_env), first compacted row, rows
+    int e_lo, n_env, r0, nrows; // envs [e_lo, e_lo + n_env), first compacted row, rows (e_lo / r0: contiguous tiles only)
     int my_env, my_start;       // lane l <-> row l of the tile: env index inside the tile (-1 beyond nrows), its first row
+    int my_src, my_out;         // ... its row of the [E*H, D] input and its compacted output row (two-team kernel: tiles need not be contiguous)
     int tile_ord;
 };
 
@@ -651,6 +653,31 @@ __device__ __forceinline__ TileCtx next_tile(const int *row_off, int e, int e_en
     for (int k = 0; k < n_env; ++k) cnt += lane >= __builtin_amdgcn_readlane(st, k) ? 1 : 0;
     t.my_env = lane < t.nrows ? cnt - 1 : -1;
     t.my_start = __shfl(st, cnt - 1 >= 0 ? cnt - 1 : 0, 64);
+    t.my_src = 0; t.my_out = t.r0 + lane; // my_src: set by the caller that needs it (it knows H)
+    return t;
+}
+
+// A tile of the row plan (row_plan.h): the envs listed for it, in the order listed.  Lane k < cnt holds item k.
+__device__ __forceinline__ TileCtx plan_tile(const int32_t *plan, int E, int H, int tile, int cnt, int tile_ord, int lane)
+{
+    TileCtx t;
+    const int it = lane < cnt ? (plan + rp_off_items(E))[(size_t)tile * 64 + lane] : 0;
+    const int rows = it >> 16, id = it & 0xffff;
+    const int out0 = (plan + rp_off_rowoff())[id]; // first output row of the env (lanes >= cnt read row_off[0]: unused)
+    int incl = rows;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    const int st = lane < cnt ? incl - rows : INT_MAX;
+    t.tile_ord = tile_ord; t.e_lo = 0; t.r0 = 0; t.n_env = cnt;
+    t.nrows = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
+    int c = 0;
+    for (int k = 0; k < cnt; ++k) c += lane >= __builtin_amdgcn_readlane(st, k) ? 1 : 0;
+    const int me = c - 1 >= 0 ? c - 1 : 0;
+    t.my_env = lane < t.nrows ? c - 1 : -1;
+    t.my_start = __shfl(st, me, 64);
+    const int off = lane - t.my_start;
+    t.my_src = __shfl(id, me, 64) * H + off;
+    t.my_out = __shfl(out0, me, 64) + off;
     return t;
 }
 
@@ -685,6 +712,10 @@ __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int
 
 // ===================================================== two-team kernel: 8 wavefronts, 63-row tiles (<= 48 humans) =====================
 namespace team {
+
+#ifndef HH_TEAM_PFC
+#define HH_TEAM_PFC 8   // cap on the k-steps of weight fragments requested across the attention chain (default: no cap below PF - 1)
+#endif
 
 constexpr int FR = 63;                       // rows per tile: at most 4 row blocks of 16; the last row of a fourth block is never live (see CTR)
 constexpr int LDS_BYTES = 163840;            // all of the CU's LDS
@@ -792,30 +823,33 @@ __device__ __forceinline__ void finish_turn(char *lds, int ctr_off, int lane)
 // out_sp rows of feature blocks 4*wave + J0, 4*wave + J0 + 1: own partial sum + the other team's (from LDS) + bias, ReLU, streamed to HBM
 template <int NRB, int J0, int RB>
 __device__ __forceinline__ void finish_rows(const TileCtx &t, const f32x4 (&acc)[4][NRB], const char *xch, const HhFusedWeights &W,
-                                            float *__restrict__ out_sp, int lane, int wave)
+                                            float *__restrict__ out_sp, int lane, int wave, const f32x4 *bpre = nullptr)
 {
     const int i = lane & 15, g = lane >> 4, loff = lane * 16;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int f0 = (4 * wave + J0 + jj) * 16 + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(W.os_b + f0);
+        const f32x4 b = bpre ? bpre[jj] : *reinterpret_cast<const f32x4 *>(W.os_b + f0);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             const f32x4 other = *reinterpret_cast<const f32x4 *>(xch + ((wave * 2 + jj) * RB + rb) * 1024 + loff);
             const int row = rb * 16 + i;
+            const int orow = __shfl(t.my_out, row, 64); // every lane takes part in the shuffle: rows 0..63 = lanes 0..63
             if (row < t.nrows) {
                 f32x4 v = acc[J0 + jj][rb] + other + b;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
                 // streamed past this XCD's L2: the reader (rn_fused) runs on other XCDs anyway, and the 24 MB of rows would push
                 // the 3.9 MB weight image, which every tile of every workgroup on the XCD re-reads, out of the 4 MB L2
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out_sp + (size_t)(t.r0 + row) * 256 + f0));
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(out_sp + (size_t)orow * 256 + f0));
             }
         }
     }
 }
 
-template <int NRB, int PF, bool XDB, bool TRAIN>
+// XM: how the q.k.v loop holds its X fragments -- 1: two sets, the next k-step's read while this one is multiplied; 2: ONE set refilled in
+// place (see the loop); 0: one set, read at the top of the step
+template <int NRB, int PF, int XM, bool TRAIN>
 __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const float *__restrict__ se, const HhFusedWeights &W, const WeightBuf &WB,
                                           float *__restrict__ out_sp, char *lds, int lane_in, int wave, int tm)
 {
@@ -836,6 +870,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     }
     constexpr int NKS = (NRB + 1) / 2; // key k-steps of 32 rows
     const int w8 = 4 * tm + wave;
+    RowBuf BB;
+    BB.rs = __builtin_amdgcn_make_buffer_rsrc((void *)W.qkv_b, 0, 1536 * 4, 0x00020000);
 #ifdef HH_TIMING
     long long tacc[16] = {0}, tlast = clock64();
 #endif
@@ -868,8 +904,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
             if (rb < NRB) {
                 int row = rb * 16 + i;
                 row = row < t.nrows ? row : t.nrows - 1; // padded rows repeat the last live row: finite values, masked later
-                const int env = __shfl(t.my_env, row, 64), st = __shfl(t.my_start, row, 64);
-                const float *xp = se + ((size_t)(t.e_lo + env) * H + (row - st)) * D;
+                const float *xp = se + (size_t)__shfl(t.my_src, row, 64) * D;
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = W.emb0_b[c0 + u];
@@ -977,10 +1012,12 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     // head's attention chain (and, for the first head, before the X epilogue above), so that every loop starts on a warm ring instead
     // of a cold L2 round trip.
     bf16x8 wf[PF][6];
+    constexpr bool XDB = XM == 1;
+    constexpr int PFC = PF - 1 < HH_TEAM_PFC ? PF - 1 : HH_TEAM_PFC; // k-steps requested across the attention chain (they hold registers there)
     auto ring_prologue = [&](const int hh_) __attribute__((always_inline)) {
         const unsigned wp_ = WB.qkv + (unsigned)((((h0 + 2 * hh_ + tm) & 7) * 4 + wave) * 16) * 6 * 1024;
 #pragma unroll
-        for (int p = 0; p < PF - 1; ++p)
+        for (int p = 0; p < PFC; ++p)
 #pragma unroll
             for (int c = 0; c < 6; ++c) wf[p][c] = ldb(WB, wp_ + (p * 6 + c) * 1024, uoff);
     };
@@ -993,6 +1030,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { aq[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[rb] = aq[rb]; av[rb] = aq[rb]; }
         const unsigned wp = WB.qkv + (unsigned)((h * 4 + wave) * 16) * 6 * 1024;
+        f32x4 bq_pf, bk_pf; float bv_pf; // this head's biases: requested under the last k-step instead of behind the loop
         constexpr int NXB = XDB ? 2 : 1;
         bf16x8 xh[NXB][NRB], xl[NXB][NRB];
         if (XDB) {
@@ -1002,6 +1040,15 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 xl[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + rb * 1024 + loff);
             }
         }
+        if (XM == 2) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) xl[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + rb * 1024 + loff);
+        }
+        // the rest of the ring's head start (steps PFC .. PF-2), requested here rather than across the chain
+#pragma unroll
+        for (int p = PFC; p < PF - 1; ++p)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) wf[p][c] = ldb(WB, wp + (p * 6 + c) * 1024, uoff);
         static_assert(16 % PF == 0, "the ring position must be compile-time inside the unrolled group");
         // a group of PF k-steps; the last group is a separate instance whose prefetches end at compile time (a run-time test would
         // cut the k-step into basic blocks and the loads could no longer be interleaved with the MFMAs)
@@ -1017,7 +1064,14 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll
                     for (int c = 0; c < 6; ++c) wf[(ku + PF - 1) % PF][c] = ldb(WB, wp + ((ks + PF - 1) * 6 + c) * 1024, uoff);
                 }
-                if (XDB) {
+                if (XM == 2) {
+                    // ONE set of X fragments, refilled in place: the lo plane is only used by the first third of the step (w_hi . x_lo),
+                    // the hi plane by the other two.  x_hi of THIS step is read during the first third (its registers died with the previous
+                    // step), x_lo of the NEXT step during the second third (its registers died with the first).  Same latency hiding as two
+                    // sets, 8 * NRB registers less -- they pay for a deeper weight ring.
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) xh[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + (ks * RB + rb) * 1024 + loff);
+                } else if (XDB) {
                     if (!TAIL || ku + 1 < PF) {
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb) {
@@ -1032,10 +1086,45 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                         xl[0][rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + (ks * RB + rb) * 1024 + loff);
                     }
                 }
-                if (!XDB) __builtin_amdgcn_sched_barrier(0); // this step's own X fragments: nothing to interleave them with
+                if (XM == 0) __builtin_amdgcn_sched_barrier(0); // this step's own X fragments: nothing to interleave them with
+            }
+            if (TAIL && ku == PF - 1) {
+                const unsigned bo = (unsigned)(h * 64 + 16 * wave) * 4;
+                bq_pf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(BB.rs, 16u * (unsigned)g, bo, 0));
+                bk_pf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(BB.rs, 16u * (unsigned)g, bo + 2048u, 0));
+                bv_pf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(BB.rs, 4u * (unsigned)i, bo + 4096u, 0));
             }
             const bf16x8 *w6 = wf[ku]; // q hi, q lo, k hi, k lo, v hi, v lo
             const bf16x8 *xhc = xh[ku & (NXB - 1)], *xlc = xl[ku & (NXB - 1)];
+            if (XM == 2) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    aq[rb] = mfma(w6[0], xl[0][rb], aq[rb]);
+                    ak[rb] = mfma(w6[2], xl[0][rb], ak[rb]);
+                    av[rb] = mfma(xl[0][rb], w6[4], av[rb]);
+                }
+                bf16x8 xn[NRB];
+                if (!TAIL || ku + 1 < PF) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) xn[rb] = *reinterpret_cast<const bf16x8 *>(lds + LDS_X + X_PLANE + ((ks + 1) * RB + rb) * 1024 + loff);
+                }
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    aq[rb] = mfma(w6[1], xh[0][rb], aq[rb]);
+                    ak[rb] = mfma(w6[3], xh[0][rb], ak[rb]);
+                    av[rb] = mfma(xh[0][rb], w6[5], av[rb]);
+                }
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    aq[rb] = mfma(w6[0], xh[0][rb], aq[rb]);
+                    ak[rb] = mfma(w6[2], xh[0][rb], ak[rb]);
+                    av[rb] = mfma(xh[0][rb], w6[4], av[rb]);
+                }
+                if (!TAIL || ku + 1 < PF) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) xl[0][rb] = xn[rb];
+                }
+            } else {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 aq[rb] = mfma(w6[1], xhc[rb], aq[rb]);
@@ -1054,11 +1143,33 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 ak[rb] = mfma(w6[2], xhc[rb], ak[rb]);
                 av[rb] = mfma(xhc[rb], w6[4], av[rb]);
             }
+            }
             // Issue order inside the k-step: one memory instruction after every few MFMAs, so that it issues in the shadow of a running
             // MFMA.  Issued as one burst at the top of the step (the plain sched_barrier version) the 6 + 2*NRB memory instructions
             // cost ~170 cycles per step during which this wavefront keeps the matrix pipe empty.
-            {
-                constexpr int NM = 9 * NRB, ND = XDB && (!TAIL || ku + 1 < PF) ? 2 * NRB : 0, NV = !TAIL || ku == 0 ? 6 : 0;
+            if (XM == 2) {
+                // x_hi reads under the first MFMAs, then the weight loads, then (once the first third is through) next step's x_lo reads
+                constexpr int NM = 9 * NRB, NV = !TAIL || ku == 0 ? 6 : (ku == PF - 1 ? 3 : 0), NL = (!TAIL || ku + 1 < PF) ? NRB : 0;
+#pragma unroll
+                for (int d = 0; d < NRB; ++d) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                constexpr int GAP = 3 * NRB > NRB + NV ? 3 * NRB - NRB - NV : 0; // the rest of the first third
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+#pragma unroll
+                for (int d = 0; d < NL; ++d) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NM - NRB - NV - GAP - NL, 0);
+            } else {
+                constexpr int NM = 9 * NRB, ND = XDB && (!TAIL || ku + 1 < PF) ? 2 * NRB : 0, NV = !TAIL || ku == 0 ? 6 : (ku == PF - 1 ? 3 : 0);
                 constexpr int A = NM >= 12 + ND ? 2 : 1;                 // MFMAs in front of each weight load
                 constexpr int B = (NM - NV * A) / (ND ? ND : 1);         // MFMAs in front of each X fragment read (unused when ND == 0)
 #pragma unroll
@@ -1085,9 +1196,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
         // partner wavefront's q.k.v loop on this SIMD (which fills whatever is left)
         __builtin_amdgcn_s_setprio(3);
         {
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(W.qkv_b + h * 64 + 16 * wave + 4 * g);
-            const f32x4 bk = *reinterpret_cast<const f32x4 *>(W.qkv_b + 512 + h * 64 + 16 * wave + 4 * g);
-            const float bv = W.qkv_b[1024 + h * 64 + 16 * wave + i];
+            const f32x4 bq = bq_pf, bk = bk_pf;
+            const float bv = bv_pf;
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 aq[rb] += bq; ak[rb] += bk;
@@ -1193,7 +1303,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int r = 0; r < 4; ++r) p[jb][r] *= inv;
         }
         HH_T(5);
-        team_barrier(lds, bar, bar_target, lane); // C: Q (H0) is dead, P may overwrite it
+        // (no barrier here: P block `wave` goes to exactly the slots of Q block `wave`, which only this wavefront has read)
         HH_T(6);
         if (wave < NRB) {
 #pragma unroll
@@ -1262,6 +1372,9 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
         HH_T(10);
     }
     // ---------------- out_sp = relu(out_team0 + out_team1 + b): each team finishes two of its four feature blocks ----------------
+    f32x4 bfin[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) bfin[jj] = *reinterpret_cast<const f32x4 *>(W.os_b + (4 * wave + 2 * tm + jj) * 16 + 4 * g);
     __syncthreads(); // both teams are through their heads: X and the scratch regions are dead
     HH_T(11);
     {
@@ -1278,8 +1391,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int rb = 0; rb < NRB; ++rb) *reinterpret_cast<f32x4 *>(xch + XCH_TEAM + ((wave * 2 + jj) * RB + rb) * 1024 + loff) = acc_os[jj][rb];
         }
         __syncthreads();
-        if (tm == 0) finish_rows<NRB, 0, RB>(t, acc_os, xch + XCH_TEAM, W, out_sp, lane, wave);
-        else finish_rows<NRB, 2, RB>(t, acc_os, xch, W, out_sp, lane, wave);
+        if (tm == 0) finish_rows<NRB, 0, RB>(t, acc_os, xch + XCH_TEAM, W, out_sp, lane, wave, bfin);
+        else finish_rows<NRB, 2, RB>(t, acc_os, xch, W, out_sp, lane, wave, bfin);
     }
     HH_T(12);
 #ifdef HH_TIMING
@@ -1301,39 +1414,78 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #ifndef HH_TEAM_PF4
 #define HH_TEAM_PF4 2   // prefetch depth of the 4-row-block body (register budget: 256)
 #endif
-#ifndef HH_TEAM_XDB4
-#define HH_TEAM_XDB4 1
+#ifndef HH_TEAM_XM3
+#define HH_TEAM_XM3 1   // X fragment mode of the q.k.v loop (tile_body) for <= 3 row blocks
+#endif
+#ifndef HH_TEAM_XM4
+#define HH_TEAM_XM4 1
 #endif
 
 // TRAIN: also write e0 / x / qkv / attn (HhFusedWeights::*_out) and scale the scores by qscale -- the training forward (cn_hh_block_fwd)
 template <bool TRAIN>
 __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
-                                                          int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
+                                                          int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp,
+                                                          const int32_t *__restrict__ plan)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (det) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
+#ifdef HH_TIMING
+    const long long k_c0 = clock64(), k_r0 = wall_clock64(); // shader-clock cycles and the constant 100 MHz counter: their ratio is the clock
+#endif
+    // a row plan made with the observation (row_plan.h) replaces the row-offset scan and the contiguous tile splitter below
+    const bool planned = !TRAIN && det && rp_usable(plan, E, H) && plan[1] == (int)gridDim.x;
+    if (det && !planned) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
+#ifdef HH_TIMING
+    const long long k_c1 = clock64();
+#endif
     __builtin_amdgcn_s_setprio(1); // above the simulator's side-stream wavefronts; the attention chains go to 3 (tile_body)
     const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = w8 & 3, tm = w8 >> 2;
-    const int total = ld_ro(row_off + E);
-    // chunk of this workgroup: envs [boundary(c), boundary(c + 1))
-    int e = chunk_boundary(row_off, E, total, (int)blockIdx.x, (int)gridDim.x, lane);
-    const int e_end = chunk_boundary(row_off, E, total, (int)blockIdx.x + 1, (int)gridDim.x, lane);
-    if (e >= e_end) return;
+    // tiles of this workgroup: the plan's tiles c, c + NW, ... -- or, without a plan, the chunk of consecutive envs [boundary(c), boundary(c + 1))
+    // cut by next_tile
+    int e = 0, e_end = 0, chunk_end_row = 0, n_plan = 0;
+    if (planned) {
+        if (live_total && blockIdx.x == 0 && threadIdx.x == 0) *live_total += (unsigned long long)plan[3];
+        n_plan = plan[2];
+        // the caller's row_off array gets the plan's offsets (it is what the kernels behind this one and the debug taps index by)
+        for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i <= E; i += (int)(gridDim.x * blockDim.x)) row_off[i] = plan[rp_off_rowoff() + i];
+    } else {
+        const int total = ld_ro(row_off + E);
+        e = chunk_boundary(row_off, E, total, (int)blockIdx.x, (int)gridDim.x, lane);
+        e_end = chunk_boundary(row_off, E, total, (int)blockIdx.x + 1, (int)gridDim.x, lane);
+        if (e >= e_end) return;
+        chunk_end_row = ld_ro(row_off + e_end);
+    }
     int tile_ord = 0;
     const team::WeightBuf WB = team::make_weight_buf(W);
-    const int chunk_end_row = ld_ro(row_off + e_end);
-    while (e < e_end) {
-        const TileCtx t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
+    for (;;) {
+        TileCtx t;
+        if (planned) {
+            if (tile_ord >= n_plan) break;
+            const int tile = (int)blockIdx.x + tile_ord * (int)gridDim.x;
+            const int cnt = (plan + rp_off_tcnt(E))[tile];
+            ++tile_ord;
+            if (cnt == 0) continue; // fewer envs than tiles
+            t = plan_tile(plan, E, H, tile, cnt, tile_ord - 1, lane);
+        } else {
+            if (e >= e_end) break;
+            t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);
+            t.my_src = (t.e_lo + t.my_env) * H + (lane - t.my_start);
+            e += t.n_env;
+        }
         const int nrb = (t.nrows + 15) >> 4;
         switch (nrb) {
-        case 1: team::tile_body<1, HH_TEAM_PF3, true, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        case 2: team::tile_body<2, HH_TEAM_PF3, true, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        case 3: team::tile_body<3, HH_TEAM_PF3, true, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
-        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XDB4, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 1: team::tile_body<1, HH_TEAM_PF3, HH_TEAM_XM3, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 2: team::tile_body<2, HH_TEAM_PF3, HH_TEAM_XM3, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        case 3: team::tile_body<3, HH_TEAM_PF3, HH_TEAM_XM3, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
+        default: team::tile_body<4, HH_TEAM_PF4, HH_TEAM_XM4, TRAIN>(t, H, D, se, W, WB, out_sp, lds, lane, wave, tm); break;
         }
-        e += t.n_env;
     }
+#ifdef HH_TIMING
+    if (g_hh_tim && (threadIdx.x & 255) == 0) { // whole-kernel span of wavefront 0 of each team: [13] cycles, [14] 10 ns ticks, [15] prologue cycles
+        long long *d = g_hh_tim + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 20;
+        d[13] += clock64() - k_c0; d[14] += wall_clock64() - k_r0; d[15] += k_c1 - k_c0;
+    }
+#endif
 }
 
 // ---- weight baking: fp32 row-major [N,K] -> bf16 hi/lo MFMA fragments in the order the kernel streams them ----
@@ -1407,7 +1559,7 @@ extern "C" int cn_hh_fused_set_debug(int *buf)
 #endif
 
 int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const float *det, int *row_off, unsigned long long *live_total,
-                     const HhFusedWeights &w, float *out_sp, hipStream_t st)
+                     const HhFusedWeights &w, float *out_sp, hipStream_t st, const int32_t *row_plan)
 {
     static thread_local int attr_dev = -1; // the opt-in above 64 KB of dynamic LDS is per device
     int dev = 0;
@@ -1419,20 +1571,20 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const floa
         attr_dev = dev;
     }
     // one workgroup per CU (the LDS footprint admits exactly one); small batches get fewer so that a chunk is >= one row block
-    long long max_rows = (long long)E * H;
-    int grid = (int)((max_rows + 15) / 16);
-    grid = grid > 256 ? 256 : (grid < 1 ? 1 : grid);
+    const int grid = rp_workgroups(E, H);
     // an env must fit one tile: the two-team kernel holds 48 rows, the wide one 64 (CN_HH_WIDE=1 forces the latter: A/B measurements)
     static int force_wide = -1;
     if (force_wide < 0) { const char *v = getenv("CN_HH_WIDE"); force_wide = v ? atoi(v) : 0; }
     const bool train = w.e0_out != nullptr;
     if (train) {
         CN_REQUIRE(H <= 48 && w.x_out && w.qkv_out && w.attn_out, "hh_fused_forward: the training outputs need H <= 48 and all four buffers");
-        hipLaunchKernelGGL(hh_fused_kernel<true>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+        hipLaunchKernelGGL(hh_fused_kernel<true>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp,
+                           (const int32_t *)nullptr);
     } else if (H > 48 || force_wide)
         hipLaunchKernelGGL(hh_fused_wide_kernel, dim3(grid), dim3(256), wide::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
     else
-        hipLaunchKernelGGL(hh_fused_kernel<false>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+        hipLaunchKernelGGL(hh_fused_kernel<false>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp,
+                           row_plan);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

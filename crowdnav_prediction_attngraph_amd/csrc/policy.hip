@@ -22,6 +22,7 @@
 #include "gemm.h"
 #include "gemm3.h"
 #include "hh_fused.h"
+#include "row_plan.h"
 #include "rn_fused.h"
 
 #include <cmath>
@@ -889,11 +890,12 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         if (hh_prio < 0) { const char *v = getenv("CN_HH_PRIO"); hh_prio = v ? atoi(v) : 1; }
         HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b, hh_prio, 1.0f, nullptr, nullptr, nullptr, nullptr};
         if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, obs->detected_human_num, p->row_off,
-                                   p->profiling ? p->live_total : (unsigned long long *)nullptr, fw, p->out_sp, st))) return rc;
+                                   p->profiling ? p->live_total : (unsigned long long *)nullptr, fw, p->out_sp, st, obs->row_plan))) return rc;
         if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
         RnFusedArgs ra{};
         ra.temporal = obs->temporal_edges; ra.robot_node = obs->robot_node; ra.hxs_in = hxs_in; ra.masks = masks; ra.eps = eps;
-        ra.out_sp = p->out_sp; ra.row_off = p->row_off;
+        ra.out_sp = p->out_sp; ra.row_off = p->row_off; ra.row_plan = obs->row_plan;
+
         ra.rl_w = p->rl_w; ra.rl_b = p->rl_b; ra.f_te = p->r_te; ra.te_b = p->te_b; ra.f_whh = p->r_whh; ra.bhh = p->bhh;
         ra.f_edge = p->r_edge; ra.edge_b = p->edge_b; ra.f_wih = p->r_wih; ra.bih = p->bih; ra.f_ac0 = p->r_ac0; ra.ac0_b = p->ac0f_b;
         ra.f_a2 = p->r_a2; ra.a2_b = p->a2_b; ra.f_c2 = p->r_c2; ra.c2_b = p->c2_b;

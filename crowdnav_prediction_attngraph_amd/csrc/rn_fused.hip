@@ -14,6 +14,7 @@
 // features of one env per lane, which is a float4 store into the next layer's [env][feature] LDS image; the B operand of the
 // next product is two float4 reads of that image (k = 32 ks + 8*(lane>>4) + 0..7), split to bf16 hi / lo once per stage.
 #include "rn_fused.h"
+#include "row_plan.h"
 
 namespace {
 
@@ -154,11 +155,12 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
         constexpr int CH = 8;
         int r0q[2], ndq[2];
         float x[2][CH][4];
+        const int *row_off = rp_usable(a.row_plan, E, H) ? a.row_plan + rp_off_rowoff() : a.row_off; // same test as the human-human kernel
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = 2 * wave + q;
             const int e = e0 + i < E ? e0 + i : E - 1;
-            r0q[q] = a.row_off[e]; ndq[q] = a.row_off[e + 1] - r0q[q];
+            r0q[q] = row_off[e]; ndq[q] = row_off[e + 1] - r0q[q];
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)

@@ -31,6 +31,10 @@ class HipEnvBatch:
             "spatial_edges": torch.zeros(E, H, D, device=dev), "detected_human_num": torch.zeros(E, 1, device=dev),
             "visible_masks": torch.zeros(E, H, dtype=torch.uint8, device=dev),
         }
+        # derived data of the newest observation, written by every reset() / step() beside it: row offsets + a packing of the envs into
+        # equally filled tiles for the policy's fused human-human kernel (csrc/row_plan.h).  Pass it to HipPolicy.act(..., row_plan=) ONLY
+        # together with the observation it was made for (the one the last reset() / step() of THIS batch returned or wrote).
+        self.row_plan = torch.zeros(int(A.lib().cn_row_plan_words(E)), dtype=torch.int32, device=dev)
         self.reward = torch.zeros(E, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self.info = torch.zeros(E, dtype=torch.uint8, device=dev)
@@ -50,7 +54,7 @@ class HipEnvBatch:
 
     def reset(self, obs=None):
         obs = self.obs if obs is None else obs
-        o = A.obs_struct(obs)
+        o = A.obs_struct(obs, self.row_plan)
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_env_reset(self._h, C.byref(o), A.stream_ptr()), "cn_env_reset")
         return obs
@@ -67,7 +71,7 @@ class HipEnvBatch:
         if actions.dtype != torch.float32 or actions.shape != (self.E, 2):
             raise A.CnError("actions must be float32 [%d,2]" % self.E)
         actions = actions.contiguous()
-        o = A.obs_struct(obs)
+        o = A.obs_struct(obs, self.row_plan)
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_env_step(self._h, A.ptr(actions), C.byref(o), A.ptr(reward), A.ptr(self.done), A.ptr(self.info),
                                         A.ptr(self.ep_return), A.ptr(self.ep_len), A.ptr(not_done), A.stream_ptr()), "cn_env_step")
@@ -111,6 +115,7 @@ class HipEnvBatch:
         buf = snap.to(self.device).contiguous()
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_env_load(self._h, A.ptr(buf), A.stream_ptr()), "cn_env_load")
+        self.row_plan[:8].zero_()   # the plan belongs to an observation of the state that was just replaced
 
     def get_danger_min_dist(self):
         """Danger.min_dist of the last step per env (float64 [E]); non-zero only in the test phase."""
@@ -183,13 +188,14 @@ class HipPolicy:
             A.check(A.lib().cn_policy_set_weights(self._h, C.byref(w), A.stream_ptr()), "cn_policy_set_weights")
         self._keep = keep  # keep sources alive until the async copies are ordered behind later work on the stream
 
-    def act(self, obs, hxs, masks, eps=None, out=None):
+    def act(self, obs, hxs, masks, eps=None, out=None, row_plan=None):
+        """row_plan: HipEnvBatch.row_plan of the batch that produced `obs` with its last reset() / step() (optional; see there)."""
         E = obs["robot_node"].shape[0]
         dev = self.device
         if out is None:
             out = dict(value=torch.empty(E, 1, device=dev), action=torch.empty(E, 2, device=dev),
                        logp=torch.empty(E, 1, device=dev), hxs=torch.empty(E, 1, 128, device=dev))
-        o = A.obs_struct(obs)
+        o = A.obs_struct(obs, row_plan)
         with torch.cuda.device(dev):
             A.check(A.lib().cn_policy_act(self._h, E, C.byref(o), A.ptr(hxs.contiguous()), A.ptr(masks.contiguous()),
                                           A.ptr(None if eps is None else eps.contiguous()), A.ptr(out["value"]), A.ptr(out["action"]),

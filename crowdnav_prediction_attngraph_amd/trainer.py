@@ -53,10 +53,14 @@ def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
     T = rollouts.num_steps
     hx = rollouts.recurrent_hidden_states["human_node_rnn"]
     eps = torch.empty(T, E, 2, device=dev).normal_(generator=generator)   # the action noise of the whole rollout in one launch
+    # the simulator writes a row plan beside every observation (hip.HipEnvBatch.row_plan): row t of the storage IS the newest observation of
+    # `env` at every t of this loop (row 0: the last one of the previous rollout, or the reset), so the plan in the buffer is the one made
+    # for it.  Not through the GST wrapper, which post-processes the observation.
+    plan = env.row_plan if envs._pretext is None else None
     for t in range(T):
         obs_t = {k: rollouts.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
         out = dict(value=rollouts.value_preds[t], action=rollouts.actions[t], logp=rollouts.action_log_probs[t], hxs=hx[t + 1])
-        pol.act(obs_t, hx[t], rollouts.masks[t], eps=eps[t], out=out)
+        pol.act(obs_t, hx[t], rollouts.masks[t], eps=eps[t], out=out, row_plan=plan)
         obs_n = {k: rollouts.obs[k][t + 1] for k in obs_t}
         obs_n["visible_masks"] = None
         if "visible_masks" in rollouts.obs:
@@ -104,7 +108,10 @@ def save_checkpoint(save_dir, update, actor_critic, agent, envs, rollouts, stats
           "rng_cuda": torch.cuda.get_rng_state(device), "env": envs.state_dict(),
           "rollout0": {"obs": {k: v[0].clone() for k, v in rollouts.obs.items()},
                        "hxs": rollouts.recurrent_hidden_states["human_node_rnn"][0].clone(), "masks": rollouts.masks[0].clone(),
-                       "bad_masks": rollouts.bad_masks[0].clone()},
+                       "bad_masks": rollouts.bad_masks[0].clone(),
+                       # derived data of that observation (hip.HipEnvBatch.row_plan): with it the first forward after a resume walks the
+                       # same tiles, i.e. sums in the same order, as the uninterrupted run
+                       "row_plan": envs._env.row_plan.clone()},
           "stats": stats.acc.clone()}
     path = stem + (".resume.pt" if rank == 0 else ".resume.rank%d.pt" % rank)
     torch.save(ck, path)
@@ -122,6 +129,8 @@ def load_checkpoint(policy_path, resume_path, actor_critic, agent, envs, rollout
         rollouts.obs[k][0].copy_(r0["obs"][k])
     rollouts.recurrent_hidden_states["human_node_rnn"][0].copy_(r0["hxs"])
     rollouts.masks[0].copy_(r0["masks"]); rollouts.bad_masks[0].copy_(r0["bad_masks"])
+    if "row_plan" in r0 and r0["row_plan"].numel() == envs._env.row_plan.numel():   # (load_state_dict above cleared it)
+        envs._env.row_plan.copy_(r0["row_plan"])
     stats.acc.copy_(ck["stats"])
     torch.set_rng_state(ck["rng_cpu"])
     torch.cuda.set_rng_state(ck["rng_cuda"], device)

@@ -126,6 +126,11 @@ typedef struct {
     float *spatial_edges;
     float *detected_human_num;
     uint8_t *visible_masks;
+    int32_t *row_plan; /* optional (may be NULL), cn_row_plan_words(E) int32: derived data of detected_human_num that cn_env_reset / cn_env_step
+                        * write beside the observation and cn_policy_act reads with it -- the row offsets of the compacted (env, human) rows
+                        * and a packing of the envs into equally filled tiles for the fused human-human kernel (csrc/row_plan.h).  Valid only
+                        * together with the observation it was written with.  Not part of the reference's observation: without it (NULL, or
+                        * a config whose step does not build one) the policy derives the same row offsets itself and walks the envs in order. */
 } cn_obs;
 
 typedef struct cn_env_batch cn_env_batch;
@@ -141,6 +146,8 @@ void cn_env_config_default(cn_env_config *cfg);
 int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t seed, int64_t first_env_index, cn_env_batch **out);
 int cn_env_destroy(cn_env_batch *env);
 int cn_env_obs_width(const cn_env_config *cfg);
+/* int32 words of a cn_obs.row_plan buffer for a batch of num_envs envs */
+int64_t cn_row_plan_words(int num_envs);
 int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);
 /* actions [E,2] float32 (raw policy output; clipped inside like srnn.clip_action).  Outputs: reward [E] float32,
  * done [E] uint8, info [E] uint8 (CN_INFO_*), ep_return [E] float64 and ep_len [E] int32 (valid where done: the

@@ -27,10 +27,11 @@ def test_vec_env_api_contract():
     assert n_ep >= 16        # everything times out after 197 steps at the latest
     assert envs.talk2Env(None) == [True] * 16
     envs.close()
-    with pytest.raises(NotImplementedError):   # settings outside what the reference itself runs fail loudly instead of falling back
-        make_vec_envs("CrowdSimPred-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"action_space.kinematics": "unicycle"}))
+    with pytest.raises(NotImplementedError):   # settings the reference itself cannot run fail loudly instead of falling back (tests/test_host_config.py)
+        make_vec_envs("CrowdSimPred-v0", 425, 16, 0.99, None, torch.device("cuda"), False,
+                      config=C.Config(**{"sim.predict_method": "const_vel", "robot.visible": True}))
     with pytest.raises(NotImplementedError):
-        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"robot.FOV": 1.0}))
+        make_vec_envs("CrowdSimVarNum-v0", 425, 16, 0.99, None, torch.device("cuda"), False, config=C.Config(**{"sim.human_num": 60, "sim.human_num_range": 10}))
     # a varying crowd (sim.human_num_range) and the unicycle robot run on the device: observations carry human_num + range rows
     var = make_vec_envs("CrowdSimVarNum-v0", 425, 8, 0.99, None, torch.device("cuda"), False,
                         config=C.Config(**{"sim.human_num": 6, "sim.human_num_range": 5, "action_space.kinematics": "unicycle"}))

@@ -58,6 +58,11 @@ L.cn_hh_fused_set_timing(C.c_void_p(0))
 raw = buf.cpu().numpy().astype(np.float64) / N
 b = raw.reshape(256, 2, 20)
 names = ["e0+bar", "emb2+bar", "qkvloop", "bias+barA", "QKwrite+barB", "wos+S+softmax", "barC", "Pwrite+barD", "PV+Owrite", "barE", "os", "endbar", "exchange+finish"]
+span_c, span_r, pro_c = b[:, 0, 13], b[:, 0, 14], b[:, 0, 15]
+ok = span_r > 0
+clk = (span_c[ok] / (span_r[ok] * 10e-9)).mean() / 1e9
+print("shader clock during the kernel: %.3f GHz (s_memtime cycles / s_memrealtime 100 MHz ticks, mean over workgroups); workgroup span mean %.1f us max %.1f us; "
+      "row-offset prologue mean %.0f cycles (%.2f us)" % (clk, span_r[ok].mean() * 0.01, span_r[ok].max() * 0.01, pro_c[ok].mean(), pro_c[ok].mean() / clk / 1e3))
 for tm in range(2):
     bt = b[:, tm]
     tot = bt[:, :13].sum(1)
