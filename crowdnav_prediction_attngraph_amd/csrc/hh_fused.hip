@@ -657,13 +657,24 @@ __device__ __forceinline__ TileCtx next_tile(const int *row_off, int e, int e_en
     return t;
 }
 
-// A tile of the row plan (row_plan.h): the envs listed for it, in the order listed.  Lane k < cnt holds item k.
-__device__ __forceinline__ TileCtx plan_tile(const int32_t *plan, int E, int H, int tile, int cnt, int tile_ord, int lane)
+// A tile of the row plan (row_plan.h): the envs listed for it, in the order listed.  The two loads (item k of the list on lane k, then the
+// first output row of that env) are issued a tile ahead (PlanPre) -- two memory round trips that would otherwise open every tile.
+struct PlanPre { int it, out0; };
+__device__ __forceinline__ PlanPre plan_prefetch(const int32_t *plan, int E, int tile, int lane)
+{
+    PlanPre p;
+    p.it = (plan + rp_off_items(E))[(size_t)tile * 64 + lane];
+    p.out0 = (plan + rp_off_rowoff())[p.it & 0xffff]; // slots behind the end of the list hold stale items: any 16-bit index stays inside the plan
+    return p;
+}
+__device__ __forceinline__ TileCtx plan_tile(const PlanPre &pre, int H, int tile_ord, int lane)
 {
     TileCtx t;
-    const int it = lane < cnt ? (plan + rp_off_items(E))[(size_t)tile * 64 + lane] : 0;
+    const unsigned long long zero = __ballot((pre.it >> 16) == 0); // the list ends at its first zero item
+    const int cnt = zero ? __ffsll((long long)zero) - 1 : 64;
+    const int it = lane < cnt ? pre.it : 0;
     const int rows = it >> 16, id = it & 0xffff;
-    const int out0 = (plan + rp_off_rowoff())[id]; // first output row of the env (lanes >= cnt read row_off[0]: unused)
+    const int out0 = pre.out0;
     int incl = rows;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
@@ -1443,9 +1454,11 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
     // tiles of this workgroup: the plan's tiles c, c + NW, ... -- or, without a plan, the chunk of consecutive envs [boundary(c), boundary(c + 1))
     // cut by next_tile
     int e = 0, e_end = 0, chunk_end_row = 0, n_plan = 0;
+    PlanPre pre{0, 0};
     if (planned) {
         if (live_total && blockIdx.x == 0 && threadIdx.x == 0) *live_total += (unsigned long long)plan[3];
         n_plan = plan[2];
+        pre = plan_prefetch(plan, E, (int)blockIdx.x, lane);
         // the caller's row_off array gets the plan's offsets (it is what the kernels behind this one and the debug taps index by)
         for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i <= E; i += (int)(gridDim.x * blockDim.x)) row_off[i] = plan[rp_off_rowoff() + i];
     } else {
@@ -1461,11 +1474,11 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
         TileCtx t;
         if (planned) {
             if (tile_ord >= n_plan) break;
-            const int tile = (int)blockIdx.x + tile_ord * (int)gridDim.x;
-            const int cnt = (plan + rp_off_tcnt(E))[tile];
+            const PlanPre cur = pre;
             ++tile_ord;
-            if (cnt == 0) continue; // fewer envs than tiles
-            t = plan_tile(plan, E, H, tile, cnt, tile_ord - 1, lane);
+            if (tile_ord < n_plan) pre = plan_prefetch(plan, E, (int)blockIdx.x + tile_ord * (int)gridDim.x, lane);
+            t = plan_tile(cur, H, tile_ord - 1, lane);
+            if (t.nrows == 0) continue; // fewer envs than tiles
         } else {
             if (e >= e_end) break;
             t = next_tile<team::FR>(row_off, e, e_end, chunk_end_row, tile_ord++, lane);

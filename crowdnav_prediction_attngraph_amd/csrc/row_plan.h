@@ -14,7 +14,8 @@
 // the step's critical path anyway.  Everything it touches more than once lives in registers or LDS (a global round trip costs a lone
 // wavefront 1-2 us, a ds_bpermute 100+ cycles: the scans and reductions are DPP).
 //
-// Layout (int32 words): header | row_off[E + 1] | tile_cnt[RP_TMAX] | items[RP_TMAX][64], item = env | rows << 16.
+// Layout (int32 words): header | row_off[E + 1] | tile_cnt[RP_TMAX] | items[RP_TMAX][64], item = env | rows << 16, a tile's list ends with
+// a zero item (or at 64).
 // Tile t belongs to workgroup t % NW; a workgroup walks tiles t = c, c + NW, ...
 #pragma once
 #include <stdint.h>
@@ -162,7 +163,12 @@ __device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart,
     }
 #pragma unroll
     for (int j = 0; j < TBP; ++j)
-        if (j < TB && ln * TB + j < T) { tcnt[ln * TB + j] = (int)((key[j] >> 4) & 127u); if ((key[j] >> 11) > 63u) bad = true; }
+        if (j < TB && ln * TB + j < T) {
+            const int cnt = (int)((key[j] >> 4) & 127u);
+            tcnt[ln * TB + j] = cnt;
+            if (cnt < 64) items[(size_t)(ln * TB + j) * 64 + cnt] = 0; // terminator: a consumer needs the item list only (rows == 0 ends it)
+            if ((key[j] >> 11) > 63u) bad = true;
+        }
     return __ballot(bad) == 0ull;
 }
 

@@ -30,16 +30,17 @@ obs = env.reset()
 h = torch.zeros(E, 1, 128, device="cuda"); m = torch.ones(E, 1, device="cuda")
 g = torch.Generator(device="cuda").manual_seed(1)
 for t in range(int(os.environ.get("BF_STEPS", "40"))):   # get a realistic mid-episode observation set
-    out = pol.act(obs, h, m, eps=torch.randn(E, 2, device="cuda", generator=g))
+    out = pol.act(obs, h, m, eps=torch.randn(E, 2, device="cuda", generator=g), row_plan=env.row_plan)
     obs, _, d, _, _, _ = env.step(out["action"].clone())
     h = out["hxs"].clone(); m = (d == 0).float().view(E, 1)
 obs = {k: v.clone() for k, v in obs.items()}
+plan = None if os.environ.get("HH_NO_PLAN") else env.row_plan.clone()   # the row plan made with this observation (HH_NO_PLAN=1: the kernel's own splitter)
 torch.cuda.synchronize()
 env.close()
 torch.cuda.synchronize()
 eps = torch.randn(E, 2, device="cuda", generator=g)
 for _ in range(20):
-    pol.act(obs, h, m, eps=eps)
+    pol.act(obs, h, m, eps=eps, row_plan=plan)
 torch.cuda.synchronize()
 L = A.lib()
 if not hasattr(L, "cn_hh_fused_set_timing"):
@@ -50,7 +51,7 @@ L.cn_hh_fused_set_timing(C.c_void_p(buf.data_ptr()))
 N = 20
 pol.set_profiling(True)
 for _ in range(N):
-    pol.act(obs, h, m, eps=eps)
+    pol.act(obs, h, m, eps=eps, row_plan=plan)
 torch.cuda.synchronize()
 kms, kn = pol.get_profile()
 print("hh kernel (timing build) mean %.1f us over %d launches" % (kms[0] / max(kn[0], 1) * 1e3, kn[0]))
