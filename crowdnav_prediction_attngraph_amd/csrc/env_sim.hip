@@ -496,15 +496,21 @@ template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(
 template <int NB, int VW>
 __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan)
 {
-    // one extra workgroup (the last) builds the row plan of the policy's human-human kernel for the observation that was just written
+    // one extra workgroup builds the row plan of the policy's human-human kernel for the observation that was just written
     // (row_plan.h): it only needs the detected-human counts, and this kernel is on the step's critical path anyway
     __shared__ rowplan::Lds rp_lds;
-    if (plan && blockIdx.x == gridDim.x - 1) { rowplan::build(s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds); return; }
+    // (workgroup 0: dispatched first; its single wavefront is the longest chain of the launch, so it also takes the issue priority)
+    if (plan && blockIdx.x == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        rowplan::build(s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds);
+        return;
+    }
+    const int blk = (int)blockIdx.x - (plan ? 1 : 0);
     typedef typename LaneVec<VW>::f vec;
-    const int agent = blockIdx.x * 64 + threadIdx.x;
+    const int agent = blk * 64 + threadIdx.x;
     const int H = s.H;
     const bool live_lane = agent < s.E * H;
-    const int e = live_lane ? agent / H : (int)(blockIdx.x * 64) / H, i = live_lane ? agent - e * H : 0;
+    const int e = live_lane ? agent / H : (blk * 64) / H, i = live_lane ? agent - e * H : 0;
     const int n = crowd_size(s, e);
     const bool active = live_lane && i < n; // (inactive lanes run along with nn = 0: the loop counters below must stay wave-uniform)
     const cn_env_config &c = s.cfg;
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     // pass 1, a per-lane gather in pass 2 -- is an LDS read instead of an L2 round trip (the kernel is a chain of dependent loads)
     __shared__ double s_px[128], s_py[128], s_vx[128], s_vy[128], s_rad[128], s_rob[65][4];
     {
-        const int a0 = blockIdx.x * 64;
+        const int a0 = blk * 64;
         const int e0 = a0 / H, e1 = (min(a0 + 63, s.E * H - 1)) / H;
         const int nrows = (e1 - e0 + 1) * H; // <= 63 + 2 H <= 127 (H <= 32)
         for (int r = threadIdx.x; r < nrows; r += 64) {
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
             }
         __syncthreads();
     }
-    const int eq = e - (int)(blockIdx.x * 64) / H, eb = eq * H; // this lane's env inside the staged block
+    const int eq = e - (blk * 64) / H, eb = eq * H; // this lane's env inside the staged block
     const double *hum = s.hum + (size_t)e * 8 * H;
     const double spx = s_px[eb + i], spy = s_py[eb + i], svx = s_vx[eb + i], svy = s_vy[eb + i], srad = s_rad[eb + i];
     const double sgx = hum[F_GX * H + i], sgy = hum[F_GY * H + i], svpref = hum[F_VPREF * H + i];
