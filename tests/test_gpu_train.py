@@ -112,7 +112,9 @@ def test_fused_rollout_equals_reference_style_stepping():
     for t in range(T):
         obs_t = {k: rb.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
         eps = eps_all[t]
-        out = hip_pol.act(obs_t, rb.recurrent_hidden_states["human_node_rnn"][t], rb.masks[t], eps=eps)
+        # (the row plan the simulator wrote beside this observation: same tile composition, hence the same fp32 summation order, as in
+        # collect_rollout -- without it the two rollouts agree to ~1e-6 instead of bit for bit)
+        out = hip_pol.act(obs_t, rb.recurrent_hidden_states["human_node_rnn"][t], rb.masks[t], eps=eps, row_plan=eb._env.row_plan)
         obs, reward, done, infos = eb.step(out["action"])
         masks = torch.FloatTensor([[0.0] if d else [1.0] for d in done])
         rb.insert(obs, {"human_node_rnn": out["hxs"]}, out["action"], out["logp"], out["value"], reward, masks, torch.ones(E, 1))
