@@ -1790,12 +1790,8 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
     // kernel, before the policy kernels take the whole LDS of every CU
     CN_HIP(hipEventRecord(env->ev_pre, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
-    static int no_pregen = -1; // CN_NO_PREGEN=1: episodes are generated inside the step that resets (A/B measurements; same results)
-    if (no_pregen < 0) { const char *v = getenv("CN_NO_PREGEN"); no_pregen = v ? atoi(v) : 0; }
-    if (!no_pregen) {
-        hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
-        CN_CHECK_LAUNCH();
-    }
+    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
+    CN_CHECK_LAUNCH();
     if (lane_path) {
         // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
         // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
