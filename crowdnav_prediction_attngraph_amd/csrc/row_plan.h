@@ -7,11 +7,12 @@
 // Packing envs into tiles regardless of their order fills them to 97-99 %: every workgroup gets 2 tiles of 45..48 rows = 6 blocks.
 //
 // The packing is longest-processing-time-first by size class, evaluated with a water-filling search instead of a priority queue so that
-// ONE wavefront does it in ~25 us: for the envs with v rows (v = H .. 1) find the highest level L that the tiles can be filled up to
-// with at most m_v envs, give tile b floor((L - load_b) / v) of them, hand the remainder to the first tiles that would gain one at
-// level L + 1.  The wavefront also writes the row offsets (prefix sum of the row counts by env index), so the consuming kernel needs
-// no scan of its own.  It runs as one extra workgroup of the simulator's ORCA lane kernel (env_sim.hip), i.e. beside work that is on
-// the step's critical path anyway.  Everything it touches more than once lives in registers or LDS (a global round trip costs a lone
+// ONE wavefront does it in ~50 us (4096 envs): for the envs with v rows (v = H .. 1) find the highest level L that the bins can be filled
+// up to with at most m_v envs, give bin b floor((L - load_b) / v) of them, hand the remainder to the first bins that would gain one at
+// level L + 1 -- with the 64 lanes as the bins, and each lane then placing its envs on the emptiest of its own tiles (build / fill below).
+// The wavefront also writes the row offsets (prefix sum of the row counts by env index), so the consuming kernel needs no scan of its
+// own.  It runs as workgroup 0 of the simulator's ORCA lane kernel (env_sim.hip), i.e. beside work that is on the step's critical path
+// anyway (that kernel: 49 -> 51 us).  Everything it touches more than once lives in registers or LDS (a global round trip costs a lone
 // wavefront 1-2 us, a ds_bpermute 100+ cycles: the scans and reductions are DPP).
 //
 // Layout (int32 words): header | row_off[E + 1] | tile_cnt[RP_TMAX] | items[RP_TMAX][64], item = env | rows << 16, a tile's list ends with
