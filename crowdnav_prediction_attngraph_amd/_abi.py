@@ -104,7 +104,7 @@ class PolicyWeights(C.Structure):
 # every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
-    "cn_env_obs_width", "cn_row_plan_words", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
+    "cn_env_obs_width", "cn_row_plan_words", "cn_env_set_pregen_budget", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
@@ -133,6 +133,7 @@ def lib():
         L.cn_env_reset.argtypes = [vp, C.POINTER(Obs), vp]
         L.cn_env_step.argtypes = [vp, vp, C.POINTER(Obs), vp, vp, vp, vp, vp, vp, vp]
         L.cn_env_join.argtypes = [vp, vp]
+        L.cn_env_set_pregen_budget.argtypes = [vp, C.c_int64]
         L.cn_row_plan_words.restype = C.c_int64
         L.cn_row_plan_words.argtypes = [C.c_int]
         L.cn_env_get_state.argtypes = [vp, vp, vp, vp]

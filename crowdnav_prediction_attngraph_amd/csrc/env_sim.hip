@@ -62,6 +62,8 @@ struct EnvDev {
     uint32_t *nx_mt;    // [E][624]
     int32_t *nx_mt_pos; // [E]
     uint8_t *nx_ready;  // [E]
+    int32_t *nx_prog;   // [E] pre-generation in progress: 0 = not started, k + 1 = seed, robot and the first k humans are staged
+    uint64_t *nx_case;  // [E] the case counter that staging was started for (a reset in between makes it stale)
     // test phase only (crowd_sim_var_num.py:386-388, :499-511): the humans' true future states rolled out with their own
     // ORCA policies, the robot's visibility flags of the last observation, and Danger's min_dist of the last step
     // robot.policy == 'orca': the robot's own rvo2 simulator, created at its first use and kept across episodes (orca.py:80-89)
@@ -1172,7 +1174,7 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int 
 
 // crowd_sim_var_num.py:303-363 reset (seed, robot, humans, potential, first observation)
 // the RNG-consuming part of reset(): seed, robot, humans (crowd_sim_var_num.py:333-340, :64-146)
-__device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, int &n)
+__device__ __forceinline__ void gen_episode_head(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, int &n)
 {
     const cn_env_config &c = s.cfg;
     const uint64_t offset = c.phase == CN_PHASE_TRAIN ? 2000ull : (c.phase == CN_PHASE_VAL ? 0ull : 1000ull);
@@ -1206,6 +1208,10 @@ __device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int 
         n = rng_randint(R, lane, c.human_num - c.human_num_range, c.human_num + c.human_num_range + 1);
     }
     rb.px = px; rb.py = py; rb.gx = gx; rb.gy = gy; rb.vx = 0.0; rb.vy = 0.0;
+}
+__device__ __forceinline__ void gen_episode(const EnvDev &s, Rng &R, int e, int lane, Robot &rb, Lane &h, double &shared_nd, int &n)
+{
+    gen_episode_head(s, R, e, lane, rb, n);
     for (int i = 0; i < n; ++i) gen_human(s, R, lane, i, i, rb, h, shared_nd);
     rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
 }
@@ -1303,19 +1309,52 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int 
 }
 
 // Generates the NEXT episode of every env whose staging slot is empty (side stream, overlapped with the policy forward).
-__global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
+// The wavefronts of this kernel keep registers on their CUs, and the policy's human-human kernel (next on the caller's stream) needs
+// every register of a CU to place a workgroup there: an env whose rejection sampling runs long (the tail reaches 150 us) used to hold
+// one CU back for that long and with it the whole launch.  So the work is BUDGETED: a wavefront that has not finished after
+// `budget` ticks of the 100 MHz clock saves where it is -- the staging arrays hold exactly the state between two humans -- and the
+// next launch resumes there.  The episode is the same whichever way it is cut; an env that resets before its staging is complete
+// generates in place, as it always could, and the stale staging is restarted (nx_case).
+__global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budget)
 {
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
     if (s.nx_ready[e]) return;
+    const long long t0 = wall_clock64();
+    const int H = s.H;
+    int prog = s.nx_prog[e];
+    if (prog > 0 && s.nx_case[e] != s.case_counter[e]) prog = 0;
     Rng R{MT_N, false};
     Robot rb{};
     Lane h{};
     h.rad = s.cfg.human_radius;
     double shared_nd = s.shared_nd[e]; // overwritten by the first Human() when randomised, unused otherwise
-    int n = s.H;
-    gen_episode(s, R, e, lane, rb, h, shared_nd, n);
-    const int H = s.H;
+    int n = H;
+    if (prog == 0) {
+        gen_episode_head(s, R, e, lane, rb, n);
+        if (lane == 0) s.nx_case[e] = s.case_counter[e];
+        prog = 1;
+    } else {
+        const int lj = lane < H ? lane : 0;
+        const double *hum = s.nx_hum + (size_t)e * 8 * H;
+        h.px = hum[F_PX * H + lj]; h.py = hum[F_PY * H + lj]; h.gx = hum[F_GX * H + lj]; h.gy = hum[F_GY * H + lj];
+        h.rad = hum[F_RAD * H + lj]; h.vpref = hum[F_VPREF * H + lj];
+        const double *r = s.nx_rob + (size_t)e * 8;
+        rb.px = r[R_PX]; rb.py = r[R_PY]; rb.gx = r[R_GX]; rb.gy = r[R_GY]; rb.theta = r[R_THETA];
+        shared_nd = s.nx_shared_nd[e];
+        n = s.nx_nh ? s.nx_nh[e] : H;
+        __syncthreads();
+        for (int k = lane; k < MT_N; k += 64) g_mt_lds[k] = s.nx_mt[(size_t)e * MT_N + k];
+        R.pos = s.nx_mt_pos[e];
+        R.loaded = true;
+        __syncthreads();
+    }
+    bool complete = true;
+    for (int i = prog - 1; i < n; ++i) {
+        gen_human(s, R, lane, i, i, rb, h, shared_nd);
+        if (i + 1 < n && __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > budget))) { prog = i + 2; complete = false; break; }
+    }
+    if (complete) rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
     if (lane < H) {
         double *hum = s.nx_hum + (size_t)e * 8 * H;
         hum[F_PX * H + lane] = h.px; hum[F_PY * H + lane] = h.py; hum[F_GX * H + lane] = h.gx; hum[F_GY * H + lane] = h.gy;
@@ -1327,11 +1366,12 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s)
         s.nx_shared_nd[e] = shared_nd;
         s.nx_mt_pos[e] = R.pos;
         if (s.nx_nh) s.nx_nh[e] = n;
+        s.nx_prog[e] = complete ? 0 : prog;
     }
     __syncthreads();
     for (int k = lane; k < MT_N; k += 64) s.nx_mt[(size_t)e * MT_N + k] = g_mt_lds[k];
     __syncthreads();
-    if (lane == 0) s.nx_ready[e] = 1;
+    if (lane == 0 && complete) s.nx_ready[e] = 1;
 }
 
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
@@ -1746,6 +1786,7 @@ struct cn_env_batch {
     hipStream_t side;
     hipEvent_t ev_state, ev_orca, ev_pre;
     bool orca_ready; // hact for the current state has been enqueued on `side`
+    long long pregen_ticks; // time budget of one env_pregen_kernel launch (prefetch_orca)
     bool plan_ok;      // this configuration's step builds the row plan (lane kernel, crowds of <= 48: what the consumer takes)
 };
 
@@ -1790,7 +1831,12 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
     // kernel, before the policy kernels take the whole LDS of every CU
     CN_HIP(hipEventRecord(env->ev_pre, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
-    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d);
+    // Budget (ticks of 10 ns; cn_env_set_pregen_budget): the lane kernel below takes ~50 us at 4096 envs x 20 humans and the policy comes
+    // right behind it.  55 us cuts the long tail of the rejection sampling (up to 150 us) and still lets the usual 60-odd new episodes of
+    // a step finish in one go.  Measured inside one box, human-human kernel of the policy: unbounded 0.138-0.139 ms, 65 us 0.139,
+    // 55 us 0.133, 45 us 0.135, 30 us 0.161 -- shorter is NOT better: the ORCA tail kernel is queued behind this one, and when it starts
+    // before the policy's kernel has its workgroups on the CUs, that kernel waits for them.
+    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d, env->pregen_ticks);
     CN_CHECK_LAUNCH();
     if (lane_path) {
         // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
@@ -1900,7 +1946,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const size_t o_sv = carve(E * H), o_snd = carve(E * H * 4), o_ssr = carve(E * H * 4), o_ssm = carve(E * H * 4);
     const size_t o_seen = cfg->randomize_attributes ? carve(E * H * H * 4) : 0;
     const size_t o_mt = carve(E * MT_N * 4), o_mp = carve(E * 4), o_ha = carve(E * 2 * H * 4);
-    const size_t o_nxh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E);
+    const size_t o_nxh = carve(E * 8 * H * 8), o_nr = carve(E * 8 * 8), o_nn = carve(E * 8), o_nm = carve(E * MT_N * 4), o_np = carve(E * 4), o_ny = carve(E),
+                 o_npg = carve(E * 4), o_ncs = carve(E * 8);
     const bool test_phase = cfg->phase == CN_PHASE_TEST;
     const bool truth_obs = cfg->predict_truth != 0;
     const bool rob_orca = cfg->robot_policy == CN_ROBOT_ORCA;
@@ -1939,6 +1986,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
     d.nx_hum = (double *)(base + o_nxh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
+    d.nx_prog = (int32_t *)(base + o_npg); d.nx_case = (uint64_t *)(base + o_ncs);
     d.tr = (test_phase || truth_obs) ? (double *)(base + o_tr) : nullptr; d.vis = (test_phase || truth_obs) ? (uint8_t *)(base + o_vis) : nullptr;
     d.pend = (uint8_t *)(base + o_pend);
     d.nh = var_n ? (int32_t *)(base + o_nh) : nullptr; d.nx_nh = var_n ? (int32_t *)(base + o_nxnh) : nullptr;
@@ -1964,7 +2012,15 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     // the row plan is built by the lane kernel's extra workgroup: only configs that run that kernel have one (and the consumer, the
     // two-team human-human kernel, takes crowds of <= 48 humans)
     b->plan_ok = lane_orca && HM <= RP_HMAX && num_envs <= RP_EMAX;
+    b->pregen_ticks = 5500;
     *out = b;
+    return CN_OK;
+}
+
+extern "C" int cn_env_set_pregen_budget(cn_env_batch *env, int64_t ticks_10ns)
+{
+    CN_REQUIRE(env && ticks_10ns >= 0, "cn_env_set_pregen_budget: null handle or negative budget");
+    env->pregen_ticks = ticks_10ns;
     return CN_OK;
 }
 

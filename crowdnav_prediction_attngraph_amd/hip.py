@@ -77,6 +77,10 @@ class HipEnvBatch:
                                         A.ptr(self.ep_return), A.ptr(self.ep_len), A.ptr(not_done), A.stream_ptr()), "cn_env_step")
         return obs, reward, self.done, self.info, self.ep_return, self.ep_len
 
+    def set_pregen_budget(self, ticks_10ns):
+        """Time budget (x 10 ns) of one launch of the episode pre-generation kernel; the episodes do not depend on it (cn_env_set_pregen_budget)."""
+        A.check(A.lib().cn_env_set_pregen_budget(self._h, int(ticks_10ns)), "cn_env_set_pregen_budget")
+
     def join(self):
         """Order the library's side-stream work (ORCA of the current state, episode pre-generation) before what the caller enqueues next
         on the current stream: needed to close a graph capture of a block of steps."""

@@ -146,6 +146,11 @@ void cn_env_config_default(cn_env_config *cfg);
 int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t seed, int64_t first_env_index, cn_env_batch **out);
 int cn_env_destroy(cn_env_batch *env);
 int cn_env_obs_width(const cn_env_config *cfg);
+/* Episodes are generated ahead of the reset that needs them (crowd_sim_var_num.py:303-363: seed, robot, humans by rejection sampling), on a
+ * side stream beside the ORCA kernel.  One launch of that generator works for at most `ticks_10ns` x 10 ns per env and resumes in the next
+ * step (default 5500 = 55 us): its wavefronts hold registers the policy's kernel, next on the caller's stream, needs.  The episodes do not
+ * depend on the budget (0 = one human per launch); an env that resets before its next episode is complete generates it in place. */
+int cn_env_set_pregen_budget(cn_env_batch *env, int64_t ticks_10ns);
 /* int32 words of a cn_obs.row_plan buffer for a batch of num_envs envs */
 int64_t cn_row_plan_words(int num_envs);
 int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);

@@ -211,6 +211,32 @@ def test_hip_env_replays_reference_golden(path):
     env.close()
 
 
+def test_episodes_do_not_depend_on_the_pregeneration_budget():
+    """Episodes are generated ahead of time on a side stream, a bounded amount of work per launch, resumed in the next step.  Three budgets
+    -- one human per launch, a few, everything at once -- give the same trajectories bit for bit (short episodes: the scripted robot runs
+    into the crowd, so envs also reset while their next episode is only half staged and fall back to generating it in place)."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch
+    E = 96
+    runs = []
+    for ticks in (0, 700, 10 ** 9):
+        env = HipEnvBatch(A.default_env_config(human_num=30, nenv=E, randomize_attributes=1, random_goal_changing=1, time_limit=6.0), E, 77)
+        env.set_pregen_budget(ticks)
+        obs = env.reset()
+        tr, n_done = [], 0
+        for t in range(160):
+            rn = obs["robot_node"].view(E, 7)
+            g = rn[:, 3:5] - rn[:, 0:2]
+            a = (g / g.norm(dim=1, keepdim=True).clamp_min(1e-6)).contiguous()
+            obs, rew, done, info, _, _ = env.step(a)
+            n_done += int(done.sum())
+            tr.append(torch.cat([obs["robot_node"].view(E, -1), obs["spatial_edges"].view(E, -1), rew.view(E, 1), done.view(E, 1).float()], 1).clone())
+        runs.append(torch.stack(tr))
+        assert n_done >= 4 * E
+        env.close()
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+
+
 def test_sharding_is_invariant_to_first_env_index():
     """Env i of a shard starting at k equals env k+i of one big batch (seeds keyed by the global env index)."""
     from crowdnav_prediction_attngraph_amd import _abi as A
