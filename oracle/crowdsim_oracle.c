@@ -64,23 +64,25 @@ static double env_random(OrcEnv *e)
 static double env_uniform(OrcEnv *e, double lo, double hi) { return lo + (hi - lo) * env_random(e); }
 /* np.random.normal(loc, scale) of the legacy RandomState: loc + scale * legacy_gauss (polar Box-Muller; the second deviate of a pair
  * is cached and returned by the next call; np.random.seed clears the cache) */
-static double env_normal(OrcEnv *e, double loc, double scale)
+double orc_mt_normal(OrcMT *mt, int32_t *has_gauss, double *gauss, double loc, double scale, uint64_t *words)
 {
     double g;
-    if (e->has_gauss) { g = e->gauss; e->has_gauss = 0; e->gauss = 0.0; }
+    if (*has_gauss) { g = *gauss; *has_gauss = 0; *gauss = 0.0; }
     else {
         double x1, x2, r2;
         do {
-            x1 = 2.0 * env_random(e) - 1.0;
-            x2 = 2.0 * env_random(e) - 1.0;
+            x1 = 2.0 * orc_mt_double(mt) - 1.0;
+            x2 = 2.0 * orc_mt_double(mt) - 1.0;
+            if (words) *words += 4;
             r2 = x1 * x1 + x2 * x2;
         } while (r2 >= 1.0 || r2 == 0.0);
         const double f = sqrt(-2.0 * orc_log(r2) / r2);
-        e->gauss = f * x1; e->has_gauss = 1;
+        *gauss = f * x1; *has_gauss = 1;
         g = f * x2;
     }
     return loc + scale * g;
 }
+static double env_normal(OrcEnv *e, double loc, double scale) { return orc_mt_normal(&e->rng, &e->has_gauss, &e->gauss, loc, scale, &e->rng_draws); }
 
 /* legacy RandomState.randint(low, high) for the default int64 dtype: numpy/random/_bounded_integers (_rand_int64 ->
  * random_bounded_uint64_fill with use_masked = 1): no draw when the range is a single value, else 32-bit words masked to the

@@ -87,6 +87,8 @@ def lib():
         L.orc_exp.argtypes = [C.c_double]
         L.orc_log.restype = C.c_double
         L.orc_log.argtypes = [C.c_double]
+        L.orc_mt_normal.restype = C.c_double
+        L.orc_mt_normal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         fp = C.POINTER(C.c_float)
         L.orc_orca_velocity.restype = C.c_int
         L.orc_orca_velocity.argtypes = [C.c_float] * 9 + [C.c_int, C.c_float, C.c_float, C.c_int, fp, fp, fp, fp, fp,
@@ -221,6 +223,11 @@ class MT:
 
     def randint(self, low, high):
         return lib().orc_mt_randint(self._buf, low, high, None)
+
+    def normal(self, loc=0.0, scale=1.0):
+        if not hasattr(self, "_hg"):
+            self._hg, self._g = C.c_int32(0), C.c_double(0.0)
+        return lib().orc_mt_normal(self._buf, C.byref(self._hg), C.byref(self._g), float(loc), float(scale), None)
 
 
 def sincos(x):
