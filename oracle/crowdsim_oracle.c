@@ -491,6 +491,15 @@ static int in_fov(const OrcConfig *c, double fov, double px1, double py1, double
     return d >= thr;
 }
 
+/* test hook: the cone test alone */
+int orc_in_fov(int unicycle, double fov, double px1, double py1, double vx1, double vy1, double theta1, double px2, double py2)
+{
+    OrcConfig c;
+    memset(&c, 0, sizeof(c));
+    c.kinematics = unicycle ? ORC_KIN_UNICYCLE : ORC_KIN_HOLONOMIC;
+    return in_fov(&c, fov, px1, py1, vx1, vy1, theta1, px2, py2);
+}
+
 /* crowd_sim.py:513-552 detect_visible(robot, human, robot1=True).  With robot FOV = 2*pi the arccos test is always true unless the two
  * agents coincide (0/0 -> NaN -> False). */
 static int robot_sees(const OrcEnv *e, const OrcHuman *h)

@@ -205,6 +205,7 @@ void orc_env_set_case_counter(OrcEnv *env, uint64_t value);
 int orc_env_human_count(const OrcEnv *env);   /* len(self.humans) right now */
 int64_t orc_mt_randint(OrcMT *mt, int64_t low, int64_t high, uint64_t *words); /* legacy RandomState.randint(low, high) */
 /* legacy RandomState.normal(loc, scale): polar Box-Muller with the cached second deviate (numpy legacy-distributions.c legacy_gauss) */
+int orc_in_fov(int unicycle, double fov, double px1, double py1, double vx1, double vy1, double theta1, double px2, double py2);
 double orc_mt_normal(OrcMT *mt, int32_t *has_gauss, double *gauss, double loc, double scale, uint64_t *words);
 int orc_sizeof_env(void);
 int orc_sizeof_obs(void);

@@ -87,6 +87,8 @@ def lib():
         L.orc_exp.argtypes = [C.c_double]
         L.orc_log.restype = C.c_double
         L.orc_log.argtypes = [C.c_double]
+        L.orc_in_fov.restype = C.c_int
+        L.orc_in_fov.argtypes = [C.c_int] + [C.c_double] * 8
         L.orc_mt_normal.restype = C.c_double
         L.orc_mt_normal.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         fp = C.POINTER(C.c_float)

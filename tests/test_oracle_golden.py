@@ -48,6 +48,35 @@ def test_normal_matches_numpy_legacy_stream():
         assert np.random.random() == m.random()
 
 
+def test_field_of_view_test_is_the_reference_decision():
+    """detect_visible's cone test (crowd_sim.py:513-537): the oracle (and the kernel) evaluate clip(v_fov . v_12) >= cos(fov / 2) on
+    v_fov = v / |v|; the reference evaluates arccos(clip(v_fov . v_12)) <= fov / 2 on v_fov = (cos, sin)(arctan2(vy, vx)).  Same decision on
+    random pairs, on agents at rest (heading +x; -x for vx = -0.0), behind / ahead exactly, and for the unicycle form (heading = theta)."""
+    rs = np.random.RandomState(5)
+
+    def ref(unicycle, fov_pi, p1, v1, th1, p2):
+        real_theta = th1 if unicycle else np.arctan2(v1[1], v1[0])
+        v_fov = np.array([np.cos(real_theta), np.sin(real_theta)])
+        v_12 = np.array([p2[0] - p1[0], p2[1] - p1[1]])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            v_fov = v_fov / np.linalg.norm(v_fov)
+            v_12 = v_12 / np.linalg.norm(v_12)
+            offset = np.arccos(np.clip(np.dot(v_fov, v_12), a_min=-1, a_max=1))
+        return bool(np.abs(offset) <= np.pi * fov_pi / 2)
+
+    cases = []
+    for _ in range(20000):
+        cases.append((int(rs.rand() < 0.3), float(rs.choice([0.5, 0.8, 1.0, 1.2, 1.5, 1.99, 2.0])), rs.uniform(-8, 8, 2), rs.uniform(-1.2, 1.2, 2),
+                      float(rs.uniform(0, 2 * np.pi)), rs.uniform(-8, 8, 2)))
+    z = np.zeros(2)
+    cases += [(0, 1.0, z, z, 0.0, np.array([1.0, 0.0])), (0, 1.0, z, z, 0.0, np.array([-1.0, 0.0])), (0, 1.0, z, np.array([-0.0, 0.0]), 0.0, np.array([-1.0, 0.0])),
+              (0, 1.0, z, np.array([-0.0, 0.0]), 0.0, np.array([1.0, 0.0])), (0, 2.0, z, np.array([1.0, 0.0]), 0.0, np.array([-3.0, 0.0])),
+              (0, 1.5, z, np.array([0.3, 0.4]), 0.0, z), (1, 1.0, z, z, np.pi / 2, np.array([0.0, 2.0])), (1, 1.0, z, z, np.pi / 2, np.array([0.0, -2.0]))]
+    for u, fov, p1, v1, th, p2 in cases:
+        got = bool(O.lib().orc_in_fov(u, fov, float(p1[0]), float(p1[1]), float(v1[0]), float(v1[1]), th, float(p2[0]), float(p2[1])))
+        assert got == ref(u, fov, p1, v1, th, p2), (u, fov, p1, v1, th, p2)
+
+
 def test_log_accuracy():
     """The deterministic log that stands in for libm's inside the normal sampler: within 1 ulp over (0, 1] and across the binades."""
     rs = np.random.RandomState(1)
