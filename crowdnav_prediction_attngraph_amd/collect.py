@@ -36,17 +36,17 @@ class CollectVecEnv(object):
     {'pred_info': ndarray [E, H, 4] float32} (crowd_sim_var_num_collect.py:36), the action is ignored (the robot is ORCA-driven).
 
     Episodes are generated in phase 'train' (seed offset 2000).  The reference's make_env switches ONE env to phase 'test'
-    (rl/networks/envs.py:54-57: seed offset 1000, case counter wrapping at test_size, Danger from the humans' true futures); that
-    single-env variant is not implemented here -- num_envs = 1 is refused rather than silently producing other episodes than the
-    reference would for the same seed (collect_data.py itself runs config.data.num_processes = 5 envs)."""
+    (rl/networks/envs.py:54-57), and in that phase the reference's own step() raises AttributeError for this env class
+    (crowd_sim_var_num.py:388 -> :225 reads self.human_visibility, which crowd_sim_var_num_collect.py never assigns): there is no
+    single-env behaviour to reproduce, so num_envs = 1 is refused (collect_data.py itself runs config.data.num_processes = 5 envs)."""
 
     def __init__(self, seed, num_envs, device, config=None, wrap_pytorch=False):
         if not torch.cuda.is_available():
             raise A.CnError("the batched crowd simulator runs on MI355X only (no CPU fallback)")
         self.num_envs = int(num_envs)
         if self.num_envs == 1:
-            raise NotImplementedError("CrowdSimVarNumCollect-v0 with ONE env runs in phase 'test' in the reference (rl/networks/envs.py:54-57); "
-                                      "only the phase-'train' collector (num_envs >= 2, as collect_data.py uses it) is implemented")
+            raise NotImplementedError("CrowdSimVarNumCollect-v0 with ONE env runs in phase 'test' in the reference (rl/networks/envs.py:54-57), where its "
+                                      "step() fails (crowd_sim_var_num.py:225: no attribute 'human_visibility'); use num_envs >= 2 as collect_data.py does")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())

@@ -7,6 +7,10 @@ The env is driven exactly like collect_data.py drives it: robot.policy = 'orca',
 `nenv`-env vec-env (thisSeed = seed + rank, phase 'train').  Recorded: the `pred_info` observation (frame id, prediction id, absolute
 position of every visible human; cast to float32 like the vec-env buffers), the info code, the robot's state (its goal is re-drawn
 whenever it reaches it) and the text lines collect_data.py would write for this env.
+
+There is no single-env trace: make_env turns ONE env into phase 'test' (rl/networks/envs.py:54-58), and the first step of this env
+class in that phase raises AttributeError in the reference (crowd_sim_var_num.py:388 -> :225 reads self.human_visibility, which
+crowd_sim_var_num_collect.py's generate_ob never assigns) -- tried here with env.nenv = 1, env.phase = 'test'.
 """
 import json
 import os
