@@ -17,7 +17,8 @@
 // the same arithmetic as gemm3.h; softmax in fp32.
 //
 // Layout tricks that keep the chain on chip:
-//   * a wavefront owns OUTPUT FEATURES (q/k/v feature block w of the head, out_sp feature blocks 4w..4w+3), never rows: a weight
+//   * a wavefront owns OUTPUT FEATURES (three 16-feature blocks of the head's q|k|v -- a PAIR of q blocks in the even wavefronts,
+//     a pair of k blocks in the odd ones, and v block w; out_sp feature blocks 4w..4w+3), never rows: a weight
 //     fragment is needed by exactly one wavefront, so it goes L2 -> VGPR with one coalesced 1 KB load (the fragments are stored in
 //     streaming order by hh_fused_bake) and is reused by every row block; only activations use LDS.
 //   * products are issued "transposed" (A operand = weight fragment, B operand = activation fragment): the C layout then has
@@ -27,7 +28,8 @@
 //   * V is produced in normal form (rows in the C layout) so that it is the A operand of O^T = V^T P^T without leaving the
 //     registers, and S^T (keys in the C layout rows) is exactly the P fragment of the same product.
 //   * LDS holds fragments in fragment-major order [plane][k-step][row block][lane][16 B]: every ds_read_b128 / ds_write_b128 is
-//     lane-linear (the 8-byte half-fragment stores of Q / K / O are 2-way: two wavefronts share a 16-byte entry).
+//     lane-linear.  Q and K are stored as whole entries (that is what the q / k pairs above are for); only the 8-byte
+//     half-fragment stores of O are 2-way (its 16-byte entries are shared by two wavefronts: a wavefront has ONE v block).
 //
 // Two kernels share this file:
 //   hh_fused_kernel       (crowds of <= 48 humans, the default): 8 wavefronts = TWO TEAMS of four, two wavefronts per SIMD, 256
@@ -302,7 +304,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
     const int h0 = ((int)blockIdx.x >> 3) & 7;
     for (int hh = 0; hh < 8; ++hh) {
         const int h = (h0 + hh) & 7;
-        // ---------------- q|k|v feature block `wave` of head h for every row block: 16 k-steps over X ----------------
+        // ---------------- head h, every row block, 16 k-steps over X: feature blocks w & ~1, (w & ~1) + 1 of q (even wavefronts) or k
+        // (odd) in aq, ak, and v feature block w in av ----------------
         f32x4 aq[NRB], ak[NRB], av[NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { aq[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[rb] = aq[rb]; av[rb] = aq[rb]; }
@@ -344,7 +347,7 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const bf16x8 *w6 = wf[ku]; // q hi, q lo, k hi, k lo, v hi, v lo
+            const bf16x8 *w6 = wf[ku]; // pair block A hi, lo, pair block B hi, lo (q in even wavefronts, k in odd), v hi, v lo
             const bf16x8 *xhc = xh[ku & 1], *xlc = xl[ku & 1];
 #ifdef HH_EXP_NO_MFMA
 #pragma unroll
@@ -377,8 +380,10 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
         }
         HH_T(4);
         {
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(W.qkv_b + h * 64 + 16 * wave + 4 * g);
-            const f32x4 bk = *reinterpret_cast<const f32x4 *>(W.qkv_b + 512 + h * 64 + 16 * wave + 4 * g);
+            // aq / ak: the two feature blocks of this wavefront's pair, of q (even wavefronts) or k (odd) -- see bake_qkv_kernel
+            const float *bp = W.qkv_b + (wave & 1) * 512 + h * 64 + 16 * (wave & ~1) + 4 * g;
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(bp);
+            const f32x4 bk = *reinterpret_cast<const f32x4 *>(bp + 16);
             const float bv = W.qkv_b[1024 + h * 64 + 16 * wave + i];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -390,21 +395,14 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
         HH_T(5);
         __syncthreads(); // A: the previous head's O fragments (H1) have been consumed by every wavefront
         HH_T(6);
-        // Q -> H0, K -> H1: this wavefront holds head features 16w + 4g + r = half (w&1) of the fragment entries of k-step w>>1
+        // Q -> H0 (even wavefronts), K -> H1 (odd): lane (i, g) holds head features 32 s + 4g + r (aq) and 32 s + 16 + 4g + r (ak), s = w >> 1,
+        // of its rows = all 8 contraction entries of lane group g in k-step s: whole fragment entries, 16-byte stores
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            bf16x4 qh, ql, kh, kl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __bf16 a, b;
-                split1(aq[rb][q], a, b); qh[q] = a; ql[q] = b;
-                split1(ak[rb][q], a, b); kh[q] = a; kl[q] = b;
-            }
-            const int o = (((wave >> 1)) * 4 + rb) * 1024 + loff + 8 * (wave & 1);
-            *reinterpret_cast<bf16x4 *>(lds + LDS_H0 + o) = qh;
-            *reinterpret_cast<bf16x4 *>(lds + LDS_H0 + 8192 + o) = ql;
-            *reinterpret_cast<bf16x4 *>(lds + LDS_H1 + o) = kh;
-            *reinterpret_cast<bf16x4 *>(lds + LDS_H1 + 8192 + o) = kl;
+            const Split8 s = split8(aq[rb], ak[rb]);
+            char *const dst = lds + ((wave & 1) ? LDS_H1 : LDS_H0) + ((wave >> 1) * 4 + rb) * 1024 + loff;
+            *reinterpret_cast<bf16x8 *>(dst) = s.hi;
+            *reinterpret_cast<bf16x8 *>(dst + 8192) = s.lo;
         }
         HH_T(7);
         __syncthreads(); // B
@@ -1036,7 +1034,8 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 #pragma unroll 1
     for (int hh = 0; hh < 4; ++hh) {
         const int h = (h0 + 2 * hh + tm) & 7;
-        // ---------------- q|k|v feature block `wave` of head h for every row block: 16 k-steps over X ----------------
+        // ---------------- head h, every row block, 16 k-steps over X: feature blocks w & ~1, (w & ~1) + 1 of q (even wavefronts) or k
+        // (odd) in aq, ak, and v feature block w in av ----------------
         f32x4 aq[NRB], ak[NRB], av[NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { aq[rb] = f32x4{0.f, 0.f, 0.f, 0.f}; ak[rb] = aq[rb]; av[rb] = aq[rb]; }
@@ -1100,12 +1099,13 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 if (XM == 0) __builtin_amdgcn_sched_barrier(0); // this step's own X fragments: nothing to interleave them with
             }
             if (TAIL && ku == PF - 1) {
-                const unsigned bo = (unsigned)(h * 64 + 16 * wave) * 4;
-                bq_pf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(BB.rs, 16u * (unsigned)g, bo, 0));
-                bk_pf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(BB.rs, 16u * (unsigned)g, bo + 2048u, 0));
+                // aq / ak: the two feature blocks of this wavefront's pair, of q (even wavefronts) or k (odd) -- see bake_qkv_kernel
+                const unsigned bo = (unsigned)(h * 64 + 16 * wave) * 4, bp = (unsigned)((wave & 1) * 512 + h * 64 + 16 * (wave & ~1)) * 4;
+                bq_pf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(BB.rs, 16u * (unsigned)g, bp, 0));
+                bk_pf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(BB.rs, 16u * (unsigned)g, bp + 64u, 0));
                 bv_pf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(BB.rs, 4u * (unsigned)i, bo + 4096u, 0));
             }
-            const bf16x8 *w6 = wf[ku]; // q hi, q lo, k hi, k lo, v hi, v lo
+            const bf16x8 *w6 = wf[ku]; // pair block A hi, lo, pair block B hi, lo (q in even wavefronts, k in odd), v hi, v lo
             const bf16x8 *xhc = xh[ku & (NXB - 1)], *xlc = xl[ku & (NXB - 1)];
             if (XM == 2) {
 #pragma unroll
@@ -1216,12 +1216,13 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
                 for (int q = 0; q < 4; ++q) av[rb][q] += bv;
             }
             if (TRAIN) {
-                // q, k: lane (i, g) holds features 16w + 4g .. +3 of row 16 rb + i; v (normal form): rows 16 rb + 4g + r of feature 16w + i
-                const int c = h * 64 + 16 * wave;
+                // q (even wavefronts) / k (odd): lane (i, g) holds features 16 (w & ~1) + 4g .. +3 (aq) and 16 more (ak) of row 16 rb + i;
+                // v (normal form): rows 16 rb + 4g + r of feature 16w + i
+                const int c = h * 64 + 16 * wave, cp = (wave & 1) * 512 + h * 64 + 16 * (wave & ~1);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    st4(o_qkv, (rb * 16 + i) * 1536 + c + 4 * g, aq[rb]);
-                    st4(o_qkv, (rb * 16 + i) * 1536 + 512 + c + 4 * g, ak[rb]);
+                    st4(o_qkv, (rb * 16 + i) * 1536 + cp + 4 * g, aq[rb]);
+                    st4(o_qkv, (rb * 16 + i) * 1536 + cp + 16 + 4 * g, ak[rb]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st1(o_qkv, (rb * 16 + 4 * g + r) * 1536 + 1024 + c + i, av[rb][r]);
                 }
@@ -1232,21 +1233,15 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
         if (L::TURNS) wait_turn(lds, LDS_CTR, 2 * hh + tm);
         else team_barrier(lds, bar, bar_target, lane);
         HH_T(3);
-        // Q -> H0, K -> H1: this wavefront holds head features 16w + 4g + r = half (w&1) of the fragment entries of k-step w>>1
+        // Q -> H0 (even wavefronts), K -> H1 (odd): lane (i, g) holds head features 32 s + 4g + r (aq) and 32 s + 16 + 4g + r (ak), s = w >> 1,
+        // of its rows = all 8 contraction entries of lane group g in k-step s: whole fragment entries, 16-byte stores with no two lanes
+        // of a store group on one bank (8-byte halves from two wavefronts at a 16-byte lane stride were 2-way conflicts)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            bf16x4 qh, ql, kh, kl;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __bf16 a, b;
-                split1(aq[rb][q], a, b); qh[q] = a; ql[q] = b;
-                split1(ak[rb][q], a, b); kh[q] = a; kl[q] = b;
-            }
-            const int o = ((wave >> 1) * RB + rb) * 1024 + loff + 8 * (wave & 1);
-            *reinterpret_cast<bf16x4 *>(H0 + o) = qh;
-            *reinterpret_cast<bf16x4 *>(H0 + H_PLANE + o) = ql;
-            *reinterpret_cast<bf16x4 *>(H1 + o) = kh;
-            *reinterpret_cast<bf16x4 *>(H1 + H_PLANE + o) = kl;
+            const Split8 s = split8(aq[rb], ak[rb]);
+            char *const dst = ((wave & 1) ? H1 : H0) + ((wave >> 1) * RB + rb) * 1024 + loff;
+            *reinterpret_cast<bf16x8 *>(dst) = s.hi;
+            *reinterpret_cast<bf16x8 *>(dst + H_PLANE) = s.lo;
         }
         team_barrier(lds, bar, bar_target, lane); // B
         HH_T(4);
@@ -1525,7 +1520,10 @@ __global__ void bake_qkv_kernel(const float *__restrict__ w, __bf16 *__restrict_
     int rest = idx >> 9;                 // ((h*4 + wv)*16 + ks)*3 + j
     const int j = rest % 3; rest /= 3;
     const int ks = rest & 15, wv = (rest >> 4) & 3, h = rest >> 6;
-    const float x = w[(size_t)(j * 512 + h * 64 + 16 * wv + (lane & 15)) * 512 + 32 * ks + koff(lane >> 4, u, true)];
+    // wavefront wv streams TWO 16-feature blocks of ONE of q / k (even wv: q blocks wv, wv + 1; odd wv: k blocks wv - 1, wv) and its own
+    // v block: a lane then holds all 8 entries of its lane group in k-step wv >> 1 of a Q or K fragment and stores them in one piece
+    const int sec = j == 2 ? 2 : (wv & 1), blk = j == 2 ? wv : (wv & ~1) + j;
+    const float x = w[(size_t)(sec * 512 + h * 64 + 16 * blk + (lane & 15)) * 512 + 32 * ks + koff(lane >> 4, u, true)];
     const __bf16 hi = (__bf16)x;
     const size_t base = (((((size_t)h * 4 + wv) * 16 + ks) * 3 + j) * 2) * 512 + lane * 8 + u;
     out[base] = hi;
