@@ -5,7 +5,9 @@ The builder is one wavefront and ~50 us, as long as the ORCA agents it rides alo
 water-filling probes are per size class whatever the batch size, but everything else scales with the envs per lane.  Split the batch into
 G index ranges; group g gets a CONTIGUOUS range of tiles whose length is proportional to its rows (largest remainders), and is packed on
 its own by the same two-level scheme -- lanes as bins, the level of a lane weighted by the number of tiles it owns (a group's tile count is
-not a multiple of 64).  No data crosses groups: every wavefront reads all detected-human counts (it needs the other groups' totals for
+not a multiple of 64; a lane owns a contiguous block of TB = ceil(T_g / 64) tiles, so the last lanes own fewer or none -- dealing the
+tiles round-robin instead, 1 or 2 per lane, makes the level of the single-tile lanes too coarse: 17 % of the steps then have a
+49-row tile at G = 8).  No data crosses groups: every wavefront reads all detected-human counts (it needs the other groups' totals for
 its row offsets and its tile range) and packs only its own envs.
 
     python tools/row_plan_groups_study.py [counts.npy | counts.npz]    # default: tools/det_counts_sample.npz
