@@ -130,9 +130,11 @@ def main():
     ap.add_argument("--dephase", type=int, default=240,
                     help="untimed pre-roll steps before the warm-up so that the envs are spread over their episodes (all envs start an episode "
                          "together at reset; SURVEY 8d asks for a de-phased steady-state window)")
-    ap.add_argument("--kernel-events-every", type=int, default=4,
+    ap.add_argument("--kernel-events-every", type=int, default=0,
                     help="the dominant kernel is timed live with a pair of HIP events on its stream around every n-th launch of the timed "
-                         "window (an event record on the critical stream costs a few microseconds of dispatch gap: 1 = every launch)")
+                         "window (0 = every launch when --steps <= 64, else every 4th: an event record on the critical stream costs a few "
+                         "microseconds of dispatch gap).  Every launch is ALSO timed by the kernel's own device-clock stamps, which cost nothing")
+    ap.add_argument("--timeline-out", default=None, help="write the stamped timeline of the decomposition window (all kernels of 24 steps) to this file")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -230,27 +232,41 @@ def main():
         if force_all_detected[0]:
             pol_obs["detected_human_num"].fill_(float(H))     # worst case of the state-dependent work: every (env, human) row is live
 
+    from crowdnav_prediction_attngraph_amd.hip import StepStamps
+    ev_every = args.kernel_events_every if args.kernel_events_every > 0 else (1 if args.steps <= 64 else 4)
     it = 0
     # untimed pre-roll: every env starts an episode at reset, so the first ~40 steps are a lock-step transient (few humans in sensor
     # range, no resets); after a few hundred steps of sampled actions the envs are spread over their episodes
     for _ in range(args.dephase + (args.dephase & 1)):
         step(it); it += 1
+    # the measurement instruments are switched on BEFORE the warm-up so that their one-off costs (the first record of a timing event
+    # switches the queue's profiling on: some hundred microseconds; the first launches with a stamp argument) fall into it, not into
+    # the timed window; what they collected during the warm-up is dropped below
+    pol.set_profiling(ev_every)
+    stamps = StepStamps(args.steps, ("hh_fused", "rn_fused"))
     for _ in range(args.warmup + (args.warmup & 1)):
         step(it); it += 1
     torch.cuda.synchronize()
+    pol.reset_profile()
     if dist is not None:
         dist.barrier()
-    pol.set_profiling(args.kernel_events_every)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        stamps.next()
         step(it + i)
+    t_enq = time.perf_counter() - t0       # host time to ENQUEUE the K steps (well below `elapsed` = the host runs ahead of the device)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    stamps.close()
     pol.set_profiling(False)
     prof_ms, prof_n = pol.get_profile()
+    ev_samples = sorted(pol.get_profile_samples())
+    dev_hh = sorted(x * 1e-3 for x in stamps.durations_us("hh_fused"))     # ms, every launch of the window
+    dev_rn = sorted(x * 1e-3 for x in stamps.durations_us("rn_fused"))
+    dev_rows = stamps.counts("hh_fused")
     it += args.steps            # the hxs / masks ping-pong follows the step index: advance by exactly the steps taken
     per_rank = None
     if dist is not None:
@@ -260,6 +276,48 @@ def main():
         dist.all_gather(allt, mine)
         per_rank = [round(E * args.steps / float(x.item()), 1) for x in allt]
         elapsed = max(float(x.item()) for x in allt)    # max over ranks
+    # step decomposition: a separate short window (NOT the timed one) in which every kernel of the step stamps the device clock --
+    # per-kernel durations and, because the clock is global, where each sits on the step's timeline (gaps, side-stream overlap)
+    decomp = None
+    if rank == 0:
+        DEC = 24
+        dst = StepStamps(DEC)
+        for i in range(DEC):
+            dst.next()
+            step(it + i)
+        torch.cuda.synchronize()
+        dst.close()
+        it += DEC
+        med = lambda v: (sorted(v)[len(v) // 2] if v else None)   # noqa: E731
+        decomp = {"window": "%d extra steps after the timed window, every kernel stamped (device clock, 10 ns)" % DEC, "median_us": {}}
+        for k in ("env_step", "orca_lane", "row_plan", "hh_fused", "rn_fused", "orca_lp3", "env_pregen"):
+            d = dst.durations_us(k)
+            if d:
+                decomp["median_us"][k] = round(med(d), 2)
+        tab = dst.table()
+        # critical path of a step on the caller's stream: hh_fused -> rn_fused -> env_step -> orca_lane -> next hh_fused
+        by = {}
+        for s_, k, a_, b_ in tab:
+            by[(s_, k)] = (a_, b_)
+        gaps = {"hh_to_rn": [], "rn_to_env_step": [], "env_step_to_orca_lane": [], "orca_lane_to_hh": [], "step": []}
+        for s_ in range(DEC - 1):
+            try:
+                gaps["hh_to_rn"].append(by[(s_, "rn_fused")][0] - by[(s_, "hh_fused")][1])
+                gaps["rn_to_env_step"].append(by[(s_, "env_step")][0] - by[(s_, "rn_fused")][1])
+                gaps["env_step_to_orca_lane"].append(by[(s_, "orca_lane")][0] - by[(s_, "env_step")][1])
+                gaps["orca_lane_to_hh"].append(by[(s_ + 1, "hh_fused")][0] - by[(s_, "orca_lane")][1])
+                gaps["step"].append(by[(s_ + 1, "hh_fused")][0] - by[(s_, "hh_fused")][0])
+            except KeyError:
+                pass
+        decomp["median_gap_us"] = {k: round(med(v), 2) for k, v in gaps.items() if v and k != "step"}
+        if gaps["step"]:
+            decomp["median_step_us"] = round(med(gaps["step"]), 2)
+        if args.timeline_out:
+            with open(args.timeline_out, "w") as f:
+                f.write("# device-clock stamps (s_memrealtime, 10 ns) of every kernel of %d consecutive rollout steps; python bench.py %s\n" % (DEC, " ".join(sys.argv[1:])))
+                f.write("# step kernel start_us end_us duration_us\n")
+                for s_, k, a_, b_ in tab:
+                    f.write("%3d %-11s %10.2f %10.2f %8.2f\n" % (s_, k, a_, b_, b_ - a_))
     worst = None
     if not args.no_worst_case and rank == 0:
         force_all_detected[0] = True
@@ -328,14 +386,17 @@ def main():
         return
     total_env_steps = E * world * args.steps
     value = total_env_steps / elapsed
-    # dominant kernel: the folded QKV projection GEMM [M,512]x[512,1536] (fp32 MFMA), timed with HIP events on its stream
-    M = prof_n[1] / max(prof_n[0], 1)      # mean live (env, human) rows per step (device-side counter): padded humans are not computed
+    # dominant kernel: timed (a) by HIP event brackets on its stream, one per launch (median over the window; a bracket also contains
+    # the dispatch of the launch, and whatever the launch waits for when the host is not ahead), and (b) by the kernel's own stamps of
+    # the device clock (first workgroup in -> last wavefront out, every launch).  The roofline uses the MEDIAN event bracket.
+    M = (sum(dev_rows) / len(dev_rows)) if dev_rows else prof_n[1] / max(prof_n[0], 1)   # mean live (env, human) rows per launch
     fused = args.gemm == "fused"
     # fused: the timed kernel is the whole human-human block; its algorithmic work = the three dense layers on the live rows
     # (embedding_layer.2 128->512, folded q|k|v 512->1536, folded out_proj∘spatial_linear 512->256); the D->128 input layer and the
     # attention core (<2 % of it) are left out of the count
     qkv_flops = 2.0 * M * (128 * 512 + 512 * 1536 + 512 * 256) if fused else 2.0 * M * 512 * 1536
-    qkv_ms = prof_ms[0] / max(prof_n[0], 1)
+    mid = lambda v: v[len(v) // 2] if v else 0.0    # noqa: E731  (v sorted)
+    qkv_ms = mid(ev_samples) if ev_samples else prof_ms[0] / max(prof_n[0], 1)
     achieved = qkv_flops / (qkv_ms * 1e-3) / 1e12 if qkv_ms > 0 else 0.0
     F = flops_per_env_step(H, D)
     split = args.gemm in ("bf16x3", "fused")
@@ -380,13 +441,26 @@ def main():
                              ("achieved = algorithmic 2*M*N*K / launch time (hipEvents on the kernel's stream); peak = 2500 TFLOP/s dense bf16 "
                               "MFMA / 3 passes of the hi/lo split; executed bf16 MFMA rate = %.1f TFLOP/s" % (3 * achieved)) if split else
                              "achieved = algorithmic 2*M*N*K / launch time on exact fp32 MFMA",
-                     "traffic_note": traffic_note, "launch_ms": round(qkv_ms, 4), "launches": int(prof_n[0]), "mean_detected_humans": round(M / E, 3),
+                     "traffic_note": traffic_note, "launch_ms": round(qkv_ms, 4), "launches": len(ev_samples), "mean_detected_humans": round(M / E, 3),
+                     "launch_ms_events": {"median": round(mid(ev_samples), 4), "min": round(ev_samples[0], 4) if ev_samples else None,
+                                          "max": round(ev_samples[-1], 4) if ev_samples else None, "mean": round(sum(ev_samples) / max(len(ev_samples), 1), 4),
+                                          "samples": len(ev_samples), "every": ev_every,
+                                          "what": "hipEventElapsedTime of a (record, launch, record) bracket on the kernel's stream, per launch of the timed window"},
+                     "launch_ms_device": {"median": round(mid(dev_hh), 4), "min": round(dev_hh[0], 4) if dev_hh else None,
+                                          "max": round(dev_hh[-1], 4) if dev_hh else None, "samples": len(dev_hh),
+                                          "frac_at_median": round(qkv_flops / (mid(dev_hh) * 1e-3) / 1e12 / peak, 4) if dev_hh and fused else None,
+                                          "what": "the kernel's own stamps of the 100 MHz device clock: first workgroup in -> last wavefront out, every launch of the timed window"},
+                     "rn_fused_launch_ms_device": {"median": round(mid(dev_rn), 4), "min": round(dev_rn[0], 4) if dev_rn else None,
+                                                   "max": round(dev_rn[-1], 4) if dev_rn else None, "samples": len(dev_rn)},
                      "whole_step": {"reference_graph_flops_per_env_step": F,
                                     "reference_graph_tflops_equivalent": round(value / world * F / 1e12, 2),
                                     "note": "env-steps/s x the FLOPs of the reference's dense, unfolded forward; NOT a hardware utilisation "
                                             "(padded humans are not computed and affine pairs are folded)"}},
     }
     line["config"]["dephase_steps"] = args.dephase
+    line["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1e3, 4)   # Python + launch cost of one step; the device needs ms_per_step
+    if decomp is not None:
+        line["step_decomposition"] = decomp
     if per_rank is not None:
         line["per_rank_env_steps_per_s"] = per_rank     # each rank's own clock over the same K steps (value uses the slowest)
     if worst is not None:

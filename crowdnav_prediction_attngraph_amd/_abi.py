@@ -11,6 +11,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcrowdnav_hip.so")
 
 CN_MAX_HUMANS = 64
+ABI_VERSION = 400          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against
+PROF_KERNELS, PROF_SLOT_WORDS = 8, 40
+PROF_KERNEL_IDS = {"env_step": 0, "orca_lane": 1, "hh_fused": 2, "rn_fused": 3, "orca_lp3": 4, "env_pregen": 5, "row_plan": 6, "other": 7}
 ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2, "CrowdSimVarNumCollect-v0": 3}
 INFO_NOTHING, INFO_TIMEOUT, INFO_COLLISION, INFO_REACHGOAL, INFO_DANGER = range(5)
 
@@ -106,7 +109,8 @@ ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
     "cn_env_obs_width", "cn_row_plan_words", "cn_env_set_pregen_budget", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
-    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
+    "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile",
+    "cn_policy_get_profile_samples", "cn_policy_reset_profile", "cn_prof_set_stamps", "cn_prof_next_step", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
@@ -125,6 +129,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
         L.cn_last_error.restype = C.c_char_p
+        if L.cn_version() != ABI_VERSION:
+            raise CnError("%s reports ABI version %d, this binding needs %d: rebuild the library (struct layouts / signatures differ)"
+                          % (LIB_PATH, L.cn_version(), ABI_VERSION))
         L.cn_env_config_default.argtypes = [C.POINTER(EnvConfig)]
         L.cn_env_config_default.restype = None
         L.cn_env_create.argtypes = [C.POINTER(EnvConfig), i32, i64, i64, C.POINTER(vp)]
@@ -156,6 +163,10 @@ def lib():
         L.cn_policy_set_gemm_mode.argtypes = [vp, i32]
         L.cn_policy_set_taps.argtypes = [vp, i32]
         L.cn_policy_get_profile.argtypes = [vp, C.POINTER(f64), C.POINTER(i64)]
+        L.cn_policy_get_profile_samples.argtypes = [vp, C.POINTER(f32), i32]
+        L.cn_policy_reset_profile.argtypes = [vp]
+        L.cn_prof_set_stamps.argtypes = [vp, i32, C.c_uint]
+        L.cn_prof_next_step.argtypes = []
         L.cn_hh_block_workspace_bytes.restype = C.c_int64
         L.cn_hh_block_workspace_bytes.argtypes = []
         L.cn_hh_block_fwd.argtypes = [i32, i32, i32] + [vp] * 10 + [f32] + [vp] * 7

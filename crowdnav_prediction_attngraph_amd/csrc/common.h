@@ -31,6 +31,28 @@ void cn_set_error(const char *fmt, ...);
 
 int cn_require_device();
 
+// ---- device-side launch stamps (measurement aid: cn_prof_set_stamps / cn_prof_next_step, include/crowdnav_hip.h) ----
+// One slot of CN_STAMP_WORDS uint64 per (step, kernel): words 0..15 receive atomicMin of the 100 MHz wall clock (s_memrealtime) at
+// workgroup entry, words 16..31 atomicMax at wavefront exit (16 sub-slots by workgroup index spread the atomics), word 32 is free for
+// a kernel-specific count (the human-human kernel: live rows).  A kernel's duration on the device = max(t1) - min(t0), in 10 ns ticks,
+// and since the clock is global the slots of a step also give the timeline (gaps, overlaps).  NULL = no stamping.
+enum { CN_K_ENV_STEP = 0, CN_K_ORCA_LANE = 1, CN_K_HH_FUSED = 2, CN_K_RN_FUSED = 3, CN_K_ORCA_LP3 = 4, CN_K_PREGEN = 5, CN_K_ROW_PLAN = 6, CN_K_OTHER = 7 };
+unsigned long long *cn_stamp_slot(int kernel_id); // host: the current step's slot of `kernel_id`, or NULL (off, masked out, ring exhausted)
+
+#ifdef __HIPCC__
+struct CnStampScope {
+    unsigned long long *s;
+    __device__ __forceinline__ explicit CnStampScope(unsigned long long *slot) : s(slot)
+    {
+        if (s && threadIdx.x == 0 && blockIdx.x < 256) atomicMin(s + (blockIdx.x & 15), (unsigned long long)wall_clock64());
+    }
+    __device__ __forceinline__ ~CnStampScope()
+    {
+        if (s && (threadIdx.x & 63) == 0) atomicMax(s + 16 + (blockIdx.x & 15), (unsigned long long)wall_clock64());
+    }
+};
+#endif
+
 #define CN_WAVE 64
 
 // ---- wave-level primitives (64 lanes) ----

@@ -14,7 +14,28 @@ void cn_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *cn_last_error(void) { return g_err; }
-extern "C" int cn_version(void) { return 100; }
+extern "C" int cn_version(void) { return CN_ABI_VERSION; }
+
+// ---- launch stamps: a caller-owned device ring, one row of CN_PROF_KERNELS slots per step (see common.h) ----
+static unsigned long long *g_stamp_ring = nullptr;
+static int g_stamp_steps = 0, g_stamp_cur = -1;
+static unsigned g_stamp_mask = 0;
+
+unsigned long long *cn_stamp_slot(int kernel_id)
+{
+    if (!g_stamp_ring || g_stamp_cur < 0 || g_stamp_cur >= g_stamp_steps || !((g_stamp_mask >> kernel_id) & 1u)) return nullptr;
+    return g_stamp_ring + ((size_t)g_stamp_cur * CN_PROF_KERNELS + kernel_id) * CN_PROF_SLOT_WORDS;
+}
+
+extern "C" int cn_prof_set_stamps(uint64_t *ring, int steps, unsigned kernel_mask)
+{
+    CN_REQUIRE((ring == nullptr) == (steps == 0) && steps >= 0, "cn_prof_set_stamps: ring and steps must both be given (or both be zero)");
+    g_stamp_ring = reinterpret_cast<unsigned long long *>(ring);
+    g_stamp_steps = steps; g_stamp_cur = -1; g_stamp_mask = kernel_mask;
+    return CN_OK;
+}
+
+extern "C" int cn_prof_next_step(void) { return g_stamp_ring ? ++g_stamp_cur : -1; }
 
 extern "C" int cn_device_count(void)
 {

@@ -92,7 +92,10 @@ struct EnvDev {
     double *desired_v;  // [E] unicycle robot only: self.desiredVelocity[0] (crowd_sim.py:82: set at construction, never reset)
     double *wheel;      // [E][4] unicycle robot in CrowdSimPred / PredRealGST: smooth_action's last_left, last_right (crowd_sim.py:84-85, never
                         // reset) and RandomState's cached normal deviate: value, has_gauss as 0 / 1 (cleared by every np.random.seed)
+    unsigned long long *stamp; // launch stamps of THIS launch (common.h: cn_stamp_slot), set on the by-value copy a launch passes; NULL = none
 };
+// the by-value kernel argument of one launch, with the stamp slot of `kernel_id` for the current step (measurement aid)
+static EnvDev stamped(const EnvDev &d, int kernel_id) { EnvDev c = d; c.stamp = cn_stamp_slot(kernel_id); return c; }
 
 __device__ __forceinline__ int crowd_size(const EnvDev &s, int e) { return s.nh ? s.nh[e] : s.H; }
 
@@ -467,6 +470,7 @@ __device__ __forceinline__ void orca_agent(const EnvDev &s, int agent, int lane)
 // grid of wavefronts that walk the agents keeps its share of the issue slots bounded instead of flooding every SIMD.
 __global__ __launch_bounds__(256) void orca_kernel(EnvDev s)
 {
+    const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x & 63;
     const int total = s.E * s.H;
     for (int agent = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); agent < total; agent += gridDim.x * 4)
@@ -496,8 +500,9 @@ template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(
 // a uniform register index (s_set_gpr_idx), not by 20-32 unrolled copies -- fully unrolled the kernel was 85 KB of straight-line
 // code that every wavefront fetched exactly once (instruction-fetch bound, slower than the cooperative kernel).
 template <int NB, int VW>
-__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan)
+__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, unsigned long long *plan_stamp)
 {
+    const CnStampScope stamp_scope((plan && blockIdx.x == 0) ? plan_stamp : s.stamp); // the plan builder's wavefront has its own slot
     // one extra workgroup builds the row plan of the policy's human-human kernel for the observation that was just written
     // (row_plan.h): it only needs the detected-human counts, and this kernel is on the step's critical path anyway
     __shared__ rowplan::Lds rp_lds;
@@ -732,6 +737,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
 // the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): one wavefront each, lane k = line k
 __global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
 {
+    const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x & 63;
     const int total = *s.lp3_cnt;
     const int H = s.H;
@@ -1317,6 +1323,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int 
 // generates in place, as it always could, and the stale staging is restarted (nx_case).
 __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budget)
 {
+    const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
     if (s.nx_ready[e]) return;
@@ -1428,6 +1435,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
                                                       uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
+    const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x;
     const int e = blockIdx.x;
     const cn_env_config &c = s.cfg;
@@ -1836,17 +1844,19 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
     // a step finish in one go.  Measured inside one box, human-human kernel of the policy: unbounded 0.138-0.139 ms, 65 us 0.139,
     // 55 us 0.133, 45 us 0.135, 30 us 0.161 -- shorter is NOT better: the ORCA tail kernel is queued behind this one, and when it starts
     // before the policy's kernel has its workgroups on the CUs, that kernel waits for them.
-    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, env->d, env->pregen_ticks);
+    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
     CN_CHECK_LAUNCH();
     if (lane_path) {
         // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
         // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
-        int32_t *plan = (plan_det && env->plan_ok) ? row_plan : nullptr;
+        int32_t *plan = (plan_det && env->plan_ok && ((uintptr_t)plan_det & 15u) == 0) ? row_plan : nullptr;
         if (plan) row_plan = nullptr; // built below
         const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
-        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, env->d, plan_det, plan);
-        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, env->d, plan_det, plan);
-        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, env->d, plan_det, plan);
+        const EnvDev dl = stamped(env->d, CN_K_ORCA_LANE);
+        unsigned long long *pst = cn_stamp_slot(CN_K_ROW_PLAN);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
         CN_CHECK_LAUNCH();
     }
     // a caller's plan buffer that this step does not fill must not keep the previous observation's plan
@@ -1860,10 +1870,10 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
             // wavefronts exit at once, longer lists are walked with a stride) keeps enough wavefronts in flight to hide the latency
             // of the cooperative routine
             const int blocks = (agents + 15) / 16;
-            hipLaunchKernelGGL(orca_lp3_kernel, dim3(blocks), dim3(256), 0, env->side, env->d);
+            hipLaunchKernelGGL(orca_lp3_kernel, dim3(blocks), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3));
             CN_CHECK_LAUNCH();
         } else {
-            hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, env->d);
+            hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3));
             CN_CHECK_LAUNCH();
         }
     }
@@ -2040,6 +2050,10 @@ static int check_obs(const cn_obs *obs)
 {
     CN_REQUIRE(obs && obs->robot_node && obs->temporal_edges && obs->spatial_edges && obs->detected_human_num,
                "observation pointers must be non-null (visible_masks may be null)");
+    // the plan builder (row_plan.h) writes the plan as int4 (and reads detected_human_num as float4: a count view at an odd offset, e.g. a
+    // storage row of a batch whose size is not a multiple of four, simply gets no plan -- prefetch_orca)
+    CN_REQUIRE(!obs->row_plan || ((uintptr_t)obs->row_plan & 15u) == 0,
+               "cn_obs.row_plan must be 16-byte aligned and hold cn_row_plan_words(E) int32 words");
     return CN_OK;
 }
 
@@ -2069,11 +2083,11 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     if (!env->orca_ready) { if (int rc = prefetch_orca(env, st, nullptr)) return rc; }
     CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // human velocities for the current state (computed on the side stream)
     if (env->d.cfg.predict_truth) {
-        hipLaunchKernelGGL(env_step_kernel<true>, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        hipLaunchKernelGGL(env_step_kernel<true>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         CN_CHECK_LAUNCH();
         if (int rc = truth_rollout_and_obs(env, obs, st)) return rc;
     } else {
-        hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, env->d, actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         CN_CHECK_LAUNCH();
     }
     return prefetch_orca(env, st, obs); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)
@@ -2142,7 +2156,8 @@ struct SnapHeader {
     cn_env_config cfg;
     int32_t reset_done, pad;
 };
-constexpr uint64_t SNAP_MAGIC = 0x434e454e56303032ull; // "CNENV002"
+constexpr uint64_t SNAP_MAGIC = 0x434e454e56303034ull; // "CNENV004" (round 4: cn_env_config gained fields since 002/003, the blob nx_prog / nx_case / wheel)
+constexpr uint64_t SNAP_MAGIC_MASK = 0xffffffffff000000ull; // "CNENV" + three digits
 
 extern "C" int64_t cn_env_snapshot_bytes(const cn_env_batch *env)
 {
@@ -2170,7 +2185,9 @@ extern "C" int cn_env_load(cn_env_batch *env, const void *src, void *stream)
     SnapHeader h{};
     CN_HIP(hipMemcpyAsync(&h, src, sizeof(h), hipMemcpyDeviceToHost, st));
     CN_HIP(hipStreamSynchronize(st));
-    CN_REQUIRE(h.magic == SNAP_MAGIC, "cn_env_load: not a cn_env snapshot (bad magic)");
+    CN_REQUIRE((h.magic & SNAP_MAGIC_MASK) == (SNAP_MAGIC & SNAP_MAGIC_MASK), "cn_env_load: not a cn_env snapshot (bad magic)");
+    CN_REQUIRE(h.magic == SNAP_MAGIC, "cn_env_load: snapshot from another layout version (CNENV%c%c%c; this library reads and writes CNENV004): "
+               "snapshots do not carry over between library versions", (char)(h.magic >> 16), (char)(h.magic >> 8), (char)h.magic);
     CN_REQUIRE(h.blob_bytes == env->blob_bytes && h.E == env->d.E && h.H == env->d.H && h.D == env->d.D && h.P == env->d.P &&
                    h.seed_base == env->d.seed_base && std::memcmp(&h.cfg, &env->d.cfg, sizeof(cn_env_config)) == 0,
                "cn_env_load: the snapshot was taken from a batch with a different shape, seed, shard or configuration "

@@ -691,10 +691,13 @@ __device__ __forceinline__ TileCtx plan_tile(const PlanPre &pre, int H, int tile
 }
 
 __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
-                                                               int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp)
+                                                               int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp,
+                                                               unsigned long long *stamp)
 {
+    const CnStampScope stamp_scope(stamp);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (det) row_offsets_prologue<256>(E, H, det, row_off, live_total, lds);
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[32] = (unsigned long long)row_off[E];
     // this kernel is the critical path of the step; the simulator's ORCA wavefronts of the side stream share the SIMDs with it and
     // are latency tolerant: win the issue arbitration against them
     if (W.prio) __builtin_amdgcn_s_setprio(3);
@@ -1431,15 +1434,30 @@ __device__ __forceinline__ void tile_body(const TileCtx &t, int H, int D, const 
 template <bool TRAIN>
 __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, const float *__restrict__ se, const float *__restrict__ det,
                                                           int *row_off, unsigned long long *live_total, HhFusedWeights W, float *__restrict__ out_sp,
-                                                          const int32_t *__restrict__ plan)
+                                                          const int32_t *__restrict__ plan, unsigned long long *stamp)
 {
+    const CnStampScope stamp_scope(TRAIN ? nullptr : stamp); // (the training variant has no registers to spare: rocprof times it)
     extern __shared__ __attribute__((aligned(16))) char lds[];
 #ifdef HH_TIMING
     const long long k_c0 = clock64(), k_r0 = wall_clock64(); // shader-clock cycles and the constant 100 MHz counter: their ratio is the clock
 #endif
     // a row plan made with the observation (row_plan.h) replaces the row-offset scan and the contiguous tile splitter below
-    const bool planned = !TRAIN && det && rp_usable(plan, E, H) && plan[1] == (int)gridDim.x;
+    bool planned = !TRAIN && det && rp_usable(plan, E, H) && plan[1] == (int)gridDim.x;
+    if (planned) {
+        // ... and it must be the plan of THIS observation: a caller that stepped / reset the batch in between, or changed
+        // detected_human_num (the worst-case leg of bench.py), still holds a complete plan of the right shape.  Every workgroup
+        // compares every env's row count in the plan with clamp(det) -- 3 coalesced loads per env, 8 envs per thread at 4096 envs --
+        // and all of them come to the same verdict; a stale plan means the scan path below, exactly as without a plan.
+        const int32_t *pro = plan + rp_off_rowoff();
+        int bad = 0;
+        for (int i = (int)threadIdx.x; i < E; i += (int)blockDim.x) {
+            int nd = (int)det[i]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
+            bad |= (pro[i + 1] - pro[i]) ^ nd;
+        }
+        planned = !__syncthreads_or(bad);
+    }
     if (det && !planned) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
+    if (!TRAIN && stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[32] = (unsigned long long)(planned ? plan[3] : row_off[E]);
 #ifdef HH_TIMING
     const long long k_c1 = clock64();
 #endif
@@ -1572,6 +1590,7 @@ extern "C" int cn_hh_fused_set_debug(int *buf)
 int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const float *det, int *row_off, unsigned long long *live_total,
                      const HhFusedWeights &w, float *out_sp, hipStream_t st, const int32_t *row_plan)
 {
+    unsigned long long *stamp = cn_stamp_slot(CN_K_HH_FUSED);
     static thread_local int attr_dev = -1; // the opt-in above 64 KB of dynamic LDS is per device
     int dev = 0;
     CN_HIP(hipGetDevice(&dev));
@@ -1590,12 +1609,12 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const floa
     if (train) {
         CN_REQUIRE(H <= 48 && w.x_out && w.qkv_out && w.attn_out, "hh_fused_forward: the training outputs need H <= 48 and all four buffers");
         hipLaunchKernelGGL(hh_fused_kernel<true>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp,
-                           (const int32_t *)nullptr);
+                           (const int32_t *)nullptr, stamp);
     } else if (H > 48 || force_wide)
-        hipLaunchKernelGGL(hh_fused_wide_kernel, dim3(grid), dim3(256), wide::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp);
+        hipLaunchKernelGGL(hh_fused_wide_kernel, dim3(grid), dim3(256), wide::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp, stamp);
     else
         hipLaunchKernelGGL(hh_fused_kernel<false>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp,
-                           row_plan);
+                           row_plan, stamp);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -22,12 +22,13 @@
 #include "gemm.h"
 #include "gemm3.h"
 #include "hh_fused.h"
-#include "row_plan.h"
 #include "rn_fused.h"
+#include "row_plan.h"
 
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <vector>
 
 namespace {
 
@@ -673,6 +674,7 @@ struct cn_policy {
     int ev_head, ev_tail;        // [tail, head) are recorded but not yet harvested
     double prof_ms[8];
     int64_t prof_n[8];
+    std::vector<float> prof_samples; // the harvested brackets one by one [ms], in launch order (cn_policy_get_profile_samples)
 };
 
 // big-M GEMMs (rows = live humans): 128-row tiles
@@ -867,6 +869,7 @@ static int harvest_profile(cn_policy *p, bool all)
         float ms = 0.f;
         CN_HIP(hipEventElapsedTime(&ms, p->ev[p->ev_tail][0], p->ev[p->ev_tail][1]));
         p->prof_ms[0] += ms; p->prof_n[0] += 1;
+        if (p->prof_samples.size() < (size_t)1 << 20) p->prof_samples.push_back(ms);
         p->ev_tail = (p->ev_tail + 1) % R;
     }
     return CN_OK;
@@ -894,7 +897,7 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
         RnFusedArgs ra{};
         ra.temporal = obs->temporal_edges; ra.robot_node = obs->robot_node; ra.hxs_in = hxs_in; ra.masks = masks; ra.eps = eps;
-        ra.out_sp = p->out_sp; ra.row_off = p->row_off; ra.row_plan = obs->row_plan;
+        ra.out_sp = p->out_sp; ra.row_off = p->row_off;
 
         ra.rl_w = p->rl_w; ra.rl_b = p->rl_b; ra.f_te = p->r_te; ra.te_b = p->te_b; ra.f_whh = p->r_whh; ra.bhh = p->bhh;
         ra.f_edge = p->r_edge; ra.edge_b = p->edge_b; ra.f_wih = p->r_wih; ra.bih = p->bih; ra.f_ac0 = p->r_ac0; ra.ac0_b = p->ac0f_b;
@@ -1018,6 +1021,26 @@ extern "C" int cn_policy_set_profiling(cn_policy *p, int enabled)
 {
     CN_REQUIRE(p && enabled >= 0, "cn_policy_set_profiling: null handle or negative stride");
     p->prof_every = enabled; p->prof_tick = 0; p->profiling = false;
+    return CN_OK;
+}
+
+extern "C" int cn_policy_get_profile_samples(cn_policy *p, float *ms_out, int cap)
+{
+    CN_REQUIRE(p && (ms_out || cap == 0) && cap >= 0, "cn_policy_get_profile_samples: null argument");
+    if (int rc = harvest_profile(p, true)) return rc;
+    const int n = (int)p->prof_samples.size();
+    for (int i = 0; i < n && i < cap; ++i) ms_out[i] = p->prof_samples[i];
+    return n;
+}
+
+extern "C" int cn_policy_reset_profile(cn_policy *p)
+{
+    CN_REQUIRE(p, "cn_policy_reset_profile: null handle");
+    if (int rc = harvest_profile(p, true)) return rc;
+    for (int i = 0; i < 8; ++i) { p->prof_ms[i] = 0.0; p->prof_n[i] = 0; }
+    p->prof_samples.clear();
+    p->prof_tick = 0;
+    CN_HIP(hipMemset(p->live_total, 0, 8));
     return CN_OK;
 }
 

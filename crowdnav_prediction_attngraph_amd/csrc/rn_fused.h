@@ -7,7 +7,6 @@ struct RnFusedArgs {
     const float *temporal, *robot_node, *hxs_in, *masks, *eps;
     const float *out_sp;  // [live rows, 256] from the human-human block
     const int *row_off;   // [E + 1]
-    const int *row_plan;  // cn_obs.row_plan or NULL: when valid for this batch (row_plan.h), ITS row offsets are the ones the human-human kernel used
     // weights: baked MFMA fragments (rn_fused_bake) + fp32 biases / small vectors
     const float *rl_w, *rl_b;             // robot_linear.0 [256,9]
     const float *f_te, *te_b;             // [u = Ws^T Wt (256) ; encoder_linear (64)] [320,256]
@@ -21,6 +20,7 @@ struct RnFusedArgs {
     float *value, *action, *logp, *hxs_out;
     // optional test taps (nullptr = not written)
     float *tap_robot, *tap_attn, *tap_hr, *tap_actor;
+    unsigned long long *stamp; // launch stamps (common.h), filled in by rn_fused_forward
 };
 
 int rn_fused_bake(int N, int K, const float *w, float *out, hipStream_t st);

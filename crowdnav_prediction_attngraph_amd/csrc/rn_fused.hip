@@ -112,6 +112,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_f
 
 __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedArgs a)
 {
+    const CnStampScope stamp_scope(a.stamp);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __builtin_amdgcn_s_setprio(3); // critical path of the step: win the issue arbitration against the side stream's simulator wavefronts
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
         constexpr int CH = 8;
         int r0q[2], ndq[2];
         float x[2][CH][4];
-        const int *row_off = rp_usable(a.row_plan, E, H) ? a.row_plan + rp_off_rowoff() : a.row_off; // same test as the human-human kernel
+        const int *row_off = a.row_off; // written by the human-human kernel in front of this one: the plan's offsets or its own scan
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = 2 * wave + q;
@@ -325,7 +326,9 @@ int rn_fused_forward(int E, int H, const RnFusedArgs &args, hipStream_t st)
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_dev = dev;
     }
-    hipLaunchKernelGGL(rn_fused_kernel, dim3((E + TE - 1) / TE), dim3(512), lds, st, E, H, args);
+    RnFusedArgs a = args;
+    a.stamp = cn_stamp_slot(CN_K_RN_FUSED);
+    hipLaunchKernelGGL(rn_fused_kernel, dim3((E + TE - 1) / TE), dim3(512), lds, st, E, H, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

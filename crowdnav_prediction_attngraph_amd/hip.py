@@ -244,6 +244,96 @@ class HipPolicy:
         A.check(A.lib().cn_policy_get_profile(self._h, ms, n), "cn_policy_get_profile")
         return list(ms), list(n)
 
+    def get_profile_samples(self):
+        """The event brackets of the dominant kernel one by one [ms], in launch order (cn_policy_get_profile_samples)."""
+        n = A.lib().cn_policy_get_profile_samples(self._h, None, 0)
+        if n < 0:
+            A.check(n, "cn_policy_get_profile_samples")
+        buf = (C.c_float * max(n, 1))()
+        n = A.lib().cn_policy_get_profile_samples(self._h, buf, n)
+        return [float(buf[i]) for i in range(n)]
+
+    def reset_profile(self):
+        """Drop the samples and sums collected so far, keep the stride (the events stay warm)."""
+        A.check(A.lib().cn_policy_reset_profile(self._h), "cn_policy_reset_profile")
+
+
+class StepStamps:
+    """Device-side launch stamps of the rollout step's kernels (cn_prof_set_stamps / cn_prof_next_step): a ring of `steps` rows, one slot per
+    kernel; a kernel stamps the 100 MHz device clock when it starts and when its last wavefront ends.  Process-wide, one at a time.
+
+        st = StepStamps(steps, ("hh_fused", "rn_fused")); for ...: st.next(); <enqueue one step>; ...; torch.cuda.synchronize(); st.close()
+        st.durations_us("hh_fused") -> per-step kernel durations;  st.table() -> start / end of every stamped kernel relative to row 0
+    """
+
+    def __init__(self, steps, kernels=tuple(A.PROF_KERNEL_IDS), device=None):
+        _need_cuda()
+        self.steps = int(steps)
+        self.kernels = tuple(kernels)
+        dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        ring = torch.zeros(self.steps, A.PROF_KERNELS, A.PROF_SLOT_WORDS, dtype=torch.int64, device=dev)
+        ring[:, :, :16] = -1            # start candidates: unsigned minimum counts
+        self.ring = ring
+        mask = 0
+        for k in self.kernels:
+            mask |= 1 << A.PROF_KERNEL_IDS[k]
+        torch.cuda.synchronize(dev)
+        A.check(A.lib().cn_prof_set_stamps(A.ptr(ring), self.steps, mask), "cn_prof_set_stamps")
+        self._open = True
+
+    def next(self):
+        return A.lib().cn_prof_next_step()
+
+    def close(self):
+        if self._open:
+            A.check(A.lib().cn_prof_set_stamps(None, 0, 0), "cn_prof_set_stamps")
+            self._open = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _host(self):
+        r = self.ring.cpu().numpy()
+        import numpy as np
+        t0 = r[:, :, :16].astype(np.uint64).min(axis=2)          # all ones = never stamped
+        t1 = r[:, :, 16:32].astype(np.uint64).max(axis=2)
+        return t0, t1, r[:, :, 32]
+
+    def durations_us(self, kernel):
+        """Per stamped step: (last wavefront's end - first workgroup's start) of `kernel` in microseconds (10 ns resolution)."""
+        import numpy as np
+        t0, t1, _ = self._host()
+        k = A.PROF_KERNEL_IDS[kernel]
+        ok = (t1[:, k] > 0) & (t0[:, k] != np.uint64(0xFFFFFFFFFFFFFFFF))
+        return ((t1[ok, k] - t0[ok, k]).astype(np.float64) * 0.01).tolist()
+
+    def counts(self, kernel):
+        import numpy as np
+        t0, t1, c = self._host()
+        k = A.PROF_KERNEL_IDS[kernel]
+        ok = (t1[:, k] > 0) & (t0[:, k] != np.uint64(0xFFFFFFFFFFFFFFFF))
+        return c[ok, k].tolist()
+
+    def table(self):
+        """[(step, kernel, start_us, end_us)] of every stamped launch, relative to the earliest stamp, sorted by start."""
+        import numpy as np
+        t0, t1, _ = self._host()
+        rows = []
+        valid = (t1 > 0) & (t0 != np.uint64(0xFFFFFFFFFFFFFFFF))
+        if not valid.any():
+            return rows
+        base = t0[valid].min()
+        names = {v: k for k, v in A.PROF_KERNEL_IDS.items()}
+        for s_ in range(self.steps):
+            for k in range(A.PROF_KERNELS):
+                if valid[s_, k]:
+                    rows.append((s_, names[k], float(t0[s_, k] - base) * 0.01, float(t1[s_, k] - base) * 0.01))
+        rows.sort(key=lambda r: r[2])
+        return rows
+
 
 class HipGST:
     """cn_gst handle: GST predictor (cn_gst_predict) and the VecPretextNormalize processing (cn_gst_wrapper_*)."""

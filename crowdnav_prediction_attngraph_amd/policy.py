@@ -197,6 +197,7 @@ class AttnGraphBase(nn.Module):
         The tiny per-env attention itself runs on zero-padded [B,8,H,64] tensors."""
         B, H, D = spatial_edges.shape
         sa = self.spatial_attn
+        det = det.clamp(1, H)   # every sample has 1..H rows, as the env guarantees (crowd_sim_var_num.py:290-292) and the kernels assume
         valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
         idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
         emb0, emb2 = sa.embedding_layer[0], sa.embedding_layer[2]
@@ -210,7 +211,7 @@ class AttnGraphBase(nn.Module):
             Wc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].weight for i in range(3)], 0)
             bc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].bias + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
             op, sl = sa.multihead_attn.out_proj, self.spatial_linear[0]
-            nd = det.clamp(max=H).to(torch.int32)
+            nd = det.clamp(1, H).to(torch.int32)   # 1..H rows per sample, like the rollout kernels (crowd_sim_var_num.py:290-292)
             row_off = torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
             o = HHBlockFused.apply(spatial_edges, x_live, row_off, emb0.weight, emb0.bias, emb2.weight, emb2.bias, Wc, bc,
                                    sl.weight @ op.weight, sl.weight @ op.bias + sl.bias)
@@ -232,7 +233,7 @@ class AttnGraphBase(nn.Module):
         if qkv.is_cuda:
             # attention core on the compacted rows, forward AND backward as hand-written HIP kernels
             from .hip import HHAttention
-            nd = det.clamp(max=H).to(torch.int32)
+            nd = det.clamp(1, H).to(torch.int32)   # 1..H rows per sample, like the rollout kernels (crowd_sim_var_num.py:290-292)
             row_off = torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
             o_live = HHAttention.apply(qkv, row_off, B, H, 0.125)
         else:

@@ -136,6 +136,9 @@ typedef struct {
 typedef struct cn_env_batch cn_env_batch;
 typedef struct cn_policy cn_policy;
 
+/* Bumped whenever a struct layout, a signature or the snapshot format changes (round 4: cn_obs.row_plan, cn_env_config.robot_fov /
+ * human_fov, the profiling entry points, snapshot layout CNENV004); the ctypes binding refuses a library that reports another number. */
+#define CN_ABI_VERSION 400
 const char *cn_last_error(void);
 int cn_version(void);
 int cn_device_count(void);
@@ -161,8 +164,9 @@ int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);
 int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs *obs, float *reward, uint8_t *done, uint8_t *info,
                 double *ep_return, int32_t *ep_len, float *not_done, void *stream);
 /* Orders everything the library has in flight on its internal side stream (ORCA of the current state, next-episode pre-generation)
- * before whatever is enqueued on `stream` next.  cn_env_step does this itself; a caller needs it to close a hipGraph capture of a block
- * of steps (a capture may not end with unjoined work on a forked stream) -- see trainer.GraphedRollout / bench.py --graph. */
+ * before whatever is enqueued on `stream` next.  cn_env_step does this itself; a caller needs it before reading simulator state from
+ * another stream, or to close a hipGraph capture of a block of steps (a capture may not end with unjoined work on a forked stream).
+ * Experimental: the only in-tree graph caller is the probe tools/graph_probe.py (replay measured slower than eager launches). */
 int cn_env_join(cn_env_batch *env, void *stream);
 /* Debug/test access to the simulator state: copies humans [E,H,8] (px,py,vx,vy,gx,gy,radius,v_pref) and robot [E,8]
  * (px,py,vx,vy,gx,gy,theta,potential) as float64 into caller DEVICE buffers (either may be NULL). */
@@ -254,6 +258,26 @@ int cn_policy_set_gemm_mode(cn_policy *p, int mode);
  * record costs a few microseconds of dispatch gap on the stream it sits on, hence the stride. */
 int cn_policy_set_profiling(cn_policy *p, int every);
 int cn_policy_get_profile(cn_policy *p, double *ms_out /*[8]*/, int64_t *launches_out /*[8]*/);
+/* The same brackets one by one (bench.py reports their median / min / max): copies up to `cap` per-launch durations [ms], oldest first,
+ * into ms_out (host memory) and returns how many there are (waits for the brackets still in flight); cn_policy_reset_profile drops
+ * the samples and the sums but keeps the stride -- the events stay warm (a timing event's first record on a queue switches the
+ * queue's profiling on, a one-off cost of some hundred microseconds that must not fall into a timed window). */
+int cn_policy_get_profile_samples(cn_policy *p, float *ms_out, int cap);
+int cn_policy_reset_profile(cn_policy *p);
+
+/* ---- device-side launch stamps (measurement aid for bench.py / tools; not part of the reference's interface) ----
+ * The kernels of the rollout step (CN_PROF_K_*) stamp the device's 100 MHz wall clock when their first workgroups start and when their
+ * last wavefront ends, into a caller-owned DEVICE ring of steps x CN_PROF_KERNELS slots of CN_PROF_SLOT_WORDS uint64 (words 0..15:
+ * candidates for the start, the minimum counts, initialise to all ones; 16..31: candidates for the end, the maximum counts, initialise to
+ * 0; word 32: a per-kernel count, the human-human kernel's live rows).  Unlike an event bracket on the stream the stamps cost no
+ * dispatch gap and do not include the time a launch waits for the host, and because the clock is global the slots of a step also give
+ * its timeline.  cn_prof_set_stamps installs the ring for the whole process (NULL, 0 removes it) with a bit mask of the kernels to
+ * stamp; cn_prof_next_step moves to the next row (the first call selects row 0; rows beyond `steps` are not stamped) and returns the
+ * row index.  Host-side state: call both from the thread that enqueues the step. */
+enum { CN_PROF_K_ENV_STEP = 0, CN_PROF_K_ORCA_LANE = 1, CN_PROF_K_HH_FUSED = 2, CN_PROF_K_RN_FUSED = 3, CN_PROF_K_ORCA_LP3 = 4, CN_PROF_K_PREGEN = 5,
+       CN_PROF_K_ROW_PLAN = 6, CN_PROF_K_OTHER = 7, CN_PROF_KERNELS = 8, CN_PROF_SLOT_WORDS = 40 };
+int cn_prof_set_stamps(uint64_t *ring, int steps, unsigned kernel_mask);
+int cn_prof_next_step(void);
 
 /* ---- the human-human block of evaluate_actions' forward as ONE launch (training path; crowds of <= 48 humans) ----
  * rl/networks/selfAttn_srnn_temp_node.py:63-91 + :408 on the compacted live rows, i.e. what cn_embed0_fwd -> cn_linear_fwd (embedding_layer.2,

@@ -38,7 +38,10 @@ def test_struct_layouts_match_the_header():
     cfg.env_kind = 1
     assert lib.cn_env_obs_width(C.byref(cfg)) == 12
     assert C.sizeof(A.PolicyWeights) == 8 * len(A.POLICY_WEIGHT_KEYS) == 8 * 45
-    assert lib.cn_version() >= 100
+    # the binding refuses a library of another ABI version (A.lib() above raised otherwise); header, library and binding agree
+    hdr = open(os.path.join(ROOT, "include", "crowdnav_hip.h")).read()
+    assert lib.cn_version() == A.ABI_VERSION == int(re.search(r"#define CN_ABI_VERSION (\d+)", hdr).group(1))
+    assert (A.PROF_KERNELS, A.PROF_SLOT_WORDS) == (int(re.search(r"CN_PROF_KERNELS = (\d+)", hdr).group(1)), int(re.search(r"CN_PROF_SLOT_WORDS = (\d+)", hdr).group(1)))
 
 
 def test_no_cpu_fallback_without_gpu():

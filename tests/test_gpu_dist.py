@@ -124,3 +124,51 @@ def test_two_rank_flat_bucket_update_and_env_shards_equal_the_single_process_uni
     for step, u in enumerate(union):
         for r in range(2):
             assert torch.equal(got[r]["trace"][step], u[r * per:(r + 1) * per]), "env shard %d differs from the union at step %d" % (r, step)
+
+
+def _rccl_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CN_FORCE_DIST="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" IS RCCL on ROCm
+    assert dist.get_backend() == "nccl"
+    pol, ro = _build(0, E_TOTAL, dev)
+    losses, flat, agent = _update(pol, ro)
+    # the three collectives of the data-parallel design on their real dtypes / sizes, on the compute stream:
+    bucket = torch.arange(2_501_255, device=dev, dtype=torch.float32) * 1e-6      # the 10 MB flat gradient bucket
+    want = bucket.clone()
+    dist.all_reduce(bucket)
+    stats = torch.tensor([1.5, 2.25, 1228800.0], device=dev, dtype=torch.float64)  # (sum a, sum a^2, n) of the advantage statistics
+    dist.all_reduce(stats)
+    from crowdnav_prediction_attngraph_amd.trainer import EpisodeStats
+    es = EpisodeStats(dev)
+    es.acc += 1.0
+    popped = es.pop()
+    torch.cuda.synchronize()
+    torch.save(dict(losses=losses, flat=flat.cpu(), allreduce_ms=agent.last_allreduce_ms, bucket_ok=bool(torch.equal(bucket, want)),
+                    stats=stats.cpu(), episodes=popped["episodes"]), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_runs_the_collectives_of_the_update(tmp_path):
+    """RCCL itself, on the one GPU a box has: the nccl backend is initialised with world_size 1 and PPO.update() takes its collective
+    branch (CN_FORCE_DIST=1): advantage statistics all-reduce (3 doubles), ONE flat-bucket gradient all-reduce per optimiser step on the
+    compute stream, the loss all-reduce -- plus the 10 MB bucket and the episode statistics stand-alone.  With one rank every all-reduce is
+    the identity and grad_scale = 1, so the result must equal the plain single-process update bit for bit; what this run adds is that RCCL
+    initialises, accepts the dtypes / sizes / stream the design uses, and that its ordering against the HIP kernels around it holds."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got["allreduce_ms"] is not None and got["allreduce_ms"] > 0, "update() must have gone through the gradient all-reduce"
+    assert got["bucket_ok"] and got["episodes"] == 1
+    np.testing.assert_array_equal(got["stats"].numpy(), np.array([1.5, 2.25, 1228800.0]))
+    dev = torch.device("cuda", 0)
+    pol, ro = _build(0, E_TOTAL, dev)
+    losses, flat, _ = _update(pol, ro)
+    np.testing.assert_array_equal(got["flat"].numpy(), flat.cpu().numpy())
+    np.testing.assert_array_equal(np.asarray(got["losses"]), np.asarray(losses))

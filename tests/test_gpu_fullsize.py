@@ -257,3 +257,141 @@ def test_full_batch_predrealgst_wrapper_kernels_equal_torch_expression():
         n_done += int(done.sum())
     assert n_done > 0, "the 30-step window must contain auto-resets (the wrapper's buffers restart with the episode)"
     env.close()
+
+
+def _plan_sample(plan_host, det_host, E, H, n_want=64):
+    """Envs to compare against the policy oracle in one step: the first and the last env of tiles spread over the row plan (when there is
+    one), envs with a single live row, envs with the most live rows, and the ends of the batch."""
+    from crowdnav_prediction_attngraph_amd import _abi as A   # noqa: F401
+    picked = []
+    if plan_host is not None and plan_host[0] == 0x52504c4e:
+        n_tiles = int(plan_host[6])
+        off_items = 8 + ((E + 1 + 3) & ~3) + 1024
+        for t in np.linspace(0, max(n_tiles - 1, 0), 16).astype(int):
+            items = plan_host[off_items + 64 * int(t): off_items + 64 * int(t) + 64]
+            rows = items >> 16
+            cnt = int(np.argmax(rows == 0)) if (rows == 0).any() else 64
+            if cnt:
+                picked += [int(items[0] & 0xffff), int(items[cnt - 1] & 0xffff)]
+    nd = det_host.reshape(E).astype(np.int64).clip(1, H)
+    picked += [int(i) for i in np.flatnonzero(nd == 1)[:8]]
+    picked += [int(i) for i in np.argsort(-nd, kind="stable")[:8]]
+    picked += [0, 1, 63, 64, E // 2, E - 2, E - 1]
+    out = []
+    for i in picked + list(range(2, E, max(E // 97, 1))):
+        if i not in out:
+            out.append(i)
+        if len(out) >= n_want:
+            break
+    return out
+
+
+@pytest.mark.parametrize("mode,H,E,T,kw", [
+    ("planned", 20, 4096, 60, dict()),                                                                  # the benchmarked configuration, as bench.py runs it
+    ("all_detected", 20, 4096, 16, dict()),                                                             # bench.py's worst-case leg: 81 920 live rows, no plan
+    ("wide_h50", 50, 8192, 24, dict(randomize_attributes=1, random_goal_changing=1, max_placement_attempts=1024)),   # BASELINE configs[4] per-GPU share
+], ids=["planned_h20_4096", "all_detected_h20_4096", "wide_h50_8192"])
+def test_full_batch_policy_matches_policy_oracle_directly(mode, H, E, T, kw):
+    """The policy forward exactly as bench.py / trainer.collect_rollout run it -- default fused mode, the simulator's row plan passed with
+    the observation it was made for, the real simulator in the loop -- compared DIRECTLY with oracle/policy_oracle.py (the numpy restatement
+    pinned to the reference's torch goldens; rl/networks/selfAttn_srnn_temp_node.py:63-91,360-449, rl/networks/model.py:56-74) on 64 sampled
+    envs per step: value, action, log-prob, next hidden state and the [H,256] spatial_linear tap at north_star's 1e-4.  The sample follows the
+    plan: first / last env of tiles, one-row envs, the fullest envs."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from oracle import policy_oracle as P
+    env = HipEnvBatch(A.default_env_config(human_num=H, nenv=E, **kw), E, 425)
+    torch.manual_seed(425)
+    ob_space, act_space = make_spaces(H, 2)
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E), base="selfAttn_merge_srnn").cuda()
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    std = np.exp(sd["dist.logstd._bias"].astype(np.float64).reshape(1, 2))
+    pol = HipPolicy(H, 2, E)            # default mode = fused
+    pol.set_weights(net.state_dict())
+    obs = env.reset()
+    h, m = torch.zeros(E, 1, 128, device="cuda"), torch.ones(E, 1, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    keys = ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")
+    worst = dict(value=0.0, action=0.0, logp=0.0, hxs=0.0, spatial_lin=0.0)
+    planned_steps = 0
+    for t in range(T):
+        eps = torch.randn(E, 2, device="cuda", generator=g)
+        o = dict(obs)
+        plan = env.row_plan
+        if mode == "all_detected":
+            o["detected_human_num"] = torch.full((E, 1), float(H), device="cuda")
+            plan = None                  # (bench.py passes none either; a stale plan would be refused by the kernel anyway)
+        plan_host = None
+        if mode == "planned":
+            plan_host = env.row_plan.cpu().numpy()
+            assert plan_host[0] == 0x52504c4e and plan_host[4] == E and plan_host[5] == H, "the step must have produced a plan for this batch"
+            planned_steps += 1
+        a = pol.act(o, h, m, eps=eps, row_plan=plan)
+        tap = pol.taps(E)["spatial_lin"]
+        det_host = o["detected_human_num"].cpu().numpy()
+        idx = _plan_sample(plan_host, det_host, E, H)
+        ti = torch.as_tensor(idx, device="cuda")
+        ob_np = {k: o[k][ti].cpu().numpy() for k in keys}
+        taps = {}
+        v, mean, _, h_new, _ = P.act(sd, ob_np, h[ti].cpu().numpy().reshape(len(idx), 128), m[ti].cpu().numpy(), taps=taps)
+        act_ref = mean + std * eps[ti].cpu().numpy().astype(np.float64)
+        logp_ref = P.log_prob(mean, np.broadcast_to(np.log(std), mean.shape), act_ref)
+        nd = det_host.reshape(E).astype(np.int64).clip(1, H)[idx]
+        live = np.arange(H)[None, :] < nd[:, None]
+        got = dict(value=a["value"][ti].cpu().numpy(), action=a["action"][ti].cpu().numpy(), logp=a["logp"][ti].cpu().numpy(),
+                   hxs=a["hxs"][ti].cpu().numpy().reshape(len(idx), 128), spatial_lin=tap[ti].cpu().numpy() * live[:, :, None])
+        ref = dict(value=v, action=act_ref, logp=logp_ref, hxs=h_new, spatial_lin=taps["spatial_lin"] * live[:, :, None])
+        for k in worst:
+            err = float(np.abs(got[k] - ref[k]).max())
+            worst[k] = max(worst[k], err)
+            assert err <= 1e-4, (mode, k, t, err)
+        h = a["hxs"].clone()
+        obs, _, d, _, _, _ = env.step(a["action"])
+        m = (d == 0).float().view(E, 1)
+    if mode == "planned":
+        assert planned_steps == T
+    print("policy vs oracle, %s: worst abs error %s" % (mode, {k: "%.2e" % x for k, x in worst.items()}))
+    env.close()
+    pol.close()
+
+
+def test_stale_row_plan_is_refused_by_the_kernel():
+    """A plan is only valid with the observation it was built from.  The kernel checks every env's row count in the plan against
+    detected_human_num and falls back to its own scan when they differ: a forward with a STALE plan (the batch stepped in between, or the
+    counts overwritten) must equal the forward without a plan bit for bit."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    E, H = 1024, 20
+    env = HipEnvBatch(A.default_env_config(human_num=H, nenv=E), E, 425)
+    torch.manual_seed(425)
+    ob_space, act_space = make_spaces(H, 2)
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E), base="selfAttn_merge_srnn").cuda()
+    pol = HipPolicy(H, 2, E)
+    pol.set_weights(net.state_dict())
+    obs = env.reset()
+    h, m = torch.zeros(E, 1, 128, device="cuda"), torch.ones(E, 1, device="cuda")
+    for t in range(30):     # walk into the episode so that the counts differ between neighbouring steps
+        obs, _, _, _, _, _ = env.step(_scripted(obs["robot_node"].view(E, 7), t))
+    old_obs = {k: v.clone() for k, v in obs.items()}
+    old_plan = env.row_plan.clone()
+    for t in range(30, 36):
+        obs, _, _, _, _, _ = env.step(_scripted(obs["robot_node"].view(E, 7), t))
+    assert not torch.equal(old_obs["detected_human_num"], obs["detected_human_num"])
+    fresh = pol.act(obs, h, m, row_plan=env.row_plan)
+    fresh = {k: v.clone() for k, v in fresh.items()}
+    none = pol.act(obs, h, m, row_plan=None)
+    none = {k: v.clone() for k, v in none.items()}
+    stale = pol.act(obs, h, m, row_plan=old_plan)           # the plan of an observation six steps ago
+    for k in ("value", "action", "logp", "hxs"):
+        assert torch.equal(stale[k], none[k]), k
+        assert torch.allclose(fresh[k], none[k], atol=2e-5, rtol=0), k
+    # ... and the old plan is still accepted with ITS observation
+    a = pol.act(old_obs, h, m, row_plan=old_plan)
+    a = {k: v.clone() for k, v in a.items()}
+    b = pol.act(old_obs, h, m, row_plan=None)
+    for k in ("value", "action", "logp", "hxs"):
+        assert torch.allclose(a[k], b[k], atol=2e-5, rtol=0), k
+    env.close()
+    pol.close()
