@@ -24,11 +24,12 @@ constexpr int GT = 5, GP = 5; // obs_seq_len, pred_seq_len
 constexpr float GST_INVALID = -999.0f;
 
 // masks + displacements (crowd_nav_interface_parallel.py:71-89).  traj element (e,h,t) lives at
-// traj[e*se + h*sh + ((t + rot) % GT)*st] (+0/+1 for x/y); mask likewise with strides me/mh/mt.
+// traj[e*se + h*sh + ((rot + t*step) % ring)*st] (+0/+1 for x/y); mask likewise with strides me/mh/mt.  (A plain [.., GT, ..] input: rot 0,
+// step 1, ring GT; the wrapper's history ring of (GT-1)*I + 1 slots read every I-th, oldest first: vec_pretext_normalize.py:56-57, :133-134.)
 // NOTE loss_mask_rel_obs[t>=1] = mask[t-1] * mask[T-1] exactly as written in the reference (:76).
 __global__ __launch_bounds__(256) void gst_obs_prep_kernel(int E, int H, const float *__restrict__ traj, long long se, long long sh, long long st,
                                                            const uint8_t *__restrict__ mask_u8, const float *__restrict__ mask_f,
-                                                           long long me, long long mh, long long mt, int rot, float *__restrict__ m_rel,
+                                                           long long me, long long mh, long long mt, int rot, int step, int ring, float *__restrict__ m_rel,
                                                            float *__restrict__ lm_fp, float *__restrict__ rel, float *__restrict__ last_pos)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void gst_obs_prep_kernel(int E, int H, const f
     float m[GT], px[GT], py[GT];
 #pragma unroll
     for (int t = 0; t < GT; ++t) {
-        const int tt = (t + rot) % GT;
+        const int tt = (rot + t * step) % ring;
         const size_t mo = (size_t)e * me + (size_t)h * mh + (size_t)tt * mt;
         m[t] = mask_u8 ? (mask_u8[mo] ? 1.0f : 0.0f) : mask_f[mo];
         const size_t to = (size_t)e * se + (size_t)h * sh + (size_t)tt * st;
@@ -529,10 +530,26 @@ struct cn_gst {
     float *m_rel, *lm_fp, *rel, *last_pos, *xs, *h, *c, *acc, *x_sample;
     float *out_traj, *out_mask; // internal buffers for the wrapper path
     // VecPretextNormalize history
-    float *ring_traj;  // [5][maxE][H][2]
-    uint8_t *ring_mask; // [5][maxE][H]
+    // (its own allocation: the length depends on the prediction stride, cn_gst_wrapper_set_interval)
+    float *ring_traj;   // [ring_len][maxE][H][2]
+    uint8_t *ring_mask; // [ring_len][maxE][H]
     int ring_E, ring_pos;
+    int interval, ring_len; // pred_interval = int(pred_timestep // time_step) and buffer_len = (GT - 1) * interval + 1 (vec_pretext_normalize.py:56-57)
 };
+
+static int gst_alloc_ring(cn_gst *g, int interval)
+{
+    const int len = (GT - 1) * interval + 1;
+    const size_t n = (size_t)len * g->maxE * g->H;
+    float *t = nullptr;
+    uint8_t *m = nullptr;
+    CN_HIP(hipMalloc((void **)&t, n * 2 * sizeof(float)));
+    if (hipMalloc((void **)&m, n) != hipSuccess) { (void)hipFree(t); cn_set_error("cn_gst: hipMalloc of the history ring failed"); return CN_ERR_HIP; }
+    if (g->ring_traj) (void)hipFree(g->ring_traj);
+    if (g->ring_mask) (void)hipFree(g->ring_mask);
+    g->ring_traj = t; g->ring_mask = m; g->interval = interval; g->ring_len = len; g->ring_E = 0; g->ring_pos = 0;
+    return CN_OK;
+}
 
 extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
 {
@@ -548,7 +565,6 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
                           carve(128 * 64), carve(128), carve(64 * 128), carve(64), carve(256 * 64), carve(256 * 64), carve(256), carve(256), carve(320), carve(5)};
     const size_t o_mrel = carve(R), o_lm = carve(N), o_rel = carve(2 * R), o_lp = carve(2 * N), o_xs = carve(R * 64);
     const size_t o_h = carve(N * 64), o_c = carve(N * 64), o_acc = carve(N * 5), o_xsamp = carve(N * 2), o_ot = carve(N * GP * 5), o_om = carve(N);
-    const size_t o_rt = carve((size_t)GT * N * 2), o_rm = carve(((size_t)GT * N + 3) / 4);
     const size_t o_wcat = carve(256 * 128), o_flstm = carve(256 * 128);
     const size_t o_fin = carve(192 * 64), o_fout = carve(64 * 64), o_fl1 = carve(128 * 64), o_fl2 = carve(64 * 128);
     char *base = nullptr;
@@ -563,8 +579,8 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     g->acc = F(o_acc); g->x_sample = F(o_xsamp); g->out_traj = F(o_ot); g->out_mask = F(o_om);
     g->w_cat = F(o_wcat); g->f_lstm = F(o_flstm);
     g->f_in = F(o_fin); g->f_out = F(o_fout); g->f_l1 = F(o_fl1); g->f_l2 = F(o_fl2);
-    g->ring_traj = F(o_rt); g->ring_mask = (uint8_t *)(base + o_rm);
-    g->ring_E = 0; g->ring_pos = 0; g->weights_set = false;
+    g->weights_set = false;
+    if (int rc = gst_alloc_ring(g, 1)) { (void)hipFree(base); delete g; return rc; }
     *out = g;
     return CN_OK;
 }
@@ -572,6 +588,8 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
 extern "C" int cn_gst_destroy(cn_gst *g)
 {
     if (!g) return CN_OK;
+    if (g->ring_traj) (void)hipFree(g->ring_traj);
+    if (g->ring_mask) (void)hipFree(g->ring_mask);
     if (g->blob) CN_HIP(hipFree(g->blob));
     delete g;
     return CN_OK;
@@ -646,12 +664,12 @@ static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *
 }
 
 static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long long sh, long long stt, const uint8_t *mask_u8, const float *mask_f,
-                       long long me, long long mh, long long mt, int rot, float *out_traj, float *out_mask, hipStream_t st)
+                       long long me, long long mh, long long mt, int rot, int step, int ring, float *out_traj, float *out_mask, hipStream_t st)
 {
     if (!g->weights_set) { cn_set_error("cn_gst: call cn_gst_set_weights first"); return CN_ERR_STATE; }
     const int H = g->H, N = E * H, R = N * GT;
     int rc;
-    hipLaunchKernelGGL(gst_obs_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, st, E, H, traj, se, sh, stt, mask_u8, mask_f, me, mh, mt, rot,
+    hipLaunchKernelGGL(gst_obs_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, st, E, H, traj, se, sh, stt, mask_u8, mask_f, me, mh, mt, rot, step, ring,
                        g->m_rel, g->lm_fp, g->rel, g->last_pos);
     CN_CHECK_LAUNCH();
     // observation period: spatial encoding of all 5 slices at once, then the LSTM over time
@@ -672,16 +690,50 @@ extern "C" int cn_gst_predict(cn_gst *g, int E, const float *in_traj, const floa
 {
     CN_REQUIRE(g && in_traj && in_mask && out_traj && out_mask && E >= 1 && E <= g->maxE, "cn_gst_predict: bad argument");
     const long long H = g->H;
-    return gst_forward(g, E, in_traj, H * GT * 2, GT * 2, 2, nullptr, in_mask, H * GT, GT, 1, 0, out_traj, out_mask, (hipStream_t)stream);
+    return gst_forward(g, E, in_traj, H * GT * 2, GT * 2, 2, nullptr, in_mask, H * GT, GT, 1, 0, 1, GT, out_traj, out_mask, (hipStream_t)stream);
 }
+
+extern "C" int cn_gst_wrapper_set_interval(cn_gst *g, int pred_interval)
+{
+    CN_REQUIRE(g && pred_interval >= 1 && pred_interval <= 64, "cn_gst_wrapper_set_interval: pred_interval must be in [1,64]");
+    if (pred_interval == g->interval) return CN_OK;
+    CN_HIP(hipDeviceSynchronize()); // the old ring may still be read by work in flight (a configuration call, never on the hot path)
+    return gst_alloc_ring(g, pred_interval);
+}
+
+extern "C" int cn_gst_wrapper_history_len(const cn_gst *g) { return g ? g->ring_len : 0; }
 
 extern "C" int cn_gst_wrapper_reset(cn_gst *g, int E, void *stream)
 {
     CN_REQUIRE(g && E >= 1 && E <= g->maxE, "cn_gst_wrapper_reset: bad argument");
-    const size_t n = (size_t)GT * E * g->H;
+    const size_t n = (size_t)g->ring_len * E * g->H;
     hipLaunchKernelGGL(pretext_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, g->ring_traj, g->ring_mask);
     CN_CHECK_LAUNCH();
     g->ring_E = E; g->ring_pos = 0;
+    return CN_OK;
+}
+
+// history in TIME order (oldest observation first), whatever the ring's rotation: traj [ring_len,E,H,2] fp32, mask [ring_len,E,H] u8
+extern "C" int cn_gst_wrapper_save(cn_gst *g, float *traj, uint8_t *mask, void *stream)
+{
+    CN_REQUIRE(g && traj && mask, "cn_gst_wrapper_save: null argument");
+    if (g->ring_E < 1) { cn_set_error("cn_gst_wrapper_save: no history (call cn_gst_wrapper_reset first)"); return CN_ERR_STATE; }
+    const size_t N = (size_t)g->ring_E * g->H;
+    for (int t = 0; t < g->ring_len; ++t) {
+        const int slot = (g->ring_pos + t) % g->ring_len; // ring_pos = the slot the next push overwrites = the oldest
+        CN_HIP(hipMemcpyAsync(traj + (size_t)t * N * 2, g->ring_traj + (size_t)slot * N * 2, N * 2 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        CN_HIP(hipMemcpyAsync(mask + (size_t)t * N, g->ring_mask + (size_t)slot * N, N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return CN_OK;
+}
+
+extern "C" int cn_gst_wrapper_load(cn_gst *g, int E, const float *traj, const uint8_t *mask, void *stream)
+{
+    CN_REQUIRE(g && traj && mask && E >= 1 && E <= g->maxE, "cn_gst_wrapper_load: bad argument");
+    const size_t n = (size_t)g->ring_len * E * g->H;
+    CN_HIP(hipMemcpyAsync(g->ring_traj, traj, n * 2 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    CN_HIP(hipMemcpyAsync(g->ring_mask, mask, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    g->ring_E = E; g->ring_pos = 0; // slot t = time t: the next push overwrites slot 0, the oldest
     return CN_OK;
 }
 
@@ -692,13 +744,15 @@ extern "C" int cn_gst_wrapper_step(cn_gst *g, int E, const cn_obs *obs, float ro
     if (g->ring_E != E) { cn_set_error("cn_gst_wrapper_step: call cn_gst_wrapper_reset(E=%d) first", E); return CN_ERR_STATE; }
     hipStream_t st = (hipStream_t)stream;
     const int H = g->H, D = 2 * (GP + 1), N = E * H;
-    // deque.append: the oldest slot is overwritten, time order = (pos+1 .. pos+5) % 5
+    // deque.append: the oldest slot is overwritten; time order = slots (pos+1 .. pos+len) % len, of which every interval-th is read
+    // (in_traj[:, :, ::pred_interval]: the oldest, ..., the newest -- len = (GT-1) * interval + 1)
     hipLaunchKernelGGL(pretext_push_kernel, dim3((N + 255) / 256), dim3(256), 0, st, E, H, D, obs->robot_node, obs->spatial_edges, obs->visible_masks,
                        g->ring_traj, g->ring_mask, g->ring_pos);
     CN_CHECK_LAUNCH();
-    const int rot = (g->ring_pos + 1) % GT;
+    const int rot = (g->ring_pos + 1) % g->ring_len;
     g->ring_pos = rot;
-    if (int rc = gst_forward(g, E, g->ring_traj, (long long)H * 2, 2, (long long)N * 2, g->ring_mask, nullptr, H, 1, N, rot, g->out_traj, g->lm_fp, st)) return rc;
+    if (int rc = gst_forward(g, E, g->ring_traj, (long long)H * 2, 2, (long long)N * 2, g->ring_mask, nullptr, H, 1, N, rot, g->interval, g->ring_len,
+                             g->out_traj, g->lm_fp, st)) return rc;
     float *rw = rewards;
     hipLaunchKernelGGL(pretext_post_kernel, dim3(E), dim3(64), 0, st, E, H, D, obs->robot_node, obs->spatial_edges, g->out_traj, g->lm_fp,
                        robot_plus_human_radius, collision_penalty, rw ? rw : g->acc /*scratch*/, spatial_edges_out);

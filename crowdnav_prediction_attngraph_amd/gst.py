@@ -139,11 +139,18 @@ class GSTPredictor(nn.Module):
 class PretextProcessor:
     """State and per-step processing of VecPretextNormalize (rl/vec_env/vec_pretext_normalize.py:85-191)."""
 
-    def __init__(self, predictor, num_envs, human_num, predict_steps, robot_radius, human_radius, collision_penalty, device, use_hip=None):
+    def __init__(self, predictor, num_envs, human_num, predict_steps, robot_radius, human_radius, collision_penalty, device, use_hip=None,
+                 pred_interval=1):
         self.pred, self.E, self.H, self.P = predictor, num_envs, human_num, predict_steps
         self.dist, self.device = robot_radius + human_radius, torch.device(device)
         self.collision_penalty = float(collision_penalty)
         self.pen = (collision_penalty / 2.0 ** torch.arange(2, predict_steps + 2, device=device, dtype=torch.float32)).view(1, 1, predict_steps)
+        # prediction stride (vec_pretext_normalize.py:56-57): the history holds (obs_seq_len - 1) * interval + 1 observations, every
+        # interval-th of them is the predictor's input (:133-134)
+        self.interval = int(pred_interval)
+        if self.interval < 1:
+            raise ValueError("pred_interval = int(data.pred_timestep // env.time_step) must be >= 1")
+        self.buffer_len = 4 * self.interval + 1
         self.hip = None
         if use_hip if use_hip is not None else self.device.type == "cuda":
             if predict_steps != 5:
@@ -151,6 +158,7 @@ class PretextProcessor:
             from .hip import HipGST
             self.hip = HipGST(human_num, num_envs, device=self.device)     # raises if the extension is missing: no fallback on a GPU
             self.hip.set_weights(predictor.state_dict())
+            self.hip.wrapper_set_interval(self.interval)
         self.reset_buffers()
 
     def reset_buffers(self):
@@ -159,8 +167,25 @@ class PretextProcessor:
         if self.hip is not None:
             self.hip.wrapper_reset(self.E)
             return
-        self.traj = torch.full((5, self.E, self.H, 2), INVALID, device=self.device)
-        self.mask = torch.zeros(5, self.E, self.H, 1, dtype=torch.bool, device=self.device)
+        self.traj = torch.full((self.buffer_len, self.E, self.H, 2), INVALID, device=self.device)
+        self.mask = torch.zeros(self.buffer_len, self.E, self.H, 1, dtype=torch.bool, device=self.device)
+
+    def state_dict(self):
+        """The observation history (traj_buffer / mask_buffer of vec_pretext_normalize.py:85-101) in time order, oldest first, as CPU tensors."""
+        if self.hip is not None:
+            traj, mask = self.hip.wrapper_state()
+            return {"traj": traj.cpu(), "mask": mask.cpu(), "interval": self.interval}
+        return {"traj": self.traj.cpu().clone(), "mask": self.mask.reshape(self.buffer_len, self.E, self.H).to(torch.uint8).cpu(), "interval": self.interval}
+
+    def load_state_dict(self, sd):
+        if int(sd.get("interval", 1)) != self.interval or tuple(sd["traj"].shape) != (self.buffer_len, self.E, self.H, 2):
+            raise ValueError("history of shape %s / stride %s does not fit this wrapper (%d x %d envs x %d humans, stride %d)"
+                             % (tuple(sd["traj"].shape), sd.get("interval"), self.buffer_len, self.E, self.H, self.interval))
+        if self.hip is not None:
+            self.hip.wrapper_load_state(sd["traj"], sd["mask"])
+            return
+        self.traj = sd["traj"].to(self.device, torch.float32).clone()
+        self.mask = sd["mask"].to(self.device).to(torch.bool).view(self.buffer_len, self.E, self.H, 1).clone()
 
     @torch.no_grad()
     def process(self, obs, rews):
@@ -176,7 +201,7 @@ class PretextProcessor:
         human_pos = robot_xy + se[:, :, :2]
         self.traj = torch.cat([self.traj[1:], human_pos.unsqueeze(0)], 0)
         self.mask = torch.cat([self.mask[1:], obs["visible_masks"].to(torch.bool).view(1, E, H, 1)], 0)
-        out_traj, out_mask = self.pred(self.traj.permute(1, 2, 0, 3), self.mask.permute(1, 2, 0, 3).float())
+        out_traj, out_mask = self.pred(self.traj[::self.interval].permute(1, 2, 0, 3), self.mask[::self.interval].permute(1, 2, 0, 3).float())
         out_mask = out_mask.bool()
         rel = out_traj[..., :2] - robot_xy.unsqueeze(1)                       # robot-frame predictions [E,H,P,2]
         coll = (rel.norm(dim=-1) < self.dist) & out_mask

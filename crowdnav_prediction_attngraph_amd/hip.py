@@ -35,11 +35,15 @@ class HipEnvBatch:
         # equally filled tiles for the policy's fused human-human kernel (csrc/row_plan.h).  Pass it to HipPolicy.act(..., row_plan=) ONLY
         # together with the observation it was made for (the one the last reset() / step() of THIS batch returned or wrote).
         self.row_plan = torch.zeros(int(A.lib().cn_row_plan_words(E)), dtype=torch.int32, device=dev)
-        self.reward = torch.zeros(E, device=dev)
-        self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
-        self.info = torch.zeros(E, dtype=torch.uint8, device=dev)
-        self.ep_return = torch.zeros(E, dtype=torch.float64, device=dev)
-        self.ep_len = torch.zeros(E, dtype=torch.int32, device=dev)
+        # the per-step host-visible outputs live in ONE buffer (ep_return f64 | reward f32 | ep_len i32 | done u8 | info u8): a caller that
+        # needs them on the host (the reference's VecPyTorch contract, vec_env.BatchedCrowdSim.step) fetches all five with one transfer
+        self._packed = torch.zeros(18 * E, dtype=torch.uint8, device=dev)
+        self.ep_return = self._packed[0:8 * E].view(torch.float64)
+        self.reward = self._packed[8 * E:12 * E].view(torch.float32)
+        self.ep_len = self._packed[12 * E:16 * E].view(torch.int32)
+        self.done = self._packed[16 * E:17 * E]
+        self.info = self._packed[17 * E:18 * E]
+        self._packed_host = None
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -76,6 +80,19 @@ class HipEnvBatch:
             A.check(A.lib().cn_env_step(self._h, A.ptr(actions), C.byref(o), A.ptr(reward), A.ptr(self.done), A.ptr(self.info),
                                         A.ptr(self.ep_return), A.ptr(self.ep_len), A.ptr(not_done), A.stream_ptr()), "cn_env_step")
         return obs, reward, self.done, self.info, self.ep_return, self.ep_len
+
+    def fetch_step_outputs(self):
+        """(reward f32 [E], done bool [E], info u8 [E], ep_return f64 [E], ep_len i32 [E]) of the last step() as numpy arrays: ONE
+        device-to-host transfer into a pinned buffer and one stream synchronisation.  The arrays are views of that buffer: valid until the
+        next call."""
+        E = self.E
+        if self._packed_host is None:
+            self._packed_host = torch.empty(18 * E, dtype=torch.uint8, pin_memory=True)
+        self._packed_host.copy_(self._packed, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        h = self._packed_host.numpy()
+        return (h[8 * E:12 * E].view("float32"), h[16 * E:17 * E].view("bool"), h[17 * E:18 * E], h[0:8 * E].view("float64"),
+                h[12 * E:16 * E].view("int32"))
 
     def set_pregen_budget(self, ticks_10ns):
         """Time budget (x 10 ns) of one launch of the episode pre-generation kernel; the episodes do not depend on it (cn_env_set_pregen_budget)."""
@@ -383,6 +400,32 @@ class HipGST:
     def wrapper_reset(self, E):
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_gst_wrapper_reset(self._h, int(E), A.stream_ptr()), "cn_gst_wrapper_reset")
+        self._wrap_E = int(E)
+
+    def wrapper_set_interval(self, pred_interval):
+        """int(data.pred_timestep // env.time_step): the history keeps 4 * pred_interval + 1 observations, every pred_interval-th is fed."""
+        A.check(A.lib().cn_gst_wrapper_set_interval(self._h, int(pred_interval)), "cn_gst_wrapper_set_interval")
+
+    def wrapper_state(self):
+        """(traj [len,E,H,2] float32, mask [len,E,H] uint8) = the observation history in time order, oldest first (cn_gst_wrapper_save)."""
+        L, E = int(A.lib().cn_gst_wrapper_history_len(self._h)), self._wrap_E
+        traj = torch.empty(L, E, self.H, 2, device=self.device)
+        mask = torch.empty(L, E, self.H, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_wrapper_save(self._h, A.ptr(traj), A.ptr(mask), A.stream_ptr()), "cn_gst_wrapper_save")
+        return traj, mask
+
+    def wrapper_load_state(self, traj, mask):
+        L = int(A.lib().cn_gst_wrapper_history_len(self._h))
+        if traj.shape[0] != L or tuple(traj.shape[2:]) != (self.H, 2) or tuple(mask.shape) != tuple(traj.shape[:3]):
+            raise A.CnError("history of shape %s / %s does not fit this wrapper (length %d, %d humans)" % (tuple(traj.shape), tuple(mask.shape), L, self.H))
+        E = int(traj.shape[1])
+        traj = traj.to(device=self.device, dtype=torch.float32).contiguous()
+        mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_gst_wrapper_load(self._h, E, A.ptr(traj), A.ptr(mask), A.stream_ptr()), "cn_gst_wrapper_load")
+        torch.cuda.current_stream(self.device).synchronize()   # the sources are temporaries
+        self._wrap_E = E
 
     def wrapper_step(self, obs, rewards, dist, collision_penalty, out=None):
         """obs: raw env observation (spatial_edges [E,H,12] by human id, visible_masks u8/bool); rewards [E] float32 updated in place."""

@@ -58,8 +58,10 @@ class BatchedCrowdSim(object):
                 raise ValueError("pretext_wrapper=True goes with CrowdSimPredRealGST-v0 (config.py:162-165)")
             from .gst import PretextProcessor, load_predictor
             pred = predictor if predictor is not None else load_predictor(config, self.device)
+            data = getattr(config, "data", None)
+            interval = int(float(getattr(data, "pred_timestep", self.cfg.time_step)) // float(self.cfg.time_step))   # vec_pretext_normalize.py:56
             self._pretext = PretextProcessor(pred.to(self.device), self.num_envs, self.human_num, int(self.cfg.predict_steps), float(self.cfg.robot_radius),
-                                             float(self.cfg.human_radius), float(self.cfg.collision_penalty), self.device)
+                                             float(self.cfg.human_radius), float(self.cfg.collision_penalty), self.device, pred_interval=interval)
 
     # ---- device-level API (no host synchronisation) ----
     def _apply_pretext(self, obs, reward):
@@ -99,19 +101,18 @@ class BatchedCrowdSim(object):
         actions = actions.to(self.device, dtype=torch.float32).reshape(self.num_envs, 2)
         obs, reward, done, info, ep_ret, ep_len = self.step_device(actions)
         out = self._export_obs(obs)
-        # one D2H transfer for everything the reference returns on the host (VecPyTorch.step_wait, envs.py:216-224)
-        reward_h, done_h, info_h, ret_h, len_h = (reward.cpu(), done.cpu().numpy().astype(bool), info.cpu().numpy(),
-                                                  ep_ret.cpu().numpy(), ep_len.cpu().numpy())
+        # ONE device-to-host transfer for everything the reference returns on the host (VecPyTorch.step_wait, envs.py:216-224); the GST
+        # wrapper's reward (env reward + social penalty) is a tensor of its own
+        reward_np, done_h, info_h, ret_h, len_h = self._env.fetch_step_outputs()
+        reward_h = torch.from_numpy(reward_np.copy()) if self._pretext is None else reward.cpu()
+        done_h = done_h.copy()
+        md = None
         if self.cfg.phase in (1, 2) and (info_h == 4).any():  # val / test phase: Danger carries the min distance to an intruded future position
             md = self._env.get_danger_min_dist().cpu().numpy()
-            infos = [{"info": I.from_code(int(c), float(md[i]))} for i, c in enumerate(info_h)]
-        else:
-            infos = [{"info": I.from_code(int(c))} for c in info_h]
-        if done_h.any():
-            now = round(time.time() - self._t0, 6)
-            for i in np.nonzero(done_h)[0]:
-                infos[i]["episode"] = {"r": round(float(ret_h[i]), 6), "l": int(len_h[i]), "t": now}
-        return out, reward_h.unsqueeze(1).float(), done_h, infos
+        # `infos` behaves like the reference's list of E dicts but builds a dict only for the envs that finished (bench.Monitor's 'episode'
+        # entry, train.py:180-182) -- O(finished envs) Python per step instead of O(E)
+        infos = I.LazyInfos(info_h, np.flatnonzero(done_h), ret_h, len_h, round(time.time() - self._t0, 6), md)
+        return out, reward_h.reshape(self.num_envs, 1).float(), done_h, infos
 
     def step_async(self, actions):
         self._pending = actions
@@ -127,14 +128,20 @@ class BatchedCrowdSim(object):
 
     # ---- checkpointing (a bit-exact --resume needs the simulator state, not only the policy: train.py:105-108 restores weights only) ----
     def state_dict(self):
-        if self._pretext is not None:
-            raise NotImplementedError("checkpointing the GST wrapper's observation history is not implemented")
-        return {"env": self._env.state_dict(), "env_name": self.env_name, "num_envs": self.num_envs}
+        sd = {"env": self._env.state_dict(), "env_name": self.env_name, "num_envs": self.num_envs}
+        if self._pretext is not None:     # VecPretextNormalize's observation history (vec_pretext_normalize.py:85-101)
+            sd["pretext"] = self._pretext.state_dict()
+        return sd
 
     def load_state_dict(self, sd):
         if sd.get("env_name") != self.env_name or sd.get("num_envs") != self.num_envs:
             raise A.CnError("checkpoint is for %s x %s envs, this vec-env is %s x %d" % (sd.get("env_name"), sd.get("num_envs"), self.env_name, self.num_envs))
+        if (self._pretext is not None) != ("pretext" in sd):
+            raise A.CnError("checkpoint %s the prediction wrapper's history, this vec-env %s one" % (("holds" if "pretext" in sd else "lacks"),
+                                                                                                     ("has" if self._pretext is not None else "has not")))
         self._env.load_state_dict(sd["env"])
+        if self._pretext is not None:
+            self._pretext.load_state_dict(sd["pretext"])
 
     def close(self):
         if not self._closed:

@@ -393,6 +393,16 @@ int cn_gst_set_weights(cn_gst *g, const cn_gst_weights *w, void *stream);
  * sigma_y, corr), positions -999 where the pedestrian is not predicted; out_mask [E,H] (0/1 float). */
 int cn_gst_predict(cn_gst *g, int E, const float *in_traj, const float *in_mask, float *out_traj, float *out_mask, void *stream);
 int cn_gst_wrapper_reset(cn_gst *g, int E, void *stream);
+/* Prediction stride (rl/vec_env/vec_pretext_normalize.py:56-57, :133-134): pred_interval = int(data.pred_timestep // env.time_step); the
+ * wrapper keeps the last (5 - 1) * pred_interval + 1 observations and feeds every pred_interval-th of them (oldest first) to the predictor.
+ * Default 1 (every shipped config).  Re-allocates the history: call before cn_gst_wrapper_reset.  cn_gst_wrapper_history_len = that length. */
+int cn_gst_wrapper_set_interval(cn_gst *g, int pred_interval);
+int cn_gst_wrapper_history_len(const cn_gst *g);
+/* Checkpointing of the wrapper's observation history (traj_buffer / mask_buffer, vec_pretext_normalize.py:85-101), in time order, oldest first:
+ * traj [len,E,H,2] float32, mask [len,E,H] uint8 (device buffers), len = cn_gst_wrapper_history_len.  With the simulator snapshot
+ * (cn_env_save) this makes a resumed CrowdSimPredRealGST-v0 run continue bit for bit. */
+int cn_gst_wrapper_save(cn_gst *g, float *traj, uint8_t *mask, void *stream);
+int cn_gst_wrapper_load(cn_gst *g, int E, const float *traj, const uint8_t *mask, void *stream);
 /* obs: the raw CrowdSimPredRealGST-v0 observation (robot_node, spatial_edges [E,H,12] by human id, visible_masks).  Pushes the
  * new positions into the 5-deep history, runs the predictor, adds the social penalty min_{h,k}(collision * penalty / 2^(k+2))
  * to rewards [E] (in place, may be NULL) and writes spatial_edges_out [E,H,12]: predictions in the robot frame where valid,

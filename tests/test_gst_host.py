@@ -181,3 +181,80 @@ def test_hip_gst_predict_with_the_shipped_weights_matches_reference_golden():
         np.testing.assert_array_equal(mask.cpu().numpy(), z["out_mask_" + case])
         valid = z["out_mask_" + case][..., 0] > 0
         np.testing.assert_allclose(out.cpu().numpy()[valid], z["out_traj_" + case][valid], rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_predrealgst_vec_env_resume_is_bit_exact():
+    """state_dict() / load_state_dict() of a vec-env WITH the prediction wrapper: simulator snapshot + the wrapper's 5-step observation
+    history (rl/vec_env/vec_pretext_normalize.py:85-101 traj_buffer / mask_buffer).  A run restored at step 17 continues exactly like the
+    uninterrupted one: observations (predictions included), rewards (social penalty included), dones -- equal bit for bit over 25 steps."""
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    z = np.load(os.path.join(GOLDEN, "gst_e4_h20.npz"))
+    pred = _model(json.loads(str(z["meta"])), "cuda")
+    cfg = C.non_randomized(**{"sim.human_num": 20, "sim.predict_method": "inferred"})
+    E = 48
+    mk = lambda: make_vec_envs("CrowdSimPredRealGST-v0", 425, E, 0.99, None, torch.device("cuda"), False, config=cfg, pretext_wrapper=True, predictor=pred)  # noqa: E731
+
+    def act(t):
+        g = torch.Generator(device="cuda").manual_seed(100 + t)
+        return torch.randn(E, 2, device="cuda", generator=g) * 0.7
+
+    a = mk()
+    a.reset()
+    for t in range(17):
+        a.step(act(t))
+    sd = a.state_dict()
+    assert "pretext" in sd and tuple(sd["pretext"]["traj"].shape) == (5, E, 20, 2)
+    want = [a.step(act(t)) for t in range(17, 42)]
+    a.close()
+    b = mk()
+    b.reset()
+    for t in range(5):           # a different past: everything that matters must come from the checkpoint
+        b.step(act(900 + t))
+    b.load_state_dict(sd)
+    n_done = 0
+    for t, (o_w, r_w, d_w, _) in zip(range(17, 42), want):
+        o, r, d, _ = b.step(act(t))
+        for k in o_w:
+            assert torch.equal(o[k], o_w[k]), (k, t)
+        assert torch.equal(r, r_w) and np.array_equal(d, d_w), t
+        n_done += int(d.sum())
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interval", [2, 3])
+def test_hip_gst_wrapper_with_a_prediction_stride_matches_torch_expression(interval):
+    """data.pred_timestep = interval x env.time_step (vec_pretext_normalize.py:56-57, :133-134): the history keeps 4 * interval + 1
+    observations and every interval-th one feeds the predictor.  HIP wrapper vs the torch-op expression of the same processing on identical
+    observation streams, from the dummy history through more than two full turns of the ring; then a save / load round trip of the history."""
+    z = np.load(os.path.join(GOLDEN, "gst_e4_h20.npz"))
+    pred = _model(json.loads(str(z["meta"])), "cuda")
+    E, H = 37, 20
+    w_hip = PretextProcessor(pred, E, H, 5, 0.3, 0.3, -20.0, torch.device("cuda"), use_hip=True, pred_interval=interval)
+    w_ref = PretextProcessor(pred, E, H, 5, 0.3, 0.3, -20.0, torch.device("cuda"), use_hip=False, pred_interval=interval)
+    assert w_ref.buffer_len == 4 * interval + 1
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pos = torch.randn(E, H, 2, device="cuda", generator=g) * 3
+    vel = torch.randn(E, H, 2, device="cuda", generator=g) * 0.2
+    rob = torch.zeros(E, 1, 7, device="cuda")
+    for t in range(3 * (4 * interval + 1)):
+        pos = pos + vel
+        rob[:, 0, :2] = 0.05 * t
+        se = torch.zeros(E, H, 12, device="cuda")
+        se[:, :, :2] = pos - rob[:, :, :2]
+        se[:, :, 2:] = 15.0
+        vis = (torch.rand(E, H, device="cuda", generator=g) > 0.25)
+        obs = {"robot_node": rob.clone(), "spatial_edges": se, "visible_masks": vis}
+        rew = torch.zeros(E, device="cuda")
+        se_h, r_h = w_hip.process(obs, rew.clone())
+        se_r, r_r = w_ref.process(obs, rew.clone())
+        same = (se_h[:, :, :2] == se_r[:, :, :2]).all(-1).all(-1)
+        assert float(same.float().mean()) > 0.95
+        assert float((se_h[same] - se_r[same]).abs().max()) <= 1e-4, t
+        assert float((r_h - r_r.reshape(E)).abs().max()) <= 1e-5, t
+        if t == 2 * (4 * interval + 1) + 1:      # mid-turn: the ring is rotated
+            sd_h, sd_r = w_hip.state_dict(), w_ref.state_dict()
+            assert torch.equal(sd_h["traj"], sd_r["traj"]) and torch.equal(sd_h["mask"], sd_r["mask"]), "history in time order, oldest first"
+            w_hip.load_state_dict(sd_h)             # un-rotated reload: the following steps must not notice
