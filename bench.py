@@ -470,6 +470,28 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline_threads(H, args.env_name, args.cpu_threads)
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        # SURVEY 8d CPU baseline (ii) / BASELINE.md 4.1: the REAL reference Python, timed in the build container (it cannot travel to this
+        # box) by tools/ref_python_cpu_baseline.py -- a labelled constant read from the committed result file, not a measurement of this run
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_python_cpu.json")))
+            rj = json.load(open(cands[-1]))
+            rec = [r for r in rj["env_step"] if r["env"] == args.env_name and r["humans"] == H]
+            if rec:
+                r0 = rec[0]
+                cores_here = line["cpu_baseline"]["cores"]
+                line["cpu_baseline"]["reference_python_container"] = {
+                    "env_steps_per_s_single_process": r0["single_process_steps_per_s"], "env_steps_per_s_%d_workers" % r0["workers"]: r0["workers_aggregate_steps_per_s"],
+                    "env_steps_per_s_per_worker": r0["per_worker_steps_per_s"], "container_logical_cpus": rj["host"]["logical_cpus"],
+                    "policy_act_cpu_1thread_batch16_env_steps_per_s": rj["policy_act_cpu_1thread_batch16"]["env_steps_per_s"],
+                    "what": "env.step of the reference's own Python (rvo2 = shim over the oracle's C RVO2), NOT measured in this run: constant from %s" % os.path.basename(cands[-1])}
+                line["speedup_vs_reference"] = {
+                    "vs_reference_python_scaled_to_this_box": round(value / (r0["per_worker_steps_per_s"] * cores_here), 1),
+                    "scaling": "%.1f env-steps/s per worker process x %d physical cores of this box (env.step only: the reference adds its policy forward on top)" % (r0["per_worker_steps_per_s"], cores_here),
+                    "vs_published_training_fps_176.5": round(value / 176.5, 1),
+                    "note": "north_star target: >= 50x; published fps = rollout + policy + PPO update, 16 worker processes, unstated hardware (BASELINE.md 1)"}
+        except Exception as exc:   # a missing / malformed constant must not cost the line
+            line["cpu_baseline"]["reference_python_container"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
