@@ -1454,7 +1454,15 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
             int nd = (int)det[i]; nd = nd < 1 ? 1 : (nd > H ? H : nd);
             bad |= (pro[i + 1] - pro[i]) ^ nd;
         }
-        planned = !__syncthreads_or(bad);
+        // (the verdict is combined through the dynamic LDS: __syncthreads_or would add a static __shared__ word, and this kernel's
+        // dynamic allocation is the whole 160 KB -- the launch attribute is refused when static + dynamic exceed it)
+        volatile int *flag = reinterpret_cast<volatile int *>(lds);
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (__ballot(bad != 0) != 0ull && (threadIdx.x & 63) == 0) *flag = 1;
+        __syncthreads();
+        planned = __builtin_amdgcn_readfirstlane(*flag) == 0;
+        __syncthreads(); // everybody has read the verdict before the LDS is reused
     }
     if (det && !planned) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
     if (!TRAIN && stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[32] = (unsigned long long)(planned ? plan[3] : row_off[E]);
