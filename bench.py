@@ -217,7 +217,7 @@ def main():
     force_all_detected = [False]
     noise_i = [0]
 
-    def step(i):
+    def forward(i):
         if noise_i[0] % NOISE_BLOCK == 0:
             eps.normal_(generator=gen)
         out["hxs"] = hxs[(i + 1) & 1]
@@ -226,12 +226,21 @@ def main():
         plan = env.row_plan if (gst is None and not force_all_detected[0]) else None
         pol.act(pol_obs, hxs[i & 1], masks2[i & 1], eps=eps[noise_i[0] % NOISE_BLOCK], out=out, row_plan=plan)
         noise_i[0] += 1
-        _, reward, done, _, _, _ = env.step(out["action"], not_done=masks2[(i + 1) & 1])   # done mask for the next forward
+
+    def step(i):
+        """One pass of the hot path: the crowd-sim step of all E envs under the actions of the last forward (ORCA humans, reward, auto-reset,
+        new observation, done mask) and the policy forward on the observation it produced.  A timed window of K steps therefore starts
+        with a simulator launch and ends with the last forward's heads: the ORCA solve a sim step leaves running for ITS successor (side
+        stream, overlapped with the forward) is over before that forward ends, so nothing of the K steps is left in flight at the closing
+        synchronize() and nothing of an earlier step is."""
+        _, reward, done, _, _, _ = env.step(out["action"], not_done=masks2[i & 1])   # done mask for the forward below
         if gst is not None:
             gst.wrapper_step(obs, reward, 0.6, -20.0, out=pol_obs["spatial_edges"])
         if force_all_detected[0]:
             pol_obs["detected_human_num"].fill_(float(H))     # worst case of the state-dependent work: every (env, human) row is live
+        forward(i)
 
+    forward(1)               # the first action (untimed): forward on the reset observation; step i then runs sim -> forward
     from crowdnav_prediction_attngraph_amd.hip import StepStamps
     ev_every = args.kernel_events_every if args.kernel_events_every > 0 else (1 if args.steps <= 64 else 4)
     it = 0
@@ -267,6 +276,8 @@ def main():
     dev_hh = sorted(x * 1e-3 for x in stamps.durations_us("hh_fused"))     # ms, every launch of the window
     dev_rn = sorted(x * 1e-3 for x in stamps.durations_us("rn_fused"))
     dev_rows = stamps.counts("hh_fused")
+    hh_starts = [a_ for (_, k_, a_, _) in stamps.table() if k_ == "hh_fused"]
+    step_intervals = [round(b_ - a_, 1) for a_, b_ in zip(hh_starts[:-1], hh_starts[1:])]     # us between consecutive human-human launches
     it += args.steps            # the hxs / masks ping-pong follows the step index: advance by exactly the steps taken
     per_rank = None
     if dist is not None:
@@ -295,18 +306,18 @@ def main():
             if d:
                 decomp["median_us"][k] = round(med(d), 2)
         tab = dst.table()
-        # critical path of a step on the caller's stream: hh_fused -> rn_fused -> env_step -> orca_lane -> next hh_fused
+        # critical path of a step on the caller's stream: env_step -> orca_lane (+ row plan) -> hh_fused -> rn_fused -> next env_step
         by = {}
         for s_, k, a_, b_ in tab:
             by[(s_, k)] = (a_, b_)
-        gaps = {"hh_to_rn": [], "rn_to_env_step": [], "env_step_to_orca_lane": [], "orca_lane_to_hh": [], "step": []}
+        gaps = {"env_step_to_orca_lane": [], "orca_lane_to_hh": [], "hh_to_rn": [], "rn_to_env_step": [], "step": []}
         for s_ in range(DEC - 1):
             try:
-                gaps["hh_to_rn"].append(by[(s_, "rn_fused")][0] - by[(s_, "hh_fused")][1])
-                gaps["rn_to_env_step"].append(by[(s_, "env_step")][0] - by[(s_, "rn_fused")][1])
                 gaps["env_step_to_orca_lane"].append(by[(s_, "orca_lane")][0] - by[(s_, "env_step")][1])
-                gaps["orca_lane_to_hh"].append(by[(s_ + 1, "hh_fused")][0] - by[(s_, "orca_lane")][1])
-                gaps["step"].append(by[(s_ + 1, "hh_fused")][0] - by[(s_, "hh_fused")][0])
+                gaps["orca_lane_to_hh"].append(by[(s_, "hh_fused")][0] - max(by[(s_, "orca_lane")][1], by.get((s_, "row_plan"), (0, 0))[1]))
+                gaps["hh_to_rn"].append(by[(s_, "rn_fused")][0] - by[(s_, "hh_fused")][1])
+                gaps["rn_to_env_step"].append(by[(s_ + 1, "env_step")][0] - by[(s_, "rn_fused")][1])
+                gaps["step"].append(by[(s_ + 1, "env_step")][0] - by[(s_, "env_step")][0])
             except KeyError:
                 pass
         decomp["median_gap_us"] = {k: round(med(v), 2) for k, v in gaps.items() if v and k != "step"}
@@ -459,6 +470,10 @@ def main():
     }
     line["config"]["dephase_steps"] = args.dephase
     line["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1e3, 4)   # Python + launch cost of one step; the device needs ms_per_step
+    if step_intervals:
+        si = sorted(step_intervals)
+        line["device_step_interval_us"] = {"median": si[len(si) // 2], "min": si[0], "max": si[-1],
+                                           "first": step_intervals[:4], "what": "start-to-start of consecutive hh_fused launches in the timed window (device clock)"}
     if decomp is not None:
         line["step_decomposition"] = decomp
     if per_rank is not None:

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libcrowdnav_hip.so")
 
 CN_MAX_HUMANS = 64
 ABI_VERSION = 400          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against
-PROF_KERNELS, PROF_SLOT_WORDS = 8, 40
+PROF_KERNELS, PROF_SLOT_WORDS = 8, 2048
 PROF_KERNEL_IDS = {"env_step": 0, "orca_lane": 1, "hh_fused": 2, "rn_fused": 3, "orca_lp3": 4, "env_pregen": 5, "row_plan": 6, "other": 7}
 ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2, "CrowdSimVarNumCollect-v0": 3}
 INFO_NOTHING, INFO_TIMEOUT, INFO_COLLISION, INFO_REACHGOAL, INFO_DANGER = range(5)

@@ -32,10 +32,12 @@ void cn_set_error(const char *fmt, ...);
 int cn_require_device();
 
 // ---- device-side launch stamps (measurement aid: cn_prof_set_stamps / cn_prof_next_step, include/crowdnav_hip.h) ----
-// One slot of CN_STAMP_WORDS uint64 per (step, kernel): words 0..15 receive atomicMin of the 100 MHz wall clock (s_memrealtime) at
-// workgroup entry, words 16..31 atomicMax at wavefront exit (16 sub-slots by workgroup index spread the atomics), word 32 is free for
-// a kernel-specific count (the human-human kernel: live rows).  A kernel's duration on the device = max(t1) - min(t0), in 10 ns ticks,
-// and since the clock is global the slots of a step also give the timeline (gaps, overlaps).  NULL = no stamping.
+// One slot of CN_PROF_SLOT_WORDS uint64 per (step, kernel) = 2 x 64 sub-slots of 16 words (128 bytes: a cache line of their own each).
+// Sub-slot b of the first half receives atomicMin of the 100 MHz wall clock (s_memrealtime) when workgroup b < 64 starts, sub-slot
+// (workgroup & 63) of the second half atomicMax when a wavefront ends; word 1 of the slot is free for a kernel-specific count (the
+// human-human kernel: live rows).  Same-address atomics serialise in the L2 at ~6 ns each -- 20 000 wavefronts stamping ONE word
+// stretched a 47 us kernel to 135 us -- hence one line per sub-slot.  A kernel's duration on the device = max(ends) - min(starts) in
+// 10 ns ticks, and since the clock is global the slots of a step also give its timeline (gaps, overlaps).  NULL = no stamping.
 enum { CN_K_ENV_STEP = 0, CN_K_ORCA_LANE = 1, CN_K_HH_FUSED = 2, CN_K_RN_FUSED = 3, CN_K_ORCA_LP3 = 4, CN_K_PREGEN = 5, CN_K_ROW_PLAN = 6, CN_K_OTHER = 7 };
 unsigned long long *cn_stamp_slot(int kernel_id); // host: the current step's slot of `kernel_id`, or NULL (off, masked out, ring exhausted)
 
@@ -44,11 +46,11 @@ struct CnStampScope {
     unsigned long long *s;
     __device__ __forceinline__ explicit CnStampScope(unsigned long long *slot) : s(slot)
     {
-        if (s && threadIdx.x == 0 && blockIdx.x < 256) atomicMin(s + (blockIdx.x & 15), (unsigned long long)wall_clock64());
+        if (s && threadIdx.x == 0 && blockIdx.x < 64) atomicMin(s + blockIdx.x * 16, (unsigned long long)wall_clock64());
     }
     __device__ __forceinline__ ~CnStampScope()
     {
-        if (s && (threadIdx.x & 63) == 0) atomicMax(s + 16 + (blockIdx.x & 15), (unsigned long long)wall_clock64());
+        if (s && (threadIdx.x & 63) == 0) atomicMax(s + (64 + (blockIdx.x & 63)) * 16, (unsigned long long)wall_clock64());
     }
 };
 #endif

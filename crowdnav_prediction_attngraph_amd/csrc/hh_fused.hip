@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int
     const CnStampScope stamp_scope(stamp);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if (det) row_offsets_prologue<256>(E, H, det, row_off, live_total, lds);
-    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[32] = (unsigned long long)row_off[E];
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[1] = (unsigned long long)row_off[E];
     // this kernel is the critical path of the step; the simulator's ORCA wavefronts of the side stream share the SIMDs with it and
     // are latency tolerant: win the issue arbitration against them
     if (W.prio) __builtin_amdgcn_s_setprio(3);
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
         __syncthreads(); // everybody has read the verdict before the LDS is reused
     }
     if (det && !planned) row_offsets_prologue<512>(E, H, det, row_off, live_total, lds);
-    if (!TRAIN && stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[32] = (unsigned long long)(planned ? plan[3] : row_off[E]);
+    if (!TRAIN && stamp && blockIdx.x == 0 && threadIdx.x == 0) stamp[1] = (unsigned long long)(planned ? plan[3] : row_off[E]);
 #ifdef HH_TIMING
     const long long k_c1 = clock64();
 #endif

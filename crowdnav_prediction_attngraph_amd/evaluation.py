@@ -38,11 +38,13 @@ def _summarise(outcomes, steps, path_len, too_close, min_dists, ep_rewards, time
 
 
 class _batch_invariant(object):
-    """Evaluation is a reproducibility protocol: run the policy with the launches whose per-env results do not depend on which other
-    envs share the batch ('bf16x3'), so that one-env-at-a-time and all-cases-in-one-batch evaluation give bit-identical episodes."""
+    """batch_invariant=True: run the policy with the launches whose per-env results do not depend on which other envs share the batch
+    ('bf16x3': the same arithmetic as separate launches), so that one-env-at-a-time and all-cases-in-one-batch evaluation give
+    bit-identical episodes.  Default (False): the policy's own rollout mode -- 'fused' unless the caller changed it, i.e. exactly the
+    arithmetic training and bench.py run; its per-env results depend on the tile neighbours at the 1e-7 level (softmax summation order)."""
 
-    def __init__(self, actor_critic):
-        self.ac = actor_critic
+    def __init__(self, actor_critic, on):
+        self.ac = actor_critic if on else None
 
     def __enter__(self):
         if self.ac is not None and hasattr(self.ac, "rollout_gemm_mode"):
@@ -56,9 +58,10 @@ class _batch_invariant(object):
         return False
 
 
-def evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging, config, args, visualize=False):
-    """Same call as the reference's `evaluate`.  eval_envs = make_vec_envs(..., num_processes=1, ...) (phase 'test')."""
-    with _batch_invariant(actor_critic):
+def evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging, config, args, visualize=False, *, batch_invariant=False):
+    """Same call as the reference's `evaluate`.  eval_envs = make_vec_envs(..., num_processes=1, ...) (phase 'test').  The policy runs in its
+    own rollout mode (the benchmarked fused kernels) unless batch_invariant=True is passed (see _batch_invariant)."""
+    with _batch_invariant(actor_critic, batch_invariant):
         return _evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging, config, args, visualize)
 
 
@@ -111,14 +114,16 @@ def _evaluate(actor_critic, eval_envs, num_processes, device, test_size, logging
     return _summarise(outcomes, steps, path_lens, too_closes, min_dists, ep_rewards, time_limit, time_step, logging)
 
 
-def evaluate_batched(actor_critic, env_name, config, seed, test_size, device=None, logging=None):
-    """The same protocol with every distinct test case as one env of one batch (all tensors stay on the GPU)."""
+def evaluate_batched(actor_critic, env_name, config, seed, test_size, device=None, logging=None, *, batch_invariant=False):
+    """The same protocol with every distinct test case as one env of one batch (all tensors stay on the GPU).  batch_invariant=True on both
+    this and evaluate() makes the two report bit-identical episodes (tests/test_gpu_eval.py); by default both run the fused kernels and
+    agree to the policy's 1e-7-level sensitivity to its tile neighbours (which can flip a chaotic episode's outcome)."""
     if env_name == "CrowdSimPredRealGST-v0":
         # the raw env observation carries placeholder futures; the policy needs the VecPretextNormalize processing (GST predictions,
         # distance sort, social penalty), which this function does not run
         raise NotImplementedError("evaluate_batched does not run the GST wrapper: evaluate CrowdSimPredRealGST-v0 with "
                                   "evaluate(actor_critic, make_vec_envs(..., pretext_wrapper=True), ...)")
-    with _batch_invariant(actor_critic):
+    with _batch_invariant(actor_critic, batch_invariant):
         return _evaluate_batched(actor_critic, env_name, config, seed, test_size, device, logging)
 
 

@@ -289,7 +289,7 @@ class StepStamps:
         self.kernels = tuple(kernels)
         dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         ring = torch.zeros(self.steps, A.PROF_KERNELS, A.PROF_SLOT_WORDS, dtype=torch.int64, device=dev)
-        ring[:, :, :16] = -1            # start candidates: unsigned minimum counts
+        ring[:, :, 0:1024:16] = -1      # start candidates (word 16 b of the first half): unsigned minimum counts
         self.ring = ring
         mask = 0
         for k in self.kernels:
@@ -315,9 +315,9 @@ class StepStamps:
     def _host(self):
         r = self.ring.cpu().numpy()
         import numpy as np
-        t0 = r[:, :, :16].astype(np.uint64).min(axis=2)          # all ones = never stamped
-        t1 = r[:, :, 16:32].astype(np.uint64).max(axis=2)
-        return t0, t1, r[:, :, 32]
+        t0 = r[:, :, 0:1024:16].astype(np.uint64).min(axis=2)          # all ones = never stamped
+        t1 = r[:, :, 1024:2048:16].astype(np.uint64).max(axis=2)
+        return t0, t1, r[:, :, 1]
 
     def durations_us(self, kernel):
         """Per stamped step: (last wavefront's end - first workgroup's start) of `kernel` in microseconds (10 ns resolution)."""

@@ -267,15 +267,16 @@ int cn_policy_reset_profile(cn_policy *p);
 
 /* ---- device-side launch stamps (measurement aid for bench.py / tools; not part of the reference's interface) ----
  * The kernels of the rollout step (CN_PROF_K_*) stamp the device's 100 MHz wall clock when their first workgroups start and when their
- * last wavefront ends, into a caller-owned DEVICE ring of steps x CN_PROF_KERNELS slots of CN_PROF_SLOT_WORDS uint64 (words 0..15:
- * candidates for the start, the minimum counts, initialise to all ones; 16..31: candidates for the end, the maximum counts, initialise to
- * 0; word 32: a per-kernel count, the human-human kernel's live rows).  Unlike an event bracket on the stream the stamps cost no
- * dispatch gap and do not include the time a launch waits for the host, and because the clock is global the slots of a step also give
- * its timeline.  cn_prof_set_stamps installs the ring for the whole process (NULL, 0 removes it) with a bit mask of the kernels to
- * stamp; cn_prof_next_step moves to the next row (the first call selects row 0; rows beyond `steps` are not stamped) and returns the
- * row index.  Host-side state: call both from the thread that enqueues the step. */
+ * wavefronts end, into a caller-owned DEVICE ring of steps x CN_PROF_KERNELS slots of CN_PROF_SLOT_WORDS uint64.  A slot is 2 x 64
+ * sub-slots of 16 words (one cache line each: same-address atomics serialise): word 16 b of the first half is a candidate for the
+ * start (the minimum counts; initialise the slot's first half to all ones), word 16 (64 + b) one for the end (the maximum counts;
+ * initialise to 0); word 1 of the slot carries a per-kernel count (the human-human kernel's live rows; initialise to 0).  Unlike an event
+ * bracket on the stream the stamps cost no dispatch gap and do not include the time a launch waits for the host, and because the
+ * clock is global the slots of a step also give its timeline.  cn_prof_set_stamps installs the ring for the whole process (NULL, 0
+ * removes it) with a bit mask of the kernels to stamp; cn_prof_next_step moves to the next row (the first call selects row 0; rows
+ * beyond `steps` are not stamped) and returns the row index.  Host-side state: call both from the thread that enqueues the step. */
 enum { CN_PROF_K_ENV_STEP = 0, CN_PROF_K_ORCA_LANE = 1, CN_PROF_K_HH_FUSED = 2, CN_PROF_K_RN_FUSED = 3, CN_PROF_K_ORCA_LP3 = 4, CN_PROF_K_PREGEN = 5,
-       CN_PROF_K_ROW_PLAN = 6, CN_PROF_K_OTHER = 7, CN_PROF_KERNELS = 8, CN_PROF_SLOT_WORDS = 40 };
+       CN_PROF_K_ROW_PLAN = 6, CN_PROF_K_OTHER = 7, CN_PROF_KERNELS = 8, CN_PROF_SLOT_WORDS = 2048 };
 int cn_prof_set_stamps(uint64_t *ring, int steps, unsigned kernel_mask);
 int cn_prof_next_step(void);
 
