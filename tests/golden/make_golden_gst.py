@@ -101,9 +101,48 @@ def main_real():
     print("gst real-weights golden -> %s (%.0f KB); out_traj_a[0,0,0]=%s" % (os.path.basename(path), os.path.getsize(path) / 1024, out["out_traj_a"][0, 0, 0]))
 
 
+def main_wide():
+    """Third fixture (round 4): VecPretextNormalize.process_obs_rew of the reference at 64 envs x 20 humans over 8 steps, with the shipped
+    prediction stride (pred_interval 1) AND with data.pred_timestep = 2 x env.time_step (pred_interval 2: a 9-deep history read every second
+    entry, vec_pretext_normalize.py:56-57, :133-134).  Inputs come from tests/policy_util.gst_wrapper_stream (regenerated by the consumer),
+    the file holds the reference's outputs only."""
+    R.install()
+    import torch
+    from rl.vec_env.vec_pretext_normalize import VecPretextNormalize
+    E, H, T = 64, 20, 8
+    pred, shapes = build_predictor(E)
+    cfg = R.make_config(**{"sim.human_num": H, "sim.predict_method": "inferred", "env.use_wrapper": True})
+    out = {}
+    for interval in (1, 2):
+        L = 4 * interval + 1
+        w = VecPretextNormalize.__new__(VecPretextNormalize)
+        w.config, w.device, w.num_envs, w.max_human_num, w.predictor = cfg, torch.device("cpu"), E, H, pred
+        w.pred_interval, w.buffer_len = interval, L                  # what __init__ derives at :56-57
+        w.traj_buffer = deque(list(-torch.ones((L, E, H, 2)) * 999), maxlen=L)      # reset(), :88-91
+        w.mask_buffer = deque(list(torch.zeros((L, E, H, 1), dtype=torch.bool)), maxlen=L)
+        w.step_counter = 0
+        w.last_pos = torch.zeros(E, H, 2)
+        se_out, rew_out = [], []
+        for t, o in enumerate(PU.gst_wrapper_stream(E, H, T + 2 * interval, 31)):
+            O = {"robot_node": torch.from_numpy(o["robot_node"]), "temporal_edges": torch.zeros(E, 1, 2), "spatial_edges": torch.from_numpy(o["spatial_edges"].copy()),
+                 "visible_masks": torch.from_numpy(o["visible_masks"]), "detected_human_num": torch.from_numpy(np.maximum(o["visible_masks"].sum(1), 1).astype(np.float32).reshape(E, 1))}
+            obs, rews = w.process_obs_rew(O, np.zeros(E), rews=o["rews_in"].copy())
+            se_out.append(obs["spatial_edges"].numpy().copy())
+            rew_out.append(np.asarray(rews, dtype=np.float32))
+        out["se_i%d" % interval] = np.stack(se_out)
+        out["rews_i%d" % interval] = np.stack(rew_out)
+    out["meta"] = np.array(json.dumps(dict(E=E, H=H, T=T, seed=31, intervals=[1, 2], steps={"1": T + 2, "2": T + 4}, args=GST_ARGS,
+                                           shapes={k: list(v) for k, v in shapes.items()})))
+    path = os.path.join(HERE, "gst_wrapper_e64_h20.npz")
+    np.savez_compressed(path, **out)
+    print("gst wrapper golden -> %s (%.0f KB); rews_i2[-1][:4]=%s" % (os.path.basename(path), os.path.getsize(path) / 1024, out["rews_i2"][-1].ravel()[:4]))
+
+
 def main():
     if "--real" in sys.argv:
         return main_real()
+    if "--wide" in sys.argv:
+        return main_wide()
     R.install()
     import torch
     E, H = 4, 20

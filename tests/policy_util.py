@@ -48,3 +48,26 @@ def synth_obs(E, H, D, seed):
             spatial[e, :det[e], 2 * k:2 * k + 2] = p + 0.25 * k * v
     return dict(robot_node=robot_node, temporal_edges=temporal, spatial_edges=spatial,
                 detected_human_num=det.astype(np.float32).reshape(E, 1))
+
+
+def gst_wrapper_stream(E, H, T, seed):
+    """Deterministic observation stream for the VecPretextNormalize tests (tests/golden/make_golden_gst.py --wide and its consumers):
+    humans drift with constant velocities, the robot random-walks, visibility = sensor range with one flickering human.  Returns T dicts of
+    numpy arrays (robot_node [E,1,7], spatial_edges [E,H,12] = the relative position tiled, visible_masks [E,H] bool, rews_in [E,1])."""
+    rs = np.random.RandomState(seed)
+    pos = rs.uniform(-5, 5, (E, H, 2))
+    vel = rs.uniform(-0.25, 0.25, (E, H, 2))
+    robot = rs.uniform(-3, 3, (E, 2))
+    out = []
+    for t in range(T):
+        pos = pos + vel
+        robot = robot + rs.uniform(-0.2, 0.2, (E, 2))
+        rel = pos - robot[:, None, :]
+        vis = np.linalg.norm(rel, axis=-1) - 0.6 <= 5.0
+        vis[:, 5 % H] = t % 3 != 0
+        se = np.where(vis[..., None], rel, 15.0)
+        out.append(dict(
+            robot_node=np.concatenate([robot, np.full((E, 1), 0.3), robot * 0, np.ones((E, 1)), np.full((E, 1), 1.57)], 1).astype(np.float32).reshape(E, 1, 7),
+            spatial_edges=np.tile(se, (1, 1, 6)).astype(np.float32), visible_masks=vis.copy(),
+            rews_in=rs.uniform(-1, 1, (E, 1)).astype(np.float32)))
+    return out

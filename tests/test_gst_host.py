@@ -258,3 +258,38 @@ def test_hip_gst_wrapper_with_a_prediction_stride_matches_torch_expression(inter
             sd_h, sd_r = w_hip.state_dict(), w_ref.state_dict()
             assert torch.equal(sd_h["traj"], sd_r["traj"]) and torch.equal(sd_h["mask"], sd_r["mask"]), "history in time order, oldest first"
             w_hip.load_state_dict(sd_h)             # un-rotated reload: the following steps must not notice
+
+
+def _check_wide(device, use_hip, interval):
+    """PretextProcessor against the reference's VecPretextNormalize.process_obs_rew at 64 envs (tests/golden/gst_wrapper_e64_h20.npz, made by
+    make_golden_gst.py --wide from the reference's own class): predictions / rewards <= 1e-4 absolute, identical row order wherever the
+    sort key has no rounding-level tie."""
+    from tests import policy_util as PU
+    z = np.load(os.path.join(GOLDEN, "gst_wrapper_e64_h20.npz"))
+    meta = json.loads(str(z["meta"]))
+    E, H, steps = meta["E"], meta["H"], meta["steps"][str(interval)]
+    m = _model(meta, device)
+    w = PretextProcessor(m, E, H, 5, 0.3, 0.3, -20.0, torch.device(device), use_hip=use_hip, pred_interval=interval)
+    n_same = 0
+    for t, o in enumerate(PU.gst_wrapper_stream(E, H, steps, meta["seed"])):
+        obs = {"robot_node": torch.from_numpy(o["robot_node"]).to(device), "spatial_edges": torch.from_numpy(o["spatial_edges"]).to(device),
+               "visible_masks": torch.from_numpy(o["visible_masks"]).to(device)}
+        se, rews = w.process(obs, torch.from_numpy(o["rews_in"]).to(device))
+        se, rews = se.cpu().numpy(), rews.cpu().numpy().reshape(E, 1)
+        want_se, want_r = z["se_i%d" % interval][t], z["rews_i%d" % interval][t].reshape(E, 1)
+        np.testing.assert_allclose(rews, want_r, rtol=0, atol=1e-4, err_msg="reward t=%d" % t)
+        same = (se[:, :, :2] == want_se[:, :, :2]).all(-1).all(-1)
+        n_same += int(same.sum())
+        np.testing.assert_allclose(se[same], want_se[same], rtol=0, atol=1e-4, err_msg="spatial_edges t=%d" % t)
+    assert n_same >= 0.98 * E * steps, "row order must agree except for rounding-level ties of the distance key"
+
+
+@pytest.mark.parametrize("interval", [1, 2])
+def test_wrapper_torch_path_matches_reference_at_64_envs_with_and_without_a_prediction_stride(interval):
+    _check_wide("cpu", False, interval)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interval", [1, 2])
+def test_hip_gst_wrapper_matches_reference_at_64_envs_with_and_without_a_prediction_stride(interval):
+    _check_wide("cuda", True, interval)
