@@ -30,7 +30,7 @@ class EnvConfig(C.Structure):
         ("end_goal_changing", C.c_int32), ("sort_humans", C.c_int32), ("phase", C.c_int32),
         ("nenv", C.c_int32), ("val_size", C.c_uint32), ("test_size", C.c_uint32), ("robot_policy", C.c_int32),
         ("robot_visible", C.c_int32), ("auto_reset", C.c_int32), ("predict_truth", C.c_int32), ("max_placement_attempts", C.c_int32),
-        ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("humans_policy", C.c_int32), ("reserved0", C.c_int32),
+        ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("humans_policy", C.c_int32), ("pred_interval", C.c_int32),
         ("time_step", C.c_double), ("time_limit", C.c_double),
         ("success_reward", C.c_double), ("collision_penalty", C.c_double),
         ("discomfort_dist", C.c_double), ("discomfort_penalty_factor", C.c_double),

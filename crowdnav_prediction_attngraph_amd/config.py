@@ -84,8 +84,11 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
     if phase not in ("train", "val", "test") or (phase == "val" and env_name != "CrowdSimPred-v0"):
         unsupported.append("phase=%r (phase 'val' only runs in CrowdSimPred-v0: the other env classes fail at crowd_sim_var_num.py:501, "
                            "self.human_future_traj is only assigned in their test phase)" % phase)
-    if float(g("env", "time_step", 0.25)) != float(g("data", "pred_timestep", 0.25)):
-        unsupported.append("data.pred_timestep != env.time_step")
+    # prediction stride (crowd_sim.py:180): 0 makes the reference slice with step 0 (ValueError at its first 'truth' roll-out); above 16 the
+    # device's roll-out buffer is not sized for it
+    pred_interval = int(float(g("data", "pred_timestep", 0.25)) // float(g("env", "time_step", 0.25)))
+    if not 1 <= pred_interval <= 16:
+        unsupported.append("int(data.pred_timestep // env.time_step) = %d outside [1, 16]" % pred_interval)
     if unsupported:
         raise NotImplementedError("not implemented on the device path yet: " + "; ".join(unsupported))
     return A.default_env_config(
@@ -94,7 +97,7 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         random_goal_changing=int(bool(g("humans", "random_goal_changing", True))),
         end_goal_changing=int(bool(g("humans", "end_goal_changing", True))),
         sort_humans=int(bool(getattr(getattr(config, "args", None), "sort_humans", True))),
-        predict_truth=int(env_name == "CrowdSimPred-v0" and pm == "truth"),
+        predict_truth=int(env_name == "CrowdSimPred-v0" and pm == "truth"), pred_interval=pred_interval,
         phase={"train": 0, "val": 1, "test": 2}[phase], nenv=int(nenv_total), robot_policy={"orca": 1, "social_force": 2}.get(rp, 0), humans_policy=int(hp == "social_force"),
         sf_A=float(g("sf", "A", 2.)), sf_B=float(g("sf", "B", 1.)), sf_KI=float(g("sf", "KI", 1.)), robot_fov=rfov, human_fov=hfov, robot_visible=int(rv), val_size=int(g("env", "val_size", 100)), test_size=int(g("env", "test_size", 500)),
         time_step=float(g("env", "time_step", 0.25)), time_limit=float(g("env", "time_limit", 50)),

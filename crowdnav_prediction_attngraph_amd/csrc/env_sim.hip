@@ -35,6 +35,7 @@ struct Lp3Hdr { int32_t agent, nn, line_fail; float rx, ry, radius; };
 struct EnvDev {
     cn_env_config cfg;
     int E, H, D, P;
+    int I, R;          // pred_interval (crowd_sim.py:180) and the 'truth' roll count R = P * I (buffer_len, :181); slice k * I of `tr` is prediction k
     int64_t seed_base; // thisSeed of env 0 of this batch
     // humans [E][8][H] double: px,py,vx,vy,gx,gy,radius,v_pref
     double *hum;
@@ -70,7 +71,7 @@ struct EnvDev {
     uint8_t *rob_sim_valid; // [E]
     float *rob_nd;          // [E]   neighbour distance frozen at creation
     float *rob_seen;        // [E][H] believed radii (+0.01 + safety space) frozen at creation
-    double *tr;       // [E][P+1][4][H] px,py,vx,vy; slice 0 unused (k = 1 reads the live state)
+    double *tr;       // [E][R+1][4][H] px,py,vx,vy of roll k = 0..R; slice 0 unused (k = 1 reads the live state)
     uint8_t *vis;     // [E][H]
     double *min_dist; // [E]
     uint8_t *pend;    // [E] predict_truth only: 1 = the env was reset by the first half of the step (observation still to be written)
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(256) void orca_truth_kernel(EnvDev s, int k)
     const int n = crowd_size(s, e);
     if (i >= n) return;
     const double *hum = s.hum + (size_t)e * 8 * H;
-    double *trk = s.tr + ((size_t)e * (s.P + 1) + k) * 4 * H;
+    double *trk = s.tr + ((size_t)e * (s.R + 1) + k) * 4 * H;
     const double *src = k == 1 ? hum : trk - 4 * H; // F_PX..F_VY are fields 0..3: the live state has the same [4][H] layout
     const bool isH = lane < n;
     const int lj = isH ? lane : 0;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64) void sf_truth_kernel(EnvDev s)
     const int lj = isH ? lane : 0;
     double px = hum[F_PX * H + lj], py = hum[F_PY * H + lj], vx = hum[F_VX * H + lj], vy = hum[F_VY * H + lj];
     const double rad = hum[F_RAD * H + lj], gx = hum[F_GX * H + lj], gy = hum[F_GY * H + lj], vpref = hum[F_VPREF * H + lj];
-    for (int k = 1; k <= s.P; ++k) {
+    for (int k = 1; k <= s.R; ++k) {
         const double dxg = gx - px, dyg = gy - py;
         const double dist_to_goal = sqrt(dxg * dxg + dyg * dyg);
         const double desired_vx = (dxg / dist_to_goal) * vpref, desired_vy = (dyg / dist_to_goal) * vpref;
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(64) void sf_truth_kernel(EnvDev s)
         // one_step_lookahead, agent.py:185-192 (every lane has read the old states: the shuffles above precede these writes)
         px = px + ax * c.time_step; py = py + ay * c.time_step; vx = ax; vy = ay;
         if (isH) {
-            double *trk = s.tr + ((size_t)e * (s.P + 1) + k) * 4 * H;
+            double *trk = s.tr + ((size_t)e * (s.R + 1) + k) * 4 * H;
             trk[0 * H + lane] = px; trk[1 * H + lane] = py; trk[2 * H + lane] = vx; trk[3 * H + lane] = vy;
         }
     }
@@ -1147,16 +1148,16 @@ __device__ __forceinline__ void write_obs(const EnvDev &s, int e, int lane, int 
             se[1] = vis ? (float)ey : 15.0f;
         } else {
             double *ft = s.ftraj ? s.ftraj + (size_t)e * P * 2 * H : nullptr;
-            const double *tre = c.predict_truth ? s.tr + (size_t)e * (P + 1) * 4 * H : nullptr;
+            const double *tre = c.predict_truth ? s.tr + (size_t)e * (s.R + 1) * 4 * H : nullptr;
             for (int k = 0; k <= P; ++k) {
                 double fx = 15.0, fy = 15.0;
                 if (vis && tre && k >= 1) {
                     // sim.predict_method = 'truth' (crowd_sim_pred.py:81 -> crowd_sim_var_num.py:180-206): the humans' own ORCA rolled
                     // forward from the state just reached, computed by orca_truth_kernel between the two halves of the step
-                    fx = tre[(k * 4 + 0) * H + lane];
-                    fy = tre[(k * 4 + 1) * H + lane];
+                    fx = tre[(k * s.I * 4 + 0) * H + lane]; // human_future_traj[::pred_interval] (crowd_sim_var_num.py:206)
+                    fy = tre[(k * s.I * 4 + 1) * H + lane];
                 } else if (vis) {
-                    const double t = (double)k * c.time_step * 1.0; // pred_interval == 1 (config.py:130-131)
+                    const double t = (double)k * c.time_step * (double)s.I; // arange(P + 1) * time_step * pred_interval (crowd_sim_var_num.py:212)
                     fx = h.px + t * prev_vx;
                     fy = h.py + t * prev_vy;
                 }
@@ -1572,12 +1573,12 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *act
     bool danger_cond = dmin < c.discomfort_dist;
     double min_danger = 0.0, rf_truth = 0.0;
     if (test_phase) {
-        const double *tre = s.tr + (size_t)e * (s.P + 1) * 4 * H;
+        const double *tre = s.tr + (size_t)e * (s.R + 1) * 4 * H;
         const bool seen = isH && s.vis[(size_t)e * H + lane];
         double best = INFINITY;
         for (int k = 1; k <= s.P; ++k) {
             if (isH) {
-                const double fx = (seen ? tre[(k * 4 + 0) * H + lane] : 15.0) - rb.px, fy = (seen ? tre[(k * 4 + 1) * H + lane] : 15.0) - rb.py;
+                const double fx = (seen ? tre[(k * s.I * 4 + 0) * H + lane] : 15.0) - rb.px, fy = (seen ? tre[(k * s.I * 4 + 1) * H + lane] : 15.0) - rb.py;
                 const double d = sqrt(fx * fx + fy * fy);
                 if (d < c.robot_radius + c.human_radius) {
                     best = fmin(best, d);
@@ -1807,7 +1808,7 @@ static int truth_rollout(cn_env_batch *env, hipStream_t st)
         return CN_OK;
     }
     const int agents = env->d.E * env->d.H;
-    for (int k = 1; k <= env->d.P; ++k) { // roll k needs all of roll k - 1 of the same env: one launch per roll
+    for (int k = 1; k <= env->d.R; ++k) { // roll k needs all of roll k - 1 of the same env: one launch per roll (R = predict_steps * pred_interval)
         hipLaunchKernelGGL(orca_truth_kernel, dim3((agents + 3) / 4), dim3(256), 0, st, env->d, k);
         CN_CHECK_LAUNCH();
     }
@@ -1921,6 +1922,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     CN_REQUIRE(cfg->humans_policy == CN_HUMANS_ORCA || cfg->humans_policy == CN_HUMANS_SOCIAL_FORCE, "cn_env_create: unknown humans_policy %d", cfg->humans_policy);
     CN_REQUIRE(cfg->robot_fov > 0.0 && cfg->human_fov > 0.0, "cn_env_create: robot_fov / human_fov are in units of pi and must be positive (2 = all round)");
     CN_REQUIRE(cfg->predict_steps >= 1 && cfg->predict_steps <= CN_MAX_PRED, "cn_env_create: predict_steps must be in [1,%d]", CN_MAX_PRED);
+    CN_REQUIRE(cfg->pred_interval >= 0 && cfg->pred_interval <= 16, "cn_env_create: pred_interval must be in [0,16] (0 = 1)");
     CN_REQUIRE(cfg->env_kind >= CN_ENV_VARNUM && cfg->env_kind <= CN_ENV_COLLECT, "cn_env_create: unknown env_kind %d", cfg->env_kind);
     CN_REQUIRE(cfg->env_kind != CN_ENV_COLLECT || (cfg->human_num_range == 0 && cfg->kinematics == CN_KIN_HOLONOMIC && cfg->phase == CN_PHASE_TRAIN &&
                                                    cfg->robot_policy == CN_ROBOT_ORCA && !cfg->predict_truth),
@@ -1945,6 +1947,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     EnvDev &d = b->d;
     d.cfg = *cfg;
     d.E = num_envs; d.H = HM; d.D = cn_env_obs_width(cfg); d.P = cfg->predict_steps;
+    d.I = cfg->pred_interval > 1 ? cfg->pred_interval : 1; d.R = d.P * d.I;
     d.seed_base = seed + first_env_index;
     const size_t E = num_envs, H = HM;
     // one allocation, carved (all sub-buffers 256-byte aligned)
@@ -1962,7 +1965,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const bool truth_obs = cfg->predict_truth != 0;
     const bool rob_orca = cfg->robot_policy == CN_ROBOT_ORCA;
     const size_t o_rsv = rob_orca ? carve(E) : 0, o_rnd = rob_orca ? carve(E * 4) : 0, o_rsn = rob_orca ? carve(E * H * 4) : 0;
-    const size_t o_tr = (test_phase || truth_obs) ? carve(E * (d.P + 1) * 4 * H * 8) : 0, o_vis = (test_phase || truth_obs) ? carve(E * H) : 0, o_md = carve(E * 8);
+    const size_t o_tr = (test_phase || truth_obs) ? carve(E * (d.R + 1) * 4 * H * 8) : 0, o_vis = (test_phase || truth_obs) ? carve(E * H) : 0, o_md = carve(E * 8);
     const size_t o_pend = carve(E);
     const bool unicycle = cfg->kinematics == CN_KIN_UNICYCLE;
     const bool var_n = cfg->human_num_range > 0 || unicycle; // a unicycle episode holds randint(1, H + 1) humans

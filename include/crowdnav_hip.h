@@ -102,7 +102,9 @@ typedef struct {
     int32_t kinematics;           /* CN_KIN_* (action_space.kinematics); unicycle: network-driven robot; in CrowdSimPred-v0 / PredRealGST-v0 the command
                                    * passes through smooth_action's noisy wheel model (crowd_sim.py:315-358) */
     int32_t humans_policy;        /* CN_HUMANS_* (humans.policy) */
-    int32_t reserved0;
+    int32_t pred_interval;        /* int(data.pred_timestep // env.time_step) (crowd_sim.py:180-181): prediction k lies k * pred_interval simulation steps
+                                   * ahead -- const_vel offsets (crowd_sim_var_num.py:212); 'truth': predict_steps * pred_interval rolls of which every
+                                   * pred_interval-th is kept (:181, :206).  0 = 1 (every shipped config); at most 16 */
     double time_step, time_limit;
     double success_reward, collision_penalty, discomfort_dist, discomfort_penalty_factor;
     double circle_radius, arena_size;

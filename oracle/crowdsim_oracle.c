@@ -407,6 +407,7 @@ void orc_config_default(OrcConfig *c)
     c->orca_neighbor_dist = 10.0; c->orca_safety_space = 0.15; c->orca_time_horizon = 5.0;
     c->orca_time_horizon_obst = 5.0;
     c->robot_fov = 2.0; c->human_fov = 2.0;
+    c->pred_interval = 1;
 }
 
 int orc_obs_width(const OrcConfig *cfg)
@@ -604,7 +605,7 @@ static void write_obs(OrcEnv *e, OrcObs *obs, int reset)
         for (int k = 0; k <= P && !c->predict_truth; ++k)
             for (int i = 0; i < H; ++i) {
                 if (e->human_visibility[i]) {
-                    const double t = (double)k * c->time_step * 1.0;
+                    const double t = (double)k * c->time_step * (double)(c->pred_interval > 1 ? c->pred_interval : 1); /* :212 */
                     e->future_traj[k][i][0] = e->humans[i].px + t * prev_vel[i][0];
                     e->future_traj[k][i][1] = e->humans[i].py + t * prev_vel[i][1];
                 } else {
@@ -818,7 +819,7 @@ static void human_sf_action(const OrcEnv *e, int i, double *avx, double *avy)
 static void truth_future_traj(OrcEnv *e)
 {
     const OrcConfig *c = &e->cfg;
-    const int H = e->n_humans, P = c->predict_steps;
+    const int H = e->n_humans, I = c->pred_interval > 1 ? c->pred_interval : 1, P = c->predict_steps * I; /* buffer_len rolls (crowd_sim.py:181) */
     double cur[ORC_MAX_HUMANS][4], nxt[ORC_MAX_HUMANS][4];
     for (int i = 0; i < H; ++i) {
         cur[i][0] = e->humans[i].px; cur[i][1] = e->humans[i].py; cur[i][2] = e->humans[i].vx; cur[i][3] = e->humans[i].vy;
@@ -873,12 +874,12 @@ static void truth_future_traj(OrcEnv *e)
         }
         for (int i = 0; i < H; ++i) {
             for (int q = 0; q < 4; ++q) cur[i][q] = nxt[i][q];
-            e->future_traj[k][i][0] = cur[i][0]; e->future_traj[k][i][1] = cur[i][1];
+            if (k % I == 0) { e->future_traj[k / I][i][0] = cur[i][0]; e->future_traj[k / I][i][1] = cur[i][1]; } /* [::pred_interval], :206 */
         }
     }
     for (int i = 0; i < H; ++i)
         if (!e->human_visibility[i])
-            for (int k = 0; k <= P; ++k) { e->future_traj[k][i][0] = 15.0; e->future_traj[k][i][1] = 15.0; }
+            for (int k = 0; k <= c->predict_steps; ++k) { e->future_traj[k][i][0] = 15.0; e->future_traj[k][i][1] = 15.0; }
 }
 
 /* crowd_sim.py:415-450 (every human, goal_change_chance) and :453-485 (update_human_goal: one human, end_goal_change_chance;

@@ -106,6 +106,10 @@ typedef struct {
     int32_t predict_truth;        /* CrowdSimPred-v0 only: config.sim.predict_method == 'truth' -- the observation carries the humans' true
                                      future positions (their own ORCA rolled forward) instead of the constant-velocity ones */
     double robot_fov, human_fov;  /* config.robot.FOV, config.humans.FOV in units of pi (crowd_sim.py:122-123); 2 = all round (the default) */
+    int32_t pred_interval;        /* int(config.data.pred_timestep // config.env.time_step) (crowd_sim.py:180): prediction k lies k * pred_interval
+                                     simulation steps ahead -- const_vel: crowd_sim_var_num.py:212; 'truth': predict_steps * pred_interval rolls, every
+                                     pred_interval-th kept (:181, :206).  0 is read as 1 (every shipped config) */
+    int32_t pad0;
 } OrcConfig;
 
 typedef struct {

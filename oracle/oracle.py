@@ -45,6 +45,7 @@ class OrcConfig(C.Structure):
         ("sf_A", C.c_double), ("sf_B", C.c_double), ("sf_KI", C.c_double),
         ("humans_policy", C.c_int32), ("human_num_range", C.c_int32), ("kinematics", C.c_int32), ("predict_truth", C.c_int32),
         ("robot_fov", C.c_double), ("human_fov", C.c_double),
+        ("pred_interval", C.c_int32), ("pad0", C.c_int32),
     ]
 
 

@@ -281,6 +281,15 @@ def env_goldens():
     trace("CrowdSimVarNum-v0", dict(RAND, **{"sim.human_num": 8, "robot.FOV": 1.0, "humans.FOV": 1.0, "robot.visible": True}), 425, 0, 1, 300,
           "varnum_h8_rand_fov_robotvisible_test_r0")
 
+    # ---- round 4: data.pred_timestep = 2 x env.time_step (pred_interval 2, crowd_sim.py:180-181): const_vel predictions lie 0.5 s apart
+    # (crowd_sim_var_num.py:212), 'truth' rolls the humans predict_steps * 2 times and keeps every second state (:181, :206)
+    S2 = {"data.pred_timestep": 0.5}
+    trace("CrowdSimPred-v0", dict(NON_RAND, **dict(S2, **{"sim.human_num": 12, "sim.predict_method": "const_vel"})), 425, 1, 4, 260, "pred_h12_constvel_stride2_r1")
+    trace("CrowdSimPred-v0", dict(RAND, **dict(S2, **{"sim.human_num": 9, "sim.predict_method": "truth"})), 425, 0, 4, 240, "pred_h9_rand_truthobs_stride2_r0")
+    trace("CrowdSimVarNum-v0", dict(NON_RAND, **dict(S2, **{"sim.human_num": 10})), 425, 0, 1, 260, "varnum_h10_stride2_test_r0")
+    trace("CrowdSimPred-v0", dict(NON_RAND, **dict(S2, **{"sim.human_num": 8, "sim.predict_method": "const_vel", "humans.policy": "social_force"})), 425, 0, 1, 240,
+          "pred_h8_sfhumans_constvel_stride2_test_r0")
+    trace("CrowdSimPredRealGST-v0", dict(RAND, **dict(S2, **{"sim.human_num": 8, "sim.predict_method": "inferred"})), 425, 0, 1, 200, "predgst_h8_rand_stride2_test_r0")
 
 
 if __name__ == "__main__":

@@ -43,6 +43,8 @@ def sim_kwargs(meta, oracle=False):
         extra["human_fov"] = float(over["humans.FOV"])
     if "env.val_size" in over:
         extra["val_size"] = int(over["env.val_size"])
+    if "data.pred_timestep" in over:      # crowd_sim.py:180 (env.time_step is 0.25 in every trace)
+        extra["pred_interval"] = int(float(over["data.pred_timestep"]) // 0.25)
     return dict(extra,
         human_num=int(over.get("sim.human_num", 20)),
         env_kind=ENV_KIND[meta["env_name"]],

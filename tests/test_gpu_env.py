@@ -123,6 +123,14 @@ CASES = {
     "varnum_h3_range2_unicycle_fov": dict(human_num=3, human_num_range=2, kinematics=1, robot_fov=1.0, human_fov=1.0),
     "varnum_h8_rand_fov_robotvisible_test": dict(human_num=8, robot_fov=1.0, human_fov=1.0, robot_visible=1, phase=2, randomize_attributes=1, random_goal_changing=1),
     "pred_h6_rand_unicycle_truthobs": dict(human_num=6, env_kind=1, kinematics=1, predict_truth=1, randomize_attributes=1, random_goal_changing=1),
+    # round 4: data.pred_timestep = pred_interval x env.time_step (crowd_sim.py:180-181): const_vel offsets scale (crowd_sim_var_num.py:212), 'truth'
+    # rolls predict_steps * pred_interval times and keeps every pred_interval-th state (:181, :206)
+    "pred_h12_constvel_stride2": dict(human_num=12, env_kind=1, pred_interval=2),
+    "pred_h9_rand_truthobs_stride2": dict(human_num=9, env_kind=1, predict_truth=1, pred_interval=2, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h10_stride3_test": dict(human_num=10, phase=2, pred_interval=3),
+    "pred_h8_sfhumans_truthobs_stride2_test": dict(human_num=8, env_kind=1, predict_truth=1, humans_policy=1, pred_interval=2, phase=2),
+    "predgst_h8_rand_robotvisible_stride2_test": dict(human_num=8, env_kind=2, robot_visible=1, pred_interval=2, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "pred_h10_constvel_stride4_val": dict(human_num=10, env_kind=1, phase=1, pred_interval=4),
 }
 
 
