@@ -134,6 +134,10 @@ def main():
                     help="the dominant kernel is timed live with a pair of HIP events on its stream around every n-th launch of the timed "
                          "window (0 = every launch when --steps <= 64, else every 4th: an event record on the critical stream costs a few "
                          "microseconds of dispatch gap).  Every launch is ALSO timed by the kernel's own device-clock stamps, which cost nothing")
+    ap.add_argument("--tail", choices=["deferred", "inline"], default="deferred",
+                    help="where a sim step's side-stream tail (ORCA fallback programs + episode pre-generation) is enqueued: 'deferred' = right "
+                         "behind the policy's human-human kernel (cn_env_set_tail_deferral + cn_policy_set_post_hh_hook), 'inline' = by the sim step itself")
+    ap.add_argument("--pregen-budget-us", type=float, default=None, help="time budget of one launch of the episode pre-generation kernel (library default 55)")
     ap.add_argument("--timeline-out", default=None, help="write the stamped timeline of the decomposition window (all kernels of 24 steps) to this file")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
@@ -191,6 +195,11 @@ def main():
     pol = HipPolicy(H, D, E)
     pol.set_gemm_mode(args.gemm)
     pol.set_weights(net.state_dict())
+    if args.tail == "deferred":
+        env.set_tail_deferral(True)
+        pol.attach_env_tail(env)
+    if args.pregen_budget_us is not None:
+        env.set_pregen_budget(int(args.pregen_budget_us * 100))
     obs = env.reset()
     gst = None
     if args.env_name == "CrowdSimPredRealGST-v0":
@@ -349,6 +358,7 @@ def main():
     # reference's train.py loop (rl/ppo.py defaults: T = 30, 5 epochs x 2 recurrent minibatches); every rank runs it,
     # gradients are all-reduced once per optimiser step (one flat bucket), time = max over ranks of the last update
     ppo = None
+    pol.attach_env_tail(None)
     if not args.no_ppo and args.env_name != "CrowdSimPredRealGST-v0":
         del env, pol, net
         torch.cuda.empty_cache()
@@ -443,7 +453,7 @@ def main():
                                "policy forward + ORCA sim step + auto-reset per step" % (
                                    "BASELINE configs[1]: " if (args.env_name, H, E, args.randomized) == ("CrowdSimVarNum-v0", 20, 4096, False) else ("randomized humans, " if args.randomized else ""), args.env_name, H, E),
                    "envs_per_gpu": E, "humans": H, "parallelism": "dp%d (envs sharded, no rollout collective)" % world,
-                   "policy_init": "orthogonal, torch.manual_seed(425)", "sampled_actions": True},
+                   "policy_init": "orthogonal, torch.manual_seed(425)", "sampled_actions": True, "side_stream_tail": args.tail},
         "roofline": {"bound": "mfma", "kernel": "%s, M=%d live rows of %d%s" % (kname, M, E * H, "" if fused else ", N=1536 K=512"),
                      "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,

@@ -107,7 +107,7 @@ class PolicyWeights(C.Structure):
 # every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
-    "cn_env_obs_width", "cn_row_plan_words", "cn_env_set_pregen_budget", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
+    "cn_env_obs_width", "cn_row_plan_words", "cn_env_set_pregen_budget", "cn_env_set_tail_deferral", "cn_env_launch_tail", "cn_policy_set_post_hh_hook", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile",
     "cn_policy_get_profile_samples", "cn_policy_reset_profile", "cn_prof_set_stamps", "cn_prof_next_step", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
@@ -141,6 +141,9 @@ def lib():
         L.cn_env_step.argtypes = [vp, vp, C.POINTER(Obs), vp, vp, vp, vp, vp, vp, vp]
         L.cn_env_join.argtypes = [vp, vp]
         L.cn_env_set_pregen_budget.argtypes = [vp, C.c_int64]
+        L.cn_env_set_tail_deferral.argtypes = [vp, i32]
+        L.cn_env_launch_tail.argtypes = [vp, vp]
+        L.cn_policy_set_post_hh_hook.argtypes = [vp, vp, vp]
         L.cn_row_plan_words.restype = C.c_int64
         L.cn_row_plan_words.argtypes = [C.c_int]
         L.cn_env_get_state.argtypes = [vp, vp, vp, vp]

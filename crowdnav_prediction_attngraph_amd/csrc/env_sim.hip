@@ -1797,6 +1797,9 @@ struct cn_env_batch {
     bool orca_ready; // hact for the current state has been enqueued on `side`
     long long pregen_ticks; // time budget of one env_pregen_kernel launch (prefetch_orca)
     bool plan_ok;      // this configuration's step builds the row plan (lane kernel, crowds of <= 48: what the consumer takes)
+    // the side-stream "tail" of a step (episode pre-generation + the infeasible third of the ORCA programs): launched by the step itself,
+    // or -- cn_env_set_tail_deferral -- held back until the caller says that its big kernel is enqueued (cn_env_launch_tail)
+    bool defer_tail, tail_pending;
 };
 
 // calc_human_future_traj(method='truth'): P rolls of every human with its own policy
@@ -1825,45 +1828,35 @@ static int truth_rollout_and_obs(cn_env_batch *env, const cn_obs *obs, hipStream
     return CN_OK;
 }
 
-static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
+static bool lane_path_of(const cn_env_batch *env)
 {
-    const float *plan_det = obs ? obs->detected_human_num : nullptr;
-    int32_t *row_plan = obs ? obs->row_plan : nullptr;
-    const int agents = env->d.E * env->d.H;
     const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0); // candidate neighbours per agent (self included)
     static int coop = -1; // CN_ORCA_COOP=1 forces the one-wavefront-per-agent kernel (A/B measurements)
     if (coop < 0) { const char *v = getenv("CN_ORCA_COOP"); coop = v ? atoi(v) : 0; }
     // (a narrowed human field of view goes through the cooperative kernel: the lane kernel has no visibility test in its inner loops)
-    const bool lane_path = env->d.cfg.humans_policy == CN_HUMANS_ORCA && slots <= 32 && !coop && env->d.cfg.human_fov >= 2.0;
-    // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial
-    // fp64 work per such env).  It only depends on the step that just ran, needs a little LDS, and is light: it runs beside the lane
-    // kernel, before the policy kernels take the whole LDS of every CU
-    CN_HIP(hipEventRecord(env->ev_pre, main));
-    CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
-    // Budget (ticks of 10 ns; cn_env_set_pregen_budget): the lane kernel below takes ~50 us at 4096 envs x 20 humans and the policy comes
-    // right behind it.  55 us cuts the long tail of the rejection sampling (up to 150 us) and still lets the usual 60-odd new episodes of
-    // a step finish in one go.  Measured inside one box, human-human kernel of the policy: unbounded 0.138-0.139 ms, 65 us 0.139,
-    // 55 us 0.133, 45 us 0.135, 30 us 0.161 -- shorter is NOT better: the ORCA tail kernel is queued behind this one, and when it starts
-    // before the policy's kernel has its workgroups on the CUs, that kernel waits for them.
+    return env->d.cfg.humans_policy == CN_HUMANS_ORCA && slots <= 32 && !coop && env->d.cfg.human_fov >= 2.0;
+}
+
+// refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial fp64
+// work per such env).  It only depends on the step that just ran; nothing needs it before those envs finish their NEXT episode.
+// Budget (ticks of 10 ns; cn_env_set_pregen_budget): see cn_env_set_pregen_budget in the header.
+static int launch_pregen(cn_env_batch *env)
+{
     hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
     CN_CHECK_LAUNCH();
-    if (lane_path) {
-        // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
-        // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
-        int32_t *plan = (plan_det && env->plan_ok && ((uintptr_t)plan_det & 15u) == 0) ? row_plan : nullptr;
-        if (plan) row_plan = nullptr; // built below
-        const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
-        const EnvDev dl = stamped(env->d, CN_K_ORCA_LANE);
-        unsigned long long *pst = cn_stamp_slot(CN_K_ROW_PLAN);
-        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        CN_CHECK_LAUNCH();
-    }
-    // a caller's plan buffer that this step does not fill must not keep the previous observation's plan
-    if (row_plan) CN_HIP(hipMemsetAsync(row_plan, 0, 4, main));
+    return CN_OK;
+}
+
+// The side-stream tail of the ORCA pass for the state the caller's stream has reached at this point: whatever the lane kernel could not
+// finish (the infeasible programs -> linearProgram3), or the whole pass for configurations without a lane kernel; the 'truth' roll-outs of
+// the test phase; and, in deferred mode, the episode pre-generation.  Ends with ev_orca, which the next step / reader waits for.
+static int launch_tail(cn_env_batch *env, hipStream_t main)
+{
+    const int agents = env->d.E * env->d.H;
+    const bool lane_path = lane_path_of(env);
     CN_HIP(hipEventRecord(env->ev_state, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
+    if (env->defer_tail && lane_path) { if (int rc = launch_pregen(env)) return rc; }
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
         if (lane_path) {
             // the infeasible programs are finished by the cooperative routine on the side stream, next to the policy forward.
@@ -1882,7 +1875,54 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
         if (int rc = truth_rollout(env, env->side)) return rc;
     CN_HIP(hipEventRecord(env->ev_orca, env->side));
     env->orca_ready = true;
+    env->tail_pending = false;
     return CN_OK;
+}
+
+// everything the library has in flight (or holds back) for the current state is ordered before what `st` gets next
+static int sync_side(cn_env_batch *env, hipStream_t st)
+{
+    if (env->tail_pending) { if (int rc = launch_tail(env, st)) return rc; }
+    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0));
+    return CN_OK;
+}
+
+static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
+{
+    const float *plan_det = obs ? obs->detected_human_num : nullptr;
+    int32_t *row_plan = obs ? obs->row_plan : nullptr;
+    const int agents = env->d.E * env->d.H;
+    const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0);
+    const bool lane_path = lane_path_of(env);
+    const bool defer = env->defer_tail && lane_path;
+    if (!defer) {
+        // beside the lane kernel, before the policy kernels take the whole LDS of every CU.  Budget: the lane kernel below takes ~50 us at
+        // 4096 envs x 20 humans and the policy comes right behind it.  55 us cuts the long tail of the rejection sampling (up to 150 us)
+        // and still lets the usual 60-odd new episodes of a step finish in one go.  Measured inside one box, human-human kernel of the
+        // policy: unbounded 0.138-0.139 ms, 65 us 0.139, 55 us 0.133, 45 us 0.135, 30 us 0.161 -- shorter is NOT better in this mode: the
+        // ORCA tail kernel is queued behind this one, and when it starts before the policy's kernel has its workgroups on the CUs, that
+        // kernel waits for them (the deferred mode removes exactly this coupling)
+        CN_HIP(hipEventRecord(env->ev_pre, main));
+        CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
+        if (int rc = launch_pregen(env)) return rc;
+    }
+    if (lane_path) {
+        // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
+        // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
+        int32_t *plan = (plan_det && env->plan_ok && ((uintptr_t)plan_det & 15u) == 0) ? row_plan : nullptr;
+        if (plan) row_plan = nullptr; // built below
+        const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
+        const EnvDev dl = stamped(env->d, CN_K_ORCA_LANE);
+        unsigned long long *pst = cn_stamp_slot(CN_K_ROW_PLAN);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        CN_CHECK_LAUNCH();
+    }
+    // a caller's plan buffer that this step does not fill must not keep the previous observation's plan
+    if (row_plan) CN_HIP(hipMemsetAsync(row_plan, 0, 4, main));
+    if (defer) { env->tail_pending = true; env->orca_ready = false; return CN_OK; } // cn_env_launch_tail, or the next call into this batch
+    return launch_tail(env, main);
 }
 
 extern "C" void cn_env_config_default(cn_env_config *c)
@@ -2066,7 +2106,7 @@ extern "C" int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream)
     if (int rc = check_obs(obs)) return rc;
     hipStream_t st = (hipStream_t)stream;
     // VecEnv.reset() resets every env; case counters keep running (crowd_sim_var_num.py:348)
-    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // an in-flight prefetch reads the old state
+    if (int rc = sync_side(env, st)) return rc; // an in-flight prefetch reads the old state
     const bool split = env->d.cfg.predict_truth != 0;
     hipLaunchKernelGGL(env_reset_kernel, dim3(env->d.E), dim3(64), 0, st, env->d, *obs, split ? 0 : 1);
     CN_CHECK_LAUNCH();
@@ -2083,8 +2123,8 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
     if (int rc = check_obs(obs)) return rc;
     CN_REQUIRE(actions && reward && done && info && ep_return && ep_len, "cn_env_step: null output/input pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (!env->orca_ready) { if (int rc = prefetch_orca(env, st, nullptr)) return rc; }
-    CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // human velocities for the current state (computed on the side stream)
+    if (!env->orca_ready && !env->tail_pending) { if (int rc = prefetch_orca(env, st, nullptr)) return rc; }
+    if (int rc = sync_side(env, st)) return rc; // human velocities for the current state (computed on the side stream; a held-back tail goes out now)
     if (env->d.cfg.predict_truth) {
         hipLaunchKernelGGL(env_step_kernel<true>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         CN_CHECK_LAUNCH();
@@ -2099,14 +2139,13 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
 extern "C" int cn_env_join(cn_env_batch *env, void *stream)
 {
     CN_REQUIRE(env, "cn_env_join: null handle");
-    if (env->orca_ready) CN_HIP(hipStreamWaitEvent((hipStream_t)stream, env->ev_orca, 0));
-    return CN_OK;
+    return sync_side(env, (hipStream_t)stream);
 }
 
 extern "C" int cn_env_get_state(cn_env_batch *env, double *humans, double *robot, void *stream)
 {
     CN_REQUIRE(env, "cn_env_get_state: null handle");
-    if (env->orca_ready) CN_HIP(hipStreamWaitEvent((hipStream_t)stream, env->ev_orca, 0)); // ORCA also (re)builds sim_* lazily
+    if (int rc = sync_side(env, (hipStream_t)stream)) return rc; // ORCA also (re)builds sim_* lazily
     const int n = env->d.E * env->d.H * 8;
     hipLaunchKernelGGL(export_state_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, humans, robot);
     CN_CHECK_LAUNCH();
@@ -2118,7 +2157,7 @@ extern "C" int cn_env_get_human_actions(cn_env_batch *env, float *out, void *str
     CN_REQUIRE(env && out, "cn_env_get_human_actions: null argument");
     // the velocities applied by the LAST step were overwritten by the prefetch for the next one: report the prefetched
     // ones (= the velocities the next step will apply), ordered behind the side stream
-    if (env->orca_ready) CN_HIP(hipStreamWaitEvent((hipStream_t)stream, env->ev_orca, 0));
+    if (int rc = sync_side(env, (hipStream_t)stream)) return rc;
     const int n = env->d.E * env->d.H * 2;
     hipLaunchKernelGGL(export_hact_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->d, out);
     CN_CHECK_LAUNCH();
@@ -2142,7 +2181,7 @@ extern "C" int cn_env_set_case_counters(cn_env_batch *env, const uint64_t *count
 {
     CN_REQUIRE(env && counters, "cn_env_set_case_counters: null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // the side stream may be pre-generating episodes
+    if (int rc = sync_side(env, st)) return rc; // the side stream may be pre-generating episodes
     CN_HIP(hipMemcpyAsync(env->d.case_counter, counters, (size_t)env->d.E * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     CN_HIP(hipMemsetAsync(env->d.nx_ready, 0, (size_t)env->d.E, st)); // staged episodes were generated for the old counters
     return CN_OK;
@@ -2171,7 +2210,7 @@ extern "C" int cn_env_save(cn_env_batch *env, void *dst, void *stream)
 {
     CN_REQUIRE(env && dst, "cn_env_save: null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0)); // the side stream owns hact / sim_* / nx_* until then
+    if (int rc = sync_side(env, st)) return rc; // the side stream owns hact / sim_* / nx_* until then
     SnapHeader h{};
     h.magic = SNAP_MAGIC; h.blob_bytes = env->blob_bytes; h.E = env->d.E; h.H = env->d.H; h.D = env->d.D; h.P = env->d.P;
     h.seed_base = env->d.seed_base; h.cfg = env->d.cfg; h.reset_done = env->reset_done ? 1 : 0;
@@ -2202,7 +2241,22 @@ extern "C" int cn_env_load(cn_env_batch *env, const void *src, void *stream)
     // the snapshot holds the prefetched velocities of its state, but the event that orders them is gone: recompute on demand
     // (orca_kernel / env_pregen_kernel are pure functions of the restored state, so the continuation is bit-identical)
     env->orca_ready = false;
+    env->tail_pending = false;
     return CN_OK;
+}
+
+extern "C" int cn_env_set_tail_deferral(cn_env_batch *env, int enabled)
+{
+    CN_REQUIRE(env, "cn_env_set_tail_deferral: null handle");
+    env->defer_tail = enabled != 0;
+    return CN_OK;
+}
+
+extern "C" int cn_env_launch_tail(cn_env_batch *env, void *stream)
+{
+    CN_REQUIRE(env, "cn_env_launch_tail: null handle");
+    if (!env->tail_pending) return CN_OK; // nothing held back (mode off, no step since, or already out)
+    return launch_tail(env, (hipStream_t)stream);
 }
 
 extern "C" int cn_env_get_danger_min_dist(cn_env_batch *env, double *out, void *stream)

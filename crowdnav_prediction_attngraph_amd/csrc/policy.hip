@@ -675,6 +675,9 @@ struct cn_policy {
     double prof_ms[8];
     int64_t prof_n[8];
     std::vector<float> prof_samples; // the harvested brackets one by one [ms], in launch order (cn_policy_get_profile_samples)
+    // called right behind the launch of the human-human kernel (cn_policy_set_post_hh_hook): side work that must not reach the CUs before it
+    int (*post_hh_hook)(void *arg, void *stream);
+    void *post_hh_arg;
 };
 
 // big-M GEMMs (rows = live humans): 128-row tiles
@@ -895,6 +898,7 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, obs->detected_human_num, p->row_off,
                                    p->profiling ? p->live_total : (unsigned long long *)nullptr, fw, p->out_sp, st, obs->row_plan))) return rc;
         if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
+        if (p->post_hh_hook) { if ((rc = p->post_hh_hook(p->post_hh_arg, (void *)st))) return rc; }
         RnFusedArgs ra{};
         ra.temporal = obs->temporal_edges; ra.robot_node = obs->robot_node; ra.hxs_in = hxs_in; ra.masks = masks; ra.eps = eps;
         ra.out_sp = p->out_sp; ra.row_off = p->row_off;
@@ -1007,6 +1011,13 @@ extern "C" int cn_policy_set_gemm_mode(cn_policy *p, int mode)
 {
     CN_REQUIRE(p && mode >= 0 && mode <= 2, "cn_policy_set_gemm_mode: mode must be 0 (fp32 MFMA), 1 (bf16x3 split, separate launches) or 2 (bf16x3 split, fused)");
     p->gemm_mode = mode;
+    return CN_OK;
+}
+
+extern "C" int cn_policy_set_post_hh_hook(cn_policy *p, int (*fn)(void *arg, void *stream), void *arg)
+{
+    CN_REQUIRE(p, "cn_policy_set_post_hh_hook: null handle");
+    p->post_hh_hook = fn; p->post_hh_arg = fn ? arg : nullptr;
     return CN_OK;
 }
 

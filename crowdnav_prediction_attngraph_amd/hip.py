@@ -94,6 +94,15 @@ class HipEnvBatch:
         return (h[8 * E:12 * E].view("float32"), h[16 * E:17 * E].view("bool"), h[17 * E:18 * E], h[0:8 * E].view("float64"),
                 h[12 * E:16 * E].view("int32"))
 
+    def set_tail_deferral(self, enabled):
+        """Hold the side-stream tail of every step (ORCA fallback programs + episode pre-generation) back until launch_tail() -- or until
+        HipPolicy.attach_env_tail(env) makes the policy release it right behind its human-human kernel (cn_env_set_tail_deferral)."""
+        A.check(A.lib().cn_env_set_tail_deferral(self._h, int(bool(enabled))), "cn_env_set_tail_deferral")
+
+    def launch_tail(self):
+        with torch.cuda.device(self.device):
+            A.check(A.lib().cn_env_launch_tail(self._h, A.stream_ptr()), "cn_env_launch_tail")
+
     def set_pregen_budget(self, ticks_10ns):
         """Time budget (x 10 ns) of one launch of the episode pre-generation kernel; the episodes do not depend on it (cn_env_set_pregen_budget)."""
         A.check(A.lib().cn_env_set_pregen_budget(self._h, int(ticks_10ns)), "cn_env_set_pregen_budget")
@@ -254,6 +263,17 @@ class HipPolicy:
     def set_profiling(self, every):
         """0 / False: off; n >= 1 (True = 1): every n-th forward's dominant kernel is timed with a pair of events on its stream."""
         A.check(A.lib().cn_policy_set_profiling(self._h, int(every)), "cn_policy_set_profiling")
+
+    def attach_env_tail(self, env):
+        """env: a HipEnvBatch in tail-deferral mode (or None to detach): every forward releases that batch's held-back side work right after
+        its human-human kernel is enqueued (cn_policy_set_post_hh_hook with cn_env_launch_tail).  Detach before closing the env."""
+        if env is None:
+            A.check(A.lib().cn_policy_set_post_hh_hook(self._h, None, None), "cn_policy_set_post_hh_hook")
+            self._tail_env = None
+            return
+        fn = C.cast(A.lib().cn_env_launch_tail, C.c_void_p)
+        A.check(A.lib().cn_policy_set_post_hh_hook(self._h, fn, env._h), "cn_policy_set_post_hh_hook")
+        self._tail_env = env          # keeps the batch alive as long as the hook points at it
 
     def get_profile(self):
         ms = (C.c_double * 8)()

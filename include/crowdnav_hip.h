@@ -156,6 +156,16 @@ int cn_env_obs_width(const cn_env_config *cfg);
  * step (default 5500 = 55 us): its wavefronts hold registers the policy's kernel, next on the caller's stream, needs.  The episodes do not
  * depend on the budget (0 = one human per launch); an env that resets before its next episode is complete generates it in place. */
 int cn_env_set_pregen_budget(cn_env_batch *env, int64_t ticks_10ns);
+/* Deferred tail.  A step leaves two pieces of work for its successor on the library's side stream: the ORCA programs the lane kernel could not
+ * finish (a third of them: the linearProgram3 fallback) and the pre-generation of the next episodes.  By default cn_env_step enqueues them itself,
+ * i.e. BEFORE whatever the caller enqueues next -- and when that is the policy's human-human kernel, which needs whole CUs, every wavefront of
+ * the tail that got a CU first holds one of its workgroups back.  With deferral on, cn_env_step holds the tail back (configurations with the lane
+ * kernel only) until cn_env_launch_tail(env, stream) -- to be called right after the big kernel went out on `stream`: the tail is ordered behind
+ * that point and then runs beside the robot-node kernel.  cn_policy_set_post_hh_hook makes cn_policy_act call it at exactly that place.  A tail
+ * nobody launched goes out with the next call that needs its results (cn_env_step, cn_env_reset, cn_env_save, the getters): results never depend
+ * on the mode, only the timeline does. */
+int cn_env_set_tail_deferral(cn_env_batch *env, int enabled);
+int cn_env_launch_tail(cn_env_batch *env, void *stream);
 /* int32 words of a cn_obs.row_plan buffer for a batch of num_envs envs */
 int64_t cn_row_plan_words(int num_envs);
 int cn_env_reset(cn_env_batch *env, const cn_obs *obs, void *stream);
@@ -245,6 +255,11 @@ int cn_policy_get_taps(cn_policy *p, int E, float *spatial_lin, float *hr_attn, 
 /* Fused mode (cn_policy_set_gemm_mode 2): the robot-node kernel writes the taps above only while they are enabled (default 1);
  * rollout loops switch them off (17 MB of stores per 4096-env forward that nothing reads). */
 int cn_policy_set_taps(cn_policy *p, int enabled);
+/* fn(arg, stream) is called by cn_policy_act / cn_policy_get_value (fused mode) right after the human-human kernel was enqueued on `stream` and
+ * before the robot-node kernel: the place for side work that must not reach the CUs before that kernel -- see cn_env_set_tail_deferral; pass
+ * fn = (int (*)(void *, void *))cn_env_launch_tail and arg = the env batch.  A non-zero return aborts the forward with that status.  fn = NULL
+ * removes the hook (do so before destroying what `arg` points to). */
+int cn_policy_set_post_hh_hook(cn_policy *p, int (*fn)(void *arg, void *stream), void *arg);
 /* Arithmetic of the three large human-human GEMMs (embedding_layer.2, folded q|k|v, folded out_proj∘spatial_linear):
  *   2 (default) = split precision (each fp32 operand as bf16 hi + lo, three bf16 MFMAs per term, fp32 accumulation; products
  *                 exact to ~2^-16 relative; outputs within 2e-5 of the fp32 path, bar 1e-4) with the whole human-human block as ONE

@@ -395,3 +395,48 @@ def test_stale_row_plan_is_refused_by_the_kernel():
         assert torch.allclose(a[k], b[k], atol=2e-5, rtol=0), k
     env.close()
     pol.close()
+
+
+@pytest.mark.parametrize("release", ["policy_hook", "next_step"])
+def test_deferred_side_stream_tail_changes_the_timeline_only(release):
+    """cn_env_set_tail_deferral: the sim step holds its side-stream tail (linearProgram3 programs + episode pre-generation) back until the
+    policy has enqueued its human-human kernel (cn_policy_set_post_hh_hook -> cn_env_launch_tail) -- or, with no hook, until the next
+    step needs the results.  Same kernels on the same data in both modes: 80 steps of the rollout loop must agree bit for bit with the
+    inline mode (observations, rewards, dones, the humans' ORCA velocities, policy outputs)."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch, HipPolicy
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    E, H = 1024, 20
+    torch.manual_seed(425)
+    ob_space, act_space = make_spaces(H, 2)
+    net = Policy(ob_space.spaces, act_space, base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=E), base="selfAttn_merge_srnn").cuda()
+    runs = []
+    for mode in ("inline", release):
+        env = HipEnvBatch(A.default_env_config(human_num=H, nenv=E, randomize_attributes=1, random_goal_changing=1), E, 425)
+        pol = HipPolicy(H, 2, E)
+        pol.set_weights(net.state_dict())
+        if mode != "inline":
+            env.set_tail_deferral(True)
+            if mode == "policy_hook":
+                pol.attach_env_tail(env)
+        obs = env.reset()
+        h, m = torch.zeros(E, 1, 128, device="cuda"), torch.ones(E, 1, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(9)
+        trace = []
+        for t in range(80):
+            eps = torch.randn(E, 2, device="cuda", generator=g)
+            a = pol.act(obs, h, m, eps=eps, row_plan=env.row_plan)
+            h = a["hxs"].clone()
+            obs, rew, done, info, _, _ = env.step(a["action"])
+            m = (done == 0).float().view(E, 1)
+            rec = [a["action"].clone(), a["value"].clone(), rew.clone(), done.clone(), info.clone()] + [obs[k].clone() for k in sorted(obs)]
+            if t % 10 == 9:
+                rec.append(env.get_human_actions())      # a reader in the middle: a held-back tail must go out for it
+            trace.append(rec)
+        pol.attach_env_tail(None)
+        env.close(); pol.close()
+        runs.append(trace)
+    for t, (ra, rb) in enumerate(zip(*runs)):
+        assert len(ra) == len(rb)
+        for i, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (release, t, i)
