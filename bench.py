@@ -134,9 +134,11 @@ def main():
                     help="the dominant kernel is timed live with a pair of HIP events on its stream around every n-th launch of the timed "
                          "window (0 = every launch when --steps <= 64, else every 4th: an event record on the critical stream costs a few "
                          "microseconds of dispatch gap).  Every launch is ALSO timed by the kernel's own device-clock stamps, which cost nothing")
-    ap.add_argument("--tail", choices=["deferred", "inline"], default="deferred",
-                    help="where a sim step's side-stream tail (ORCA fallback programs + episode pre-generation) is enqueued: 'deferred' = right "
-                         "behind the policy's human-human kernel (cn_env_set_tail_deferral + cn_policy_set_post_hh_hook), 'inline' = by the sim step itself")
+    ap.add_argument("--tail", choices=["deferred", "inline"], default="inline",
+                    help="where a sim step's side-stream tail (ORCA fallback programs + episode pre-generation) is enqueued: 'inline' = by the sim step "
+                         "itself (default, fastest: 0.287 ms per step), 'deferred' = right behind the policy's human-human kernel (cn_env_set_tail_deferral + "
+                         "cn_policy_set_post_hh_hook: every kernel runs undisturbed and 5-12 us shorter, but the cross-stream event that releases the "
+                         "tail costs 15-25 us and its chain ends after the robot-node kernel: 0.325-0.33 ms per step, profiles/HISTORY.md)")
     ap.add_argument("--pregen-budget-us", type=float, default=None, help="time budget of one launch of the episode pre-generation kernel (library default 55)")
     ap.add_argument("--timeline-out", default=None, help="write the stamped timeline of the decomposition window (all kernels of 24 steps) to this file")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")

@@ -1800,6 +1800,9 @@ struct cn_env_batch {
     // the side-stream "tail" of a step (episode pre-generation + the infeasible third of the ORCA programs): launched by the step itself,
     // or -- cn_env_set_tail_deferral -- held back until the caller says that its big kernel is enqueued (cn_env_launch_tail)
     bool defer_tail, tail_pending;
+    hipStream_t side2;   // deferred mode: the pre-generation runs beside the ORCA tail, not in front of it
+    hipEvent_t ev_pg;
+    bool pg_pending;     // ev_pg was recorded for work the next reader of the staging arrays has to wait for
 };
 
 // calc_human_future_traj(method='truth'): P rolls of every human with its own policy
@@ -1840,9 +1843,9 @@ static bool lane_path_of(const cn_env_batch *env)
 // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial fp64
 // work per such env).  It only depends on the step that just ran; nothing needs it before those envs finish their NEXT episode.
 // Budget (ticks of 10 ns; cn_env_set_pregen_budget): see cn_env_set_pregen_budget in the header.
-static int launch_pregen(cn_env_batch *env)
+static int launch_pregen(cn_env_batch *env, hipStream_t on)
 {
-    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, env->side, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
+    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1856,7 +1859,14 @@ static int launch_tail(cn_env_batch *env, hipStream_t main)
     const bool lane_path = lane_path_of(env);
     CN_HIP(hipEventRecord(env->ev_state, main));
     CN_HIP(hipStreamWaitEvent(env->side, env->ev_state, 0));
-    if (env->defer_tail && lane_path) { if (int rc = launch_pregen(env)) return rc; }
+    if (env->defer_tail && lane_path) {
+        // beside the ORCA tail and the caller's robot-node kernel, on a stream of its own (behind the tail on ONE stream the two chains add
+        // up to ~105 us and the next step waits for them: measured 0.36 ms per step instead of 0.28)
+        CN_HIP(hipStreamWaitEvent(env->side2, env->ev_state, 0));
+        if (int rc = launch_pregen(env, env->side2)) return rc;
+        CN_HIP(hipEventRecord(env->ev_pg, env->side2));
+        env->pg_pending = true;
+    }
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
         if (lane_path) {
             // the infeasible programs are finished by the cooperative routine on the side stream, next to the policy forward.
@@ -1884,6 +1894,7 @@ static int sync_side(cn_env_batch *env, hipStream_t st)
 {
     if (env->tail_pending) { if (int rc = launch_tail(env, st)) return rc; }
     if (env->orca_ready) CN_HIP(hipStreamWaitEvent(st, env->ev_orca, 0));
+    if (env->pg_pending) { CN_HIP(hipStreamWaitEvent(st, env->ev_pg, 0)); env->pg_pending = false; }
     return CN_OK;
 }
 
@@ -1904,7 +1915,7 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
         // kernel waits for them (the deferred mode removes exactly this coupling)
         CN_HIP(hipEventRecord(env->ev_pre, main));
         CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
-        if (int rc = launch_pregen(env)) return rc;
+        if (int rc = launch_pregen(env, env->side)) return rc;
     }
     if (lane_path) {
         // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
@@ -2059,7 +2070,8 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest); // side work yields to the caller's stream (critical path)
     if (hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, prio_least) != hipSuccess || hipEventCreateWithFlags(&b->ev_state, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_pre, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&b->ev_orca, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_pre, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&b->side2, hipStreamNonBlocking, prio_least) != hipSuccess || hipEventCreateWithFlags(&b->ev_pg, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(base); delete b; cn_set_error("cn_env_create: stream/event creation failed"); return CN_ERR_HIP;
     }
     // the row plan is built by the lane kernel's extra workgroup: only configs that run that kernel have one (and the consumer, the
@@ -2083,6 +2095,8 @@ extern "C" int cn_env_destroy(cn_env_batch *env)
 {
     if (!env) return CN_OK;
     (void)hipStreamSynchronize(env->side);
+    if (env->side2) { (void)hipStreamSynchronize(env->side2); (void)hipStreamDestroy(env->side2); }
+    if (env->ev_pg) (void)hipEventDestroy(env->ev_pg);
     (void)hipEventDestroy(env->ev_state); (void)hipEventDestroy(env->ev_orca); (void)hipEventDestroy(env->ev_pre); (void)hipStreamDestroy(env->side);
     if (env->blob) CN_HIP(hipFree(env->blob));
     delete env;
@@ -2235,6 +2249,8 @@ extern "C" int cn_env_load(cn_env_batch *env, const void *src, void *stream)
                "cn_env_load: the snapshot was taken from a batch with a different shape, seed, shard or configuration "
                "(E=%d H=%d seed_base=%lld vs E=%d H=%d seed_base=%lld)", h.E, h.H, (long long)h.seed_base, env->d.E, env->d.H, (long long)env->d.seed_base);
     CN_HIP(hipStreamSynchronize(env->side)); // nothing of ours may still be writing the blob
+    CN_HIP(hipStreamSynchronize(env->side2));
+    env->pg_pending = false;
     CN_HIP(hipMemcpyAsync(env->blob, (const char *)src + sizeof(h), env->blob_bytes, hipMemcpyDeviceToDevice, st));
     CN_HIP(hipMemsetAsync(env->d.lp3_cnt, 0, sizeof(int32_t), st)); // scratch of the ORCA pass (normally cleared by the step / reset kernels)
     env->reset_done = h.reset_done != 0;
