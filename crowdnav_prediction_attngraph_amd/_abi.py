@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile",
     "cn_policy_get_profile_samples", "cn_policy_reset_profile", "cn_prof_set_stamps", "cn_prof_next_step", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
-    "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gst_wrapper_set_interval", "cn_gst_wrapper_history_len", "cn_gst_wrapper_save", "cn_gst_wrapper_load", "cn_gae", "cn_adv_stats", "cn_adv_normalize",
+    "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gst_wrapper_set_interval", "cn_gst_wrapper_history_len", "cn_gst_wrapper_save", "cn_gst_wrapper_load", "cn_gae", "cn_adv_stats", "cn_adv_normalize", "cn_episode_stats_update",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
 ]
 
@@ -200,6 +200,7 @@ def lib():
         L.cn_gst_wrapper_load.argtypes = [vp, i32, vp, vp, vp]
         L.cn_gst_wrapper_step.argtypes = [vp, i32, C.POINTER(Obs), f32, f32, vp, vp, vp]
         L.cn_gae.argtypes = [i32, i32, vp, vp, vp, f64, f64, vp, vp]
+        L.cn_episode_stats_update.argtypes = [i32, vp, vp, vp, vp, vp, vp]
         L.cn_adv_stats.argtypes = [i64, vp, vp, vp, vp]
         L.cn_adv_normalize.argtypes = [i64, vp, vp, vp, vp, vp]
         L.cn_ppo_loss_workspace_doubles.argtypes = []

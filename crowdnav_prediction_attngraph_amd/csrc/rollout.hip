@@ -60,7 +60,42 @@ __global__ __launch_bounds__(256) void adv_norm_kernel(int64_t n, const float *_
         adv[i] = ((returns[i] - values[i]) - meanf) / denom;
 }
 
+// bench.Monitor's aggregate over one vec-env step (rl/networks/envs.py:70-73 wraps every env; train.py:180-182 collects info['episode']['r']):
+// acc[0] += finished episodes, [1] += their returns, [2] += their lengths, [3..5] += timeouts / collisions / goals.  One workgroup, fixed
+// summation order: the sums do not depend on scheduling (a resumed run reports the same statistics as the uninterrupted one).
+__global__ __launch_bounds__(1024) void episode_stats_kernel(int E, const uint8_t *__restrict__ done, const uint8_t *__restrict__ info,
+                                                             const double *__restrict__ ep_ret, const int32_t *__restrict__ ep_len, double *acc)
+{
+    __shared__ double part[6][16];
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int e = threadIdx.x; e < E; e += 1024) {
+        if (!done[e]) continue;
+        const int c = info[e];
+        v[0] += 1.0; v[1] += ep_ret[e]; v[2] += (double)ep_len[e];
+        v[3] += c == CN_INFO_TIMEOUT ? 1.0 : 0.0; v[4] += c == CN_INFO_COLLISION ? 1.0 : 0.0; v[5] += c == CN_INFO_REACHGOAL ? 1.0 : 0.0;
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double t = wv_sum(v[k]); if ((threadIdx.x & 63) == 0) part[k][w] = t; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double a = 0.0;
+        for (int k = 0; k < 16; ++k) a += part[threadIdx.x][k];
+        acc[threadIdx.x] += a;
+    }
+}
+
 } // namespace
+
+extern "C" int cn_episode_stats_update(int E, const uint8_t *done, const uint8_t *info, const double *ep_return, const int32_t *ep_len, double *acc,
+                                       void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(E > 0 && done && info && ep_return && ep_len && acc, "cn_episode_stats_update: bad argument");
+    hipLaunchKernelGGL(episode_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, E, done, info, ep_return, ep_len, acc);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 extern "C" int cn_gae(int T, int N, const float *rewards, const float *values, const float *masks, double gamma, double lam,
                       float *returns, void *stream)

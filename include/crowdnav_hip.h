@@ -437,6 +437,11 @@ int cn_adv_stats(int64_t n, const float *returns, const float *values, double *s
 /* adv = ((returns - values) - mean) / (std_unbiased + 1e-5) with mean/std derived from stats (possibly all-reduced) */
 int cn_adv_normalize(int64_t n, const float *returns, const float *values, const double *stats, float *adv, void *stream);
 
+/* bench.Monitor's aggregate of one vec-env step (rl/networks/envs.py:70-73, train.py:180-182) from the outputs of cn_env_step: acc[8] (float64,
+ * device) += {finished episodes, sum of their returns, sum of their lengths, timeouts, collisions, goals reached, -, -}.  One launch with a
+ * fixed summation order instead of two dozen small reductions per rollout step. */
+int cn_episode_stats_update(int E, const uint8_t *done, const uint8_t *info, const double *ep_return, const int32_t *ep_len, double *acc, void *stream);
+
 /* ---- PPO losses (rl/ppo/ppo.py:66-84) ----
  * values, logp (new policy), old_logp, adv (normalised advantages), value_preds, returns: [n] float32 (the [T*N,1] minibatch
  * tensors of recurrent_generator).  fwd: losses[0] = value_loss = 0.5 * mean(max((v - R)^2, (vp + clamp(v - vp, +-clip) - R)^2))

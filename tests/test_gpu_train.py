@@ -411,3 +411,27 @@ def test_fused_hh_block_forward_equals_the_per_layer_kernels(B, H, D):
     for name, t in zip(("e0", "x", "qkv", "attn", "out_sp"), outs):
         assert int((t[R:] != 7777.0).sum()) == 0, "%s: rows behind the live rows were written" % name
         assert int((t[:R] == 7777.0).sum()) == 0, "%s: live entries left unwritten" % name
+
+
+def test_episode_stats_kernel_equals_the_torch_expression():
+    """trainer.EpisodeStats.update on the step outputs of the simulator (uint8 done / info, float64 returns, int32 lengths): one fixed-order
+    launch (cn_episode_stats_update) against the torch-op form it replaces; and identical bits on a repeat (no atomics)."""
+    from crowdnav_prediction_attngraph_amd.trainer import EpisodeStats
+    g = torch.Generator(device="cuda").manual_seed(4)
+    E = 4096
+    a, b = EpisodeStats("cuda"), EpisodeStats("cuda")
+    ref = torch.zeros(8, dtype=torch.float64, device="cuda")
+    for t in range(5):
+        done = (torch.rand(E, device="cuda", generator=g) < 0.02).to(torch.uint8)
+        info = torch.randint(0, 5, (E,), device="cuda", generator=g).to(torch.uint8)
+        ep_ret = torch.randn(E, device="cuda", generator=g, dtype=torch.float64) * 10
+        ep_len = torch.randint(1, 200, (E,), device="cuda", generator=g).to(torch.int32)
+        a.update(done, info, ep_ret, ep_len)
+        b.update(done, info, ep_ret, ep_len)
+        d = done.to(torch.float64)
+        ref[0] += d.sum(); ref[1] += (ep_ret * d).sum(); ref[2] += (ep_len.to(torch.float64) * d).sum()
+        for code in (1, 2, 3):
+            ref[2 + code] += ((info == code).to(torch.float64) * d).sum()
+    assert torch.equal(a.acc, b.acc)
+    assert torch.allclose(a.acc, ref, rtol=1e-12, atol=1e-9), (a.acc, ref)
+    assert float(a.acc[0]) > 0
