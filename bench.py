@@ -112,6 +112,68 @@ def cpu_baseline_threads(H, env_name="CrowdSimVarNum-v0", threads=None, target_s
             "host_logical_cpus": logical}
 
 
+def dropin_leg(E, H, env_name, steps=24):
+    """The rollout loop in the shape the reference's train.py runs it (train.py:152-189), through the reference-compatible interfaces
+    (make_vec_envs / Policy.act / envs.step -> CPU rewards, numpy dones, infos list / RolloutStorage.insert) at this bench's batch size.
+    Everything the zero-sync path (trainer.collect_rollout) avoids is in here: one device-to-host transfer + stream synchronisation per
+    step in envs.step(), and train.py's OWN per-env Python (two list comprehensions over the envs building FloatTensors, the infos loop)."""
+    import torch
+    from crowdnav_prediction_attngraph_amd import config as CFG
+    from crowdnav_prediction_attngraph_amd.policy import Policy
+    from crowdnav_prediction_attngraph_amd.storage import RolloutStorage
+    from crowdnav_prediction_attngraph_amd.vec_env import make_vec_envs
+    dev = torch.device("cuda", torch.cuda.current_device())
+    over = {"sim.human_num": H}
+    if env_name == "CrowdSimPred-v0":
+        over["sim.predict_method"] = "const_vel"
+    cfg = CFG.non_randomized(**over)
+    envs = make_vec_envs(env_name, 425, E, 0.99, None, dev, False, config=cfg)
+    torch.manual_seed(425)
+    ac = Policy(envs.observation_space.spaces, envs.action_space, base="selfAttn_merge_srnn",
+                base_kwargs=dict(env_name=env_name, num_processes=E, num_mini_batch=2, seq_length=steps)).to(dev)
+    ro = RolloutStorage(steps, E, envs.observation_space.spaces, envs.action_space, 128, 256)
+    obs = envs.reset()
+    for k in obs:
+        ro.obs[k][0].copy_(obs[k])
+    ro.to(dev)
+    ep_rewards = []
+    t = dict(act=0.0, env_step=0.0, loop_python=0.0, insert=0.0)
+
+    def one(step, timed):
+        c0 = time.perf_counter()
+        with torch.no_grad():
+            o = {k: ro.obs[k][step] for k in ro.obs}
+            hx = {k: ro.recurrent_hidden_states[k][step] for k in ro.recurrent_hidden_states}
+            value, action, logp, hxs = ac.act(o, hx, ro.masks[step])
+        c1 = time.perf_counter()
+        obs, reward, done, infos = envs.step(action)
+        c2 = time.perf_counter()
+        for info in infos:
+            if "episode" in info.keys():
+                ep_rewards.append(info["episode"]["r"])
+        masks = torch.FloatTensor([[0.0] if d else [1.0] for d in done])
+        bad_masks = torch.FloatTensor([[0.0] if "bad_transition" in info.keys() else [1.0] for info in infos])
+        c3 = time.perf_counter()
+        ro.insert(obs, hxs, action, logp, value, reward, masks, bad_masks)
+        c4 = time.perf_counter()
+        if timed:
+            t["act"] += c1 - c0; t["env_step"] += c2 - c1; t["loop_python"] += c3 - c2; t["insert"] += c4 - c3
+    for s_ in range(steps):          # warm-up pass over the storage, then the timed pass
+        one(s_, False)
+    ro.after_update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        one(s_, True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    envs.close()
+    return {"env_steps_per_s": round(E * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+            "host_ms_per_step": {k: round(v / steps * 1e3, 4) for k, v in t.items()},
+            "what": "train.py-shaped rollout loop through make_vec_envs / Policy.act / envs.step (CPU rewards, numpy dones, infos) / RolloutStorage.insert; "
+                    "env_step includes the per-step device-to-host transfer and synchronisation, loop_python is train.py's own per-env list building"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +204,7 @@ def main():
     ap.add_argument("--pregen-budget-us", type=float, default=None, help="time budget of one launch of the episode pre-generation kernel (library default 55)")
     ap.add_argument("--timeline-out", default=None, help="write the stamped timeline of the decomposition window (all kernels of 24 steps) to this file")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the leg that times the reference-shaped rollout loop through the drop-in interfaces")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: put every rank on GPU 0 (use with --dist-backend gloo)")
@@ -407,6 +470,12 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    dropin = None
+    if not args.no_dropin and args.env_name != "CrowdSimPredRealGST-v0":
+        try:
+            dropin = dropin_leg(E, H, args.env_name)
+        except Exception as exc:
+            dropin = {"error": "%s: %s" % (type(exc).__name__, exc)}
     total_env_steps = E * world * args.steps
     value = total_env_steps / elapsed
     # dominant kernel: timed (a) by HIP event brackets on its stream, one per launch (median over the window; a bracket also contains
@@ -488,6 +557,10 @@ def main():
                                            "first": step_intervals[:4], "what": "start-to-start of consecutive hh_fused launches in the timed window (device clock)"}
     if decomp is not None:
         line["step_decomposition"] = decomp
+    if dropin is not None:
+        if "env_steps_per_s" in dropin:
+            dropin["fraction_of_zero_sync_path"] = round(dropin["env_steps_per_s"] / (value / world), 3)
+        line["dropin_train_loop"] = dropin
     if per_rank is not None:
         line["per_rank_env_steps_per_s"] = per_rank     # each rank's own clock over the same K steps (value uses the slowest)
     if worst is not None:
