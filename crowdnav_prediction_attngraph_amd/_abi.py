@@ -96,6 +96,21 @@ GST_WEIGHT_KEYS = [
 ]
 
 
+RN_WEIGHT_FIELDS = ["rl_w", "rl_b", "te_w", "te_b", "edge_w", "edge_b", "wih", "bih", "whh", "bhh", "ac0_w", "ac0_b", "a2_w", "a2_b", "c2_w", "c2_b",
+                    "cl_w", "cl_b", "fm_w", "fm_b", "logstd"]                  # cn_rn_weights / cn_rn_grads, in field order
+RN_WEIGHT_SHAPES = [(256, 9), (256,), (320, 256), (320,), (64, 256), (64,), (384, 128), (384,), (384, 128), (384,), (512, 128), (512,),
+                    (256, 256), (256,), (256, 256), (256,), (1, 256), (1,), (2, 256), (2,), (2, 1)]
+RN_SAVED_FIELDS = ["rs", "z", "hr", "attn", "gi", "hs", "hms", "gates", "a1", "a2"]   # cn_rn_saved
+
+
+class RnWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in RN_WEIGHT_FIELDS]
+
+
+class RnSaved(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in RN_SAVED_FIELDS]
+
+
 class GstWeights(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _ in GST_WEIGHT_KEYS]
 
@@ -110,7 +125,7 @@ ABI_SYMBOLS = [
     "cn_env_obs_width", "cn_row_plan_words", "cn_env_set_pregen_budget", "cn_env_set_tail_deferral", "cn_env_launch_tail", "cn_policy_set_post_hh_hook", "cn_env_reset", "cn_env_step", "cn_env_join", "cn_env_get_state", "cn_env_get_human_actions", "cn_env_get_danger_min_dist", "cn_env_get_human_counts", "cn_env_set_case_counters", "cn_env_snapshot_bytes", "cn_env_save", "cn_env_load", "cn_orca_solve",
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile",
-    "cn_policy_get_profile_samples", "cn_policy_reset_profile", "cn_prof_set_stamps", "cn_prof_next_step", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
+    "cn_policy_get_profile_samples", "cn_policy_reset_profile", "cn_prof_set_stamps", "cn_prof_next_step", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_rn_seq_workspace_floats", "cn_rn_seq_fwd", "cn_rn_seq_bwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
     "cn_split_bf16", "cn_linear_fwd", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gst_wrapper_set_interval", "cn_gst_wrapper_history_len", "cn_gst_wrapper_save", "cn_gst_wrapper_load", "cn_gae", "cn_adv_stats", "cn_adv_normalize", "cn_episode_stats_update",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
@@ -173,6 +188,10 @@ def lib():
         L.cn_hh_block_workspace_bytes.restype = C.c_int64
         L.cn_hh_block_workspace_bytes.argtypes = []
         L.cn_hh_block_fwd.argtypes = [i32, i32, i32] + [vp] * 10 + [f32] + [vp] * 7
+        L.cn_rn_seq_workspace_floats.restype = C.c_int64
+        L.cn_rn_seq_workspace_floats.argtypes = [i32, i32]
+        L.cn_rn_seq_fwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RnWeights), C.POINTER(RnSaved), vp, vp, vp]
+        L.cn_rn_seq_bwd.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(RnWeights), C.POINTER(RnSaved), vp, vp, vp, vp, vp, C.POINTER(RnWeights), vp]
         L.cn_hh_attention_workspace_ints.restype = C.c_int64
         L.cn_hh_attention_workspace_ints.argtypes = [i32]
         L.cn_hh_attention_fwd.argtypes = [i32, i32, vp, vp, f32, vp, vp, vp]

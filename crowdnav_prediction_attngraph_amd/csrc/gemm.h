@@ -7,7 +7,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2,
+       // backward epilogues (training path, rn_train in policy.hip): the product is a gradient w.r.t. an activation whose forward VALUE y is
+       // handed over in GemmBatch::resid -- multiply by relu'(y) = [y > 0] or tanh'(.) = 1 - y^2 instead of adding a residual
+       ACT_MUL_DRELU = 3, ACT_MUL_DTANH = 4 };
 
 // XCD-aware tile mapping.  Workgroups are dispatched round-robin over the 8 XCDs (linear id L -> XCD L % 8), each with a
 // private L2.  With the natural (x = column tile fastest) order the N/BN workgroups that share one A row-tile land on
@@ -139,7 +142,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
                     float v = acc[i][j][r] + b;
                     if (ACT == ACT_RELU || extra_relu) v = fmaxf(v, 0.0f);
                     if (ACT == ACT_TANH) v = tanhf(v);
-                    if (gb.resid) v += gb.resid[(size_t)row * gb.ldr + col];
+                    if (ACT == ACT_MUL_DRELU) v = gb.resid[(size_t)row * gb.ldr + col] > 0.0f ? v : 0.0f;
+                    else if (ACT == ACT_MUL_DTANH) { const float y = gb.resid[(size_t)row * gb.ldr + col]; v *= 1.0f - y * y; }
+                    else if (gb.resid) v += gb.resid[(size_t)row * gb.ldr + col];
                     C[(size_t)row * ldc + col] = v;
                 }
             }

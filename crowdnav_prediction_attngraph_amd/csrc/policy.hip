@@ -494,14 +494,14 @@ __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const f
 //   dp_j = d_hr . o_j ; g_j = T p_j (dp_j - sum_k p_k dp_k) ; d_u = sum_j g_j o_j ; d_o_j = p_j d_hr + g_j u
 __global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, const float *__restrict__ u, const float *__restrict__ out_sp,
                                                                const int *__restrict__ row_off, const float *__restrict__ attn,
-                                                               const float *__restrict__ d_hr, float *__restrict__ d_u, float *__restrict__ d_o)
+                                                               const float *__restrict__ d_hr, float *__restrict__ d_u, float *__restrict__ d_o, int u_ld, int du_ld)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 4 + wave;
     if (e >= B) return;
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
     const float a = lane < nd ? attn[(size_t)e * H + lane] : 0.0f; // lanes = humans
-    const float *g = d_hr + (size_t)e * 256, *ue = u + (size_t)e * 256;
+    const float *g = d_hr + (size_t)e * 256, *ue = u + (size_t)e * u_ld;
     const float g0 = g[lane], g1 = g[64 + lane], g2 = g[128 + lane], g3 = g[192 + lane];
     const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
     float dp = 0.0f;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, con
         d0 += gj * row[lane]; d1 += gj * row[64 + lane]; d2 += gj * row[128 + lane]; d3 += gj * row[192 + lane];
         dor[lane] = aj * g0 + gj * u0; dor[64 + lane] = aj * g1 + gj * u1; dor[128 + lane] = aj * g2 + gj * u2; dor[192 + lane] = aj * g3 + gj * u3;
     }
-    float *du = d_u + (size_t)e * 256;
+    float *du = d_u + (size_t)e * du_ld;
     du[lane] = d0; du[64 + lane] = d1; du[128 + lane] = d2; du[192 + lane] = d3;
 }
 
@@ -627,6 +627,138 @@ __global__ void fold_bias_tn_kernel(int N, int J, const float *__restrict__ A, c
 }
 
 constexpr size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Training path of the robot-node sequence (cn_rn_seq_fwd / cn_rn_seq_bwd below): small helpers
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// out [C,R] = in [R,C]^T (weights of a few hundred rows: the dX products of the backward read W^T through the same NT kernel)
+__global__ __launch_bounds__(256) void rn_transpose_kernel(int R, int C, const float *__restrict__ in, float *__restrict__ out)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) t[j][tx] = in[(size_t)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) out[(size_t)(c0 + j) * R + r0 + tx] = t[tx][j];
+}
+
+// critic_linear + DiagGaussian.log_probs of GIVEN actions (model.py:82-90, distributions.py:36-44): one wavefront per sample
+__global__ __launch_bounds__(256) void rn_head_fwd_kernel(int B, const float *__restrict__ ac, const float *__restrict__ wv, const float *__restrict__ bv,
+                                                          const float *__restrict__ wm, const float *__restrict__ bm, const float *__restrict__ logstd,
+                                                          const float *__restrict__ actions, float *__restrict__ value, float *__restrict__ logp)
+{
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= B) return;
+    const float *a = ac + (size_t)e * 512, *c = a + 256;
+    float sv = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = lane + 64 * k;
+        sv += c[d] * wv[d]; s0 += a[d] * wm[d]; s1 += a[d] * wm[256 + d];
+    }
+    sv = wv_sum(sv); s0 = wv_sum(s0); s1 = wv_sum(s1);
+    if (lane == 0) {
+        value[e] = sv + bv[0];
+        const float mean0 = s0 + bm[0], mean1 = s1 + bm[1], ls0 = logstd[0], ls1 = logstd[1];
+        const float sd0 = expf(ls0), sd1 = expf(ls1);
+        const float HALF_LOG_2PI = 0.91893853320467274178f;
+        const float d0 = actions[2 * e] - mean0, d1 = actions[2 * e + 1] - mean1;
+        logp[e] = (-(d0 * d0) / (2.0f * sd0 * sd0) - ls0 - HALF_LOG_2PI) + (-(d1 * d1) / (2.0f * sd1 * sd1) - ls1 - HALF_LOG_2PI);
+    }
+}
+
+// Backward of the heads AND of the second trunk layers' tanh: from d_value [B], d_logp [B]
+//   d_mean_j = d_logp (a_j - mean_j) / sd_j^2 ; d_logstd_j += d_logp ((a_j - mean_j)^2 / sd_j^2 - 1)
+//   d2[:, 0:256]   = (d_mean_0 wm[0] + d_mean_1 wm[1]) (1 - actor^2) ;  d2[:, 256:512] = d_value wv (1 - critic^2)
+// and the heads' own weight gradients (they are reductions over all B samples into 3 x 256 + 5 numbers): every workgroup keeps its sums in
+// registers and writes ONE partial row; rn_reduce_rows_kernel adds the rows in order (deterministic).
+constexpr int RN_HEAD_COLS = 3 * 256 + 8; // d fm_w[0] | d fm_w[1] | d cl_w | d fm_b (2) d cl_b d logstd (2) pad (3)
+__global__ __launch_bounds__(256) void rn_head_bwd_kernel(int B, const float *__restrict__ ac, const float *__restrict__ wv, const float *__restrict__ wm,
+                                                          const float *__restrict__ bm, const float *__restrict__ logstd, const float *__restrict__ actions,
+                                                          const float *__restrict__ d_value, const float *__restrict__ d_logp, float *__restrict__ d2,
+                                                          float *__restrict__ partials)
+{
+    __shared__ float red[4][RN_HEAD_COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w0[4], w1[4], wc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int d = lane + 64 * k; w0[k] = wm[d]; w1[k] = wm[256 + d]; wc[k] = wv[d]; }
+    const float ls0 = logstd[0], ls1 = logstd[1];
+    const float iv0 = expf(-2.0f * ls0), iv1 = expf(-2.0f * ls1);
+    float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, gc[4] = {0.f, 0.f, 0.f, 0.f};
+    float sb0 = 0.f, sb1 = 0.f, sbc = 0.f, sl0 = 0.f, sl1 = 0.f;
+    for (int e = blockIdx.x * 4 + wave; e < B; e += gridDim.x * 4) {
+        const float *a = ac + (size_t)e * 512, *c = a + 256;
+        float av[4], cv[4], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int d = lane + 64 * k; av[k] = a[d]; cv[k] = c[d]; s0 += av[k] * w0[k]; s1 += av[k] * w1[k]; }
+        s0 = wv_sum(s0); s1 = wv_sum(s1);
+        const float dv = d_value[e], dl = d_logp[e];
+        const float e0 = actions[2 * e] - (s0 + bm[0]), e1 = actions[2 * e + 1] - (s1 + bm[1]);
+        const float dm0 = dl * e0 * iv0, dm1 = dl * e1 * iv1;
+        float *o = d2 + (size_t)e * 512;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = lane + 64 * k;
+            o[d] = (dm0 * w0[k] + dm1 * w1[k]) * (1.0f - av[k] * av[k]);
+            o[256 + d] = dv * wc[k] * (1.0f - cv[k] * cv[k]);
+            g0[k] += dm0 * av[k]; g1[k] += dm1 * av[k]; gc[k] += dv * cv[k];
+        }
+        sb0 += dm0; sb1 += dm1; sbc += dv; sl0 += dl * (e0 * e0 * iv0 - 1.0f); sl1 += dl * (e1 * e1 * iv1 - 1.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int d = lane + 64 * k; red[wave][d] = g0[k]; red[wave][256 + d] = g1[k]; red[wave][512 + d] = gc[k]; }
+    if (lane == 0) { red[wave][768] = sb0; red[wave][769] = sb1; red[wave][770] = sbc; red[wave][771] = sl0; red[wave][772] = sl1; red[wave][773] = red[wave][774] = red[wave][775] = 0.f; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < RN_HEAD_COLS; j += 256)
+        partials[(size_t)blockIdx.x * RN_HEAD_COLS + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+
+// out[j] = sum over rows r = 0 .. R-1 (in this order) of part[r][j]
+__global__ __launch_bounds__(256) void rn_reduce_rows_kernel(int R, int Cn, const float *__restrict__ part, float *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Cn) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += part[(size_t)r * Cn + j];
+    out[j] = s;
+}
+
+// robot_linear.0's weight gradient: dW [256,9] and db [256] from drs [B,256] (already gated by the ReLU) and the 9 inputs
+// (temporal_edges 2 | robot_node 7).  thread = output feature; every workgroup writes one partial [256,10] (9 weights + bias)
+__global__ __launch_bounds__(256) void rn_rl_wgrad_kernel(int B, const float *__restrict__ drs, const float *__restrict__ temporal,
+                                                          const float *__restrict__ robot_node, float *__restrict__ partials)
+{
+    const int n = threadIdx.x;
+    float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = blockIdx.x; e < B; e += gridDim.x) {
+        const float d = drs[(size_t)e * 256 + n];
+        acc[0] += d * temporal[e * 2]; acc[1] += d * temporal[e * 2 + 1];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) acc[2 + q] += d * robot_node[e * 7 + q];
+        acc[9] += d;
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) partials[((size_t)blockIdx.x * 256 + n) * 10 + q] = acc[q];
+}
+// [256,10] sums -> dW [256,9] and db [256]
+__global__ __launch_bounds__(256) void rn_rl_wgrad_finish_kernel(int R, const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db)
+{
+    const int n = threadIdx.x;
+    float s[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < 10; ++q) s[q] += part[((size_t)r * 256 + n) * 10 + q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dW[n * 9 + q] = s[q];
+    db[n] = s[9];
+}
 
 } // namespace
 
@@ -1125,7 +1257,7 @@ extern "C" int cn_hr_attention_bwd(int B, int H, const float *u, const float *ou
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && u && out_sp && row_off && attn && d_hr && d_u && d_o, "cn_hr_attention_bwd: bad argument");
-    hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, H, u, out_sp, row_off, attn, d_hr, d_u, d_o);
+    hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, H, u, out_sp, row_off, attn, d_hr, d_u, d_o, 256, 256);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1146,5 +1278,164 @@ extern "C" int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *ro
     if (H > 8 && (rc = launch_hh_attention_bwd<16>(B, qkv, row_off, cls, 1, d_out, d_qkv, scale, st))) return rc;
     if (H > 16 && (rc = launch_hh_attention_bwd<32>(B, qkv, row_off, cls, 2, d_out, d_qkv, scale, st))) return rc;
     if (H > 32 && (rc = launch_hh_attention_bwd<64>(B, qkv, row_off, cls, 3, d_out, d_qkv, scale, st))) return rc;
+    return CN_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// cn_rn_seq_fwd / cn_rn_seq_bwd: the robot-node sequence of evaluate_actions (see include/crowdnav_hip.h).  A sequence of the kernels of
+// the separate-launch rollout forward run over all B = T * N samples at once (every layer but the GRU is independent across samples), the
+// GRU as ONE launch per direction (cn_gru_seq_*), and their backward counterparts: dX products on the exact-fp32 NT kernel with the
+// activation derivative in the epilogue, weight gradients on the split-K TN kernel (cn_linear_wgrad), small reductions in fixed order.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct RnWs { // carve-up of the backward workspace (floats)
+    size_t d2, d1, dhs, dgi, dgh, dz, dhr, drs, a2T, c2T, ac0T, wihT, edgeT, teT, part, dbp, small, total;
+    int small_rows;
+};
+RnWs rn_ws(int T, int N)
+{
+    const size_t B = (size_t)T * N;
+    RnWs w{};
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
+    w.d2 = carve(B * 512); w.d1 = carve(B * 512); w.dhs = carve(B * 128); w.dgi = carve(B * 384); w.dgh = carve(B * 384); w.dz = carve(B * 384);
+    w.dhr = carve(B * 256); w.drs = carve(B * 256);
+    w.a2T = carve(256 * 256); w.c2T = carve(256 * 256); w.ac0T = carve(128 * 512); w.wihT = carve(128 * 384); w.edgeT = carve(256 * 64); w.teT = carve(256 * 320);
+    // weight-gradient partials: the largest of the seven products (splits <= 66 by construction of cn_linear_wgrad_splits)
+    size_t pmax = 0, bmax = 0;
+    const int shp[7][2] = {{256, 256}, {256, 256}, {512, 128}, {384, 128}, {384, 128}, {64, 256}, {320, 256}};
+    for (auto &q : shp) {
+        const size_t sp = (size_t)cn_linear_wgrad_splits((int)B, q[0], q[1]);
+        pmax = pmax > sp * q[0] * q[1] ? pmax : sp * q[0] * q[1];
+        bmax = bmax > sp * q[0] ? bmax : sp * q[0];
+    }
+    w.part = carve(pmax); w.dbp = carve(bmax);
+    w.small_rows = 1024;
+    w.small = carve((size_t)w.small_rows * (RN_HEAD_COLS > 2560 ? RN_HEAD_COLS : 2560)); // head partials [1024, 776] / robot_linear partials [1024, 256, 10]
+    w.total = off;
+    return w;
+}
+int rn_wgrad(int M, int N, int K, const float *dY, int ldy, const float *X, int ldx, float *ws, const RnWs &L, float *dW, float *db, hipStream_t st)
+{
+    const int splits = cn_linear_wgrad_splits(M, N, K);
+    CN_REQUIRE(splits >= 1, "cn_rn_seq_bwd: no split-K plan for a %d x %d weight gradient over %d rows", N, K, M);
+    return cn_linear_wgrad(M, N, K, dY, ldy, nullptr, X, ldx, splits, ws + L.part, ws + L.dbp, dW, db, (void *)st);
+}
+int rn_transpose(int R, int C, const float *in, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(rn_transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, R, C, in, out);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+template <int ACT>
+int rn_gemm(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st, const float *aux = nullptr, int ldaux = 0,
+            int relu_from = 1 << 30)
+{
+    return launch_gemm_t<64, 64, ACT>(M, N, K, A, lda, W, bias, C, ldc, st, nullptr, 1, GemmBatch{0, 0, 0, 0, aux, ldaux}, relu_from);
+}
+} // namespace
+
+extern "C" int64_t cn_rn_seq_workspace_floats(int T, int N) { return (T > 0 && N > 0) ? (int64_t)rn_ws(T, N).total : 0; }
+
+static int rn_check(int T, int N, int H, const void *a, const void *b, const void *c, const void *d, const cn_rn_weights *w, const cn_rn_saved *sv)
+{
+    CN_REQUIRE(T >= 1 && N >= 1 && H >= 1 && H <= CN_MAX_HUMANS, "cn_rn_seq: bad shape T=%d N=%d H=%d", T, N, H);
+    CN_REQUIRE(a && b && c && d && w && sv, "cn_rn_seq: null argument");
+    const void *const *wp = reinterpret_cast<const void *const *>(w);
+    for (size_t i = 0; i < sizeof(cn_rn_weights) / sizeof(void *); ++i) CN_REQUIRE(wp[i], "cn_rn_seq: weight pointer #%zu is null", i);
+    const void *const *sp = reinterpret_cast<const void *const *>(sv);
+    for (size_t i = 0; i < sizeof(cn_rn_saved) / sizeof(void *); ++i) CN_REQUIRE(sp[i], "cn_rn_seq: saved-activation pointer #%zu is null", i);
+    return CN_OK;
+}
+
+extern "C" int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *h0,
+                             const float *masks, const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, float *value, float *logp, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    if (int rc = rn_check(T, N, H, robot_node, temporal, out_sp, row_off, w, sv)) return rc;
+    CN_REQUIRE(h0 && masks && actions && value && logp, "cn_rn_seq_fwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = T * N;
+    int rc;
+    hipLaunchKernelGGL(robot_embed_kernel, dim3(B < 2048 ? B : 2048), dim3(256), 0, st, B, temporal, robot_node, w->rl_w, w->rl_b, sv->rs);
+    CN_CHECK_LAUNCH();
+    // z = [u (256) | relu(enc) (64) | .] in one product (both read robot_states), then the attention over the compacted rows, then edge -> z[320:384]
+    if ((rc = rn_gemm<ACT_NONE>(B, 320, 256, sv->rs, 256, w->te_w, w->te_b, sv->z, 384, st, nullptr, 0, 256))) return rc;
+    hipLaunchKernelGGL(hr_attention_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, sv->z, 384, out_sp, row_off, sv->hr, sv->attn);
+    CN_CHECK_LAUNCH();
+    if ((rc = rn_gemm<ACT_RELU>(B, 64, 256, sv->hr, 256, w->edge_w, w->edge_b, sv->z + 320, 384, st))) return rc;
+    if ((rc = rn_gemm<ACT_NONE>(B, 384, 128, sv->z + 256, 384, w->wih, w->bih, sv->gi, 384, st))) return rc;
+    if ((rc = cn_gru_seq_fwd(T, N, sv->gi, h0, masks, w->whh, w->bhh, sv->hs, sv->hms, sv->gates, stream))) return rc;
+    if ((rc = rn_gemm<ACT_TANH>(B, 512, 128, sv->hs, 128, w->ac0_w, w->ac0_b, sv->a1, 512, st))) return rc;
+    if ((rc = rn_gemm<ACT_TANH>(B, 256, 256, sv->a1, 512, w->a2_w, w->a2_b, sv->a2, 512, st))) return rc;
+    if ((rc = rn_gemm<ACT_TANH>(B, 256, 256, sv->a1 + 256, 512, w->c2_w, w->c2_b, sv->a2 + 256, 512, st))) return rc;
+    hipLaunchKernelGGL(rn_head_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, sv->a2, w->cl_w, w->cl_b, w->fm_w, w->fm_b, w->logstd, actions, value, logp);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
+                             const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
+                             float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    if (int rc = rn_check(T, N, H, robot_node, temporal, out_sp, row_off, w, sv)) return rc;
+    CN_REQUIRE(masks && actions && d_value && d_logp && ws && d_out_sp && d_h0 && g, "cn_rn_seq_bwd: null argument");
+    {
+        const void *const *gp = reinterpret_cast<const void *const *>(g);
+        for (size_t i = 0; i < sizeof(cn_rn_grads) / sizeof(void *); ++i) CN_REQUIRE(gp[i], "cn_rn_seq_bwd: gradient pointer #%zu is null", i);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int B = T * N;
+    const RnWs L = rn_ws(T, N);
+    float *d2 = ws + L.d2, *d1 = ws + L.d1, *dhs = ws + L.dhs, *dgi = ws + L.dgi, *dgh = ws + L.dgh, *dz = ws + L.dz, *dhr = ws + L.dhr, *drs = ws + L.drs;
+    int rc;
+    // ---- heads + the tanh of the second trunk layers; the heads' own weight gradients ----
+    {
+        const int blocks = B < 4 * L.small_rows ? (B + 3) / 4 : L.small_rows;
+        hipLaunchKernelGGL(rn_head_bwd_kernel, dim3(blocks), dim3(256), 0, st, B, sv->a2, w->cl_w, w->fm_w, w->fm_b, w->logstd, actions, d_value, d_logp, d2, ws + L.small);
+        CN_CHECK_LAUNCH();
+        float *red = ws + L.dbp; // RN_HEAD_COLS floats, free until the first weight gradient below
+        hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3((RN_HEAD_COLS + 255) / 256), dim3(256), 0, st, blocks, RN_HEAD_COLS, ws + L.small, red);
+        CN_CHECK_LAUNCH();
+        CN_HIP(hipMemcpyAsync(g->fm_w, red, 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CN_HIP(hipMemcpyAsync(g->cl_w, red + 512, 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CN_HIP(hipMemcpyAsync(g->fm_b, red + 768, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CN_HIP(hipMemcpyAsync(g->cl_b, red + 770, 1 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        CN_HIP(hipMemcpyAsync(g->logstd, red + 771, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    // ---- transposed weights for the dX products (dX = dY W as an NT product with W^T) ----
+    if ((rc = rn_transpose(256, 256, w->a2_w, ws + L.a2T, st)) || (rc = rn_transpose(256, 256, w->c2_w, ws + L.c2T, st)) ||
+        (rc = rn_transpose(512, 128, w->ac0_w, ws + L.ac0T, st)) || (rc = rn_transpose(384, 128, w->wih, ws + L.wihT, st)) ||
+        (rc = rn_transpose(64, 256, w->edge_w, ws + L.edgeT, st)) || (rc = rn_transpose(320, 256, w->te_w, ws + L.teT, st))) return rc;
+    // ---- second trunk layers: weight gradients, then d1 = (d2 W2) (1 - a1^2) ----
+    if ((rc = rn_wgrad(B, 256, 256, d2, 512, sv->a1, 512, ws, L, g->a2_w, g->a2_b, st))) return rc;
+    if ((rc = rn_wgrad(B, 256, 256, d2 + 256, 512, sv->a1 + 256, 512, ws, L, g->c2_w, g->c2_b, st))) return rc;
+    if ((rc = rn_gemm<ACT_MUL_DTANH>(B, 256, 256, d2, 512, ws + L.a2T, nullptr, d1, 512, st, sv->a1, 512))) return rc;
+    if ((rc = rn_gemm<ACT_MUL_DTANH>(B, 256, 256, d2 + 256, 512, ws + L.c2T, nullptr, d1 + 256, 512, st, sv->a1 + 256, 512))) return rc;
+    // ---- first trunk layers (output_linear folded in) ----
+    if ((rc = rn_wgrad(B, 512, 128, d1, 512, sv->hs, 128, ws, L, g->ac0_w, g->ac0_b, st))) return rc;
+    if ((rc = rn_gemm<ACT_NONE>(B, 128, 512, d1, 512, ws + L.ac0T, nullptr, dhs, 128, st))) return rc;
+    // ---- GRU over the sequence ----
+    if ((rc = cn_gru_seq_bwd(T, N, sv->gates, sv->hms, masks, w->whh, dhs, dgi, dgh, d_h0, stream))) return rc;
+    if ((rc = rn_wgrad(B, 384, 128, dgh, 384, sv->hms, 128, ws, L, g->whh, g->bhh, st))) return rc;
+    if ((rc = rn_wgrad(B, 384, 128, dgi, 384, sv->z + 256, 384, ws, L, g->wih, g->bih, st))) return rc;
+    // ---- d[enc | edge] = (dgi W_ih) relu'(.) -> dz[:, 256:384]; d hr = d edge W_e; attention backward; d u -> dz[:, 0:256] ----
+    if ((rc = rn_gemm<ACT_MUL_DRELU>(B, 128, 384, dgi, 384, ws + L.wihT, nullptr, dz + 256, 384, st, sv->z + 256, 384))) return rc;
+    if ((rc = rn_wgrad(B, 64, 256, dz + 320, 384, sv->hr, 256, ws, L, g->edge_w, g->edge_b, st))) return rc;
+    if ((rc = rn_gemm<ACT_NONE>(B, 256, 64, dz + 320, 384, ws + L.edgeT, nullptr, dhr, 256, st))) return rc;
+    hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, sv->z, out_sp, row_off, sv->attn, dhr, dz, d_out_sp, 384, 384);
+    CN_CHECK_LAUNCH();
+    // ---- [u | enc] layer and robot_linear ----
+    if ((rc = rn_wgrad(B, 320, 256, dz, 384, sv->rs, 256, ws, L, g->te_w, g->te_b, st))) return rc;
+    if ((rc = rn_gemm<ACT_MUL_DRELU>(B, 256, 320, dz, 384, ws + L.teT, nullptr, drs, 256, st, sv->rs, 256))) return rc;
+    {
+        const int blocks = B < L.small_rows ? B : L.small_rows;
+        hipLaunchKernelGGL(rn_rl_wgrad_kernel, dim3(blocks), dim3(256), 0, st, B, drs, temporal, robot_node, ws + L.small);
+        CN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(rn_rl_wgrad_finish_kernel, dim3(1), dim3(256), 0, st, blocks, ws + L.small, g->rl_w, g->rl_b);
+        CN_CHECK_LAUNCH();
+    }
     return CN_OK;
 }

@@ -765,6 +765,56 @@ class HHBlockFused(torch.autograd.Function):
         return (None, None, None, dwb[:, :D].contiguous(), dwb[:, D].contiguous(), d_emb2_w, d_emb2_b, d_qkv_w, d_qkv_b, d_os_w, d_os_b)
 
 
+class RnSequence(torch.autograd.Function):
+    """Everything behind the human-human block in evaluate_actions for a [T, N] rollout slice -- robot_linear, [u | encoder_linear], robot-human
+    attention, edge_attention_embed, the GRU over the T steps with the done mask, the actor / critic trunks, critic_linear and the log-probability
+    of the given actions -- as ONE call forward (cn_rn_seq_fwd) and ONE backward (cn_rn_seq_bwd).  robot_node [B,7], temporal [B,2], out_sp [R,256]
+    (compacted rows of the human-human block), row_off [B+1] int32, h0 [N,128], masks [B], actions [B,2]; weights in the order of
+    _abi.RN_WEIGHT_FIELDS as the mirror composes them (te = [Ws^T Wt ; encoder_linear], ac0 = (actor.0 ; critic.0) o output_linear).
+    Returns value [B,1], logp [B,1] and the final hidden state [N,128] (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, robot_node, temporal, out_sp, row_off, h0, masks, actions, T, N, H, *weights):
+        B, dev = T * N, out_sp.device
+        f = lambda t: t.detach().to(torch.float32).contiguous()   # noqa: E731
+        rn, te, osp, h0c, m, act = f(robot_node).view(B, 7), f(temporal).view(B, 2), f(out_sp), f(h0).view(N, 128), f(masks).view(B), f(actions).view(B, 2)
+        ws = [f(w) for w in weights]
+        for w, shp, name in zip(ws, A.RN_WEIGHT_SHAPES, A.RN_WEIGHT_FIELDS):
+            if tuple(w.shape) != shp:
+                raise A.CnError("RnSequence: weight %s has shape %s, expected %s" % (name, tuple(w.shape), shp))
+        wst = A.RnWeights(*[w.data_ptr() for w in ws])
+        widths = dict(rs=256, z=384, hr=256, attn=H, gi=384, hs=128, hms=128, gates=512, a1=512, a2=512)
+        saved = {k: torch.empty(B, widths[k], device=dev) for k in A.RN_SAVED_FIELDS}
+        sst = A.RnSaved(*[saved[k].data_ptr() for k in A.RN_SAVED_FIELDS])
+        value, logp = torch.empty(B, 1, device=dev), torch.empty(B, 1, device=dev)
+        A.check(A.lib().cn_rn_seq_fwd(T, N, H, A.ptr(rn), A.ptr(te), A.ptr(osp), A.ptr(row_off), A.ptr(h0c), A.ptr(m), A.ptr(act), C.byref(wst), C.byref(sst),
+                                      A.ptr(value), A.ptr(logp), A.stream_ptr()), "cn_rn_seq_fwd")
+        ctx.save_for_backward(rn, te, osp, row_off, m, act, *ws, *[saved[k] for k in A.RN_SAVED_FIELDS])
+        ctx.meta = (T, N, H, len(ws))
+        h_last = saved["hs"][(T - 1) * N:].clone()
+        ctx.mark_non_differentiable(h_last)
+        return value, logp, h_last
+
+    @staticmethod
+    def backward(ctx, d_value, d_logp, _d_h):
+        T, N, H, nw = ctx.meta
+        t = ctx.saved_tensors
+        rn, te, osp, row_off, m, act = t[:6]
+        ws, sv = t[6:6 + nw], t[6 + nw:]
+        B, dev = T * N, osp.device
+        wst = A.RnWeights(*[w.data_ptr() for w in ws])
+        sst = A.RnSaved(*[x.data_ptr() for x in sv])
+        grads = [torch.empty_like(w) for w in ws]
+        gst = A.RnWeights(*[g.data_ptr() for g in grads])
+        work = torch.empty(int(A.lib().cn_rn_seq_workspace_floats(T, N)), device=dev)
+        d_osp, d_h0 = torch.empty_like(osp), torch.empty(N, 128, device=dev)
+        dv = d_value.reshape(B).to(torch.float32).contiguous()
+        dl = d_logp.reshape(B).to(torch.float32).contiguous()
+        A.check(A.lib().cn_rn_seq_bwd(T, N, H, A.ptr(rn), A.ptr(te), A.ptr(osp), A.ptr(row_off), A.ptr(m), A.ptr(act), C.byref(wst), C.byref(sst), A.ptr(dv), A.ptr(dl),
+                                      A.ptr(work), A.ptr(d_osp), A.ptr(d_h0), C.byref(gst), A.stream_ptr()), "cn_rn_seq_bwd")
+        return (None, None, d_osp, None, None, None, None, None, None, None, *grads)
+
+
 class PPOLoss(torch.autograd.Function):
     """(value_loss, action_loss) of rl/ppo/ppo.py:66-84 as one tensor [2]: forward = cn_ppo_loss_fwd, backward =
     cn_ppo_loss_bwd (gradients w.r.t. `values` and `logp` only -- everything else is rollout data)."""

@@ -14,6 +14,7 @@ Parameter construction order follows the reference so that `torch.manual_seed(s)
 initial weights (tests/test_host_policy.py checks this against checksums captured from the reference).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -164,6 +165,29 @@ class AttnGraphBase(nn.Module):
     train_gemm_mode = "bf16x3"
     # the human-human block of the update's forward as one fused launch (hip.HHBlockFused; crowds of <= 48 humans) instead of five
     train_fused_hh = True
+    # everything behind the human-human block (robot node, robot-human attention, GRU sequence, trunks, heads, log-prob) as ONE call forward and
+    # ONE backward (hip.RnSequence: cn_rn_seq_fwd / cn_rn_seq_bwd) instead of torch modules with HIP Functions spliced in
+    train_fused_rn = os.environ.get("CN_TRAIN_FUSED_RN", "1") != "0"   # (the environment switch is for A/B timing: bench.py's PPO leg)
+
+    def rn_sequence(self, inputs, out_sp, row_off, h0, masks, actions, T, N, dist):
+        """(value [B,1], logp [B,1], h_T [N,128]) through hip.RnSequence.  The two affine pairs without a nonlinearity in between are composed
+        here in torch ops (tiny products, autograd carries the folded gradients back to both factors): u = Ws^T (Wt r + bt) -- the
+        spatial_edge_layer projection moved to the robot side, its bias keeps an exactly-zero gradient -- and (actor.0 ; critic.0) o output_linear."""
+        from .hip import RnSequence
+        B = T * N
+        sl, tl, rnn = self.attn.spatial_edge_layer[0], self.attn.temporal_edge_layer[0], self.humanNodeRNN
+        te_w = torch.cat([sl.weight.t() @ tl.weight, rnn.encoder_linear.weight], 0)
+        te_b = torch.cat([sl.weight.t() @ tl.bias + 0.0 * sl.bias.sum(), rnn.encoder_linear.bias], 0)
+        w0 = torch.cat([self.actor[0].weight, self.critic[0].weight], 0)
+        ac0_w = w0 @ rnn.output_linear.weight
+        ac0_b = w0 @ rnn.output_linear.bias + torch.cat([self.actor[0].bias, self.critic[0].bias], 0)
+        g = rnn.gru
+        return RnSequence.apply(inputs["robot_node"].reshape(B, 7), inputs["temporal_edges"].reshape(B, 2), out_sp, row_off, h0.reshape(N, -1), masks.reshape(B),
+                                actions.reshape(B, 2), T, N, self.human_num,
+                                self.robot_linear[0].weight, self.robot_linear[0].bias, te_w, te_b, rnn.edge_attention_embed.weight, rnn.edge_attention_embed.bias,
+                                g.weight_ih_l0, g.bias_ih_l0, g.weight_hh_l0, g.bias_hh_l0, ac0_w, ac0_b, self.actor[2].weight, self.actor[2].bias,
+                                self.critic[2].weight, self.critic[2].bias, self.critic_linear.weight, self.critic_linear.bias, dist.fc_mean.weight, dist.fc_mean.bias,
+                                dist.logstd._bias)
 
     def _big_linear(self, x, w, b, relu=False):
         if x.is_cuda and self.train_gemm_mode == "bf16x3":
@@ -414,6 +438,16 @@ class Policy(nn.Module):
         B = inputs["robot_node"].shape[0]
         N = rnn_hxs["human_node_rnn"].shape[0]
         T = B // N
+        base = self.base
+        if inputs["robot_node"].is_cuda and base.train_fused_rn and base.human_node_rnn_size == 128:
+            # train-mode forward as two boundary calls: the human-human block (cn_hh_block_fwd behind _hh_block) and the robot-node sequence
+            # (cn_rn_seq_fwd), each with ONE backward entry
+            det = inputs["detected_human_num"].reshape(B).to(torch.int64).clamp(min=1)
+            out_sp, row_off = base._hh_block(inputs["spatial_edges"].reshape(B, base.human_num, base.edge_width), det)
+            value, logp, h = base.rn_sequence(inputs, out_sp, row_off, rnn_hxs["human_node_rnn"], masks, action, T, N, self.dist)
+            logstd = self.dist.logstd._bias.t().view(1, -1)
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).mean()   # FixedNormal.entropy().mean(): the same for every sample
+            return value, logp, entropy, {"human_node_rnn": h.view(N, 1, -1), "human_human_edge_rnn": self._edge_zeros(N, h.device)}
         value, feat, h = self.base.forward_sequence(inputs, rnn_hxs["human_node_rnn"], masks, T, N)
         mean = _skinny_linear(feat, self.dist.fc_mean.weight, self.dist.fc_mean.bias)
         logstd = self.dist.logstd(torch.zeros_like(mean))

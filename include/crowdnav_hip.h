@@ -311,6 +311,49 @@ int cn_hh_block_fwd(int B, int H, int D, const float *spatial_edges, const int *
                     const float *emb2_w, const float *emb2_b, const float *qkv_w, const float *qkv_b, const float *os_w, const float *os_b,
                     float q_scale, void *workspace, float *e0, float *x, float *qkv, float *attn, float *out_sp, void *stream);
 
+/* ---- the robot-node sequence of evaluate_actions' forward and backward as ONE call each (training path) ----
+ * Everything behind the human-human block in rl/networks/model.py:82-90 -> selfAttn_srnn_temp_node.py:395-449 + srnn_model.py:35-105 +
+ * distributions.py:36-44 for a [T, N] rollout slice (B = T * N samples, T-major): robot_linear -> [u | encoder_linear] -> robot-human attention over
+ * the compacted out_sp rows -> edge_attention_embed -> GRU over the T steps with the done mask -> actor / critic trunks -> critic_linear and the
+ * log-probability of the GIVEN actions under the DiagGaussian head.  Together with cn_hh_block_fwd (+ the per-layer backward kernels) this is
+ * the train-mode policy forward of the boundary: no library GEMM and no framework pointwise kernel is left between the observation and
+ * (value, log-prob).  Weights are the fp32 training weights as the host composes them (two affine pairs folded by the caller, whose autograd
+ * carries the gradients of the folded matrices back to the factors): te = [spatial_edge_layer^T temporal_edge_layer ; encoder_linear],
+ * ac0 = (actor.0 ; critic.0) o output_linear.  Exact fp32 MFMA products forward and for dX, bf16x3 split-K for the weight gradients.
+ * cn_rn_seq_fwd writes every activation the backward needs into the caller's `saved` buffers; cn_rn_seq_bwd takes d_value / d_logp [B] and
+ * returns d_out_sp [R,256] (gradient into the human-human block), d_h0 [N,128] and the gradient of every weight (fixed summation orders). */
+typedef struct {
+    const float *rl_w, *rl_b;               /* robot_linear.0 [256,9], [256] */
+    const float *te_w, *te_b;               /* [320,256], [320]: rows 0..255 u = Ws^T (Wt . + bt), rows 256..319 encoder_linear */
+    const float *edge_w, *edge_b;           /* edge_attention_embed [64,256], [64] */
+    const float *wih, *bih, *whh, *bhh;     /* GRU [384,128], [384] */
+    const float *ac0_w, *ac0_b;             /* [512,128], [512]: (actor.0 ; critic.0) o output_linear */
+    const float *a2_w, *a2_b, *c2_w, *c2_b; /* actor.2, critic.2 [256,256], [256] */
+    const float *cl_w, *cl_b, *fm_w, *fm_b, *logstd; /* critic_linear [1,256],[1]; dist.fc_mean [2,256],[2]; dist.logstd [2] */
+} cn_rn_weights;
+typedef struct { /* gradients, same shapes as cn_rn_weights (device buffers, overwritten) */
+    float *rl_w, *rl_b, *te_w, *te_b, *edge_w, *edge_b, *wih, *bih, *whh, *bhh, *ac0_w, *ac0_b, *a2_w, *a2_b, *c2_w, *c2_b, *cl_w, *cl_b, *fm_w, *fm_b, *logstd;
+} cn_rn_grads;
+typedef struct { /* activations kept for the backward (device buffers of the caller) */
+    float *rs;    /* [B,256] relu(robot_linear) */
+    float *z;     /* [B,384] u (256) | relu(enc) (64) | relu(edge) (64) */
+    float *hr;    /* [B,256] attended human features */
+    float *attn;  /* [B,H]   robot-human attention weights */
+    float *gi;    /* [B,384] x W_ih^T + b_ih */
+    float *hs;    /* [B,128] GRU outputs (hs[(T-1) N ..] is the final hidden state) */
+    float *hms;   /* [B,128] masked previous states */
+    float *gates; /* [B,512] r, z, n, gh_n */
+    float *a1;    /* [B,512] tanh of the first trunk layers (actor | critic) */
+    float *a2;    /* [B,512] tanh of the second trunk layers (actor | critic) */
+} cn_rn_saved;
+int64_t cn_rn_seq_workspace_floats(int T, int N);   /* scratch of cn_rn_seq_bwd */
+int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node /*[B,7]*/, const float *temporal_edges /*[B,2]*/, const float *out_sp /*[R,256]*/,
+                  const int *row_off /*[B+1]*/, const float *h0 /*[N,128]*/, const float *masks /*[B]*/, const float *actions /*[B,2]*/,
+                  const cn_rn_weights *w, const cn_rn_saved *saved, float *value /*[B]*/, float *logp /*[B]*/, void *stream);
+int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const float *temporal_edges, const float *out_sp, const int *row_off, const float *masks,
+                  const float *actions, const cn_rn_weights *w, const cn_rn_saved *saved, const float *d_value /*[B]*/, const float *d_logp /*[B]*/,
+                  float *workspace, float *d_out_sp /*[R,256]*/, float *d_h0 /*[N,128]*/, const cn_rn_grads *grads, void *stream);
+
 /* ---- human-human attention core, stand-alone (training path) ----
  * The (env, head) units of torch.nn.MultiheadAttention's scaled-dot-product core (selfAttn_srnn_temp_node.py:89) on COMPACTED
  * rows: sample b owns rows row_off[b] .. row_off[b+1]-1 (its detected humans); qkv [R,1536] = [q | k | v] (8 heads x 64).
