@@ -720,18 +720,22 @@ __global__ __launch_bounds__(256) void rn_head_bwd_kernel(int B, const float *__
         partials[(size_t)blockIdx.x * RN_HEAD_COLS + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
-// out[j] = sum over rows r = 0 .. R-1 (in this order) of part[r][j]
+// out[j] = sum over the rows of part[R][Cn], in a fixed order: a workgroup owns 64 columns, its four thread groups each walk every fourth row
+// (coalesced, independent loads) and meet in LDS as (g0 + g1) + (g2 + g3)
 __global__ __launch_bounds__(256) void rn_reduce_rows_kernel(int R, int Cn, const float *__restrict__ part, float *__restrict__ out)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Cn) return;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += part[(size_t)r * Cn + j];
-    out[j] = s;
+    if (j < Cn)
+        for (int r = g; r < R; r += 4) s += part[(size_t)r * Cn + j];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && j < Cn) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // robot_linear.0's weight gradient: dW [256,9] and db [256] from drs [B,256] (already gated by the ReLU) and the 9 inputs
-// (temporal_edges 2 | robot_node 7).  thread = output feature; every workgroup writes one partial [256,10] (9 weights + bias)
+// (temporal_edges 2 | robot_node 7).  thread = output feature; every workgroup writes one partial [10][256] (9 weights + bias, feature innermost)
 __global__ __launch_bounds__(256) void rn_rl_wgrad_kernel(int B, const float *__restrict__ drs, const float *__restrict__ temporal,
                                                           const float *__restrict__ robot_node, float *__restrict__ partials)
 {
@@ -745,19 +749,15 @@ __global__ __launch_bounds__(256) void rn_rl_wgrad_kernel(int B, const float *__
         acc[9] += d;
     }
 #pragma unroll
-    for (int q = 0; q < 10; ++q) partials[((size_t)blockIdx.x * 256 + n) * 10 + q] = acc[q];
+    for (int q = 0; q < 10; ++q) partials[((size_t)blockIdx.x * 10 + q) * 256 + n] = acc[q];
 }
-// [256,10] sums -> dW [256,9] and db [256]
+// partial sums [R][10][256] -> dW [256,9] and db [256]: workgroup q, thread n, rows in order
 __global__ __launch_bounds__(256) void rn_rl_wgrad_finish_kernel(int R, const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db)
 {
-    const int n = threadIdx.x;
-    float s[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int q = 0; q < 10; ++q) s[q] += part[((size_t)r * 256 + n) * 10 + q];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) dW[n * 9 + q] = s[q];
-    db[n] = s[9];
+    const int n = threadIdx.x, q = blockIdx.x;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += part[((size_t)r * 10 + q) * 256 + n];
+    if (q < 9) dW[n * 9 + q] = s; else db[n] = s;
 }
 
 } // namespace
@@ -1397,7 +1397,7 @@ extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const
         hipLaunchKernelGGL(rn_head_bwd_kernel, dim3(blocks), dim3(256), 0, st, B, sv->a2, w->cl_w, w->fm_w, w->fm_b, w->logstd, actions, d_value, d_logp, d2, ws + L.small);
         CN_CHECK_LAUNCH();
         float *red = ws + L.dbp; // RN_HEAD_COLS floats, free until the first weight gradient below
-        hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3((RN_HEAD_COLS + 255) / 256), dim3(256), 0, st, blocks, RN_HEAD_COLS, ws + L.small, red);
+        hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3((RN_HEAD_COLS + 63) / 64), dim3(256), 0, st, blocks, RN_HEAD_COLS, ws + L.small, red);
         CN_CHECK_LAUNCH();
         CN_HIP(hipMemcpyAsync(g->fm_w, red, 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
         CN_HIP(hipMemcpyAsync(g->cl_w, red + 512, 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1431,10 +1431,10 @@ extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const
     if ((rc = rn_wgrad(B, 320, 256, dz, 384, sv->rs, 256, ws, L, g->te_w, g->te_b, st))) return rc;
     if ((rc = rn_gemm<ACT_MUL_DRELU>(B, 256, 320, dz, 384, ws + L.teT, nullptr, drs, 256, st, sv->rs, 256))) return rc;
     {
-        const int blocks = B < L.small_rows ? B : L.small_rows;
+        const int blocks = B < 512 ? B : 512;
         hipLaunchKernelGGL(rn_rl_wgrad_kernel, dim3(blocks), dim3(256), 0, st, B, drs, temporal, robot_node, ws + L.small);
         CN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(rn_rl_wgrad_finish_kernel, dim3(1), dim3(256), 0, st, blocks, ws + L.small, g->rl_w, g->rl_b);
+        hipLaunchKernelGGL(rn_rl_wgrad_finish_kernel, dim3(10), dim3(256), 0, st, blocks, ws + L.small, g->rl_w, g->rl_b);
         CN_CHECK_LAUNCH();
     }
     return CN_OK;
