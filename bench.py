@@ -112,6 +112,53 @@ def cpu_baseline_threads(H, env_name="CrowdSimVarNum-v0", threads=None, target_s
             "host_logical_cpus": logical}
 
 
+def pmc_traffic_live(argv_tail, timeout_s=170):
+    """HBM-side traffic of the dominant kernel measured IN this run: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE -- they do not fit one
+    pass, MI355X_MICROARCH.md) over a short child run of this very script on this box and build; per launch = the mean over every
+    hh_fused_kernel dispatch of the child.  FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 B, same guide); WRITE_SIZE
+    as reported.  Returns a dict or raises; the caller falls back to the committed constant."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    out = {}
+    child_line = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cn_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, (r.stderr or "")[-300:]))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if lines:
+                child_line = json.loads(lines[-1])
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if not dbs:
+                raise RuntimeError("no rocpd database from the %s pass" % counter)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            row = list(cur.execute(
+                "select count(*), avg(p.value) from rocpd_pmc_event p join rocpd_info_pmc i on p.pmc_id = i.id "
+                "join rocpd_kernel_dispatch d on p.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+                "where s.kernel_name like '%hh_fused_kernel%' and i.name = ?", (counter,)))[0]
+            if not row[0]:
+                raise RuntimeError("no %s samples of hh_fused_kernel" % counter)
+            out[counter] = (int(row[0]), float(row[1]))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kb, write_kb = out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]
+    res = {"hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024), "fetch_size_kb": round(fetch_kb, 1), "write_size_kb": round(write_kb, 1),
+           "launches": out["FETCH_SIZE"][0], "child_live_rows": None}
+    if child_line is not None:
+        import re
+        m = re.search(r"M=(\d+) live rows", child_line["roofline"]["kernel"])
+        res["child_live_rows"] = int(m.group(1)) if m else None
+    return res
+
+
 def dropin_leg(E, H, env_name, steps=24):
     """The rollout loop in the shape the reference's train.py runs it (train.py:152-189), through the reference-compatible interfaces
     (make_vec_envs / Policy.act / envs.step -> CPU rewards, numpy dones, infos list / RolloutStorage.insert) at this bench's batch size.
@@ -204,6 +251,9 @@ def main():
     ap.add_argument("--pregen-budget-us", type=float, default=None, help="time budget of one launch of the episode pre-generation kernel (library default 55)")
     ap.add_argument("--timeline-out", default=None, help="write the stamped timeline of the decomposition window (all kernels of 24 steps) to this file")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs of this script, ~1 min); the committed "
+                         "constant of the same kernel source is printed instead when there is one")
     ap.add_argument("--no-dropin", action="store_true", help="skip the leg that times the reference-shaped rollout loop through the drop-in interfaces")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -502,20 +552,37 @@ def main():
     # time of the measurement) matches the kernel source of this build; a stale constant is reported as null with the reason
     traffic = None
     traffic_note = None
-    if fused and (args.env_name, E, H, args.randomized) == ("CrowdSimVarNum-v0", 4096, 20, False):
+    if fused and world == 1 and not args.no_pmc_traffic:
+        try:
+            child = ["--gpus", "1", "--steps", "10", "--warmup", "10", "--dephase", str(args.dephase), "--envs", str(E), "--humans", str(H), "--env-name", args.env_name,
+                     "--no-cpu-baseline", "--no-ppo", "--no-worst-case", "--no-dropin", "--no-pmc-traffic", "--tail", args.tail] + (["--randomized"] if args.randomized else [])
+            tl = pmc_traffic_live(child)
+            traffic = tl["hbm_bytes_per_launch"]
+            rows_c = tl["child_live_rows"] or M
+            alg_c = rows_c * (D + 256) * 4 + 3932160
+            traffic_note = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child runs of this script on this box, %d "
+                            "hh_fused_kernel launches each): FETCH_SIZE %.0f KB x 2 (gfx950 correction) + WRITE_SIZE %.0f KB per launch = %.2fx the algorithmic "
+                            "%.1f MB (%d live rows x (%d input + 256 output floats) + the 3.93 MB weight image once)"
+                            % (tl["launches"], tl["fetch_size_kb"], tl["write_size_kb"], traffic / alg_c, alg_c / 1e6, rows_c, D))
+        except Exception as exc:
+            traffic_note = "live PMC measurement failed (%s: %s)" % (type(exc).__name__, str(exc)[:200])
+    if traffic is None and fused and (args.env_name, E, H, args.randomized) == ("CrowdSimVarNum-v0", 4096, 20, False):
+        # fall back to the committed PMC passes of the same command (tools/profile_step.sh -> tools/mk_traffic.py) -- but only while their stamp
+        # (sha256 of csrc/hh_fused.hip at the time of the measurement) matches the kernel source of this build
         import glob
         import hashlib
         src = os.path.join(ROOT, "crowdnav_prediction_attngraph_amd", "csrc", "hh_fused.hip")
         stamp = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] if os.path.exists(src) else None
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
         tj = json.load(open(cands[-1])) if cands else None
+        prev = (traffic_note + "; ") if traffic_note else ""
         if tj is not None and stamp is not None and tj.get("kernel_source_sha16") == stamp:
             traffic = tj["hbm_bytes_per_launch_corrected"]
-            traffic_note = ("not measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same command on the same kernel "
-                            "source (%s, stamp %s; %.2fx the algorithmic bytes)" % (os.path.basename(cands[-1]), stamp, tj["ratio"]))
+            traffic_note = prev + ("constant from the committed passes of the same kernel source (%s, stamp %s; %.2fx the algorithmic bytes)"
+                                   % (os.path.basename(cands[-1]), stamp, tj["ratio"]))
         else:
-            traffic_note = ("null: the newest committed PMC result (%s) was measured on a different hh_fused.hip (stamp %s, this build %s)"
-                            % (os.path.basename(cands[-1]) if cands else "none", tj.get("kernel_source_sha16") if tj else None, stamp))
+            traffic_note = prev + ("null: the newest committed PMC result (%s) was measured on a different hh_fused.hip (stamp %s, this build %s)"
+                                   % (os.path.basename(cands[-1]) if cands else "none", tj.get("kernel_source_sha16") if tj else None, stamp))
     line = {
         "metric": "env-steps/sec (sim+policy fwd) at %d humans" % H, "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
