@@ -501,19 +501,19 @@ template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(
 // a uniform register index (s_set_gpr_idx), not by 20-32 unrolled copies -- fully unrolled the kernel was 85 KB of straight-line
 // code that every wavefront fetched exactly once (instruction-fetch bound, slower than the cooperative kernel).
 template <int NB, int VW>
-__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, int plan_groups, unsigned long long *plan_stamp)
+__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, unsigned long long *plan_stamp)
 {
-    const CnStampScope stamp_scope((plan && (int)blockIdx.x < plan_groups) ? plan_stamp : s.stamp); // the plan builders' wavefronts have their own slot
-    // the first workgroups (one wavefront each, rp_groups(E) of them) build the row plan of the policy's human-human kernel for the observation
-    // that was just written (row_plan.h): they only need the detected-human counts, and this kernel is on the step's critical path anyway
+    const CnStampScope stamp_scope((plan && blockIdx.x == 0) ? plan_stamp : s.stamp); // the plan builder's wavefront has its own slot
+    // one extra workgroup builds the row plan of the policy's human-human kernel for the observation that was just written
+    // (row_plan.h): it only needs the detected-human counts, and this kernel is on the step's critical path anyway
     __shared__ rowplan::Lds rp_lds;
-    // (dispatched first; a builder is the longest chain of the launch, so it also takes the issue priority)
-    if (plan && (int)blockIdx.x < plan_groups) {
+    // (workgroup 0: dispatched first; its single wavefront is the longest chain of the launch, so it also takes the issue priority)
+    if (plan && blockIdx.x == 0) {
         __builtin_amdgcn_s_setprio(3);
-        rowplan::build((int)blockIdx.x, plan_groups, s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds);
+        rowplan::build(s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds);
         return;
     }
-    const int blk = (int)blockIdx.x - (plan ? plan_groups : 0);
+    const int blk = (int)blockIdx.x - (plan ? 1 : 0);
     typedef typename LaneVec<VW>::f vec;
     const int agent = blk * 64 + threadIdx.x;
     const int H = s.H;
@@ -1922,13 +1922,12 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
         // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
         int32_t *plan = (plan_det && env->plan_ok && ((uintptr_t)plan_det & 15u) == 0) ? row_plan : nullptr;
         if (plan) row_plan = nullptr; // built below
-        const int pg = plan ? rp_groups(env->d.E) : 0;
-        const dim3 grid((agents + 63) / 64 + pg), blk(64);
+        const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
         const EnvDev dl = stamped(env->d, CN_K_ORCA_LANE);
         unsigned long long *pst = cn_stamp_slot(CN_K_ROW_PLAN);
-        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
-        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
-        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
         CN_CHECK_LAUNCH();
     }
     // a caller's plan buffer that this step does not fill must not keep the previous observation's plan

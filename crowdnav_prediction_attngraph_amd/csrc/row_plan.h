@@ -37,16 +37,6 @@ __host__ __device__ inline int rp_workgroups(int E, int H)
     long long g = ((long long)E * H + 15) / 16;
     return g > 256 ? 256 : (g < 1 ? 1 : (int)g);
 }
-// Wavefronts that build the plan (round 4): the batch is cut into G index ranges of E / G envs, group g owns a CONTIGUOUS range of tiles
-// proportional to its rows and is packed by its own wavefront with the same two-level scheme; nothing crosses groups (every wavefront
-// reads all counts: it needs the other groups' totals for its tile range).  With 8 groups a lane holds 8 envs and one tile instead of
-// 64 and 8: the per-env chains (counting sort, placement) shrink eightfold, what remains are the ~6 probes per size class.  Groups need
-// E to be a multiple of 256 (a group is then a whole number of lanes of the count scan) and at least 256 envs each.
-__host__ __device__ inline int rp_groups(int E)
-{
-    if (E <= 0 || (E & 255)) return 1;
-    return E >= 2048 ? 8 : (E >= 1024 ? 4 : (E >= 512 ? 2 : 1));
-}
 
 #ifdef __HIPCC__
 // the consumers' test: a plan that was completed (the builder writes the magic last) for a batch of exactly this shape
@@ -98,8 +88,7 @@ __device__ __forceinline__ int wave_max(int x) { return -wave_min(-x); }
 // The tiles of the plan: lane l owns tiles l * TB .. l * TB + TB - 1 (TBP = TB rounded up to a power of two: the per-lane loops over the
 // tiles are unrolled without guards, surplus slots hold an all-ones key and never win).  Returns false when the envs do not fit.
 template <int TBP>
-__device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart, int id_base, int32_t *__restrict__ items, int32_t *__restrict__ tcnt, Lds &lds,
-                                     long long *tim)
+__device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart, int32_t *__restrict__ items, int32_t *__restrict__ tcnt, Lds &lds, long long *tim)
 {
     const int ln = threadIdx.x & 63;
     // key of tile j of this lane: rows << 11 | envs << 4 | j -- the smallest key is the emptiest tile (ties: fewer envs, then lower j)
@@ -107,12 +96,8 @@ __device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart,
 #pragma unroll
     for (int j = 0; j < TBP; ++j) key[j] = (j < TB && ln * TB + j < T) ? (unsigned)j : 0xffffffffu;
     int lt = 0; // rows on this lane's tiles
-    // tiles this lane owns: TB, fewer on the last lane that owns any, none behind it (a group's tile count is not a multiple of 64).  The level
-    // L of the water filling is in rows per TB tiles: a lane with ntl tiles is filled to L * ntl / TB (tools/row_plan_groups_study.py)
-    const int ntl = ln * TB < T ? ((ln + 1) * TB <= T ? TB : T - ln * TB) : 0;
-    const int lcap = ntl * 63;
-    const int nact = __popcll(__ballot(lcap > 0)); // lanes that own tiles (all 64 unless the group is small)
-    const unsigned inv_tb = ((1u << 20) + (unsigned)TB - 1u) / (unsigned)TB;   // floor(x / TB) = x * inv_tb >> 20 for x < 2^16
+    const int lcap = (ln * TB < T ? ((ln + 1) * TB <= T ? TB : T - ln * TB) : 0) * 63;
+    const int nact = __popcll(__ballot(lcap > 0)); // lanes that own tiles (all 64 unless the batch is tiny)
     bool bad = false;
     for (int v = H; v >= 1; --v) {
         const int m = __builtin_amdgcn_readlane(hist, v);
@@ -122,30 +107,27 @@ __device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart,
         // level 1: envs of this class per lane = water filling on the lanes' row totals.  floor(r / v) = r * ceil(2^20 / v) >> 20 for r (v - 1) < 2^20
         const unsigned inv = ((1u << 20) + (unsigned)v - 1u) / (unsigned)v;
         auto take = [&](int L) __attribute__((always_inline)) -> int {
-            const int lvl = ntl == TB ? L : (int)(((unsigned)(L * ntl) * inv_tb) >> 20);
-            const int room = (lvl < lcap ? lvl : lcap) - lt;
+            const int room = (L < lcap ? L : lcap) - lt;
             return room > 0 ? (int)(((unsigned)room * inv) >> 20) : 0;
         };
-        // Largest level whose demand is at most m.  With every lane taking part it lies in [mean, mean + v TB], mean = the level at which the
-        // tiles hold exactly the rows AFTER this class; lanes that are already above the level (or full) move it down: then bisect from the
-        // lowest total.
-        int lo = (int)(((long long)(wave_sum(lt) + m * v) * TB) / T), hi = lo + v * TB;
-        if (wave_sum(take(lo)) > m) { hi = lo - 1; lo = wave_min(ntl ? (lt * TB) / ntl : (1 << 30)); }
+        // Largest level whose demand is at most m.  With every lane taking part it lies in [mean, mean + v], mean = the lanes' average
+        // total AFTER this class; lanes that are already above the level (or full) move it down: then bisect from the lowest total.
+        int lo = (wave_sum(lt) + m * v) / nact, hi = lo + v;
+        if (wave_sum(take(lo)) > m) { hi = lo - 1; lo = wave_min(lcap ? lt : (1 << 30)); }
         for (;;) {
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (wave_sum(take(mid)) <= m) lo = mid; else hi = mid - 1;
             }
             // ended on the upper end of the bracket: make sure the level really stops there (lanes at their cap shift the mean argument)
-            const int top = wave_max(ntl ? (lt * TB + ntl - 1) / ntl : 0) + v * TB * ((m + nact - 1) / nact + 1);
+            const int top = wave_max(lcap ? lt : 0) + v * ((m + nact - 1) / nact + 1);
             if (lo >= top || wave_sum(take(lo + 1)) > m) break;
             lo = lo + 1; hi = top;
         }
         int k = take(lo);
         const int rem = m - wave_sum(k);
-        if (rem > 0) { // the remainder goes to the first lanes that gain one more at the next level(s)
-            int gain = take(lo + 1) > k ? 1 : 0;
-            if (wave_sum(gain) < rem) gain = take(lo + v * TB) > k ? 1 : 0;  // (partial lanes step in coarser units: look a whole env ahead)
+        if (rem > 0) { // the remainder goes to the first lanes that gain one more at the next level
+            const int gain = take(lo + 1) > k ? 1 : 0;
             const int incl = wave_incl_scan(gain);
             if (gain && incl <= rem) k += 1;
             if (__builtin_amdgcn_readlane(incl, 63) < rem) bad = true; // they do not fit: no plan, the consumer falls back
@@ -159,7 +141,7 @@ __device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart,
         for (int q0 = 0; q0 < kmax; q0 += 8) {
             int id8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) id8[u] = q0 + u < k ? (int)lds.ids[at + q0 + u] + id_base : 0;
+            for (int u = 0; u < 8; ++u) id8[u] = q0 + u < k ? (int)lds.ids[at + q0 + u] : 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (q0 + u >= kmax) break;
@@ -191,141 +173,97 @@ __device__ __forceinline__ bool fill(int H, int T, int TB, int hist, int cstart,
     return __ballot(bad) == 0ull;
 }
 
-// Wavefront g of G (all 64 lanes active; G = rp_groups(E), every wavefront its own workgroup / Lds).  det: detected_human_num of the
-// observation the plan is for.
+// One wavefront (all 64 lanes active).  det: detected_human_num of the observation the plan is for.
 //
 // Two levels, so that almost nothing needs the other lanes: (1) the envs of a size class are dealt to the 64 LANES by water filling on
 // the lanes' row totals (one division per lane and probe); (2) each lane puts the envs it was dealt, one by one, on the emptiest of ITS
 // OWN tiles (tile = lane * TB + j: at most 16 per lane, loads and counts packed into one register key each).
-// The wavefronts meet once, at the end: each adds itself to the counter in header word 7 (a failed group adds a flag), the last one
-// publishes the header (magic last) and clears the counter for the next build.
-__device__ __forceinline__ void build(int g, int G, int E, int H, int NW, const float *__restrict__ det, int32_t *__restrict__ plan, Lds &lds, long long *tim = nullptr)
+__device__ __forceinline__ void build(int E, int H, int NW, const float *__restrict__ det, int32_t *__restrict__ plan, Lds &lds, long long *tim = nullptr)
 {
     const int ln = threadIdx.x & 63;
     int32_t *hdr = plan, *row_off = plan + rp_off_rowoff(), *tcnt = plan + rp_off_tcnt(E), *items = plan + rp_off_items(E);
     RP_T(0);
-    if (ln == 0) hdr[0] = 0;   // (every group: the magic only comes back once ALL of them are through)
+    if (ln == 0) hdr[0] = 0;
     if (H > RP_HMAX || E > RP_EMAX || (E & 3)) return;
-    // ---- rows per env of the WHOLE batch: lane l owns envs [CH * l, CH * l + CH) (CH = 4 * ceil(E / 256) <= 64): totals of every group ----
+    // ---- rows per env: lane l owns envs [CH * l, CH * l + CH) (CH = 4 * ceil(E / 256) <= 64), all in registers ----
     const int CH = ((E + 255) >> 8) << 2;
-    int mysum = 0;
-    {
-        int c[64];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float4 d = float4{0.f, 0.f, 0.f, 0.f};
-            const int e0 = ln * CH + 4 * q;
-            if (4 * q < CH && e0 < E) d = *reinterpret_cast<const float4 *>(det + e0); // E % 4 == 0: a float4 never straddles the end
-            const float dd[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int r = (int)dd[u];
-                r = r < 1 ? 1 : (r > H ? H : r); // no detected human still occupies one (dummy) row: crowd_sim_var_num.py:290-292
-                c[4 * q + u] = (4 * q < CH && e0 < E) ? r : 0;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 64; ++i) mysum += c[i];
-        // row offsets of the lanes of THIS group (serial inside the lane, one scan across)
-        const int incl0 = wave_incl_scan(mysum);
-        const int LG = 64 / G;  // lanes of the count scan per group (G > 1 only when E % 256 == 0: CH = E / 64, a group = LG whole lanes)
-        if (ln / LG == g || G == 1) {
-            int run = incl0 - mysum;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int4 o;
-                o.x = run; run += c[4 * q]; o.y = run; run += c[4 * q + 1]; o.z = run; run += c[4 * q + 2]; o.w = run; run += c[4 * q + 3];
-                if (4 * q < CH && ln * CH + 4 * q < E) *reinterpret_cast<int4 *>(row_off + ln * CH + 4 * q) = o; // row_off is 16-byte aligned (RP_HDR = 8)
-            }
-        }
-        mysum = incl0; // from here on: the inclusive scan
-    }
-    const int total = __builtin_amdgcn_readlane(mysum, 63);
-    if (g == 0 && ln == 0) row_off[E] = total;
-    // ---- tiles of the batch, and the contiguous share of this group: proportional to its rows ----
-    int n = (total + 62 * NW - 1) / (62 * NW);
-    n = n < 1 ? 1 : n;
-    const int Tall = n * NW;
-    if (Tall > RP_TMAX) return;
-    int e_base = 0, Eg = E, t0 = 0, T = Tall;
-    if (G > 1) {
-        const int LG = 64 / G;
-        const int cum0 = g ? __builtin_amdgcn_readlane(mysum, g * LG - 1) : 0, cum1 = __builtin_amdgcn_readlane(mysum, (g + 1) * LG - 1);
-        t0 = (int)(((long long)cum0 * Tall + total / 2) / total);
-        const int t1 = g == G - 1 ? Tall : (int)(((long long)cum1 * Tall + total / 2) / total);
-        T = t1 - t0;
-        Eg = E / G; e_base = g * Eg;
-    }
-    bool ok = T >= 1;
     int c[64];
-    int hist = 0, cstart = 0; // lane v: number of envs of this group with v rows, first position of the class
-    if (ok) {
-        // ---- rows per env of THIS group: lane l owns local envs [CHg * l, CHg * l + CHg), CHg = 4 * ceil(Eg / 256) ----
-        const int CHg = ((Eg + 255) >> 8) << 2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float4 d = float4{0.f, 0.f, 0.f, 0.f};
+        const int e0 = ln * CH + 4 * q;
+        if (4 * q < CH && e0 < E) d = *reinterpret_cast<const float4 *>(det + e0); // E % 4 == 0: a float4 never straddles the end
+        const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int r = (int)dd[u];
+            r = r < 1 ? 1 : (r > H ? H : r); // no detected human still occupies one (dummy) row: crowd_sim_var_num.py:290-292
+            c[4 * q + u] = (4 * q < CH && e0 < E) ? r : 0;
+        }
+    }
+    // ---- row offsets (serial inside the lane, one scan across); per-lane size histogram in LDS (column `lane` is private to the lane) ----
+    for (int k = ln; k < (H + 1) * 64; k += 64) lds.tbl[k] = 0;
+    int mysum = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) mysum += c[i];
+    const int incl0 = wave_incl_scan(mysum);
+    const int total = __builtin_amdgcn_readlane(incl0, 63);
+    {
+        int run = incl0 - mysum;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            float4 d = float4{0.f, 0.f, 0.f, 0.f};
-            const int e0 = ln * CHg + 4 * q;
-            const bool in = 4 * q < CHg && e0 < Eg;
-            if (in) d = *reinterpret_cast<const float4 *>(det + e_base + e0);
-            const float dd[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int r = (int)dd[u];
-                r = r < 1 ? 1 : (r > H ? H : r);
-                c[4 * q + u] = in ? r : 0;
-            }
+            int4 o;
+            o.x = run; run += c[4 * q]; o.y = run; run += c[4 * q + 1]; o.z = run; run += c[4 * q + 2]; o.w = run; run += c[4 * q + 3];
+            if (4 * q < CH && ln * CH + 4 * q < E) *reinterpret_cast<int4 *>(row_off + ln * CH + 4 * q) = o; // row_off is 16-byte aligned (RP_HDR = 8)
         }
-        // ---- per-lane size histogram in LDS (column `lane` is private to the lane) ----
-        for (int k = ln; k < (H + 1) * 64; k += 64) lds.tbl[k] = 0;
+    }
+    if (ln == 0) row_off[E] = total;
+#pragma unroll
+    for (int i = 0; i < 64; ++i)
+        if (c[i]) __hip_atomic_fetch_add(&lds.tbl[c[i] * 64 + ln], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    RP_T(1);
+    // ---- hand-out order: by rows descending; inside a size class by (lane, i).  tbl[v][lane] becomes the lane's next position ----
+    int hist = 0, cstart = 0; // lane v: number of envs with v rows, first position of the class
+    {
+        int at = 0;
+        for (int v = H; v >= 1; --v) {
+            const int mine = lds.tbl[v * 64 + ln];
+            const int incl = wave_incl_scan(mine);
+            lds.tbl[v * 64 + ln] = at + incl - mine;
+            const int m = __builtin_amdgcn_readlane(incl, 63);
+            if (ln == v) { hist = m; cstart = at; }
+            at += m;
+        }
+    }
+    {
+        int pos[64];
 #pragma unroll
         for (int i = 0; i < 64; ++i)
-            if (c[i]) __hip_atomic_fetch_add(&lds.tbl[c[i] * 64 + ln], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        RP_T(1);
-        // ---- hand-out order: by rows descending; inside a size class by (lane, i).  tbl[v][lane] becomes the lane's next position ----
-        {
-            int at = 0;
-            for (int v = H; v >= 1; --v) {
-                const int mine = lds.tbl[v * 64 + ln];
-                const int incl = wave_incl_scan(mine);
-                lds.tbl[v * 64 + ln] = at + incl - mine;
-                const int m = __builtin_amdgcn_readlane(incl, 63);
-                if (ln == v) { hist = m; cstart = at; }
-                at += m;
-            }
-        }
-        {
-            int pos[64];
+            pos[i] = c[i] ? __hip_atomic_fetch_add(&lds.tbl[c[i] * 64 + ln], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
 #pragma unroll
-            for (int i = 0; i < 64; ++i)
-                pos[i] = c[i] ? __hip_atomic_fetch_add(&lds.tbl[c[i] * 64 + ln], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                if (c[i]) lds.ids[pos[i]] = (unsigned short)(ln * CHg + i);   // local index: the group's base is added at the hand-out
-        }
-        RP_T(2);
-        const int TB = (T + 63) >> 6;
-        int32_t *it = items + (size_t)t0 * 64, *tc = tcnt + t0;
-        if (TB <= 1) ok = fill<1>(H, T, TB, hist, cstart, e_base, it, tc, lds, tim);
-        else if (TB <= 2) ok = fill<2>(H, T, TB, hist, cstart, e_base, it, tc, lds, tim);
-        else if (TB <= 4) ok = fill<4>(H, T, TB, hist, cstart, e_base, it, tc, lds, tim);
-        else if (TB <= 8) ok = fill<8>(H, T, TB, hist, cstart, e_base, it, tc, lds, tim);
-        else ok = fill<16>(H, T, TB, hist, cstart, e_base, it, tc, lds, tim);
+        for (int i = 0; i < 64; ++i)
+            if (c[i]) lds.ids[pos[i]] = (unsigned short)(ln * CH + i);
     }
+    RP_T(2);
+    // ---- tiles ----
+    int n = (total + 62 * NW - 1) / (62 * NW);
+    n = n < 1 ? 1 : n;
+    const int T = n * NW;
+    if (T > RP_TMAX) return;
+    const int TB = (T + 63) >> 6;
+    bool ok;
+    if (TB <= 1) ok = fill<1>(H, T, TB, hist, cstart, items, tcnt, lds, tim);
+    else if (TB <= 2) ok = fill<2>(H, T, TB, hist, cstart, items, tcnt, lds, tim);
+    else if (TB <= 4) ok = fill<4>(H, T, TB, hist, cstart, items, tcnt, lds, tim);
+    else if (TB <= 8) ok = fill<8>(H, T, TB, hist, cstart, items, tcnt, lds, tim);
+    else ok = fill<16>(H, T, TB, hist, cstart, items, tcnt, lds, tim);
     RP_T(3);
+    if (!ok) return;
     __threadfence();
     if (ln == 0) {
-        // the groups meet here: count in the low half of word 7, a failure flag in the high half; the last one through decides
-        const int old = G > 1 ? atomicAdd(&hdr[7], ok ? 1 : 0x10001) : (ok ? 0 : 0x10000);
-        if ((old & 0xffff) == G - 1) {
-            const bool all_ok = ok && (old >> 16) == 0;
-            hdr[7] = 0;
-            if (all_ok) {
-                hdr[1] = NW; hdr[2] = n; hdr[3] = total; hdr[4] = E; hdr[5] = H; hdr[6] = Tall;
-                __threadfence();
-                hdr[0] = RP_MAGIC;
-            }
-        }
+        hdr[1] = NW; hdr[2] = n; hdr[3] = total; hdr[4] = E; hdr[5] = H; hdr[6] = T; hdr[7] = 0;
+        __threadfence();
+        hdr[0] = RP_MAGIC;
     }
     RP_T(4);
 }
