@@ -203,8 +203,8 @@ def test_hh_attention_size_classes_match_fp64_autograd(H, B):
 @pytest.mark.parametrize("M,N,K,relu", [(1000, 512, 128, True), (4097, 1536, 512, False), (300, 256, 512, True), (64, 128, 128, False),
                                          (20000, 512, 128, True),
                                          # >= 32768 rows: the pipelined weight-gradient kernel (whole 32-row tiles; the row tail goes to the
-                                         # two-barrier kernel as one more split), 128 x 256 and 128 x 128 tiles
-                                         (40001, 256, 512, True), (33000, 384, 128, False)])
+                                         # two-barrier kernel as one more split), 128 x 512, 128 x 256 and 128 x 128 tiles
+                                         (40001, 256, 512, True), (33000, 384, 128, False), (36000, 256, 256, True), (34017, 128, 512, False)])
 def test_hip_linear_forward_and_gradients_match_fp64(M, N, K, relu):
     """cn_linear_fwd / cn_linear_wgrad (bf16x3 split precision) against an fp64 torch graph: outputs and all three
     gradients within 1e-4 of the largest reference magnitude (the fp32 reference itself sits at ~1e-6)."""
