@@ -20,7 +20,8 @@
 namespace {
 
 // W in fragment order: element (cb, kk, lane, e) = W'[cb * 32 + (lane & 31)][kk * 16 + (lane >> 5) * 8 + e], W' = w or w^T
-__global__ void split_bf16_frag_kernel(int Nw, int Kw, int transpose, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo)
+// Nreal <= Nw: rows Nreal .. Nw-1 of W' are zero padding (a weight whose row count is not a multiple of the 128-column tile)
+__global__ void split_bf16_frag_kernel(int Nw, int Kw, int transpose, const float *__restrict__ w, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo, int Nreal)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)Nw * Kw) return;
@@ -28,7 +29,7 @@ __global__ void split_bf16_frag_kernel(int Nw, int Kw, int transpose, const floa
     const size_t blk = idx >> 9;
     const int kk = (int)(blk % (Kw / 16)), cb = (int)(blk / (Kw / 16));
     const int n = cb * 32 + (lane & 31), k = kk * 16 + (lane >> 5) * 8 + e;
-    const float x = transpose ? w[(size_t)k * Nw + n] : w[(size_t)n * Kw + k];
+    const float x = n >= Nreal ? 0.0f : (transpose ? w[(size_t)k * Nreal + n] : w[(size_t)n * Kw + k]);
     const __bf16 h = (__bf16)x;
     hi[idx] = h;
     lo[idx] = (__bf16)(x - (float)h);
@@ -38,8 +39,12 @@ __global__ void split_bf16_frag_kernel(int Nw, int Kw, int transpose, const floa
 template <int NB, int ACT, bool GATE, int KO = 0>
 __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ Agate,
                                                            const __bf16 *__restrict__ Whi, const __bf16 *__restrict__ Wlo,
-                                                           const float *__restrict__ bias, float *__restrict__ C, int ldc)
+                                                           const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                           const float *__restrict__ aux, int ldaux, int relu_from)
 {
+    // Epilogues (ACT, gemm.h): none / ReLU / tanh on the sum, or -- backward products of the robot-node sequence -- the sum times the
+    // derivative of the activation whose forward VALUE y sits in aux [M, ldaux]: [y > 0] (ACT_MUL_DRELU) or 1 - y^2 (ACT_MUL_DTANH).
+    // Columns >= relu_from get a ReLU on top of ACT (one launch produces [u | relu(enc)]); pass relu_from >= N for none.
     constexpr int TBM = 128, MI = 4, BN = 128 * NB;
     constexpr int PK = 32, PS = 40;     // K tile (two k-steps), LDS row stride in bf16 (80 B: conflict-free 16-byte fragment reads)
     constexpr int BUF = 2 * TBM * PS;   // bf16 elements per LDS buffer: A hi and lo planes of one K tile (20 480 B)
@@ -210,15 +215,30 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                float *cp = C + (size_t)(m_blk + i * 32 + 4 * half) * ldc + n_blk + j * 32 + l31;
+                const int row0 = m_blk + i * 32 + 4 * half, col = n_blk + j * 32 + l31;
+                float *cp = C + (size_t)row0 * ldc + col;
+                constexpr bool AUX = ACT == ACT_MUL_DRELU || ACT == ACT_MUL_DTANH;
+                float y[AUX ? 16 : 1]; // the block's 16 activation values first, then the 16 stores (a load between two stores would wait for the first)
+                if (AUX) {
+                    const float *ap = aux + (size_t)row0 * ldaux + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        y[AUX ? r : 0] = guard(row0 + ro) ? ap[(size_t)ro * ldaux] : 0.0f;
+                    }
+                }
+                const bool extra_relu = col >= relu_from;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bv[j];
-                    if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_RELU || extra_relu) v = fmaxf(v, 0.0f);
+                    if (ACT == ACT_TANH) v = tanhf(v);
+                    if (ACT == ACT_MUL_DRELU) v = y[AUX ? r : 0] > 0.0f ? v : 0.0f;
+                    if (ACT == ACT_MUL_DTANH) v *= 1.0f - y[AUX ? r : 0] * y[AUX ? r : 0];
                     acc[i][j][r] = 0.0f;
                     if ((KO & 1) && v != 12345.678f) continue;
-                    if (guard(m_blk + i * 32 + 4 * half + ro)) __builtin_nontemporal_store(v, cp + (size_t)ro * ldc); // streaming result: keep A / W in the L2
+                    if (guard(row0 + ro)) __builtin_nontemporal_store(v, cp + (size_t)ro * ldc); // streaming result: keep A / W in the L2
                 }
             }
     };
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, 
 
 template <int ACT, int KO = 0>
 static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __bf16 *Whi, const __bf16 *Wlo, const float *bias, float *C, int ldc,
-                         hipStream_t st, const float *Agate)
+                         hipStream_t st, const float *Agate, const float *aux = nullptr, int ldaux = 0, int relu_from = 1 << 30)
 {
     CN_REQUIRE(N % 128 == 0 && K % 64 == 0 && lda % 4 == 0, "gemm3p: unsupported shape M=%d N=%d K=%d lda=%d", M, N, K, lda);
     CN_REQUIRE((long long)M * lda < (1LL << 31) && (long long)N * K < (1LL << 31), "gemm3p: operand too large for 32-bit element offsets (M=%d lda=%d)", M, lda);
@@ -249,11 +269,11 @@ static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __b
     const int per_xcd = N / (128 * nb) * gy / 8;                 // output tiles per XCD
     const dim3 grid(8 * (per_xcd < 32 ? per_xcd : 32));          // persistent: one workgroup per CU, 32 CUs per XCD
     if (nb == 2) {
-        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, true, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
-        else hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, false, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, true, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, aux, ldaux, relu_from);
+        else hipLaunchKernelGGL((gemm3p_nt_kernel<2, ACT, false, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, aux, ldaux, relu_from);
     } else {
-        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, true, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
-        else hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, false, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc);
+        if (Agate) hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, true, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, aux, ldaux, relu_from);
+        else hipLaunchKernelGGL((gemm3p_nt_kernel<1, ACT, false, KO>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, aux, ldaux, relu_from);
     }
     CN_CHECK_LAUNCH();
     return CN_OK;

@@ -106,37 +106,54 @@ __global__ __launch_bounds__(128) void embed0_bwd_kernel(int R, int D, const flo
 // a pointwise kernel per step and direction) it is launch- and latency-bound.  Here a workgroup owns 32 rows (envs) for
 // the whole sequence and W_hh never leaves the register file:
 //   * forward: wavefront w owns hidden units 32w .. 32w+31, i.e. the three gate columns {u, 128+u, 256+u}; its 96 x 128
-//     slice of W_hh is loaded once as 48 float4 fragments per lane (192 VGPRs).  Per step the masked state hm (32 x 128,
-//     LDS, double buffered) is the A operand of 192 exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32, K order remapped so that one
-//     16-byte LDS read feeds four k-steps); the accumulators of the r, z, n gates of one (row, unit) sit in the same lane and
-//     register index, so the cell's pointwise part needs no exchange at all; one barrier per step.
+//     slice of W_hh is loaded once and kept as bf16 hi / lo MFMA fragments (192 VGPRs).  Per step the masked state hm (32 x 128,
+//     LDS, double buffered: fp32 for the cell's z * h term, bf16 hi / lo planes written by the lane that computed the value) is
+//     the A operand of 72 split-precision MFMAs (v_mfma_f32_32x32x16_bf16: lo*hi, hi*lo, hi*hi per gate and k-step -- 2.3 k
+//     matrix cycles; the exact-fp32 instruction needed 192 x 64 = 12.3 k of a step's ~30 k); the accumulators of the r, z, n
+//     gates of one (row, unit) sit in the same lane and register index, so the cell's pointwise part needs no exchange at all;
+//     one barrier per step.
 //   * backward (reverse time): the same wavefront computes d(gates) for its units from the saved (r, z, n, gh_n), publishes
-//     d(gh) [32 x 384] in LDS, and multiplies it with its 384 x 32 slice of W_hh (again 192 resident VGPRs) to get d(hm);
-//     the carried gradient stays in registers in the accumulator layout.  d(W_hh) is one product over all T*N rows afterwards.
-constexpr int GR = 32, GHS = 132, GDS = 388; // rows per workgroup; LDS row strides (floats): 16-byte reads of 16 rows tile all banks
+//     d(gh) [32 x 384] as hi / lo planes in LDS, and multiplies it with its 384 x 32 slice of W_hh (again 192 resident VGPRs) to
+//     get d(hm); the carried gradient stays in registers in the accumulator layout.  d(W_hh) is one product over all T*N rows afterwards.
+constexpr int GR = 32, GHS = 132;   // rows per workgroup; LDS row stride (floats) of the fp32 state
+constexpr int GPS = 136, GQS = 392; // row strides (bf16) of the hi / lo planes of hm / d(gh): 272 / 784 bytes = 4 banks mod 64, so the
+                                    // 16-byte fragment reads of 16 rows tile all banks
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const __bf16 h = (__bf16)x[e]; hi[e] = h; lo[e] = (__bf16)(x[e] - (float)h); }
+}
 
 __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const float *__restrict__ gi, const float *__restrict__ h0,
                                                           const float *__restrict__ m, const float *__restrict__ Whh, const float *__restrict__ bhh,
                                                           float *__restrict__ hs, float *__restrict__ hms, float *__restrict__ gates)
 {
     __shared__ __attribute__((aligned(16))) float hm[2][GR * GHS];
+    __shared__ __attribute__((aligned(16))) __bf16 hmh[2][GR * GPS], hml[2][GR * GPS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int row0 = blockIdx.x * GR, u = 32 * wave + l31;
-    f32x4 wf[3][16];
+    // B fragments: column n = this lane's unit u of gate j, k = 16 kk + 8 half + e
+    bf16x8 wh[3][8], wl[3][8];
     float bias[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const float *wr = Whh + (size_t)(j * 128 + u) * 128 + 4 * half;
+        const float *wr = Whh + (size_t)(j * 128 + u) * 128 + 8 * half;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) wf[j][g] = *reinterpret_cast<const f32x4 *>(wr + 8 * g);
+        for (int kk = 0; kk < 8; ++kk) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = wr[16 * kk + e];
+            split8(x, wh[j][kk], wl[j][kk]);
+        }
         bias[j] = bhh[j * 128 + u];
     }
     for (int i = tid; i < GR * 128; i += 256) {
         const int r = i >> 7, c = i & 127, row = row0 + r;
         const float v = row < N ? h0[(size_t)row * 128 + c] * m[row] : 0.0f;
-        hm[0][r * GHS + c] = v;
+        const __bf16 h = (__bf16)v;
+        hm[0][r * GHS + c] = v; hmh[0][r * GPS + c] = h; hml[0][r * GPS + c] = (__bf16)(v - (float)h);
         if (row < N) hms[(size_t)row * 128 + c] = v;
     }
     __syncthreads();
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
         const int cur = t & 1;
         // this step's inputs do not depend on the state: request them before the MFMAs, unpredicated (surplus rows of the last
         // workgroup read row N-1).  Loaded inside the per-row `if (row < N)` blocks below, every row paid its own memory round
-        // trip behind an s_waitcnt vmcnt(0): 16 of them in series per step (24 us per step, ~5 of them MFMA).
+        // trip behind an s_waitcnt vmcnt(0): 16 of them in series per step.
         float gir[16], giz[16], gin[16], mk[16];
         const int tn = min(t + 1, T - 1);
 #pragma unroll
@@ -159,13 +176,17 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        // term-major inside a k-step: consecutive MFMAs write different accumulators
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(&hm[cur][l31 * GHS + 8 * g + 4 * half]);
+        for (int kk = 0; kk < 8; ++kk) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&hmh[cur][l31 * GPS + 16 * kk + 8 * half]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&hml[cur][l31 * GPS + 16 * kk + 8 * half]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[j][kk], acc[j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wf[j][g][s], acc[j], 0, 0, 0);
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[j][kk], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[j][kk], acc[j], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -183,7 +204,10 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
                 gp[u] = rg; gp[128 + u] = zg; gp[256 + u] = ng; gp[384 + u] = hn;
                 if (t + 1 < T) hms[(tr + N) * 128 + u] = next;
             }
-            if (t + 1 < T) hm[cur ^ 1][rl * GHS + u] = next;
+            if (t + 1 < T) {
+                const __bf16 h = (__bf16)next;
+                hm[cur ^ 1][rl * GHS + u] = next; hmh[cur ^ 1][rl * GPS + u] = h; hml[cur ^ 1][rl * GPS + u] = (__bf16)(next - (float)h);
+            }
         }
         __syncthreads();
     }
@@ -193,20 +217,23 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const fl
                                                           const float *__restrict__ m, const float *__restrict__ Whh, const float *__restrict__ d_hs,
                                                           float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh0)
 {
-    __shared__ __attribute__((aligned(16))) float dg[GR * GDS];
+    __shared__ __attribute__((aligned(16))) __bf16 dgp_h[GR * GQS], dgp_l[GR * GQS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int row0 = blockIdx.x * GR, u = 32 * wave + l31;
-    // d(hm)[row][n] = sum_c d(gh)[row][c] * W_hh[c][n]: this lane's column n = u, k runs over the 384 gate columns
-    f32x4 wf[48];
+    // d(hm)[row][n] = sum_c d(gh)[row][c] * W_hh[c][n]: this lane's column n = u, k = c = 16 kk + 8 half + e runs over the 384 gate columns
+    bf16x8 wh[24], wl[24];
 #pragma unroll
-    for (int g = 0; g < 48; ++g)
+    for (int kk = 0; kk < 24; ++kk) {
+        float x[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wf[g][s] = Whh[(size_t)(8 * g + 4 * half + s) * 128 + u];
+        for (int e = 0; e < 8; ++e) x[e] = Whh[(size_t)(16 * kk + 8 * half + e) * 128 + u];
+        split8(x, wh[kk], wl[kk]);
+    }
     f32x16 carry;
 #pragma unroll
     for (int r = 0; r < 16; ++r) carry[r] = 0.0f;
     // The saved gates / states / incoming gradients of a step do not depend on the carried gradient: they are requested one step
-    // ahead, unpredicated (surplus rows read row N-1), right behind the barrier that ends their last use -- the 192 MFMAs of the
+    // ahead, unpredicated (surplus rows read row N-1), right behind the barrier that ends their last use -- the MFMAs of the
     // current step hide the round trip.  Loaded inside the per-row `if (row < N)` blocks they cost 16 serial round trips per step.
     float s_rg[16], s_zg[16], s_ng[16], s_hn[16], s_h[16], s_d[16], s_m[16];
     auto preload = [&](int t) {
@@ -221,6 +248,7 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const fl
             s_m[r] = m[tr];
         }
     };
+    auto put = [&](int off, float v) { const __bf16 h = (__bf16)v; dgp_h[off] = h; dgp_l[off] = (__bf16)(v - (float)h); };
     preload(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         float direct[16], mt[16];
@@ -242,25 +270,30 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const fl
                 a[u] = dr; a[128 + u] = dz; a[256 + u] = din;
                 b[u] = dr; b[128 + u] = dz; b[256 + u] = dn;
             }
-            dg[rl * GDS + u] = dr; dg[rl * GDS + 128 + u] = dz; dg[rl * GDS + 256 + u] = dn;
+            put(rl * GQS + u, dr); put(rl * GQS + 128 + u, dz); put(rl * GQS + 256 + u, dn);
         }
         __syncthreads();
         preload(t > 0 ? t - 1 : 0);
-        f32x16 acc;
+        // one accumulator per term: 72 MFMAs into a single accumulator would each wait for the one before
+        f32x16 acc[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int g = 0; g < 48; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(&dg[l31 * GDS + 8 * g + 4 * half]);
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wf[g][s], acc, 0, 0, 0);
+        for (int kk = 0; kk < 24; ++kk) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&dgp_h[l31 * GQS + 16 * kk + 8 * half]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&dgp_l[l31 * GQS + 16 * kk + 8 * half]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[kk], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[kk], acc[2], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            carry[r] = row < N ? (direct[r] + acc[r]) * mt[r] : 0.0f;
+            carry[r] = row < N ? (direct[r] + ((acc[0][r] + acc[1][r]) + acc[2][r])) * mt[r] : 0.0f;
         }
-        __syncthreads(); // the next (earlier) step overwrites dg
+        __syncthreads(); // the next (earlier) step overwrites the planes
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -333,19 +366,24 @@ extern "C" int cn_gru_cell_bwd(int N, const float *gates, const float *hm, const
     return CN_OK;
 }
 
-extern "C" int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream)
+extern "C" int cn_split_bf16_padded(const float *w, int rows, int cols, int transpose, int n_padded, void *hi, void *lo, void *stream)
 {
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(w && hi && lo && rows > 0 && cols > 0, "cn_split_bf16: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    // W' = w (transpose = 0) or w^T: [Nw, Kw]; stored in the MFMA fragment order gemm3p_nt_kernel loads (gemm3p.h)
-    const int Nw = transpose ? cols : rows, Kw = transpose ? rows : cols;
-    CN_REQUIRE(Nw % 32 == 0 && Kw % 16 == 0, "cn_split_bf16: the weight seen by the product must be [32 a, 16 b], got [%d, %d]", Nw, Kw);
-    const size_t n = (size_t)rows * cols;
+    // W' = w (transpose = 0) or w^T: [Nreal, Kw], zero-padded to n_padded rows; stored in the MFMA fragment order gemm3p_nt_kernel loads (gemm3p.h)
+    const int Nreal = transpose ? cols : rows, Kw = transpose ? rows : cols;
+    const int Nw = n_padded > 0 ? n_padded : Nreal;
+    CN_REQUIRE(Nw >= Nreal && Nw % 32 == 0 && Kw % 16 == 0, "cn_split_bf16: the weight seen by the product must be [32 a, 16 b], got [%d (padded %d), %d]", Nreal, Nw, Kw);
+    const size_t n = (size_t)Nw * Kw;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(split_bf16_frag_kernel, dim3(blocks), dim3(256), 0, st, Nw, Kw, transpose, w, (__bf16 *)hi, (__bf16 *)lo);
+    hipLaunchKernelGGL(split_bf16_frag_kernel, dim3(blocks), dim3(256), 0, st, Nw, Kw, transpose, w, (__bf16 *)hi, (__bf16 *)lo, Nreal);
     CN_CHECK_LAUNCH();
     return CN_OK;
+}
+extern "C" int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream)
+{
+    return cn_split_bf16_padded(w, rows, cols, transpose, 0, hi, lo, stream);
 }
 
 extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const float *relu_gate, const void *Whi, const void *Wlo, const float *bias,
@@ -367,6 +405,25 @@ extern "C" int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const
 #endif
     return act == 1 ? launch_gemm3p<ACT_RELU>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, relu_gate)
                     : launch_gemm3p<ACT_NONE>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, relu_gate);
+}
+
+extern "C" int cn_linear_fwd_act(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act,
+                                 const float *aux, int ldaux, int relu_from, float *Y, int ldy, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(X && Whi && Wlo && Y && M >= 0, "cn_linear_fwd_act: bad argument");
+    CN_REQUIRE(act >= 0 && act <= 4, "cn_linear_fwd_act: act must be 0 (none), 1 (relu), 2 (tanh), 3 (x relu'(aux)) or 4 (x tanh'(aux))");
+    CN_REQUIRE(act < 3 || (aux && ldaux >= N), "cn_linear_fwd_act: act %d needs the forward activation aux [M, ldaux >= N]", act);
+    CN_REQUIRE(ldx >= K && ldy >= N, "cn_linear_fwd_act: leading dimension smaller than the row length");
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *wh = (const __bf16 *)Whi, *wl = (const __bf16 *)Wlo;
+    switch (act) {
+    case 0: return launch_gemm3p<ACT_NONE>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, nullptr, nullptr, 0, relu_from);
+    case 1: return launch_gemm3p<ACT_RELU>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, nullptr, nullptr, 0, relu_from);
+    case 2: return launch_gemm3p<ACT_TANH>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, nullptr, nullptr, 0, relu_from);
+    case 3: return launch_gemm3p<ACT_MUL_DRELU>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, nullptr, aux, ldaux, relu_from);
+    default: return launch_gemm3p<ACT_MUL_DTANH>(M, N, K, X, ldx, wh, wl, bias, Y, ldy, st, nullptr, aux, ldaux, relu_from);
+    }
 }
 
 // shapes the pipelined TN kernel takes: whole 128-column tiles of dY, enough rows to fill the machine

@@ -635,18 +635,6 @@ constexpr size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-// out [C,R] = in [R,C]^T (weights of a few hundred rows: the dX products of the backward read W^T through the same NT kernel)
-__global__ __launch_bounds__(256) void rn_transpose_kernel(int R, int C, const float *__restrict__ in, float *__restrict__ out)
-{
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8)
-        if (r0 + j < R && c0 + tx < C) t[j][tx] = in[(size_t)(r0 + j) * C + c0 + tx];
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8)
-        if (c0 + j < C && r0 + tx < R) out[(size_t)(c0 + j) * R + r0 + tx] = t[tx][j];
-}
-
 // critic_linear + DiagGaussian.log_probs of GIVEN actions (model.py:82-90, distributions.py:36-44): one wavefront per sample
 __global__ __launch_bounds__(256) void rn_head_fwd_kernel(int B, const float *__restrict__ ac, const float *__restrict__ wv, const float *__restrict__ bv,
                                                           const float *__restrict__ wm, const float *__restrict__ bm, const float *__restrict__ logstd,
@@ -720,18 +708,30 @@ __global__ __launch_bounds__(256) void rn_head_bwd_kernel(int B, const float *__
         partials[(size_t)blockIdx.x * RN_HEAD_COLS + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
-// out[j] = sum over the rows of part[R][Cn], in a fixed order: a workgroup owns 64 columns, its four thread groups each walk every fourth row
-// (coalesced, independent loads) and meet in LDS as (g0 + g1) + (g2 + g3)
-__global__ __launch_bounds__(256) void rn_reduce_rows_kernel(int R, int Cn, const float *__restrict__ part, float *__restrict__ out)
+// out[j] = sum over the rows of part[R][Cn], in a fixed order: a workgroup owns 16 columns, its sixteen thread groups each walk every
+// sixteenth row (independent loads) and meet in LDS as a fixed binary tree.  rl_layout: the columns are robot_linear's [10][256] partials
+// (9 weights + bias, feature innermost) and land in dW [256,9] / db [256] (out = dW, out2 = db).
+__global__ __launch_bounds__(256) void rn_reduce_rows_kernel(int R, int Cn, const float *__restrict__ part, float *__restrict__ out, float *__restrict__ out2,
+                                                             int rl_layout)
 {
-    __shared__ float red[4][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4, j = blockIdx.x * 16 + c;
     float s = 0.f;
     if (j < Cn)
-        for (int r = g; r < R; r += 4) s += part[(size_t)r * Cn + j];
+        for (int r = g; r < R; r += 16) s += part[(size_t)r * Cn + j];
     red[g][c] = s;
     __syncthreads();
-    if (g == 0 && j < Cn) out[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (g == 0 && j < Cn) {
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = red[k][c];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; ++k) t[k] = t[k] + t[k + w];
+        if (!rl_layout) out[j] = t[0];
+        else { const int q = j >> 8, n = j & 255; if (q < 9) out[n * 9 + q] = t[0]; else out2[n] = t[0]; }
+    }
 }
 
 // robot_linear.0's weight gradient: dW [256,9] and db [256] from drs [B,256] (already gated by the ReLU) and the 9 inputs
@@ -751,15 +751,6 @@ __global__ __launch_bounds__(256) void rn_rl_wgrad_kernel(int B, const float *__
 #pragma unroll
     for (int q = 0; q < 10; ++q) partials[((size_t)blockIdx.x * 10 + q) * 256 + n] = acc[q];
 }
-// partial sums [R][10][256] -> dW [256,9] and db [256]: workgroup q, thread n, rows in order
-__global__ __launch_bounds__(256) void rn_rl_wgrad_finish_kernel(int R, const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db)
-{
-    const int n = threadIdx.x, q = blockIdx.x;
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += part[((size_t)r * 10 + q) * 256 + n];
-    if (q < 9) dW[n * 9 + q] = s; else db[n] = s;
-}
-
 } // namespace
 
 struct cn_policy {
@@ -1285,8 +1276,9 @@ extern "C" int cn_hh_attention_bwd(int B, int H, const float *qkv, const int *ro
 // ---------------------------------------------------------------------------------------------------------------------------------
 // cn_rn_seq_fwd / cn_rn_seq_bwd: the robot-node sequence of evaluate_actions (see include/crowdnav_hip.h).  A sequence of the kernels of
 // the separate-launch rollout forward run over all B = T * N samples at once (every layer but the GRU is independent across samples), the
-// GRU as ONE launch per direction (cn_gru_seq_*), and their backward counterparts: dX products on the exact-fp32 NT kernel with the
-// activation derivative in the epilogue, weight gradients on the split-K TN kernel (cn_linear_wgrad), small reductions in fixed order.
+// GRU as ONE launch per direction (cn_gru_seq_*), and their backward counterparts: products on the split-precision NT kernel of the big
+// layers (activation or activation derivative in the epilogue), weight gradients on the split-K TN kernel (cn_linear_wgrad), small
+// reductions in fixed order.
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 struct RnWs { // carve-up of the backward workspace (floats)
@@ -1322,21 +1314,39 @@ int rn_wgrad(int M, int N, int K, const float *dY, int ldy, const float *X, int 
     CN_REQUIRE(splits >= 1, "cn_rn_seq_bwd: no split-K plan for a %d x %d weight gradient over %d rows", N, K, M);
     return cn_linear_wgrad(M, N, K, dY, ldy, nullptr, X, ldx, splits, ws + L.part, ws + L.dbp, dW, db, (void *)st);
 }
-int rn_transpose(int R, int C, const float *in, float *out, hipStream_t st)
-{
-    hipLaunchKernelGGL(rn_transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, R, C, in, out);
-    CN_CHECK_LAUNCH();
-    return CN_OK;
-}
 template <int ACT>
 int rn_gemm(int M, int N, int K, const float *A, int lda, const float *W, const float *bias, float *C, int ldc, hipStream_t st, const float *aux = nullptr, int ldaux = 0,
             int relu_from = 1 << 30)
 {
     return launch_gemm_t<64, 64, ACT>(M, N, K, A, lda, W, bias, C, ldc, st, nullptr, 1, GemmBatch{0, 0, 0, 0, aux, ldaux}, relu_from);
 }
+// The products with N % 128 == 0 and K % 64 == 0 -- all but edge_attention_embed's forward (64 outputs) -- run on the split-precision
+// kernel of the update's big layers (cn_linear_fwd_act, gemm3p.h): three bf16 MFMA products per term at ~5x the rate of the exact-fp32
+// instruction.  `planes` = hi plane followed by lo plane (N * K bf16 each = the N * K floats of the slot) in that kernel's fragment order.
+int rn_split(const float *w, int rows, int cols, int transpose, int n_padded, float *planes, hipStream_t st)
+{
+    const size_t n = (size_t)(n_padded ? n_padded : (transpose ? cols : rows)) * (transpose ? rows : cols);
+    return cn_split_bf16_padded(w, rows, cols, transpose, n_padded, planes, reinterpret_cast<uint16_t *>(planes) + n, (void *)st);
+}
+int rn_gemm3(int act, int M, int N, int K, const float *A, int lda, const float *planes, const float *bias, float *C, int ldc, hipStream_t st,
+             const float *aux = nullptr, int ldaux = 0, int relu_from = 1 << 30)
+{
+    return cn_linear_fwd_act(M, N, K, A, lda, planes, reinterpret_cast<const uint16_t *>(planes) + (size_t)N * K, bias, act, aux, ldaux, relu_from, C, ldc, (void *)st);
+}
+struct RnFwdWs { size_t te, teb, wih, ac0, a2, c2, total; }; // forward workspace (floats): split planes of the five weights + the padded te bias
+RnFwdWs rn_fwd_ws()
+{
+    RnFwdWs w{};
+    size_t off = 0;
+    auto carve = [&](size_t n) { size_t o = off; off += (n + 63) & ~size_t(63); return o; };
+    w.te = carve(384 * 256); w.teb = carve(384); w.wih = carve(384 * 128); w.ac0 = carve(512 * 128); w.a2 = carve(256 * 256); w.c2 = carve(256 * 256);
+    w.total = off;
+    return w;
+}
 } // namespace
 
 extern "C" int64_t cn_rn_seq_workspace_floats(int T, int N) { return (T > 0 && N > 0) ? (int64_t)rn_ws(T, N).total : 0; }
+extern "C" int64_t cn_rn_seq_fwd_workspace_floats(void) { return (int64_t)rn_fwd_ws().total; }
 
 static int rn_check(int T, int N, int H, const void *a, const void *b, const void *c, const void *d, const cn_rn_weights *w, const cn_rn_saved *sv)
 {
@@ -1350,26 +1360,35 @@ static int rn_check(int T, int N, int H, const void *a, const void *b, const voi
 }
 
 extern "C" int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *h0,
-                             const float *masks, const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, float *value, float *logp, void *stream)
+                             const float *masks, const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, float *ws, float *value, float *logp,
+                             void *stream)
 {
     if (int rc = cn_require_device()) return rc;
     if (int rc = rn_check(T, N, H, robot_node, temporal, out_sp, row_off, w, sv)) return rc;
-    CN_REQUIRE(h0 && masks && actions && value && logp, "cn_rn_seq_fwd: null argument");
+    CN_REQUIRE(h0 && masks && actions && ws && value && logp, "cn_rn_seq_fwd: null argument");
     hipStream_t st = (hipStream_t)stream;
     const int B = T * N;
+    const RnFwdWs F = rn_fwd_ws();
     int rc;
+    // split planes of this optimiser step's weights (te: 320 rows padded to 384 = three 128-column tiles; its bias padded with zeros)
+    if ((rc = rn_split(w->te_w, 320, 256, 0, 384, ws + F.te, st)) || (rc = rn_split(w->wih, 384, 128, 0, 0, ws + F.wih, st)) ||
+        (rc = rn_split(w->ac0_w, 512, 128, 0, 0, ws + F.ac0, st)) || (rc = rn_split(w->a2_w, 256, 256, 0, 0, ws + F.a2, st)) ||
+        (rc = rn_split(w->c2_w, 256, 256, 0, 0, ws + F.c2, st))) return rc;
+    CN_HIP(hipMemsetAsync(ws + F.teb, 0, 384 * sizeof(float), st));
+    CN_HIP(hipMemcpyAsync(ws + F.teb, w->te_b, 320 * sizeof(float), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(robot_embed_kernel, dim3(B < 2048 ? B : 2048), dim3(256), 0, st, B, temporal, robot_node, w->rl_w, w->rl_b, sv->rs);
     CN_CHECK_LAUNCH();
     // z = [u (256) | relu(enc) (64) | .] in one product (both read robot_states), then the attention over the compacted rows, then edge -> z[320:384]
-    if ((rc = rn_gemm<ACT_NONE>(B, 320, 256, sv->rs, 256, w->te_w, w->te_b, sv->z, 384, st, nullptr, 0, 256))) return rc;
+    // (the padded product writes zeros into z[:, 320:384]; the edge layer below overwrites them)
+    if ((rc = rn_gemm3(ACT_NONE, B, 384, 256, sv->rs, 256, ws + F.te, ws + F.teb, sv->z, 384, st, nullptr, 0, 256))) return rc;
     hipLaunchKernelGGL(hr_attention_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, sv->z, 384, out_sp, row_off, sv->hr, sv->attn);
     CN_CHECK_LAUNCH();
     if ((rc = rn_gemm<ACT_RELU>(B, 64, 256, sv->hr, 256, w->edge_w, w->edge_b, sv->z + 320, 384, st))) return rc;
-    if ((rc = rn_gemm<ACT_NONE>(B, 384, 128, sv->z + 256, 384, w->wih, w->bih, sv->gi, 384, st))) return rc;
+    if ((rc = rn_gemm3(ACT_NONE, B, 384, 128, sv->z + 256, 384, ws + F.wih, w->bih, sv->gi, 384, st))) return rc;
     if ((rc = cn_gru_seq_fwd(T, N, sv->gi, h0, masks, w->whh, w->bhh, sv->hs, sv->hms, sv->gates, stream))) return rc;
-    if ((rc = rn_gemm<ACT_TANH>(B, 512, 128, sv->hs, 128, w->ac0_w, w->ac0_b, sv->a1, 512, st))) return rc;
-    if ((rc = rn_gemm<ACT_TANH>(B, 256, 256, sv->a1, 512, w->a2_w, w->a2_b, sv->a2, 512, st))) return rc;
-    if ((rc = rn_gemm<ACT_TANH>(B, 256, 256, sv->a1 + 256, 512, w->c2_w, w->c2_b, sv->a2 + 256, 512, st))) return rc;
+    if ((rc = rn_gemm3(ACT_TANH, B, 512, 128, sv->hs, 128, ws + F.ac0, w->ac0_b, sv->a1, 512, st))) return rc;
+    if ((rc = rn_gemm3(ACT_TANH, B, 256, 256, sv->a1, 512, ws + F.a2, w->a2_b, sv->a2, 512, st))) return rc;
+    if ((rc = rn_gemm3(ACT_TANH, B, 256, 256, sv->a1 + 256, 512, ws + F.c2, w->c2_b, sv->a2 + 256, 512, st))) return rc;
     hipLaunchKernelGGL(rn_head_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, sv->a2, w->cl_w, w->cl_b, w->fm_w, w->fm_b, w->logstd, actions, value, logp);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -1397,7 +1416,7 @@ extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const
         hipLaunchKernelGGL(rn_head_bwd_kernel, dim3(blocks), dim3(256), 0, st, B, sv->a2, w->cl_w, w->fm_w, w->fm_b, w->logstd, actions, d_value, d_logp, d2, ws + L.small);
         CN_CHECK_LAUNCH();
         float *red = ws + L.dbp; // RN_HEAD_COLS floats, free until the first weight gradient below
-        hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3((RN_HEAD_COLS + 63) / 64), dim3(256), 0, st, blocks, RN_HEAD_COLS, ws + L.small, red);
+        hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3((RN_HEAD_COLS + 15) / 16), dim3(256), 0, st, blocks, RN_HEAD_COLS, ws + L.small, red, nullptr, 0);
         CN_CHECK_LAUNCH();
         CN_HIP(hipMemcpyAsync(g->fm_w, red, 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
         CN_HIP(hipMemcpyAsync(g->cl_w, red + 512, 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1405,36 +1424,36 @@ extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const
         CN_HIP(hipMemcpyAsync(g->cl_b, red + 770, 1 * sizeof(float), hipMemcpyDeviceToDevice, st));
         CN_HIP(hipMemcpyAsync(g->logstd, red + 771, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    // ---- transposed weights for the dX products (dX = dY W as an NT product with W^T) ----
-    if ((rc = rn_transpose(256, 256, w->a2_w, ws + L.a2T, st)) || (rc = rn_transpose(256, 256, w->c2_w, ws + L.c2T, st)) ||
-        (rc = rn_transpose(512, 128, w->ac0_w, ws + L.ac0T, st)) || (rc = rn_transpose(384, 128, w->wih, ws + L.wihT, st)) ||
-        (rc = rn_transpose(64, 256, w->edge_w, ws + L.edgeT, st)) || (rc = rn_transpose(320, 256, w->te_w, ws + L.teT, st))) return rc;
+    // ---- split planes of the transposed weights for the dX products (dX = dY W as an NT product with W^T) ----
+    if ((rc = rn_split(w->a2_w, 256, 256, 1, 0, ws + L.a2T, st)) || (rc = rn_split(w->c2_w, 256, 256, 1, 0, ws + L.c2T, st)) ||
+        (rc = rn_split(w->ac0_w, 512, 128, 1, 0, ws + L.ac0T, st)) || (rc = rn_split(w->wih, 384, 128, 1, 0, ws + L.wihT, st)) ||
+        (rc = rn_split(w->edge_w, 64, 256, 1, 0, ws + L.edgeT, st)) || (rc = rn_split(w->te_w, 320, 256, 1, 0, ws + L.teT, st))) return rc;
     // ---- second trunk layers: weight gradients, then d1 = (d2 W2) (1 - a1^2) ----
     if ((rc = rn_wgrad(B, 256, 256, d2, 512, sv->a1, 512, ws, L, g->a2_w, g->a2_b, st))) return rc;
     if ((rc = rn_wgrad(B, 256, 256, d2 + 256, 512, sv->a1 + 256, 512, ws, L, g->c2_w, g->c2_b, st))) return rc;
-    if ((rc = rn_gemm<ACT_MUL_DTANH>(B, 256, 256, d2, 512, ws + L.a2T, nullptr, d1, 512, st, sv->a1, 512))) return rc;
-    if ((rc = rn_gemm<ACT_MUL_DTANH>(B, 256, 256, d2 + 256, 512, ws + L.c2T, nullptr, d1 + 256, 512, st, sv->a1 + 256, 512))) return rc;
+    if ((rc = rn_gemm3(ACT_MUL_DTANH, B, 256, 256, d2, 512, ws + L.a2T, nullptr, d1, 512, st, sv->a1, 512))) return rc;
+    if ((rc = rn_gemm3(ACT_MUL_DTANH, B, 256, 256, d2 + 256, 512, ws + L.c2T, nullptr, d1 + 256, 512, st, sv->a1 + 256, 512))) return rc;
     // ---- first trunk layers (output_linear folded in) ----
     if ((rc = rn_wgrad(B, 512, 128, d1, 512, sv->hs, 128, ws, L, g->ac0_w, g->ac0_b, st))) return rc;
-    if ((rc = rn_gemm<ACT_NONE>(B, 128, 512, d1, 512, ws + L.ac0T, nullptr, dhs, 128, st))) return rc;
+    if ((rc = rn_gemm3(ACT_NONE, B, 128, 512, d1, 512, ws + L.ac0T, nullptr, dhs, 128, st))) return rc;
     // ---- GRU over the sequence ----
     if ((rc = cn_gru_seq_bwd(T, N, sv->gates, sv->hms, masks, w->whh, dhs, dgi, dgh, d_h0, stream))) return rc;
     if ((rc = rn_wgrad(B, 384, 128, dgh, 384, sv->hms, 128, ws, L, g->whh, g->bhh, st))) return rc;
     if ((rc = rn_wgrad(B, 384, 128, dgi, 384, sv->z + 256, 384, ws, L, g->wih, g->bih, st))) return rc;
     // ---- d[enc | edge] = (dgi W_ih) relu'(.) -> dz[:, 256:384]; d hr = d edge W_e; attention backward; d u -> dz[:, 0:256] ----
-    if ((rc = rn_gemm<ACT_MUL_DRELU>(B, 128, 384, dgi, 384, ws + L.wihT, nullptr, dz + 256, 384, st, sv->z + 256, 384))) return rc;
+    if ((rc = rn_gemm3(ACT_MUL_DRELU, B, 128, 384, dgi, 384, ws + L.wihT, nullptr, dz + 256, 384, st, sv->z + 256, 384))) return rc;
     if ((rc = rn_wgrad(B, 64, 256, dz + 320, 384, sv->hr, 256, ws, L, g->edge_w, g->edge_b, st))) return rc;
-    if ((rc = rn_gemm<ACT_NONE>(B, 256, 64, dz + 320, 384, ws + L.edgeT, nullptr, dhr, 256, st))) return rc;
+    if ((rc = rn_gemm3(ACT_NONE, B, 256, 64, dz + 320, 384, ws + L.edgeT, nullptr, dhr, 256, st))) return rc;
     hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, sv->z, out_sp, row_off, sv->attn, dhr, dz, d_out_sp, 384, 384);
     CN_CHECK_LAUNCH();
     // ---- [u | enc] layer and robot_linear ----
     if ((rc = rn_wgrad(B, 320, 256, dz, 384, sv->rs, 256, ws, L, g->te_w, g->te_b, st))) return rc;
-    if ((rc = rn_gemm<ACT_MUL_DRELU>(B, 256, 320, dz, 384, ws + L.teT, nullptr, drs, 256, st, sv->rs, 256))) return rc;
+    if ((rc = rn_gemm3(ACT_MUL_DRELU, B, 256, 320, dz, 384, ws + L.teT, nullptr, drs, 256, st, sv->rs, 256))) return rc;
     {
         const int blocks = B < 512 ? B : 512;
         hipLaunchKernelGGL(rn_rl_wgrad_kernel, dim3(blocks), dim3(256), 0, st, B, drs, temporal, robot_node, ws + L.small);
         CN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(rn_rl_wgrad_finish_kernel, dim3(10), dim3(256), 0, st, blocks, ws + L.small, g->rl_w, g->rl_b);
+        hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3(2560 / 16), dim3(256), 0, st, blocks, 2560, ws + L.small, g->rl_w, g->rl_b, 1);
         CN_CHECK_LAUNCH();
     }
     return CN_OK;

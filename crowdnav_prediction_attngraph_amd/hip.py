@@ -787,8 +787,9 @@ class RnSequence(torch.autograd.Function):
         saved = {k: torch.empty(B, widths[k], device=dev) for k in A.RN_SAVED_FIELDS}
         sst = A.RnSaved(*[saved[k].data_ptr() for k in A.RN_SAVED_FIELDS])
         value, logp = torch.empty(B, 1, device=dev), torch.empty(B, 1, device=dev)
+        work = torch.empty(int(A.lib().cn_rn_seq_fwd_workspace_floats()), device=dev)
         A.check(A.lib().cn_rn_seq_fwd(T, N, H, A.ptr(rn), A.ptr(te), A.ptr(osp), A.ptr(row_off), A.ptr(h0c), A.ptr(m), A.ptr(act), C.byref(wst), C.byref(sst),
-                                      A.ptr(value), A.ptr(logp), A.stream_ptr()), "cn_rn_seq_fwd")
+                                      A.ptr(work), A.ptr(value), A.ptr(logp), A.stream_ptr()), "cn_rn_seq_fwd")
         ctx.save_for_backward(rn, te, osp, row_off, m, act, *ws, *[saved[k] for k in A.RN_SAVED_FIELDS])
         ctx.meta = (T, N, H, len(ws))
         h_last = saved["hs"][(T - 1) * N:].clone()

@@ -140,7 +140,7 @@ typedef struct cn_policy cn_policy;
 
 /* Bumped whenever a struct layout, a signature or the snapshot format changes (round 4: cn_obs.row_plan, cn_env_config.robot_fov /
  * human_fov, the profiling entry points, snapshot layout CNENV004); the ctypes binding refuses a library that reports another number. */
-#define CN_ABI_VERSION 400
+#define CN_ABI_VERSION 401
 const char *cn_last_error(void);
 int cn_version(void);
 int cn_device_count(void);
@@ -319,7 +319,8 @@ int cn_hh_block_fwd(int B, int H, int D, const float *spatial_edges, const int *
  * the train-mode policy forward of the boundary: no library GEMM and no framework pointwise kernel is left between the observation and
  * (value, log-prob).  Weights are the fp32 training weights as the host composes them (two affine pairs folded by the caller, whose autograd
  * carries the gradients of the folded matrices back to the factors): te = [spatial_edge_layer^T temporal_edge_layer ; encoder_linear],
- * ac0 = (actor.0 ; critic.0) o output_linear.  Exact fp32 MFMA products forward and for dX, bf16x3 split-K for the weight gradients.
+ * ac0 = (actor.0 ; critic.0) o output_linear.  bf16x3 split-precision products (cn_linear_fwd_act) forward and for dX -- edge_attention_embed's
+ * 64-output forward on the exact-fp32 kernel --, bf16x3 split-K for the weight gradients.
  * cn_rn_seq_fwd writes every activation the backward needs into the caller's `saved` buffers; cn_rn_seq_bwd takes d_value / d_logp [B] and
  * returns d_out_sp [R,256] (gradient into the human-human block), d_h0 [N,128] and the gradient of every weight (fixed summation orders). */
 typedef struct {
@@ -347,9 +348,10 @@ typedef struct { /* activations kept for the backward (device buffers of the cal
     float *a2;    /* [B,512] tanh of the second trunk layers (actor | critic) */
 } cn_rn_saved;
 int64_t cn_rn_seq_workspace_floats(int T, int N);   /* scratch of cn_rn_seq_bwd */
+int64_t cn_rn_seq_fwd_workspace_floats(void);       /* scratch of cn_rn_seq_fwd (the split planes of this step's weights) */
 int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node /*[B,7]*/, const float *temporal_edges /*[B,2]*/, const float *out_sp /*[R,256]*/,
                   const int *row_off /*[B+1]*/, const float *h0 /*[N,128]*/, const float *masks /*[B]*/, const float *actions /*[B,2]*/,
-                  const cn_rn_weights *w, const cn_rn_saved *saved, float *value /*[B]*/, float *logp /*[B]*/, void *stream);
+                  const cn_rn_weights *w, const cn_rn_saved *saved, float *workspace, float *value /*[B]*/, float *logp /*[B]*/, void *stream);
 int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const float *temporal_edges, const float *out_sp, const int *row_off, const float *masks,
                   const float *actions, const cn_rn_weights *w, const cn_rn_saved *saved, const float *d_value /*[B]*/, const float *d_logp /*[B]*/,
                   float *workspace, float *d_out_sp /*[R,256]*/, float *d_h0 /*[N,128]*/, const cn_rn_grads *grads, void *stream);
@@ -417,6 +419,11 @@ int cn_gru_seq_bwd(int T, int N, const float *gates, const float *hms, const flo
  *                  With the transposed split of W [N,K] passed as a [K,N] weight it computes dX = dY W (no bias).
  *                  relu_gate (optional, same shape and leading dimension as X): X is replaced by X * [relu_gate > 0] while it
  *                  is loaded -- the backward of Linear+ReLU without a separate masking pass.  N % 128 == 0, K % 64 == 0.
+ * cn_linear_fwd_act: the same product with the epilogues of the robot-node sequence (rl/networks/srnn_model.py actor / critic trunks: tanh): act 0 = none,
+ *                  1 = ReLU, 2 = tanh, 3 = times relu'(.) = [aux > 0], 4 = times tanh'(.) = 1 - aux^2, aux [M, ldaux] being the forward VALUE of
+ *                  the activation the product is a gradient of; columns >= relu_from get a ReLU on top (pass relu_from >= N for none).
+ * cn_split_bf16_padded: cn_split_bf16 with the weight the product sees zero-padded to n_padded rows (a layer whose output count is not a
+ *                  multiple of 128; 0 = no padding).
  * cn_linear_wgrad: dW[N,K] = dY[M,N]^T X[M,K] and (optional) db[N] = column sums of dY (dY gated by relu_gate > 0 when that
  *                  pointer, shaped like dY, is given).  The M reduction is cut into
  *                  `splits` ranges whose partial products land in partials [splits,N,K] (db_partials [splits,N]) and are
@@ -425,6 +432,9 @@ int cn_gru_seq_bwd(int T, int N, const float *gates, const float *hms, const flo
 int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream);
 int cn_linear_fwd(int M, int N, int K, const float *X, int ldx, const float *relu_gate, const void *Whi, const void *Wlo,
                   const float *bias, int act, float *Y, int ldy, void *stream);
+int cn_split_bf16_padded(const float *w, int rows, int cols, int transpose, int n_padded, void *hi, void *lo, void *stream);
+int cn_linear_fwd_act(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act,
+                      const float *aux, int ldaux, int relu_from, float *Y, int ldy, void *stream);
 int cn_linear_wgrad_splits(int M, int N, int K);
 int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *relu_gate, const float *X, int ldx, int splits,
                     float *partials, float *db_partials, float *dW, float *db, void *stream);
