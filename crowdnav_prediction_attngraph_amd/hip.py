@@ -518,7 +518,7 @@ class GRUSequence(torch.autograd.Function):
     """The human-node GRU over a [T,N] rollout slice with the done mask applied to h before every step (the reference's
     split-at-done trick, rl/networks/srnn_model.py:52-104, is arithmetically this).  gi [T,N,384] = x W_ih^T + b_ih,
     h0 [N,128], m [T,N,1] -> hs [T,N,128].  ONE launch for the whole forward sequence and one for the backward
-    (cn_gru_seq_fwd / cn_gru_seq_bwd: W_hh resident in registers, exact-fp32 MFMA); the weight gradient of W_hh is one
+    (cn_gru_seq_fwd / cn_gru_seq_bwd: W_hh resident in registers as bf16 hi / lo fragments, bf16x3 MFMA); the weight gradient of W_hh is one
     product over all T*N rows at the end."""
 
     @staticmethod
