@@ -157,20 +157,21 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
         if (row < N) hms[(size_t)row * 128 + c] = v;
     }
     __syncthreads();
+    // A step's inputs (gi of the step, the mask of the next) do not depend on the state: row r's are requested one step ahead, right
+    // after the cell has used the current ones, unpredicated (surplus rows of the last workgroup read row N-1) -- a whole step hides
+    // the round trip (requested at the top of their own step, the 1.1 us of MFMAs did not).  Loaded inside the per-row `if (row < N)`
+    // blocks below, every row paid its own memory round trip behind an s_waitcnt vmcnt(0): 16 of them in series per step.
+    float gir[16], giz[16], gin[16], mk[16];
+    auto request = [&](int r, int t) {
+        const int rowc = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, N - 1);
+        const float *gip = gi + ((size_t)min(t, T - 1) * N + rowc) * 384 + u;
+        gir[r] = gip[0]; giz[r] = gip[128]; gin[r] = gip[256];
+        mk[r] = m[(size_t)min(t + 1, T - 1) * N + rowc];
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) request(r, 0);
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        // this step's inputs do not depend on the state: request them before the MFMAs, unpredicated (surplus rows of the last
-        // workgroup read row N-1).  Loaded inside the per-row `if (row < N)` blocks below, every row paid its own memory round
-        // trip behind an s_waitcnt vmcnt(0): 16 of them in series per step.
-        float gir[16], giz[16], gin[16], mk[16];
-        const int tn = min(t + 1, T - 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowc = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, N - 1);
-            const float *gip = gi + ((size_t)t * N + rowc) * 384 + u;
-            gir[r] = gip[0]; giz[r] = gip[128]; gin[r] = gip[256];
-            mk[r] = m[(size_t)tn * N + rowc];
-        }
         f32x16 acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
                 const __bf16 h = (__bf16)next;
                 hm[cur ^ 1][rl * GHS + u] = next; hmh[cur ^ 1][rl * GPS + u] = h; hml[cur ^ 1][rl * GPS + u] = (__bf16)(next - (float)h);
             }
+            request(r, t + 1);
         }
         __syncthreads();
     }

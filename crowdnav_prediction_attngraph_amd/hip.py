@@ -561,6 +561,33 @@ def split_bf16(w, transpose=False):
     return hi, lo
 
 
+def linear_act(x, w, b, act, aux=None, relu_from=None, pad_to=0):
+    """act(x w^T + b) on the split-precision kernel with the robot-node sequence's epilogues (cn_linear_fwd_act): act 0 none, 1 ReLU, 2 tanh,
+    3 = times [aux > 0], 4 = times (1 - aux^2); columns >= relu_from also get a ReLU; pad_to = the weight's row count padded with zero rows
+    to a multiple of 128 (the result then has pad_to columns).  x [M,K] (row stride may exceed K), w [N,K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    Np = pad_to or N
+
+    def rows_ptr(t):   # a column slice of a wider row-major buffer: unit column stride, any row stride
+        if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+            raise A.CnError("linear_act: operands must be fp32 GPU matrices with unit column stride")
+        return C.c_void_p(t.data_ptr())
+    w = w.detach().contiguous()
+    hi = torch.empty(Np, K, dtype=torch.int16, device=x.device)
+    lo = torch.empty(Np, K, dtype=torch.int16, device=x.device)
+    A.check(A.lib().cn_split_bf16_padded(A.ptr(w), N, K, 0, Np if pad_to else 0, A.ptr(hi), A.ptr(lo), A.stream_ptr()), "cn_split_bf16_padded")
+    bias = None
+    if b is not None:
+        bias = torch.zeros(Np, device=x.device)
+        bias[:N] = b.detach()
+    y = torch.empty(M, Np, device=x.device)
+    A.check(A.lib().cn_linear_fwd_act(M, Np, K, rows_ptr(x), x.stride(0), A.ptr(hi), A.ptr(lo), A.ptr(bias) if bias is not None else None, int(act),
+                                      rows_ptr(aux) if aux is not None else None, aux.stride(0) if aux is not None else 0,
+                                      int(relu_from) if relu_from is not None else 1 << 30, A.ptr(y), Np, A.stream_ptr()), "cn_linear_fwd_act")
+    return y
+
+
 def linear_supported(x, w):
     """Shapes the split-precision training kernels cover (the three large human-human Linear layers)."""
     N, K = w.shape

@@ -246,6 +246,47 @@ def test_hip_linear_forward_and_gradients_match_fp64(M, N, K, relu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,act,relu_from,pad_to", [(61440, 256, 256, 2, None, 0), (5000, 512, 128, 2, None, 0), (4099, 320, 256, 0, 256, 384),
+                                                          (40000, 256, 320, 3, None, 0), (777, 128, 384, 3, None, 0), (33001, 256, 256, 4, None, 0),
+                                                          (2048, 128, 512, 0, None, 0), (9000, 256, 64, 1, None, 0)])
+def test_linear_act_epilogues_match_fp64(M, N, K, act, relu_from, pad_to):
+    """cn_linear_fwd_act / cn_split_bf16_padded (the robot-node sequence's products on the bf16x3 kernel: tanh, times relu'(aux), times
+    tanh'(aux), a ReLU column range, a weight padded to whole 128-column tiles; A and aux with row strides wider than the product) against
+    fp64, at the shapes cn_rn_seq_fwd / cn_rn_seq_bwd use: within 1e-4 of the largest reference magnitude (the bar of the big layers' test above;
+    measured: 2.3e-5 on 15 M tanh outputs whose arguments reach +-5)."""
+    from crowdnav_prediction_attngraph_amd import hip
+    g = torch.Generator().manual_seed(M + 7 * N + K + act)
+    xw = torch.randn(M, K + 64, generator=g)                       # the product reads a column slice of a wider buffer
+    x = xw[:, 32:32 + K]
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1 if act < 3 else None
+    auxw = torch.tanh(torch.randn(M, N + 128, generator=g)) * (torch.rand(M, N + 128, generator=g) > 0.3)
+    aux = auxw[:, 64:64 + N]
+    y = hip.linear_act(xw.cuda()[:, 32:32 + K], w.cuda(), b.cuda() if b is not None else None, act, aux=auxw.cuda()[:, 64:64 + N] if act >= 3 else None,
+                       relu_from=relu_from, pad_to=pad_to)
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if act == 1:
+        ref = ref.clamp(min=0)
+    elif act == 2:
+        ref = torch.tanh(ref)
+    elif act == 3:
+        ref = ref * (aux > 0).double()
+    elif act == 4:
+        ref = ref * (1.0 - aux.double() ** 2)
+    if relu_from is not None:
+        ref[:, relu_from:] = ref[:, relu_from:].clamp(min=0)
+    got = y.cpu().double()
+    assert got.shape == (M, pad_to or N)
+    err = float((got[:, :N] - ref).abs().max())
+    assert err <= 1e-4 * max(float(ref.abs().max()), 1.0), (err, float(ref.abs().max()))
+    if pad_to:
+        assert float(got[:, N:].abs().max()) == 0.0               # zero rows of the padded weight, zero bias, ReLU range
+
+
+@pytest.mark.gpu
 def test_hr_attention_forward_backward_matches_dense_torch():
     """cn_hr_attention_fwd/bwd on compacted rows, in the u = Ws^T t form, vs the reference's dense masked formulation
     (att_func, selfAttn_srnn_temp_node.py:145-177: t . (Ws o + bs) * H/8, masked_fill(-1e9), softmax, bmm) under torch
