@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libcrowdnav_hip.so")
+LIB_PATH = os.environ.get("CN_HIP_LIB") or os.path.join(_PKG, "libcrowdnav_hip.so")   # CN_HIP_LIB: another build of the same ABI (A/B measurements)
 
 CN_MAX_HUMANS = 64
 ABI_VERSION = 401          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against

@@ -284,7 +284,8 @@ static int launch_gemm3p(int M, int N, int K, const float *A, int lda, const __b
 // the LDS (transposed on the way in: a thread loads 8 consecutive m of ONE column with 8 coalesced dword loads and stores them as
 // one 16-byte fragment word per plane), the X columns belong to exactly one wavefront each (32 NB of them) and go straight from
 // global memory into fragment registers: lane (l31, half) of block j loads X[m0 + 8 half + e][k0 + 32 j + l31], e = 0..7 -- eight
-// dword loads of two full 128-byte lines each.  One barrier per 32 rows of m; no LDS traffic for X at all.
+// dword loads of two full 128-byte lines each.  One barrier per 32 rows of m; no LDS traffic for X at all.  NB = 1, 2 or 4 (a wavefront
+// then owns 32 / 64 / 128 X columns and 64 / 128 / 256 accumulator registers).
 template <int NB, bool GATE>
 __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, const float *__restrict__ dY, int ldy, const float *__restrict__ Ygate,
                                                            const float *__restrict__ X, int ldx, int rows_per_split, int nsplit,
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
     constexpr int MI = 4, PS = 40, BUF = 2 * 128 * PS;
     extern __shared__ __attribute__((aligned(16))) char smem3p[];
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem3p);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (uniform: the buffer resources below live in SGPRs)
     const int half = lane >> 5, l31 = lane & 31;
     // XCD-aware 1-D grid: workgroup L runs on XCD L % 8 (round-robin dispatch); all tiles of one split go to ONE XCD, so the rows
     // of dY and X that the split owns stream through one L2 once (the tiles advance over m together) instead of through up to 8 of
@@ -319,22 +320,28 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
 
     // dY staging: thread (column c, half-tile g0) owns m groups g0 and g0 + 2 (8 rows each) of the 32-row tile
     const int c = tid & 127, g0 = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const float *yp = dY + n_blk, *gp = GATE ? Ygate + n_blk : nullptr;
+    // Buffer addressing relative to the split's first row: a load is ONE instruction (per-lane byte offset register + wave-uniform
+    // scalar offset + immediate).  With flat 64-bit addresses every one of the 48 loads of a 32-row tile carried a 64-bit VALU add
+    // and three scalar multiplies / adds -- 130 of the loop's 460 instructions, on a wavefront that is alone on its SIMD.
+    // (a split spans < 2^31 bytes of either operand: rows_per_split * ld * 4)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)(dY + (size_t)m_begin * ldy + n_blk), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)((GATE ? Ygate : dY) + (size_t)m_begin * ldy + n_blk), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (size_t)m_begin * ldx + k_blk), 0, 0x7fffffff, 0x00020000);
+    unsigned yv[8], xv[8]; // per-lane byte offsets of row e of a group: column c of dY; the lane's X column, its 8 rows start 8 * half below the k-step's first row
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { yv[e] = (unsigned)(e * ldy + c) * 4u; xv[e] = (unsigned)((half * 8 + e) * ldx + l31) * 4u; }
     float sy[2][8], sg[GATE ? 2 : 1][8];
     // X: raw rows of this lane's fragments, [k-step][block][e]
-    const float *xp = X + k_blk;
-    const int x_lane = half * 8 * ldx + l31; // the lane's part of the address: its 8 rows start 8 * half below the k-step's first row
     float rx[2][NB][8];
     bf16x8 fah[2][MI], fal[2][MI], fwh[2][NB], fwl[2][NB];
     float colsum = 0.0f;
     // tiles past the end of the split (the pipeline runs two ahead) read its last tile again; what they stage is never multiplied
     auto load_y = [&](int q, int tile) {
-        const int m0 = m_begin + min(tile, T - 1) * 32 + (g0 + 2 * q) * 8;
+        const unsigned so = (unsigned)((min(tile, T - 1) * 32 + (g0 + 2 * q) * 8) * ldy) * 4u; // wave-uniform
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const size_t o = (size_t)(m0 + e) * ldy;
-            sy[q][e] = (yp + o)[c];
-            if (GATE) sg[GATE ? q : 0][e] = (gp + o)[c];
+            sy[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yv[e], so, 0));
+            if (GATE) sg[GATE ? q : 0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, yv[e], so, 0));
         }
     };
     auto stage_y = [&](int q, int tile, int b) {
@@ -354,9 +361,9 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
         *reinterpret_cast<bf16x8 *>(&Al[c * PS + (g0 + 2 * q) * 8]) = lo;
     };
     auto load_x = [&](int ks, int j, int tile) {
-        const int m0 = m_begin + min(tile, T - 1) * 32 + ks * 16;
+        const unsigned so = (unsigned)((min(tile, T - 1) * 32 + ks * 16) * ldx) * 4u; // wave-uniform
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rx[ks][j][e] = (xp + (size_t)(m0 + e) * ldx + 32 * j)[x_lane];
+        for (int e = 0; e < 8; ++e) rx[ks][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xv[e] + 128u * j, so, 0));
     };
     auto convert_x = [&](int ks, int j) {
 #pragma unroll
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
             mfma_one(0, 3 * g);
 #pragma unroll
             for (int r = 0; r < RPG; ++r) read_a(1, g * RPG + r, cur);
+            if (RPG == 0 && g % (G / 8) == 0) read_a(1, g / (G / 8), cur);
             mfma_one(0, 3 * g + 1);
             if (g == 0 || g == G / 2) { const int q = g ? 1 : 0; stage_y(q, t + 1, cur ^ 1); load_y(q, t + 2); }
             if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(1, j); load_x(1, j, t + 1); }
@@ -413,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void gemm3p_tn_kernel(int M, int N, int K, 
             mfma_one(1, 3 * g);
 #pragma unroll
             for (int r = 0; r < RPG; ++r) read_a(0, g * RPG + r, cur ^ 1);
+            if (RPG == 0 && g % (G / 8) == 0) read_a(0, g / (G / 8), cur ^ 1);
             mfma_one(1, 3 * g + 1);
             if (g % (G / NB) == G / NB - 1) { const int j = g / (G / NB); convert_x(0, j); load_x(0, j, t + 2); }
             mfma_one(1, 3 * g + 2);

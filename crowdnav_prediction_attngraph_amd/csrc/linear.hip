@@ -430,14 +430,18 @@ extern "C" int cn_linear_fwd_act(int M, int N, int K, const float *X, int ldx, c
 
 // shapes the pipelined TN kernel takes: whole 128-column tiles of dY, enough rows to fill the machine
 static bool wgrad_pipelined(int M, int N, int K) { return N % 128 == 0 && K % 128 == 0 && M >= 32768; }
+// X columns per workgroup tile of gemm3p_tn_kernel, in units of 128: the widest that divides K.  A 128 x 512 tile reads dY once per
+// split instead of twice (the q.k.v gradient: 13.2 -> 11.0 GB of L2 requests per launch) at 484 registers, still one wavefront per SIMD:
+// 2.17 -> 1.79 ms stand-alone at 358 k rows (128 x 256 with the same addressing: 2.02).
+static int tn_nb(int K) { return K % 512 == 0 ? 4 : (K % 256 == 0 ? 2 : 1); }
 
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 128) return 0;
-    if (wgrad_pipelined(M, N, K)) { // gemm3p_tn_kernel: one workgroup per CU, tiles of 128 x 256 (128 x 128 when K is not a multiple of 256)
+    if (wgrad_pipelined(M, N, K)) { // gemm3p_tn_kernel: one workgroup per CU, tiles of 128 x 512 / 256 / 128 (tn_nb)
         // every XCD (32 CUs, one workgroup each) takes whole splits: s = 8 a with a * tiles a multiple of 32 fills the XCDs in
         // whole rounds; prefer the smallest such s with at least two rounds of work, bounded by 64 partials
-        const long long tiles = (long long)(N / 128) * (K / (K % 256 ? 128 : 256));
+        const long long tiles = (long long)(N / 128) * (K / (128 * tn_nb(K)));
         long long s = 64;
         for (long long a = 1; a <= 8; ++a)
             if ((a * tiles) % 32 == 0 && a * tiles >= 64) { s = 8 * a; break; }
@@ -482,9 +486,12 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         rows = (rows + 31) / 32 * 32;
         used = (M32 + rows - 1) / rows;
         constexpr size_t lds2 = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16);
-        const int tiles = (N / 128) * (K / (K % 256 ? 128 : 256));
+        const int nbk = tn_nb(K), tiles = (N / 128) * (K / (128 * nbk));
         const dim3 grid(8 * ((used + 7) / 8) * tiles); // XCD-aware 1-D grid, see the kernel
-        if (K % 256 == 0) {
+        if (nbk == 4) {
+            if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<4, true>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
+            else hipLaunchKernelGGL((gemm3p_tn_kernel<4, false>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
+        } else if (nbk == 2) {
             if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<2, true>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
             else hipLaunchKernelGGL((gemm3p_tn_kernel<2, false>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
         } else {
