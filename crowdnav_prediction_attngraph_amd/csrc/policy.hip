@@ -430,10 +430,182 @@ __global__ __launch_bounds__(256) void hh_attention_bwd_kernel(int B, const floa
     }
 }
 
+// The classes of 9 .. 16 and 17 .. 32 detected humans on the matrix pipe (exact fp32: v_mfma_f32_16x16x4_f32).  One wavefront per (sample, head) unit as
+// above, the unit's five small products as 16 x 16 MFMA tiles instead of ~nd^2 dependent LDS reads and FMAs per lane:
+//   S = Q K^T, dP = dO V^T            A / B = 16 consecutive features of row (lane & 15), feature block lane >> 4: four 16-byte LDS reads each
+//   softmax / dS                      in the accumulator layout (lane holds rows 4 (lane >> 4) + r of column lane & 15): row sums by DPP rotations
+//   dV = P^T dO, dK = dS^T Q          A = the accumulator registers themselves (P[4 kb + s][lane & 15] IS register s of this lane)
+//   dQ = dS K                         A = dS read back transposed from a 16 x 17 LDS tile
+// With the k index of a product taken as (lane >> 4, step) -> 4 (lane >> 4) + step (same permutation for A and B, so the sums are unchanged).
+// Rows at or past nd hold stale finite data of earlier units: P is masked to zero there, which zeroes every term they appear in.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int CTRL>
+__device__ __forceinline__ float row_rot(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float row16_sum(float v) { v += row_rot<0x128>(v); v += row_rot<0x124>(v); v += row_rot<0x122>(v); v += row_rot<0x121>(v); return v; }
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, row_rot<0x128>(v)); v = fmaxf(v, row_rot<0x124>(v)); v = fmaxf(v, row_rot<0x122>(v)); v = fmaxf(v, row_rot<0x121>(v));
+    return v;
+}
+template <int NT> // NT x NT tiles of 16 x 16: classes of <= 16 (NT = 1) and <= 32 (NT = 2) detected humans
+__global__ __launch_bounds__(256) void hh_attention_bwd_mfma_kernel(int B, const float *__restrict__ qkv, const int *__restrict__ row_off,
+                                                                    const int *__restrict__ cls_cnt, const int *__restrict__ cls_list,
+                                                                    const float *__restrict__ d_out, float *__restrict__ d_qkv, float scale)
+{
+    constexpr int CAP = 16 * NT, RS = 68, TS = CAP + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int n_units = (cls_list ? *cls_cnt : B) * 8;
+    float *Qs = smem + (size_t)wave * (4 * CAP * RS + CAP * TS);
+    float *Ks = Qs + CAP * RS, *Vs = Ks + CAP * RS, *Gs = Vs + CAP * RS; // Gs = dO rows
+    float *dSt = Gs + CAP * RS;                                           // dS, CAP x (CAP + 1)
+    for (int x = lane; x < 4 * CAP * RS; x += 64) Qs[x] = 0.0f;
+    const int l15 = lane & 15, kb = lane >> 4;
+    float pq[CAP], pk[CAP], pv[CAP], pg[CAP];
+    const int stride = gridDim.x * wpb;
+    int unit = blockIdx.x * wpb + wave;
+    auto sample_of = [&](int u) { return u < n_units ? (cls_list ? cls_list[u >> 3] : u >> 3) : 0; };
+    auto request_rows = [&](int r0n, int ndn, int head) {
+        const float *base = qkv + (size_t)r0n * 1536 + head * 64 + lane;
+        const float *gbase = d_out + (size_t)r0n * 512 + head * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j)
+            if (j < ndn) { // wave-uniform
+                pq[j] = base[(size_t)j * 1536]; pk[j] = base[(size_t)j * 1536 + 512]; pv[j] = base[(size_t)j * 1536 + 1024];
+                pg[j] = gbase[(size_t)j * 512];
+            }
+    };
+    int c_r0 = 0, c_nd = 0, n_lo = 0, n_hi = 0, b2 = 0;
+    if (unit < n_units) {
+        const int b0 = sample_of(unit), b1 = sample_of(unit + stride);
+        b2 = sample_of(unit + 2 * stride);
+        c_r0 = row_off[b0]; c_nd = row_off[b0 + 1] - c_r0;
+        n_lo = row_off[b1]; n_hi = row_off[b1 + 1];
+        request_rows(c_r0, c_nd, unit & 7);
+    }
+    for (; unit < n_units; unit += stride) {
+        const int head = unit & 7;
+        const int r0 = c_r0, nd = c_nd;
+#pragma unroll
+        for (int j = 0; j < CAP; ++j)
+            if (j < nd && nd <= CAP) { Qs[j * RS + lane] = pq[j]; Ks[j * RS + lane] = pk[j]; Vs[j * RS + lane] = pv[j]; Gs[j * RS + lane] = pg[j]; }
+        c_r0 = n_lo; c_nd = n_hi - n_lo;
+        request_rows(c_r0, c_nd, (unit + stride) & 7);        // (past the end: sample 0 again, never used)
+        n_lo = row_off[b2]; n_hi = row_off[b2 + 1];
+        b2 = sample_of(unit + 3 * stride);
+        if (nd > CAP) continue; // (only without a class list: another launch handles it)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // ---- S = Q K^T and dP = dO V^T: tile (ti, tj) = rows 16 ti .., columns 16 tj .. ----
+        f32x4m S[NT][NT], dP[NT][NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj) { S[ti][tj] = f32x4m{0.f, 0.f, 0.f, 0.f}; dP[ti][tj] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4m q4[NT], k4[NT], g4[NT], v4[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int o = (16 * tt + l15) * RS + 16 * kb + 4 * t;
+                q4[tt] = *reinterpret_cast<const f32x4m *>(Qs + o); k4[tt] = *reinterpret_cast<const f32x4m *>(Ks + o);
+                g4[tt] = *reinterpret_cast<const f32x4m *>(Gs + o); v4[tt] = *reinterpret_cast<const f32x4m *>(Vs + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        S[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[ti][u], k4[tj][u], S[ti][tj], 0, 0, 0);
+                        dP[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(g4[ti][u], v4[tj][u], dP[ti][tj], 0, 0, 0);
+                    }
+        }
+        // ---- softmax over the keys (column 16 tj + lane & 15) of every query row 16 ti + 4 kb + r; dS = scale * P * (dP - sum_j dP P) ----
+        f32x4m P[NT][NT], dS[NT][NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool rowv = 16 * ti + 4 * kb + r < nd;
+                float sv[NT], mx = -INFINITY;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) { sv[tj] = (rowv && 16 * tj + l15 < nd) ? S[ti][tj][r] * scale : -INFINITY; mx = fmaxf(mx, sv[tj]); }
+                mx = row16_max(mx);
+                float e[NT], sum = 0.0f;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) { e[tj] = (rowv && 16 * tj + l15 < nd) ? expf(sv[tj] - mx) : 0.0f; sum += e[tj]; }
+                sum = row16_sum(sum);
+                const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+                float rd = 0.0f;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) { e[tj] *= inv; rd += dP[ti][tj][r] * e[tj]; } // (e = 0 where masked)
+                rd = row16_sum(rd);
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    const float d = scale * e[tj] * (dP[ti][tj][r] - rd);
+                    P[ti][tj][r] = e[tj];
+                    dS[ti][tj][r] = d;
+                    dSt[(16 * ti + 4 * kb + r) * TS + 16 * tj + l15] = d;
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // ---- dV = P^T dO, dK = dS^T Q (rows = keys 16 tj ..), dQ = dS K (rows = queries 16 ti ..): four 16-feature column blocks each ----
+        float *ob = d_qkv + (size_t)r0 * 1536 + head * 64 + l15;
+#pragma unroll
+        for (int to = 0; to < NT; ++to) {   // output row tile
+            float dsT[NT][4];               // dS[16 to + lane & 15][16 tj + 4 kb + s]
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) dsT[tj][sI] = dSt[(16 * to + l15) * TS + 16 * tj + 4 * kb + sI];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4m aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tc = 0; tc < NT; ++tc)  // contraction tile
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) {
+                        const int ro = (16 * tc + 4 * kb + sI) * RS + 16 * cb + l15;
+                        av = __builtin_amdgcn_mfma_f32_16x16x4f32(P[tc][to][sI], Gs[ro], av, 0, 0, 0);
+                        ak = __builtin_amdgcn_mfma_f32_16x16x4f32(dS[tc][to][sI], Qs[ro], ak, 0, 0, 0);
+                        aq = __builtin_amdgcn_mfma_f32_16x16x4f32(dsT[tc][sI], Ks[ro], aq, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * to + 4 * kb + r;
+                    if (row < nd) {
+                        float *o = ob + (size_t)row * 1536 + 16 * cb;
+                        o[0] = aq[r]; o[512] = ak[r]; o[1024] = av[r];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); // the next unit reuses this wavefront's LDS slices
+    }
+}
+
 template <int CAP>
 static int launch_hh_attention_bwd(int B, const float *qkv, const int *row_off, const int *cls, int c, const float *d_out, float *d_qkv, float scale,
                                    hipStream_t st)
 {
+    if (CAP == 16 || CAP == 32) {
+        constexpr int NT = CAP == 32 ? 2 : 1;
+        const size_t per_wave = (size_t)(4 * CAP * 68 + CAP * (CAP + 1)) * sizeof(float); // 18.5 KB / 39 KB
+        const int wpb = CAP == 16 ? 4 : 2, per_cu = 2;                                    // 8 / 4 wavefronts per CU
+        int blocks = (B * 8 + wpb - 1) / wpb;
+        if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+        static bool attr_set = false;
+        if (!attr_set) {
+            CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(hh_attention_bwd_mfma_kernel<NT>, dim3(blocks), dim3(64 * wpb), per_wave * wpb, st, B, qkv, row_off, cls + c, cls + 4 + (size_t)c * B,
+                           d_out, d_qkv, scale);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
     const size_t per_wave = (size_t)(4 * CAP * 68 + (CAP <= 32 ? 4 : 2) * CAP * CAP) * sizeof(float);
     int wpb = (int)(65536 / per_wave); wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
     int per_cu = (int)((160 * 1024) / (per_wave * wpb)); per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
