@@ -433,7 +433,14 @@ static bool wgrad_pipelined(int M, int N, int K) { return N % 128 == 0 && K % 12
 // X columns per workgroup tile of gemm3p_tn_kernel, in units of 128: the widest that divides K.  A 128 x 512 tile reads dY once per
 // split instead of twice (the q.k.v gradient: 13.2 -> 11.0 GB of L2 requests per launch) at 484 registers, still one wavefront per SIMD:
 // 2.17 -> 1.79 ms stand-alone at 358 k rows (128 x 256 with the same addressing: 2.02).
-static int tn_nb(int K) { return K % 512 == 0 ? 4 : (K % 256 == 0 ? 2 : 1); }
+// ... as long as the 64 splits the launcher allows still give every CU a workgroup (N = 256, K = 512: two 128 x 512 tiles x 64 = half
+// the machine, 0.59 ms; four 128 x 256 tiles, 0.48 ms).
+static int tn_nb(int N, int K)
+{
+    int nb = K % 512 == 0 ? 4 : (K % 256 == 0 ? 2 : 1);
+    while (nb > 1 && (long long)(N / 128) * (K / (128 * nb)) * 64 < 256) nb >>= 1;
+    return nb;
+}
 
 extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
 {
@@ -441,7 +448,7 @@ extern "C" int cn_linear_wgrad_splits(int M, int N, int K)
     if (wgrad_pipelined(M, N, K)) { // gemm3p_tn_kernel: one workgroup per CU, tiles of 128 x 512 / 256 / 128 (tn_nb)
         // every XCD (32 CUs, one workgroup each) takes whole splits: s = 8 a with a * tiles a multiple of 32 fills the XCDs in
         // whole rounds; prefer the smallest such s with at least two rounds of work, bounded by 64 partials
-        const long long tiles = (long long)(N / 128) * (K / (128 * tn_nb(K)));
+        const long long tiles = (long long)(N / 128) * (K / (128 * tn_nb(N, K)));
         long long s = 64;
         for (long long a = 1; a <= 8; ++a)
             if ((a * tiles) % 32 == 0 && a * tiles >= 64) { s = 8 * a; break; }
@@ -486,7 +493,7 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         rows = (rows + 31) / 32 * 32;
         used = (M32 + rows - 1) / rows;
         constexpr size_t lds2 = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16);
-        const int nbk = tn_nb(K), tiles = (N / 128) * (K / (128 * nbk));
+        const int nbk = tn_nb(N, K), tiles = (N / 128) * (K / (128 * nbk));
         const dim3 grid(8 * ((used + 7) / 8) * tiles); // XCD-aware 1-D grid, see the kernel
         if (nbk == 4) {
             if (relu_gate) hipLaunchKernelGGL((gemm3p_tn_kernel<4, true>), grid, dim3(256), lds2, st, M32, N, K, dY, ldy, relu_gate, X, ldx, rows, used, partials, db_partials);
