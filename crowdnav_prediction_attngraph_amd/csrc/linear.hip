@@ -103,21 +103,22 @@ __global__ __launch_bounds__(128) void embed0_bwd_kernel(int R, int D, const flo
 
 // ---- whole GRU sequence in one launch (forward) / one launch (backward) ---------------------------------------------------
 // The update runs the human-node GRU over T = 30 steps with only N x 128 of state: as separate launches (a BLAS product and
-// a pointwise kernel per step and direction) it is launch- and latency-bound.  Here a workgroup owns 32 rows (envs) for
-// the whole sequence and W_hh never leaves the register file:
-//   * forward: wavefront w owns hidden units 32w .. 32w+31, i.e. the three gate columns {u, 128+u, 256+u}; its 96 x 128
-//     slice of W_hh is loaded once and kept as bf16 hi / lo MFMA fragments (192 VGPRs).  Per step the masked state hm (32 x 128,
-//     LDS, double buffered: fp32 for the cell's z * h term, bf16 hi / lo planes written by the lane that computed the value) is
-//     the A operand of 72 split-precision MFMAs (v_mfma_f32_32x32x16_bf16: lo*hi, hi*lo, hi*hi per gate and k-step -- 2.3 k
-//     matrix cycles; the exact-fp32 instruction needed 192 x 64 = 12.3 k of a step's ~30 k); the accumulators of the r, z, n
-//     gates of one (row, unit) sit in the same lane and register index, so the cell's pointwise part needs no exchange at all;
-//     one barrier per step.
+// a pointwise kernel per step and direction) it is launch- and latency-bound.  Here a workgroup owns 16 rows (envs) for
+// the whole sequence (2048 envs of a minibatch = 128 workgroups; with 32 rows it was 64 of 256 CUs) and W_hh never leaves
+// the register file:
+//   * forward: wavefront w owns hidden units 32w .. 32w+31 as two blocks of 16, i.e. six 16-column blocks (gate j, block a);
+//     its 96 x 128 slice of W_hh is loaded once and kept as bf16 hi / lo MFMA fragments (192 VGPRs).  Per step the masked state
+//     hm (16 x 128, LDS, double buffered: fp32 for the cell's z * h term, bf16 hi / lo planes written by the lane that computed
+//     the value) is the A operand of 72 split-precision MFMAs (v_mfma_f32_16x16x32_bf16: lo*hi, hi*lo, hi*hi per column block
+//     and k-step); the accumulators of the r, z, n gates of one (row, unit) sit in the same lane and register index, so the
+//     cell's pointwise part -- eight cells per lane -- needs no exchange at all; one barrier per step.
 //   * backward (reverse time): the same wavefront computes d(gates) for its units from the saved (r, z, n, gh_n), publishes
-//     d(gh) [32 x 384] as hi / lo planes in LDS, and multiplies it with its 384 x 32 slice of W_hh (again 192 resident VGPRs) to
+//     d(gh) [16 x 384] as hi / lo planes in LDS, and multiplies it with its 384 x 32 slice of W_hh (again 192 resident VGPRs) to
 //     get d(hm); the carried gradient stays in registers in the accumulator layout.  d(W_hh) is one product over all T*N rows afterwards.
-constexpr int GR = 32, GHS = 132;   // rows per workgroup; LDS row stride (floats) of the fp32 state
+constexpr int GR = 16, GHS = 132;   // rows per workgroup; LDS row stride (floats) of the fp32 state
 constexpr int GPS = 136, GQS = 392; // row strides (bf16) of the hi / lo planes of hm / d(gh): 272 / 784 bytes = 4 banks mod 64, so the
                                     // 16-byte fragment reads of 16 rows tile all banks
+typedef float f32x4g __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &lo)
@@ -126,29 +127,34 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &
     for (int e = 0; e < 8; ++e) { const __bf16 h = (__bf16)x[e]; hi[e] = h; lo[e] = (__bf16)(x[e] - (float)h); }
 }
 
+// Accumulator layout of the 16 x 16 MFMA: lane (l15 = lane & 15, kg = lane >> 4) holds rows 4 kg + r (r = 0..3) of column l15.
+// Operand layout of v_mfma_f32_16x16x32_bf16: lane (l15, kg) supplies 8 consecutive k = 32 kk + 8 kg + e of row / column l15.
 __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const float *__restrict__ gi, const float *__restrict__ h0,
                                                           const float *__restrict__ m, const float *__restrict__ Whh, const float *__restrict__ bhh,
                                                           float *__restrict__ hs, float *__restrict__ hms, float *__restrict__ gates)
 {
     __shared__ __attribute__((aligned(16))) float hm[2][GR * GHS];
     __shared__ __attribute__((aligned(16))) __bf16 hmh[2][GR * GPS], hml[2][GR * GPS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int row0 = blockIdx.x * GR, u = 32 * wave + l31;
-    // B fragments: column n = this lane's unit u of gate j, k = 16 kk + 8 half + e
-    bf16x8 wh[3][8], wl[3][8];
-    float bias[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, l15 = lane & 15;
+    const int row0 = blockIdx.x * GR;
+    // B fragments: column = unit u(a) = 32 wave + 16 a + l15 of gate j, k = 32 kk + 8 kg + e
+    bf16x8 wh[3][2][4], wl[3][2][4];
+    float bias[3][2];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const float *wr = Whh + (size_t)(j * 128 + u) * 128 + 8 * half;
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float x[8];
+        for (int a = 0; a < 2; ++a) {
+            const int u = 32 * wave + 16 * a + l15;
+            const float *wr = Whh + (size_t)(j * 128 + u) * 128 + 8 * kg;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = wr[16 * kk + e];
-            split8(x, wh[j][kk], wl[j][kk]);
+            for (int kk = 0; kk < 4; ++kk) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = wr[32 * kk + e];
+                split8(x, wh[j][a][kk], wl[j][a][kk]);
+            }
+            bias[j][a] = bhh[j * 128 + u];
         }
-        bias[j] = bhh[j * 128 + u];
-    }
     for (int i = tid; i < GR * 128; i += 256) {
         const int r = i >> 7, c = i & 127, row = row0 + r;
         const float v = row < N ? h0[(size_t)row * 128 + c] * m[row] : 0.0f;
@@ -157,60 +163,70 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(int T, int N, const fl
         if (row < N) hms[(size_t)row * 128 + c] = v;
     }
     __syncthreads();
-    // A step's inputs (gi of the step, the mask of the next) do not depend on the state: row r's are requested one step ahead, right
-    // after the cell has used the current ones, unpredicated (surplus rows of the last workgroup read row N-1) -- a whole step hides
-    // the round trip (requested at the top of their own step, the 1.1 us of MFMAs did not).  Loaded inside the per-row `if (row < N)`
-    // blocks below, every row paid its own memory round trip behind an s_waitcnt vmcnt(0): 16 of them in series per step.
-    float gir[16], giz[16], gin[16], mk[16];
-    auto request = [&](int r, int t) {
-        const int rowc = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, N - 1);
-        const float *gip = gi + ((size_t)min(t, T - 1) * N + rowc) * 384 + u;
-        gir[r] = gip[0]; giz[r] = gip[128]; gin[r] = gip[256];
-        mk[r] = m[(size_t)min(t + 1, T - 1) * N + rowc];
+    // A step's inputs (gi of the step, the mask of the next) do not depend on the state: cell (a, r)'s are requested one step ahead,
+    // right after the cell has used the current ones, unpredicated (surplus rows of the last workgroup read row N-1) -- a whole step
+    // hides the round trip.  Loaded inside the per-row `if (row < N)` blocks below, every row paid its own memory round trip.
+    float gir[2][4], giz[2][4], gin[2][4], mk[4];
+    auto request = [&](int a, int r, int t) {
+        const int rowc = min(row0 + 4 * kg + r, N - 1);
+        const float *gip = gi + ((size_t)min(t, T - 1) * N + rowc) * 384 + 32 * wave + 16 * a + l15;
+        gir[a][r] = gip[0]; giz[a][r] = gip[128]; gin[a][r] = gip[256];
+        if (a == 0) mk[r] = m[(size_t)min(t + 1, T - 1) * N + rowc];
     };
 #pragma unroll
-    for (int r = 0; r < 16; ++r) request(r, 0);
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) request(a, r, 0);
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        f32x16 acc[3];
+        f32x4g acc[3][2];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            for (int a = 0; a < 2; ++a) acc[j][a] = f32x4g{0.f, 0.f, 0.f, 0.f};
         // term-major inside a k-step: consecutive MFMAs write different accumulators
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&hmh[cur][l31 * GPS + 16 * kk + 8 * half]);
-            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&hml[cur][l31 * GPS + 16 * kk + 8 * half]);
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&hmh[cur][l15 * GPS + 32 * kk + 8 * kg]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&hml[cur][l15 * GPS + 32 * kk + 8 * kg]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[j][kk], acc[j], 0, 0, 0);
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[j][kk], acc[j], 0, 0, 0);
+                for (int a = 0; a < 2; ++a) acc[j][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[j][a][kk], acc[j][a], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[j][kk], acc[j], 0, 0, 0);
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[j][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[j][a][kk], acc[j][a], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[j][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[j][a][kk], acc[j][a], 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + rl;
-            const float hn = acc[2][r] + bias[2];
-            const float rg = sigmoidf_(gir[r] + acc[0][r] + bias[0]);
-            const float zg = sigmoidf_(giz[r] + acc[1][r] + bias[1]);
-            const float ng = tanhf(gin[r] + rg * hn);
-            const float hnew = (1.0f - zg) * ng + zg * hm[cur][rl * GHS + u];
-            const float next = row < N ? hnew * mk[r] : 0.0f;
-            if (row < N) { // stores only: nothing in here waits for memory
-                const size_t tr = (size_t)t * N + row;
-                hs[tr * 128 + u] = hnew;
-                float *gp = gates + tr * 512;
-                gp[u] = rg; gp[128 + u] = zg; gp[256 + u] = ng; gp[384 + u] = hn;
-                if (t + 1 < T) hms[(tr + N) * 128 + u] = next;
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 4 * kg + r, row = row0 + rl, u = 32 * wave + 16 * a + l15;
+                const float hn = acc[2][a][r] + bias[2][a];
+                const float rg = sigmoidf_(gir[a][r] + acc[0][a][r] + bias[0][a]);
+                const float zg = sigmoidf_(giz[a][r] + acc[1][a][r] + bias[1][a]);
+                const float ng = tanhf(gin[a][r] + rg * hn);
+                const float hnew = (1.0f - zg) * ng + zg * hm[cur][rl * GHS + u];
+                const float next = row < N ? hnew * mk[r] : 0.0f;
+                if (row < N) { // stores only: nothing in here waits for memory
+                    const size_t tr = (size_t)t * N + row;
+                    hs[tr * 128 + u] = hnew;
+                    float *gp = gates + tr * 512;
+                    gp[u] = rg; gp[128 + u] = zg; gp[256 + u] = ng; gp[384 + u] = hn;
+                    if (t + 1 < T) hms[(tr + N) * 128 + u] = next;
+                }
+                if (t + 1 < T) {
+                    const __bf16 h = (__bf16)next;
+                    hm[cur ^ 1][rl * GHS + u] = next; hmh[cur ^ 1][rl * GPS + u] = h; hml[cur ^ 1][rl * GPS + u] = (__bf16)(next - (float)h);
+                }
+                if (a == 1) request(0, r, t + 1); // (mk[r] is shared by the two blocks: its reload goes behind the second one's use)
+                if (a == 1) request(1, r, t + 1);
             }
-            if (t + 1 < T) {
-                const __bf16 h = (__bf16)next;
-                hm[cur ^ 1][rl * GHS + u] = next; hmh[cur ^ 1][rl * GPS + u] = h; hml[cur ^ 1][rl * GPS + u] = (__bf16)(next - (float)h);
-            }
-            request(r, t + 1);
-        }
         __syncthreads();
     }
 }
@@ -220,88 +236,107 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(int T, int N, const fl
                                                           float *__restrict__ dgi, float *__restrict__ dgh, float *__restrict__ dh0)
 {
     __shared__ __attribute__((aligned(16))) __bf16 dgp_h[GR * GQS], dgp_l[GR * GQS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int row0 = blockIdx.x * GR, u = 32 * wave + l31;
-    // d(hm)[row][n] = sum_c d(gh)[row][c] * W_hh[c][n]: this lane's column n = u, k = c = 16 kk + 8 half + e runs over the 384 gate columns
-    bf16x8 wh[24], wl[24];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, l15 = lane & 15;
+    const int row0 = blockIdx.x * GR;
+    // d(hm)[row][n] = sum_c d(gh)[row][c] * W_hh[c][n]: this lane's columns n = u(a), k = c = 32 kk + 8 kg + e runs over the 384 gate columns
+    bf16x8 wh[2][12], wl[2][12];
 #pragma unroll
-    for (int kk = 0; kk < 24; ++kk) {
-        float x[8];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = Whh[(size_t)(16 * kk + 8 * half + e) * 128 + u];
-        split8(x, wh[kk], wl[kk]);
-    }
-    f32x16 carry;
+        for (int kk = 0; kk < 12; ++kk) {
+            float x[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) carry[r] = 0.0f;
+            for (int e = 0; e < 8; ++e) x[e] = Whh[(size_t)(32 * kk + 8 * kg + e) * 128 + 32 * wave + 16 * a + l15];
+            split8(x, wh[a][kk], wl[a][kk]);
+        }
+    float carry[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) carry[a][r] = 0.0f;
     // The saved gates / states / incoming gradients of a step do not depend on the carried gradient: they are requested one step
     // ahead, unpredicated (surplus rows read row N-1), right behind the barrier that ends their last use -- the MFMAs of the
-    // current step hide the round trip.  Loaded inside the per-row `if (row < N)` blocks they cost 16 serial round trips per step.
-    float s_rg[16], s_zg[16], s_ng[16], s_hn[16], s_h[16], s_d[16], s_m[16];
+    // current step hide the round trip.
+    float s_rg[2][4], s_zg[2][4], s_ng[2][4], s_hn[2][4], s_h[2][4], s_d[2][4], s_m[4];
     auto preload = [&](int t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowc = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, N - 1);
+        for (int r = 0; r < 4; ++r) {
+            const int rowc = min(row0 + 4 * kg + r, N - 1);
             const size_t tr = (size_t)t * N + rowc;
-            const float *gp = gates + tr * 512 + u;
-            s_rg[r] = gp[0]; s_zg[r] = gp[128]; s_ng[r] = gp[256]; s_hn[r] = gp[384];
-            s_h[r] = hms[tr * 128 + u];
-            s_d[r] = d_hs[tr * 128 + u];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int u = 32 * wave + 16 * a + l15;
+                const float *gp = gates + tr * 512 + u;
+                s_rg[a][r] = gp[0]; s_zg[a][r] = gp[128]; s_ng[a][r] = gp[256]; s_hn[a][r] = gp[384];
+                s_h[a][r] = hms[tr * 128 + u];
+                s_d[a][r] = d_hs[tr * 128 + u];
+            }
             s_m[r] = m[tr];
         }
     };
     auto put = [&](int off, float v) { const __bf16 h = (__bf16)v; dgp_h[off] = h; dgp_l[off] = (__bf16)(v - (float)h); };
     preload(T - 1);
     for (int t = T - 1; t >= 0; --t) {
-        float direct[16], mt[16];
+        float direct[2][4], mt[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * half, row = row0 + rl;
+        for (int r = 0; r < 4; ++r) {
+            const int rl = 4 * kg + r, row = row0 + rl;
             const bool ok = row < N;
-            const float rg = s_rg[r], zg = s_zg[r], ng = s_ng[r], hn = s_hn[r], h = s_h[r];
-            const float d = s_d[r] + carry[r];
-            const float din = d * (1.0f - zg) * (1.0f - ng * ng);
-            const float dr = ok ? din * hn * rg * (1.0f - rg) : 0.0f;
-            const float dz = ok ? d * (h - ng) * zg * (1.0f - zg) : 0.0f;
-            const float dn = ok ? din * rg : 0.0f;
-            direct[r] = ok ? d * zg : 0.0f;
             mt[r] = s_m[r];
-            if (ok) { // stores only
-                const size_t tr = (size_t)t * N + row;
-                float *a = dgi + tr * 384, *b = dgh + tr * 384;
-                a[u] = dr; a[128 + u] = dz; a[256 + u] = din;
-                b[u] = dr; b[128 + u] = dz; b[256 + u] = dn;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int u = 32 * wave + 16 * a + l15;
+                const float rg = s_rg[a][r], zg = s_zg[a][r], ng = s_ng[a][r], hn = s_hn[a][r], h = s_h[a][r];
+                const float d = s_d[a][r] + carry[a][r];
+                const float din = d * (1.0f - zg) * (1.0f - ng * ng);
+                const float dr = ok ? din * hn * rg * (1.0f - rg) : 0.0f;
+                const float dz = ok ? d * (h - ng) * zg * (1.0f - zg) : 0.0f;
+                const float dn = ok ? din * rg : 0.0f;
+                direct[a][r] = ok ? d * zg : 0.0f;
+                if (ok) { // stores only
+                    const size_t tr = (size_t)t * N + row;
+                    float *p1 = dgi + tr * 384, *p2 = dgh + tr * 384;
+                    p1[u] = dr; p1[128 + u] = dz; p1[256 + u] = din;
+                    p2[u] = dr; p2[128 + u] = dz; p2[256 + u] = dn;
+                }
+                put(rl * GQS + u, dr); put(rl * GQS + 128 + u, dz); put(rl * GQS + 256 + u, dn);
             }
-            put(rl * GQS + u, dr); put(rl * GQS + 128 + u, dz); put(rl * GQS + 256 + u, dn);
         }
         __syncthreads();
         preload(t > 0 ? t - 1 : 0);
-        // one accumulator per term: 72 MFMAs into a single accumulator would each wait for the one before
-        f32x16 acc[3];
+        // one accumulator per term and column block: 72 MFMAs into two accumulators would each wait for the one before
+        f32x4g acc[3][2];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+            for (int a = 0; a < 2; ++a) acc[q][a] = f32x4g{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 24; ++kk) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&dgp_h[l31 * GQS + 16 * kk + 8 * half]);
-            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&dgp_l[l31 * GQS + 16 * kk + 8 * half]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[kk], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[kk], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[kk], acc[2], 0, 0, 0);
+        for (int kk = 0; kk < 12; ++kk) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&dgp_h[l15 * GQS + 32 * kk + 8 * kg]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&dgp_l[l15 * GQS + 32 * kk + 8 * kg]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[a][kk], acc[0][a], 0, 0, 0);
+                acc[1][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[a][kk], acc[1][a], 0, 0, 0);
+                acc[2][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[a][kk], acc[2][a], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            carry[r] = row < N ? (direct[r] + ((acc[0][r] + acc[1][r]) + acc[2][r])) * mt[r] : 0.0f;
-        }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * kg + r;
+                carry[a][r] = row < N ? (direct[a][r] + ((acc[0][a][r] + acc[1][a][r]) + acc[2][a][r])) * mt[r] : 0.0f;
+            }
         __syncthreads(); // the next (earlier) step overwrites the planes
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < N) dh0[(size_t)row * 128 + u] = carry[r];
-    }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 4 * kg + r;
+            if (row < N) dh0[(size_t)row * 128 + 32 * wave + 16 * a + l15] = carry[a][r];
+        }
 }
 
 } // namespace
