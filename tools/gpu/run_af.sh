@@ -2,7 +2,7 @@
 # attention backward of the 9..16 class on the matrix pipe (M) against the VALU kernel (A)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/af
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_ppo.py tests/test_gpu_policy.py -x -q -m gpu 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_ppo.py -x -q -m gpu 2>&1 | tail -4
 B="timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-worst-case --no-dropin --no-pmc-traffic"
 for v in A M A M; do
   CN_HIP_LIB=$GRAFT_REPO_ROOT/.ab/lib$v.so $B 2>> gpurun_out/af/err.log | python -c "
