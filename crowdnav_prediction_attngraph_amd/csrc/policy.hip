@@ -1474,6 +1474,8 @@ RnWs rn_ws(int T, int N)
         pmax = pmax > sp * q[0] * q[1] ? pmax : sp * q[0] * q[1];
         bmax = bmax > sp * q[0] ? bmax : sp * q[0];
     }
+    if (bmax < (size_t)RN_HEAD_COLS) bmax = RN_HEAD_COLS; // dbp also receives the reduced head gradients (cn_rn_seq_bwd): with one split per product
+                                                          // (a few samples) 512 floats would let them run into `small`, which that reduction is reading
     w.part = carve(pmax); w.dbp = carve(bmax);
     w.small_rows = 1024;
     w.small = carve((size_t)w.small_rows * (RN_HEAD_COLS > 2560 ? RN_HEAD_COLS : 2560)); // head partials [1024, 776] / robot_linear partials [1024, 256, 10]

@@ -518,3 +518,43 @@ def test_fused_robot_node_sequence_equals_the_module_path(T, N, H):
         scale = max(float(gb[k].abs().max()), 1e-4)
         err = float((ga[k] - gb[k]).abs().max())
         assert err <= 2e-4 * scale + 1e-7, (k, err, scale)
+
+
+def test_fused_robot_node_sequence_head_gradients_at_a_few_samples():
+    """T * N = 10 samples: every weight-gradient product of cn_rn_seq_bwd runs as ONE split, the smallest its scratch carve-up gets.  The
+    reduced head gradients (776 floats) used to run past a 512-float region into the partial rows their own reduction was still reading:
+    a race that showed as a handful of wrong dist.fc_mean.weight gradients once in a few runs.  100 backward passes must agree bit for bit
+    with each other, and with the per-op module path."""
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from tests import policy_util as PU
+    torch.manual_seed(3)
+    T, N, H, D = 5, 2, 5, 2
+    ob_space, act_space = make_spaces(H, D)
+    pol = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn", base_kwargs=dict(env_name="CrowdSimVarNum-v0", num_processes=N, num_mini_batch=1, seq_length=T)).cuda()
+    pol.base.train_fused_rn = True
+    obs = {k: torch.from_numpy(v).cuda() for k, v in PU.synth_obs(T * N, H, D, seed=9).items()}
+    g = torch.Generator(device="cuda").manual_seed(4)
+    h0 = torch.randn(N, 1, 128, device="cuda", generator=g)
+    masks = torch.ones(T * N, 1, device="cuda")
+    actions = torch.randn(T * N, 2, device="cuda", generator=g)
+    wv = torch.randn(T * N, 1, device="cuda", generator=g)
+    wl = torch.randn(T * N, 1, device="cuda", generator=g)
+    keys = ("dist.fc_mean.weight", "dist.fc_mean.bias", "base.critic_linear.weight", "base.critic_linear.bias", "dist.logstd._bias")
+    first = None
+    for _ in range(100):
+        v, lp, _, _ = pol.evaluate_actions(obs, {"human_node_rnn": h0}, masks, actions)
+        pol.zero_grad()
+        ((v * wv).sum() + (lp * wl).sum()).backward()
+        grads = {k: p.grad.detach().clone() for k, p in pol.named_parameters() if k in keys}
+        if first is None:
+            first = grads
+        for k in keys:
+            assert torch.equal(grads[k], first[k]), k
+    # ... and with the per-op module path (autograd over the torch heads) on the same weights
+    pol.base.train_fused_rn = False
+    v, lp, _, _ = pol.evaluate_actions(obs, {"human_node_rnn": h0}, masks, actions)
+    pol.zero_grad()
+    ((v * wv).sum() + (lp * wl).sum()).backward()
+    ref = {k: p.grad.detach().clone() for k, p in pol.named_parameters() if k in keys}
+    for k in keys:
+        assert float((first[k] - ref[k]).abs().max()) <= 2e-4 * max(float(ref[k].abs().max()), 1e-4) + 1e-7, k
