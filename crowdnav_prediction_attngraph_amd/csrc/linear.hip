@@ -527,6 +527,10 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         int rows = (M32 + main_splits - 1) / main_splits;
         rows = (rows + 31) / 32 * 32;
         used = (M32 + rows - 1) / rows;
+        // the kernel addresses a split's rows through buffer loads: 32-bit byte offsets from the split's first row, 2 GB of records --
+        // a load past that returns zero without a fault
+        CN_REQUIRE((long long)rows * (ldy > ldx ? ldy : ldx) * 4 < (1LL << 31),
+                   "cn_linear_wgrad: %d rows per split x leading dimension %d exceed the 2 GB a split may span (more splits needed)", rows, ldy > ldx ? ldy : ldx);
         constexpr size_t lds2 = (size_t)2 * 2 * 128 * 40 * sizeof(__bf16);
         const int nbk = tn_nb(N, K), tiles = (N / 128) * (K / (128 * nbk));
         const dim3 grid(8 * ((used + 7) / 8) * tiles); // XCD-aware 1-D grid, see the kernel
