@@ -111,4 +111,6 @@ def to_env_config(config, env_name, nenv_total, phase="train"):
         goal_change_chance=float(g("humans", "goal_change_chance", 0.5)),
         end_goal_change_chance=float(g("humans", "end_goal_change_chance", 1.0)),
         orca_neighbor_dist=float(g("orca", "neighbor_dist", 10)), orca_safety_space=float(g("orca", "safety_space", 0.15)),
-        orca_time_horizon=float(g("orca", "time_horizon", 5)), orca_time_horizon_obst=float(g("orca", "time_horizon_obst", 5)))
+        orca_time_horizon=float(g("orca", "time_horizon", 5)), orca_time_horizon_obst=float(g("orca", "time_horizon_obst", 5)),
+        # not a reference switch: the bound of the reference's unbounded placement loops (cn_env_config.max_placement_attempts; 0 = 65536)
+        max_placement_attempts=int(g("sim", "max_placement_attempts", 0)))

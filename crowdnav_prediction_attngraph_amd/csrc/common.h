@@ -29,6 +29,21 @@ void cn_set_error(const char *fmt, ...);
         }                                   \
     } while (0)
 
+// The opt-in above 64 KB of dynamic LDS (hipFuncSetAttribute) is per DEVICE: a call site keeps one of these as a function-local static and
+// repeats the opt-in whenever the calling thread's current device is one it has not served yet (a process-wide "done" flag left every
+// device but the first without the attribute: the launch then fails there).  Races between threads only repeat an idempotent call.
+struct CnLdsOptIn {
+    unsigned long long served = 0; // bit d: done on device d
+    bool needed(int *dev_out)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        *dev_out = dev;
+        return !(served & (1ull << (dev & 63)));
+    }
+    void done(int dev) { served |= 1ull << (dev & 63); }
+};
+
 int cn_require_device();
 
 // ---- device-side launch stamps (measurement aid: cn_prof_set_stamps / cn_prof_next_step, include/crowdnav_hip.h) ----

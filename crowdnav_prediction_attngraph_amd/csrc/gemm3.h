@@ -189,11 +189,12 @@ static int launch_gemm3_t(int M, int N, int K, const float *A, int lda, const __
     if (M == 0) return CN_OK;
     dim3 grid(N / BN, (((M + TBM - 1) / TBM) + 7) & ~7);
     constexpr size_t lds = (size_t)(2 * TBM + 2 * BN) * L3_STRIDE * sizeof(__bf16); // 73.7 KB at 128 x 128: needs the opt-in above 64 KB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CnLdsOptIn opt_in; // per device
+    int opt_dev;
+    if (opt_in.needed(&opt_dev)) {
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<TBM, BN, ACT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_nt_kernel<TBM, BN, ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        opt_in.done(opt_dev);
     }
     if (Agate) hipLaunchKernelGGL((gemm3_nt_kernel<TBM, BN, ACT, true>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, m_dev);
     else hipLaunchKernelGGL((gemm3_nt_kernel<TBM, BN, ACT, false>), grid, dim3(256), lds, st, M, N, K, A, lda, Agate, Whi, Wlo, bias, C, ldc, m_dev);

@@ -509,11 +509,12 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
     CN_REQUIRE(ldy >= N && ldx >= K, "cn_linear_wgrad: leading dimension smaller than the row length");
     hipStream_t st = (hipStream_t)stream;
     constexpr size_t lds = (size_t)(2 * BM + 2 * 128) * L3_STRIDE * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CnLdsOptIn opt_in; // per device
+    int opt_dev;
+    if (opt_in.needed(&opt_dev)) {
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm3_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        opt_in.done(opt_dev);
     }
     auto launch_tn = [&](int m, const float *dy, const float *gate, const float *x, int rows_per, int nsplit, float *part, float *dbp) {
         if (gate) hipLaunchKernelGGL(gemm3_tn_kernel<true>, dim3((N + 127) / 128, K / 128, nsplit), dim3(256), lds, st, m, N, K, dy, ldy, gate, x, ldx, rows_per, part, dbp);

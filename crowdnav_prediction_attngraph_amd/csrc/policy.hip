@@ -596,10 +596,11 @@ static int launch_hh_attention_bwd(int B, const float *qkv, const int *row_off, 
         const int wpb = CAP == 16 ? 4 : 2, per_cu = 2;                                    // 8 / 4 wavefronts per CU
         int blocks = (B * 8 + wpb - 1) / wpb;
         if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static CnLdsOptIn opt_in; // per device
+        int opt_dev;
+        if (opt_in.needed(&opt_dev)) {
             CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            opt_in.done(opt_dev);
         }
         hipLaunchKernelGGL(hh_attention_bwd_mfma_kernel<NT>, dim3(blocks), dim3(64 * wpb), per_wave * wpb, st, B, qkv, row_off, cls + c, cls + 4 + (size_t)c * B,
                            d_out, d_qkv, scale);
@@ -612,10 +613,11 @@ static int launch_hh_attention_bwd(int B, const float *qkv, const int *row_off, 
     int blocks = (B * 8 + wpb - 1) / wpb;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu; // resident-sized grid walking the class list
     if (per_wave * wpb > 65536) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static CnLdsOptIn opt_in; // per device
+        int opt_dev;
+        if (opt_in.needed(&opt_dev)) {
             CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hh_attention_bwd_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            opt_in.done(opt_dev);
         }
     }
     hipLaunchKernelGGL(hh_attention_bwd_kernel<CAP>, dim3(blocks), dim3(64 * wpb), per_wave * wpb, st, B, qkv, row_off, cls + c, cls + 4 + (size_t)c * B,

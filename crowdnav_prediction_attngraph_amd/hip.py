@@ -44,9 +44,17 @@ class HipEnvBatch:
         self.done = self._packed[16 * E:17 * E]
         self.info = self._packed[17 * E:18 * E]
         self._packed_host = None
+        self._reward_in_packed = False    # did the last step() write its reward into the packed buffer (fetch_step_outputs reads it there)?
+        self._tail_policies = []          # weak references to the HipPolicy objects whose post-hh hook points at this batch (attach_env_tail)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            # a policy whose hook still holds this handle would call cn_env_launch_tail on freed memory at its next forward: detach first
+            for ref in list(getattr(self, "_tail_policies", ())):
+                pol = ref()
+                if pol is not None and getattr(pol, "_tail_env", None) is self:
+                    pol.attach_env_tail(None)
+            self._tail_policies = []
             A.lib().cn_env_destroy(self._h)
             self._h = None
 
@@ -79,12 +87,18 @@ class HipEnvBatch:
         with torch.cuda.device(self.device):
             A.check(A.lib().cn_env_step(self._h, A.ptr(actions), C.byref(o), A.ptr(reward), A.ptr(self.done), A.ptr(self.info),
                                         A.ptr(self.ep_return), A.ptr(self.ep_len), A.ptr(not_done), A.stream_ptr()), "cn_env_step")
+        self._reward_in_packed = reward.data_ptr() == self.reward.data_ptr()
         return obs, reward, self.done, self.info, self.ep_return, self.ep_len
 
     def fetch_step_outputs(self):
         """(reward f32 [E], done bool [E], info u8 [E], ep_return f64 [E], ep_len i32 [E]) of the last step() as numpy arrays: ONE
         device-to-host transfer into a pinned buffer and one stream synchronisation.  The arrays are views of that buffer: valid until the
-        next call."""
+        next call.  The reward is whatever the packed buffer holds at the time of the call: the raw env reward, or -- when a wrapper
+        (gst.PretextProcessor / HipGST.wrapper_step) has added its prediction penalty to that buffer in place -- the reward after the penalty.
+        After a step(reward=<caller's tensor>) the packed buffer does not hold that step's reward at all, and the call raises."""
+        if not self._reward_in_packed:
+            raise A.CnError("fetch_step_outputs: the last step() wrote its reward into a caller-supplied tensor (or no step ran yet), "
+                            "the packed buffer holds an older one; read the tensor passed as step(reward=...)")
         E = self.E
         if self._packed_host is None:
             self._packed_host = torch.empty(18 * E, dtype=torch.uint8, pin_memory=True)
@@ -268,12 +282,17 @@ class HipPolicy:
         """env: a HipEnvBatch in tail-deferral mode (or None to detach): every forward releases that batch's held-back side work right after
         its human-human kernel is enqueued (cn_policy_set_post_hh_hook with cn_env_launch_tail).  Detach before closing the env."""
         if env is None:
-            A.check(A.lib().cn_policy_set_post_hh_hook(self._h, None, None), "cn_policy_set_post_hh_hook")
+            if getattr(self, "_h", None) is not None and self._h:
+                A.check(A.lib().cn_policy_set_post_hh_hook(self._h, None, None), "cn_policy_set_post_hh_hook")
             self._tail_env = None
             return
+        if getattr(env, "_h", None) is None or not env._h:
+            raise A.CnError("attach_env_tail: the env batch is closed")
         fn = C.cast(A.lib().cn_env_launch_tail, C.c_void_p)
         A.check(A.lib().cn_policy_set_post_hh_hook(self._h, fn, env._h), "cn_policy_set_post_hh_hook")
         self._tail_env = env          # keeps the batch alive as long as the hook points at it
+        import weakref
+        env._tail_policies.append(weakref.ref(self))   # ... and env.close() detaches the hook before the handle is freed
 
     def get_profile(self):
         ms = (C.c_double * 8)()

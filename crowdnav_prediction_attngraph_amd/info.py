@@ -58,6 +58,21 @@ class _SharedInfo(dict):
 
     __setitem__ = __delitem__ = update = pop = popitem = clear = setdefault = _ro
 
+    # copies and pickles are PLAIN dicts (writable, private to whoever made them): gym / baselines-style wrappers deepcopy, pickle or
+    # annotate the infos list they are handed, which the reference's list of E fresh dicts allows
+    def __copy__(self):
+        return dict(self)
+
+    def copy(self):
+        return dict(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+        return {k: copy.deepcopy(v, memo) for k, v in self.items()}
+
+    def __reduce__(self):
+        return (dict, (dict(self),))
+
 
 class LazyInfos(object):
     """The `infos` list of VecEnv.step() (list of E dicts, shmem_vec_env.py:136-142 + bench.Monitor) without E dict constructions per step:

@@ -169,6 +169,18 @@ class AttnGraphBase(nn.Module):
     # ONE backward (hip.RnSequence: cn_rn_seq_fwd / cn_rn_seq_bwd) instead of torch modules with HIP Functions spliced in
     train_fused_rn = os.environ.get("CN_TRAIN_FUSED_RN", "1") != "0"   # (the environment switch is for A/B timing: bench.py's PPO leg)
 
+    def fused_rn_shapes_ok(self):
+        """hip.RnSequence hard-codes every layer shape of the robot-node sequence (_abi.RN_WEIGHT_SHAPES) and computes its products as bf16x3
+        splits: evaluate_actions takes it only when the modules have exactly those shapes and train_gemm_mode asks for that arithmetic
+        ('fp32' keeps the torch / exact-fp32 path of forward_sequence)."""
+        rnn, g = self.humanNodeRNN, self.humanNodeRNN.gru
+        return (tuple(self.robot_linear[0].weight.shape) == (256, 9) and tuple(rnn.edge_attention_embed.weight.shape) == (64, 256)
+                and tuple(rnn.encoder_linear.weight.shape) == (64, 256) and tuple(self.attn.temporal_edge_layer[0].weight.shape) == (64, 256)
+                and tuple(self.attn.spatial_edge_layer[0].weight.shape) == (64, 256)
+                and tuple(g.weight_ih_l0.shape) == (384, 128) and tuple(g.weight_hh_l0.shape) == (384, 128)
+                and tuple(rnn.output_linear.weight.shape) == (256, 128) and tuple(self.actor[2].weight.shape) == (256, 256)
+                and tuple(self.critic_linear.weight.shape) == (1, 256))
+
     def rn_sequence(self, inputs, out_sp, row_off, h0, masks, actions, T, N, dist):
         """(value [B,1], logp [B,1], h_T [N,128]) through hip.RnSequence.  The two affine pairs without a nonlinearity in between are composed
         here in torch ops (tiny products, autograd carries the folded gradients back to both factors): u = Ws^T (Wt r + bt) -- the
@@ -439,7 +451,7 @@ class Policy(nn.Module):
         N = rnn_hxs["human_node_rnn"].shape[0]
         T = B // N
         base = self.base
-        if inputs["robot_node"].is_cuda and base.train_fused_rn and base.human_node_rnn_size == 128:
+        if inputs["robot_node"].is_cuda and base.train_fused_rn and base.train_gemm_mode == "bf16x3" and base.fused_rn_shapes_ok():
             # train-mode forward as two boundary calls: the human-human block (cn_hh_block_fwd behind _hh_block) and the robot-node sequence
             # (cn_rn_seq_fwd), each with ONE backward entry
             det = inputs["detected_human_num"].reshape(B).to(torch.int64).clamp(min=1)

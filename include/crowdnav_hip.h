@@ -95,7 +95,12 @@ typedef struct {
     int32_t max_placement_attempts; /* bound of the reference's UNBOUNDED rejection sampling of human positions / goals
                                    * (crowd_sim_var_num.py:116-146, crowd_sim.py:415-450): after this many attempts the last
                                    * candidate is accepted; 0 = 65536.  Dense randomised crowds have seeds where the reference
-                                   * loop runs for minutes, and a batch waits for its slowest env. */
+                                   * loop runs for minutes, and a batch waits for its slowest env.
+                                   * SEMANTIC DEVIATION from the reference (which never gives up): an episode / goal change whose
+                                   * loop reaches the bound places that human at a position that still violates the minimum
+                                   * distance.  The C oracle has the same bound, so the bit-exact tests hold; none of the
+                                   * reference-generated traces or shipped evaluation logs reaches it (20 humans: < 300 attempts
+                                   * at worst); it matters for crowds of ~50 randomised humans (BASELINE configs[4]). */
     int32_t human_num_range;      /* sim.human_num_range: the crowd holds human_num - range .. human_num + range humans (drawn at reset,
                                    * changed every 5 s: crowd_sim_var_num.py:103-104, :404-437, crowd_sim_pred.py:165-190); observations
                                    * always have human_num + human_num_range rows, which must be <= CN_MAX_HUMANS */

@@ -58,3 +58,23 @@ def test_lazy_infos_build_dicts_only_for_finished_envs_and_shared_ones_are_read_
     d = lazy[int(np.flatnonzero(done)[0])]
     d["extra"] = 1                      # a finished env's dict is its own
     assert lazy[int(np.flatnonzero(done)[0])]["extra"] == 1
+
+
+def test_lazy_infos_copy_deepcopy_and_pickle_like_the_reference_list():
+    """Wrappers in the gym / baselines style deepcopy, pickle or annotate the infos they are handed (the reference returns E fresh dicts):
+    the copies must be plain writable dicts and the shared originals must stay untouched."""
+    import copy
+    import pickle
+    codes, done, ep_ret, ep_len, md, lazy = _mk(E=64, seed=3, with_danger=True)
+    want = _eager(codes, done, ep_ret, ep_len, md)
+    for clone in (copy.deepcopy(list(lazy)), pickle.loads(pickle.dumps(list(lazy))), [copy.copy(d) for d in lazy], [d.copy() for d in lazy]):
+        assert len(clone) == len(want)
+        for got, w in zip(clone, want):
+            assert type(got) is dict and set(got) == set(w)
+            assert type(got["info"]) is type(w["info"]) and got.get("episode") == w.get("episode")
+        for got in clone:
+            got["bad_transition"] = True            # writable, and private to the copy (deepcopy / pickle keep ONE copy per shared original)
+    assert all("bad_transition" not in d for d in lazy)
+    # the LazyInfos object itself survives a deepcopy / pickle round trip as a list-like of the same content
+    for clone in (copy.deepcopy(lazy), pickle.loads(pickle.dumps(lazy))):
+        assert [str(d["info"]) for d in clone] == [str(w["info"]) for w in want]
