@@ -898,7 +898,9 @@ __device__ __forceinline__ void rng_store(Rng &R, const EnvDev &s, int e, int la
 __device__ __forceinline__ void rng_seed(Rng &R, uint32_t seed, int lane)
 {
     __syncthreads();
-    uint32_t sd = seed;
+    // (the seed comes out of vector loads: without this the 624-step chain runs on the vector ALU -- shift, xor, a quarter-rate 32-bit
+    // multiply and an add per step, ~13 us -- instead of four scalar instructions)
+    uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed);
     for (int base = 0; base < MT_N; base += 64) {
         uint32_t mine = 0;
         for (int t = 0; t < 64; ++t) {
@@ -1007,6 +1009,16 @@ struct Lane {
 struct Robot { double px, py, vx, vy, gx, gy, theta, pot; };
 
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
+// norm2(x, y) < d, decided without the square root whenever the squared distance is not within a few ulps of d * d: sqrt is correctly
+// rounded and monotone, so outside that band the comparison of the squares gives the same answer; inside it (practically never) the
+// reference expression itself is evaluated.  d >= 0.
+__device__ __forceinline__ bool closer_than(double x, double y, double d)
+{
+    const double q = x * x + y * y, dd = d * d;
+    if (q < dd * (1.0 - 0x1p-48)) return true;
+    if (q > dd * (1.0 + 0x1p-48)) return false;
+    return sqrt(q) < d;
+}
 
 // crowd_sim_var_num.py:116-146 generate_circle_crossing_human (+ Agent.__init__/sample_random_attributes draws).
 // All lanes compute the candidate position identically; the min-distance test against the existing agents is
@@ -1031,9 +1043,9 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
         py = c.circle_radius * sn + py_noise;
         // :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal
         const double md_r = c.kinematics == CN_KIN_UNICYCLE ? c.circle_radius / 2.0 : radius + c.robot_radius + c.discomfort_dist;
-        const bool coll_r = norm2(px - rb.px, py - rb.py) < md_r || norm2(px - rb.gx, py - rb.gy) < md_r;
+        const bool coll_r = closer_than(px - rb.px, py - rb.py, md_r) || closer_than(px - rb.gx, py - rb.gy, md_r);
         const double md = radius + h.rad + c.discomfort_dist;
-        const bool coll_h = lane < n_existing && (norm2(px - h.px, py - h.py) < md || norm2(px - h.gx, py - h.gy) < md);
+        const bool coll_h = lane < n_existing && (closer_than(px - h.px, py - h.py, md) || closer_than(px - h.gx, py - h.gy, md));
         if (!(coll_r || wv_any(coll_h)) || attempt >= (c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS)) break;
     }
     if (lane == slot) {
