@@ -329,6 +329,136 @@ __device__ __forceinline__ void lp3_wave(const LpLine &L, int n, int beginLine, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// linearProgram3 for TWO programs per wavefront: lanes 0..31 hold the lines of one, lanes 32..63 those of another (at most 32 lines
+// each: the lane kernel's limit).  Per program the arithmetic is lp3_wave's; what is wave-uniform there (the result, the bounds, the
+// index of the line being processed) is uniform per HALF here and lives in vector registers, each half's walk is predicated on its
+// own state, and a loop ends when both halves are through.  hl = lane & 31.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hw_ballot(bool p, int lane)
+{
+    const uint64_t b = __ballot(p);
+    return (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+}
+__device__ __forceinline__ float hw_read(float v, int lane, int i) // v of lane i of this lane's half (i uniform per half)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) + i) << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ float hw_last(float v, int lane) // lanes 31 / 63 -> every lane of their half
+{
+    const float a = wv_readlane(v, 31), b = wv_readlane(v, 63);
+    return (lane & 32) ? b : a;
+}
+__device__ __forceinline__ float hw_min(float v, int lane)
+{
+    const float I = __builtin_inff();
+    v = fminf(v, wv_dpp<0x111, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x112, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x114, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x118, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x142, 0xa>(v, I)); // row_bcast:15 into rows 1 and 3: lane 31 = lanes 0..31, lane 63 = lanes 32..63
+    return hw_last(v, lane);
+}
+__device__ __forceinline__ float hw_max(float v, int lane)
+{
+    const float I = -__builtin_inff();
+    v = fmaxf(v, wv_dpp<0x111, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x112, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x114, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x118, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x142, 0xa>(v, I));
+    return hw_last(v, lane);
+}
+
+// lp1_wave with dirOpt = true for both halves at once; commits the new result only where `act` and the program is feasible
+__device__ __forceinline__ bool lp1_pair(const LpLine &L, uint32_t valid, int i, float ipx, float ipy, float idx, float idy, float radius,
+                                         float optx, float opty, bool act, int lane, float &rx, float &ry)
+{
+    const int hl = lane & 31;
+    const float dotProduct = ipx * idx + ipy * idy;
+    const float discriminant = dotProduct * dotProduct + radius * radius - (ipx * ipx + ipy * ipy);
+    bool ok = !(discriminant < 0.0f);
+    const float sq = sqrtf(discriminant);
+    float tLeft = -dotProduct - sq;
+    float tRight = -dotProduct + sq;
+    const bool mine = hl < i && ((valid >> hl) & 1u);
+    const float denominator = idx * L.dy - idy * L.dx;
+    const float numerator = L.dx * (ipy - L.py) - L.dy * (ipx - L.px);
+    const bool parallel = fabsf(denominator) <= RVO_EPS;
+    const bool pfail = mine && parallel && numerator < 0.0f;
+    const float t = numerator / denominator;
+    const float candR = (mine && !parallel && denominator >= 0.0f) ? t : INFINITY;
+    const float candL = (mine && !parallel && denominator < 0.0f) ? t : -INFINITY;
+    tRight = fminf(tRight, hw_min(candR, lane));
+    tLeft = fmaxf(tLeft, hw_max(candL, lane));
+    const uint32_t pf = hw_ballot(pfail, lane); // (every cross-lane operation of these routines sits outside their predicated parts)
+    ok = ok & (pf == 0u) & !(tLeft > tRight);
+    const float t_opt = (optx * idx + opty * idy > 0.0f) ? tRight : tLeft;
+    if (act && ok) {
+        rx = ipx + t_opt * idx;
+        ry = ipy + t_opt * idy;
+    }
+    return ok;
+}
+
+// lp2_wave with dirOpt = true over the lines 0 .. n-1 of each half (n, radius, opt uniform per half).  Returns n or the failing line.
+__device__ __forceinline__ int lp2_pair(const LpLine &L, uint32_t valid, int n, float radius, float optx, float opty, bool act, int lane,
+                                        float &rx, float &ry)
+{
+    if (act) { rx = radius * optx; ry = radius * opty; }
+    uint32_t todo = valid & ((1u << n) - 1u); // n <= 31: line n itself is the one being projected on
+    int res = n;
+    bool running = act;
+    for (;;) {
+        const uint32_t vm = hw_ballot(L.dx * (L.py - ry) - L.dy * (L.px - rx) > 0.0f, lane) & todo;
+        const bool go = running && vm != 0u;
+        if (__ballot(go) == 0ull) return res;
+        running = go; // a half without a violated line left is through
+        const int i = go ? __ffs((int)vm) - 1 : 0;
+        if (go) todo &= ~((2u << i) - 1u);
+        const float ipx = hw_read(L.px, lane, i), ipy = hw_read(L.py, lane, i);
+        const float idx = hw_read(L.dx, lane, i), idy = hw_read(L.dy, lane, i);
+        const bool ok = lp1_pair(L, valid, i, ipx, ipy, idx, idy, radius, optx, opty, go, lane, rx, ry);
+        if (go && !ok) { res = i; running = false; } // (lp1_pair left the result alone)
+    }
+}
+
+__device__ __forceinline__ void lp3_pair(const LpLine &L, int n, int beginLine, float radius, bool act, int lane, float &rx, float &ry)
+{
+    const int hl = lane & 31;
+    float distance = 0.0f;
+    uint32_t todo = (n >= 32 ? ~0u : ((1u << n) - 1u)) & ~((1u << beginLine) - 1u);
+    bool running = act;
+    for (;;) {
+        const uint32_t vm = hw_ballot(L.dx * (L.py - ry) - L.dy * (L.px - rx) > distance, lane) & todo;
+        const bool go = running && vm != 0u;
+        if (__ballot(go) == 0ull) return;
+        running = go;
+        const int i = go ? __ffs((int)vm) - 1 : 0;
+        if (go) todo &= ~((2u << i) - 1u);
+        const float ipx = hw_read(L.px, lane, i), ipy = hw_read(L.py, lane, i);
+        const float idx = hw_read(L.dx, lane, i), idy = hw_read(L.dy, lane, i);
+        LpLine Pj;
+        const float determinant = idx * L.dy - idy * L.dx;
+        const bool par = fabsf(determinant) <= RVO_EPS;
+        const bool skip = par && (idx * L.dx + idy * L.dy > 0.0f);
+        if (par) {
+            Pj.px = 0.5f * (ipx + L.px); Pj.py = 0.5f * (ipy + L.py);
+        } else {
+            const float s = (L.dx * (ipy - L.py) - L.dy * (ipx - L.px)) / determinant;
+            Pj.px = ipx + s * idx; Pj.py = ipy + s * idy;
+        }
+        const float ddx = L.dx - idx, ddy = L.dy - idy;
+        const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+        Pj.dx = ddx * inv; Pj.dy = ddy * inv;
+        const uint32_t pvalid = hw_ballot(hl < i && !skip, lane);
+        const float tx = rx, ty = ry;
+        const int f = lp2_pair(Pj, pvalid, i, radius, -idy, idx, go, lane, rx, ry);
+        if (go && f < i) { rx = tx; ry = ty; }
+        if (go) distance = idx * (ipy - ry) - idy * (ipx - rx);
+    }
+}
+
 // One agent's new velocity.  Lane j < nl holds candidate neighbour j (cand == true) in index order.
 // RVO2 Agent::computeNeighbors (range filter, ascending distSq, at most maxNeighbors) + computeNewVelocity.
 __device__ __forceinline__ void orca_wave(int lane, int nl, bool cand, float opx, float opy, float ovx, float ovy, float orad,
@@ -735,21 +865,24 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     }
 }
 
-// the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): one wavefront each, lane k = line k
+// the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): two per wavefront, lane k of a half = line k
 __global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
 {
     const CnStampScope stamp_scope(s.stamp);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int total = *s.lp3_cnt;
+    const int pairs = (total + 1) >> 1;
     const int H = s.H;
-    for (int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); k < total; k += gridDim.x * 4) {
+    for (int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); p < pairs; p += gridDim.x * 4) {
+        const bool act = 2 * p + half < total;
+        const int k = act ? 2 * p + half : 2 * p; // (an odd list: the upper half of the last wavefront idles on a copy of the lower one's data)
         const Lp3Hdr hd = s.lp3_hdr[k];
-        const float4 ln = lane < hd.nn ? s.lp3_lines[(size_t)k * 32 + lane] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        const float4 ln = hl < hd.nn ? s.lp3_lines[(size_t)k * 32 + hl] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         LpLine L;
         L.px = ln.x; L.py = ln.y; L.dx = ln.z; L.dy = ln.w;
         float rx = hd.rx, ry = hd.ry;
-        lp3_wave(L, hd.nn, hd.line_fail, hd.radius, lane, rx, ry);
-        if (lane == 0) {
+        lp3_pair(L, hd.nn, hd.line_fail, hd.radius, act, lane, rx, ry);
+        if (act && hl == 0) {
             const int e = hd.agent / H, i = hd.agent - e * H;
             s.hact[(size_t)e * 2 * H + i] = rx;
             s.hact[(size_t)e * 2 * H + H + i] = ry;
