@@ -453,6 +453,29 @@ def main():
                 f.write("# step kernel start_us end_us duration_us\n")
                 for s_, k, a_, b_ in tab:
                     f.write("%3d %-11s %10.2f %10.2f %8.2f\n" % (s_, k, a_, b_, b_ - a_))
+                # when do the human-human kernel's workgroups get their CUs?  (it needs whole CUs: 160 KB of LDS -- a CU on which a
+                # wavefront of another launch still holds LDS admits it only when that wavefront is gone).  Start stamps of its
+                # workgroups 0..63 and end stamps by workgroup & 63, relative to the end of the ORCA lane launch of the same step
+                import numpy as np
+                raw = dst.ring.cpu().numpy()
+                kid = A.PROF_KERNEL_IDS
+                f.write("# hh_fused workgroups 0..63 of each step, us after the end of the step's orca_lane launch: first instruction min / median / p90 / max | "
+                        "last wavefront out (by workgroup & 63) min / median / max | env_pregen's last wavefront out\n")
+                for s_ in range(DEC):
+                    late = raw[s_, kid["hh_fused"], 8:1024:16].astype(np.uint64)
+                    st0 = raw[s_, kid["hh_fused"], 0:1024:16].astype(np.uint64)
+                    en0 = raw[s_, kid["hh_fused"], 1024:2048:16].astype(np.uint64)
+                    lane_end = max(raw[s_, kid["orca_lane"], 1024:2048:16].astype(np.uint64).max(), raw[s_, kid["row_plan"], 1024:2048:16].astype(np.uint64).max())
+                    pg_end = raw[s_, kid["env_pregen"], 1024:2048:16].astype(np.uint64).max()
+                    ok = st0 != np.uint64(0xFFFFFFFFFFFFFFFF)
+                    if not ok.any() or lane_end == 0:
+                        continue
+                    a_ = np.sort((st0[ok].astype(np.int64) - np.int64(lane_end)) * 0.01)
+                    b_ = np.sort((en0[en0 > 0].astype(np.int64) - np.int64(lane_end)) * 0.01)
+                    l_ = np.sort((late[late > 0].astype(np.int64) - np.int64(lane_end)) * 0.01)
+                    f.write("#   step %2d: start %6.2f %6.2f %6.2f %6.2f | latest start per slot (all workgroups) %6.2f %6.2f %6.2f | end %7.2f %7.2f %7.2f | pregen end %7.2f\n" % (
+                        s_, a_[0], a_[len(a_) // 2], a_[int(len(a_) * 0.9)], a_[-1], l_[0] if len(l_) else -1, l_[len(l_) // 2] if len(l_) else -1, l_[-1] if len(l_) else -1,
+                        b_[0], b_[len(b_) // 2], b_[-1], (np.int64(pg_end) - np.int64(lane_end)) * 0.01))
     worst = None
     if not args.no_worst_case and rank == 0:
         force_all_detected[0] = True

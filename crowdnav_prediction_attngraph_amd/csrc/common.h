@@ -46,7 +46,11 @@ struct CnStampScope {
     unsigned long long *s;
     __device__ __forceinline__ explicit CnStampScope(unsigned long long *slot) : s(slot)
     {
-        if (s && threadIdx.x == 0 && blockIdx.x < 64) atomicMin(s + blockIdx.x * 16, (unsigned long long)wall_clock64());
+        if (s && threadIdx.x == 0) {
+            const unsigned long long now = (unsigned long long)wall_clock64();
+            if (blockIdx.x < 64) atomicMin(s + blockIdx.x * 16, now);
+            atomicMax(s + (blockIdx.x & 63) * 16 + 8, now);   // latest first instruction among the workgroups b with b & 63 == slot
+        }
     }
     __device__ __forceinline__ ~CnStampScope()
     {
