@@ -631,19 +631,21 @@ template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(
 // a uniform register index (s_set_gpr_idx), not by 20-32 unrolled copies -- fully unrolled the kernel was 85 KB of straight-line
 // code that every wavefront fetched exactly once (instruction-fetch bound, slower than the cooperative kernel).
 template <int NB, int VW>
-__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, unsigned long long *plan_stamp)
+__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, int plan_groups, unsigned long long *plan_stamp)
 {
-    const CnStampScope stamp_scope((plan && blockIdx.x == 0) ? plan_stamp : s.stamp); // the plan builder's wavefront has its own slot
-    // one extra workgroup builds the row plan of the policy's human-human kernel for the observation that was just written
-    // (row_plan.h): it only needs the detected-human counts, and this kernel is on the step's critical path anyway
-    __shared__ rowplan::Lds rp_lds;
-    // (workgroup 0: dispatched first; its single wavefront is the longest chain of the launch, so it also takes the issue priority)
-    if (plan && blockIdx.x == 0) {
+    const CnStampScope stamp_scope((plan && (int)blockIdx.x < plan_groups) ? plan_stamp : s.stamp); // the plan builders' wavefronts have their own slot
+    // the first workgroups (one wavefront each, rp_groups(E) of them) build the row plan of the policy's human-human kernel for the observation
+    // that was just written (row_plan.h): they only need the detected-human counts, and this kernel is on the step's critical path anyway
+    // (a builder's tables and the agents' line table below share one buffer: a workgroup is one or the other)
+    constexpr int RAW = (int)sizeof(rowplan::Lds) > NB * 64 * 16 ? (int)sizeof(rowplan::Lds) : NB * 64 * 16;
+    __shared__ __attribute__((aligned(16))) char s_raw[RAW];
+    // (dispatched first; a builder is the longest chain of the launch, so it also takes the issue priority)
+    if (plan && (int)blockIdx.x < plan_groups) {
         __builtin_amdgcn_s_setprio(3);
-        rowplan::build(s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds);
+        rowplan::build((int)blockIdx.x, plan_groups, s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, *reinterpret_cast<rowplan::Lds *>(s_raw));
         return;
     }
-    const int blk = (int)blockIdx.x - (plan ? 1 : 0);
+    const int blk = (int)blockIdx.x - (plan ? plan_groups : 0);
     typedef typename LaneVec<VW>::f vec;
     const int agent = blk * 64 + threadIdx.x;
     const int H = s.H;
@@ -654,7 +656,9 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     const cn_env_config &c = s.cfg;
     // the agent records of the 1 + 63/H (+1) envs this wavefront's lanes belong to, staged once: every later access -- uniform in
     // pass 1, a per-lane gather in pass 2 -- is an LDS read instead of an L2 round trip (the kernel is a chain of dependent loads)
-    __shared__ double s_px[128], s_py[128], s_vx[128], s_vy[128], s_rad[128], s_rob[65][4];
+    // (the kernel for NB slots serves crowds of more than NB' agents, NB' the next smaller network: at most 63 / (NB' - 1) + 2 envs per wavefront)
+    constexpr int NENV = NB == 8 ? 65 : (NB == 20 ? 10 : 5);
+    __shared__ double s_px[128], s_py[128], s_vx[128], s_vy[128], s_rad[128], s_rob[NENV][4];
     {
         const int a0 = blk * 64;
         const int e0 = a0 / H, e1 = (min(a0 + 63, s.E * H - 1)) / H;
@@ -729,9 +733,14 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     int nmax = nn; // wave-uniform loop bound
     for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
-    // pass 2: the ORCA half-plane of the k-th nearest neighbour (Agent::computeNewVelocity)
-    const float th = (float)c.orca_time_horizon, dt = (float)c.time_step;
-    vec Lpx, Lpy, Ldx, Ldy;
+    // pass 2: the ORCA half-plane of the k-th nearest neighbour (Agent::computeNewVelocity), kept in LDS as s_line[k][lane]: the
+    // linear program below reads lines of OTHER lanes' agents at per-lane line numbers, which registers cannot do.
+    // The three cases of RVO2 (cut-off circle, legs, collision) go through ONE sqrtf and ONE division whose operands are selected per
+    // case -- the same operations on the same operands as the branchy form (no contraction in this file), so the same bits, but no
+    // divergence: with 64 agents in a wavefront every branch was taken by somebody.
+    const float invTH = 1.0f / (float)c.orca_time_horizon, invDT = 1.0f / (float)c.time_step;
+    float4 *const s_line = reinterpret_cast<float4 *>(s_raw);
+    const int tid = threadIdx.x;
 #pragma unroll 1
     for (int k = 0; k < nmax; ++k) {
         float o_px = 0.0f, o_py = 0.0f, o_dx = 1.0f, o_dy = 0.0f;
@@ -753,45 +762,27 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
             const float distSq = rpx * rpx + rpy * rpy;
             const float cr = self_r + orad;
             const float crSq = cr * cr;
-            float ldx, ldy, ux, uy;
-            if (distSq > crSq) {
-                const float invTH = 1.0f / th;
-                const float wx = rvx - invTH * rpx, wy = rvy - invTH * rpy;
-                const float wLenSq = wx * wx + wy * wy;
-                const float dot1 = wx * rpx + wy * rpy;
-                if (dot1 < 0.0f && dot1 * dot1 > crSq * wLenSq) {
-                    const float wLen = sqrtf(wLenSq);
-                    const float inv = 1.0f / wLen;
-                    const float uwx = wx * inv, uwy = wy * inv;
-                    ldx = uwy; ldy = -uwx;
-                    const float sc = cr * invTH - wLen;
-                    ux = sc * uwx; uy = sc * uwy;
-                } else {
-                    const float leg = sqrtf(distSq - crSq);
-                    const float invD = 1.0f / distSq;
-                    if (rpx * wy - rpy * wx > 0.0f) {
-                        ldx = (rpx * leg - rpy * cr) * invD;
-                        ldy = (rpx * cr + rpy * leg) * invD;
-                    } else {
-                        ldx = -((rpx * leg + rpy * cr) * invD);
-                        ldy = -((-rpx * cr + rpy * leg) * invD);
-                    }
-                    const float dot2 = rvx * ldx + rvy * ldy;
-                    ux = dot2 * ldx - rvx; uy = dot2 * ldy - rvy;
-                }
-            } else {
-                const float invDT = 1.0f / dt;
-                const float wx = rvx - invDT * rpx, wy = rvy - invDT * rpy;
-                const float wLen = sqrtf(wx * wx + wy * wy);
-                const float inv = 1.0f / wLen;
-                const float uwx = wx * inv, uwy = wy * inv;
-                ldx = uwy; ldy = -uwx;
-                const float sc = cr * invDT - wLen;
-                ux = sc * uwx; uy = sc * uwy;
-            }
+            const bool collide = !(distSq > crSq);
+            const float invT = collide ? invDT : invTH;
+            const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
+            const float wLenSq = wx * wx + wy * wy;
+            const float dot1 = wx * rpx + wy * rpy;
+            const bool circle = collide || (dot1 < 0.0f && dot1 * dot1 > crSq * wLenSq); // project on the cut-off circle
+            const float sq = sqrtf(circle ? wLenSq : distSq - crSq);                        // wLen, or the leg length
+            const float inv = 1.0f / (circle ? sq : distSq);                                // 1 / wLen, or 1 / distSq
+            // cut-off circle (time horizon, or the time step on collision)
+            const float uwx = wx * inv, uwy = wy * inv;
+            const float sc = cr * invT - sq;
+            // legs
+            const bool left = rpx * wy - rpy * wx > 0.0f;
+            const float lgx = left ? (rpx * sq - rpy * cr) * inv : -((rpx * sq + rpy * cr) * inv);
+            const float lgy = left ? (rpx * cr + rpy * sq) * inv : -((-rpx * cr + rpy * sq) * inv);
+            const float dot2 = rvx * lgx + rvy * lgy;
+            const float ldx = circle ? uwy : lgx, ldy = circle ? -uwx : lgy;
+            const float ux = circle ? sc * uwx : dot2 * lgx - rvx, uy = circle ? sc * uwy : dot2 * lgy - rvy;
             o_px = fvx + 0.5f * ux; o_py = fvy + 0.5f * uy; o_dx = ldx; o_dy = ldy;
         }
-        Lpx[k] = o_px; Lpy[k] = o_py; Ldx[k] = o_dx; Ldy[k] = o_dy;
+        s_line[k * 64 + tid] = make_float4(o_px, o_py, o_dx, o_dy);
     }
     // preferred velocity: orca.py:97-100
     double gvx = sgx - spx, gvy = sgy - spy;
@@ -806,30 +797,63 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     } else {
         rx = optx; ry = opty;
     }
+    // linearProgram1 of a violated line li cuts it against every earlier line lj < li of the same agent.  An agent violates ~1.2 of
+    // its lines, but some agent of the 64 violates almost every line: a loop over lj run by the whole wavefront did 80 iterations per
+    // wavefront for a handful of agents each time.  Instead the (violating agent, earlier line) pairs of a line are dealt to the 64
+    // lanes, and the bounds of an agent are combined in LDS with integer min / max on order-preserving keys (min and max do not
+    // depend on the order of their operands: the same tLeft / tRight as the sequential loop).
+    // (their four 256-byte tables sit in row NB - 1 of the line table: an agent has at most NB - 1 neighbours.  The static LDS of a workgroup
+    // stays below 1/6 of the CU's: five per CU would leave the 1281st workgroup of a 4096 x 20 batch waiting for a whole generation)
+    unsigned *const s_tl = reinterpret_cast<unsigned *>(s_line + (NB - 1) * 64), *const s_tr = s_tl + 64;
+    int *const s_pf = reinterpret_cast<int *>(s_tr + 64), *const s_vl = s_pf + 64;
+    auto okey = [](float f) { const unsigned u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); };
+    auto okey_inv = [](unsigned o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu)); };
     bool failed = false;
     int line_fail = 0;
 #pragma unroll 1
     for (int li = 0; li < nmax; ++li) {
-        const float ipx = Lpx[li], ipy = Lpy[li], idx_ = Ldx[li], idy = Ldy[li];
+        const float4 Li = s_line[li * 64 + tid];
+        const float ipx = Li.x, ipy = Li.y, idx_ = Li.z, idy = Li.w;
         const bool viol = li < nn && !failed && idx_ * (ipy - ry) - idy * (ipx - rx) > 0.0f;
-        if (__ballot(viol) == 0ull) continue; // wave-uniform: nobody has to re-optimise on this line
-        // linearProgram1 on line li against the disc and the earlier lines
+        const unsigned long long vm = __ballot(viol);
+        if (vm == 0ull) continue; // wave-uniform: nobody has to re-optimise on this line
+        // linearProgram1 on line li against the disc ...
         const float dotProduct = ipx * idx_ + ipy * idy;
         const float discriminant = dotProduct * dotProduct + radius * radius - (ipx * ipx + ipy * ipy);
         bool ok = !(discriminant < 0.0f);
         const float sq = sqrtf(discriminant);
         float tLeft = -dotProduct - sq, tRight = -dotProduct + sq;
         bool pfail = false;
+        // ... and against the earlier lines
+        const int npairs = __popcll(vm) * li;
+        if (npairs > 0) {
+            if (viol) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                s_vl[rank] = tid; s_tl[tid] = okey(tLeft); s_tr[tid] = okey(tRight); s_pf[tid] = 0;
+            }
+            __syncthreads(); // (one wavefront: orders the LDS traffic, costs a waitcnt)
+            const unsigned inv20 = ((1u << 20) + (unsigned)li - 1u) / (unsigned)li; // p / li = p * inv20 >> 20 for p (li - 1) < 2^20
 #pragma unroll 1
-        for (int lj = 0; lj < li; ++lj) {
-            const float jpx = Lpx[lj], jpy = Lpy[lj], jdx = Ldx[lj], jdy = Ldy[lj];
-            const float denominator = idx_ * jdy - idy * jdx;
-            const float numerator = jdx * (ipy - jpy) - jdy * (ipx - jpx);
-            const bool parallel = fabsf(denominator) <= RVO_EPS;
-            pfail = pfail || (parallel && numerator < 0.0f);
-            const float t = numerator / denominator;
-            if (!parallel && denominator >= 0.0f) tRight = fminf(tRight, t);
-            if (!parallel && denominator < 0.0f) tLeft = fmaxf(tLeft, t);
+            for (int p0 = 0; p0 < npairs; p0 += 64) {
+                const int p = p0 + tid;
+                const bool on = p < npairs;
+                const int r = on ? (int)(((unsigned)p * inv20) >> 20) : 0;
+                const int lj = on ? p - r * li : 0;
+                const int a = s_vl[r];
+                const float4 A = s_line[li * 64 + a], B = s_line[lj * 64 + a];
+                const float denominator = A.z * B.w - A.w * B.z;
+                const float numerator = B.z * (A.y - B.y) - B.w * (A.x - B.x);
+                const bool parallel = fabsf(denominator) <= RVO_EPS;
+                const float t = numerator / denominator;
+                if (on) {
+                    if (parallel) { if (numerator < 0.0f) s_pf[a] = 1; }
+                    else if (denominator >= 0.0f) atomicMin(&s_tr[a], okey(t));
+                    else atomicMax(&s_tl[a], okey(t));
+                }
+            }
+            __syncthreads();
+            if (viol) { tLeft = okey_inv(s_tl[tid]); tRight = okey_inv(s_tr[tid]); pfail = s_pf[tid] != 0; }
+            __syncthreads(); // the slots are rewritten by the next violated line
         }
         // (sequential RVO2 fails at the first prefix that crosses; the bounds are monotone, so this is the same decision)
         ok = ok && !pfail && !(tLeft > tRight);
@@ -859,7 +883,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     if (__ballot(slot >= 0) != 0ull) {
 #pragma unroll 1
         for (int k = 0; k < nmax; ++k) {
-            const float4 ln = make_float4(Lpx[k], Lpy[k], Ldx[k], Ldy[k]);
+            const float4 ln = s_line[k * 64 + tid];
             if (slot >= 0 && k < nn) s.lp3_lines[(size_t)slot * 32 + k] = ln;
         }
     }
@@ -2067,12 +2091,13 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
         // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
         int32_t *plan = (plan_det && env->plan_ok && ((uintptr_t)plan_det & 15u) == 0) ? row_plan : nullptr;
         if (plan) row_plan = nullptr; // built below
-        const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
+        const int pg = plan ? rp_groups(env->d.E) : 0;
+        const dim3 grid((agents + 63) / 64 + pg), blk(64);
         const EnvDev dl = stamped(env->d, CN_K_ORCA_LANE);
         unsigned long long *pst = cn_stamp_slot(CN_K_ROW_PLAN);
-        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
         CN_CHECK_LAUNCH();
     }
     // a caller's plan buffer that this step does not fill must not keep the previous observation's plan
