@@ -329,6 +329,136 @@ __device__ __forceinline__ void lp3_wave(const LpLine &L, int n, int beginLine, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// linearProgram3 for TWO programs per wavefront: lanes 0..31 hold the lines of one, lanes 32..63 those of another (at most 32 lines
+// each: the lane kernel's limit).  Per program the arithmetic is lp3_wave's; what is wave-uniform there (the result, the bounds, the
+// index of the line being processed) is uniform per HALF here and lives in vector registers, each half's walk is predicated on its
+// own state, and a loop ends when both halves are through.  hl = lane & 31.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hw_ballot(bool p, int lane)
+{
+    const uint64_t b = __ballot(p);
+    return (lane & 32) ? (uint32_t)(b >> 32) : (uint32_t)b;
+}
+__device__ __forceinline__ float hw_read(float v, int lane, int i) // v of lane i of this lane's half (i uniform per half)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) + i) << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ float hw_last(float v, int lane) // lanes 31 / 63 -> every lane of their half
+{
+    const float a = wv_readlane(v, 31), b = wv_readlane(v, 63);
+    return (lane & 32) ? b : a;
+}
+__device__ __forceinline__ float hw_min(float v, int lane)
+{
+    const float I = __builtin_inff();
+    v = fminf(v, wv_dpp<0x111, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x112, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x114, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x118, 0xf>(v, I));
+    v = fminf(v, wv_dpp<0x142, 0xa>(v, I)); // row_bcast:15 into rows 1 and 3: lane 31 = lanes 0..31, lane 63 = lanes 32..63
+    return hw_last(v, lane);
+}
+__device__ __forceinline__ float hw_max(float v, int lane)
+{
+    const float I = -__builtin_inff();
+    v = fmaxf(v, wv_dpp<0x111, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x112, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x114, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x118, 0xf>(v, I));
+    v = fmaxf(v, wv_dpp<0x142, 0xa>(v, I));
+    return hw_last(v, lane);
+}
+
+// lp1_wave with dirOpt = true for both halves at once; commits the new result only where `act` and the program is feasible
+__device__ __forceinline__ bool lp1_pair(const LpLine &L, uint32_t valid, int i, float ipx, float ipy, float idx, float idy, float radius,
+                                         float optx, float opty, bool act, int lane, float &rx, float &ry)
+{
+    const int hl = lane & 31;
+    const float dotProduct = ipx * idx + ipy * idy;
+    const float discriminant = dotProduct * dotProduct + radius * radius - (ipx * ipx + ipy * ipy);
+    bool ok = !(discriminant < 0.0f);
+    const float sq = sqrtf(discriminant);
+    float tLeft = -dotProduct - sq;
+    float tRight = -dotProduct + sq;
+    const bool mine = hl < i && ((valid >> hl) & 1u);
+    const float denominator = idx * L.dy - idy * L.dx;
+    const float numerator = L.dx * (ipy - L.py) - L.dy * (ipx - L.px);
+    const bool parallel = fabsf(denominator) <= RVO_EPS;
+    const bool pfail = mine && parallel && numerator < 0.0f;
+    const float t = numerator / denominator;
+    const float candR = (mine && !parallel && denominator >= 0.0f) ? t : INFINITY;
+    const float candL = (mine && !parallel && denominator < 0.0f) ? t : -INFINITY;
+    tRight = fminf(tRight, hw_min(candR, lane));
+    tLeft = fmaxf(tLeft, hw_max(candL, lane));
+    const uint32_t pf = hw_ballot(pfail, lane); // (every cross-lane operation of these routines sits outside their predicated parts)
+    ok = ok & (pf == 0u) & !(tLeft > tRight);
+    const float t_opt = (optx * idx + opty * idy > 0.0f) ? tRight : tLeft;
+    if (act && ok) {
+        rx = ipx + t_opt * idx;
+        ry = ipy + t_opt * idy;
+    }
+    return ok;
+}
+
+// lp2_wave with dirOpt = true over the lines 0 .. n-1 of each half (n, radius, opt uniform per half).  Returns n or the failing line.
+__device__ __forceinline__ int lp2_pair(const LpLine &L, uint32_t valid, int n, float radius, float optx, float opty, bool act, int lane,
+                                        float &rx, float &ry)
+{
+    if (act) { rx = radius * optx; ry = radius * opty; }
+    uint32_t todo = valid & ((1u << n) - 1u); // n <= 31: line n itself is the one being projected on
+    int res = n;
+    bool running = act;
+    for (;;) {
+        const uint32_t vm = hw_ballot(L.dx * (L.py - ry) - L.dy * (L.px - rx) > 0.0f, lane) & todo;
+        const bool go = running && vm != 0u;
+        if (__ballot(go) == 0ull) return res;
+        running = go; // a half without a violated line left is through
+        const int i = go ? __ffs((int)vm) - 1 : 0;
+        if (go) todo &= ~((2u << i) - 1u);
+        const float ipx = hw_read(L.px, lane, i), ipy = hw_read(L.py, lane, i);
+        const float idx = hw_read(L.dx, lane, i), idy = hw_read(L.dy, lane, i);
+        const bool ok = lp1_pair(L, valid, i, ipx, ipy, idx, idy, radius, optx, opty, go, lane, rx, ry);
+        if (go && !ok) { res = i; running = false; } // (lp1_pair left the result alone)
+    }
+}
+
+__device__ __forceinline__ void lp3_pair(const LpLine &L, int n, int beginLine, float radius, bool act, int lane, float &rx, float &ry)
+{
+    const int hl = lane & 31;
+    float distance = 0.0f;
+    uint32_t todo = (n >= 32 ? ~0u : ((1u << n) - 1u)) & ~((1u << beginLine) - 1u);
+    bool running = act;
+    for (;;) {
+        const uint32_t vm = hw_ballot(L.dx * (L.py - ry) - L.dy * (L.px - rx) > distance, lane) & todo;
+        const bool go = running && vm != 0u;
+        if (__ballot(go) == 0ull) return;
+        running = go;
+        const int i = go ? __ffs((int)vm) - 1 : 0;
+        if (go) todo &= ~((2u << i) - 1u);
+        const float ipx = hw_read(L.px, lane, i), ipy = hw_read(L.py, lane, i);
+        const float idx = hw_read(L.dx, lane, i), idy = hw_read(L.dy, lane, i);
+        LpLine Pj;
+        const float determinant = idx * L.dy - idy * L.dx;
+        const bool par = fabsf(determinant) <= RVO_EPS;
+        const bool skip = par && (idx * L.dx + idy * L.dy > 0.0f);
+        if (par) {
+            Pj.px = 0.5f * (ipx + L.px); Pj.py = 0.5f * (ipy + L.py);
+        } else {
+            const float s = (L.dx * (ipy - L.py) - L.dy * (ipx - L.px)) / determinant;
+            Pj.px = ipx + s * idx; Pj.py = ipy + s * idy;
+        }
+        const float ddx = L.dx - idx, ddy = L.dy - idy;
+        const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+        Pj.dx = ddx * inv; Pj.dy = ddy * inv;
+        const uint32_t pvalid = hw_ballot(hl < i && !skip, lane);
+        const float tx = rx, ty = ry;
+        const int f = lp2_pair(Pj, pvalid, i, radius, -idy, idx, go, lane, rx, ry);
+        if (go && f < i) { rx = tx; ry = ty; }
+        if (go) distance = idx * (ipy - ry) - idy * (ipx - rx);
+    }
+}
+
 // One agent's new velocity.  Lane j < nl holds candidate neighbour j (cand == true) in index order.
 // RVO2 Agent::computeNeighbors (range filter, ascending distSq, at most maxNeighbors) + computeNewVelocity.
 __device__ __forceinline__ void orca_wave(int lane, int nl, bool cand, float opx, float opy, float ovx, float ovy, float orad,
@@ -501,19 +631,21 @@ template <> struct LaneVec<32> { typedef float f __attribute__((ext_vector_type(
 // a uniform register index (s_set_gpr_idx), not by 20-32 unrolled copies -- fully unrolled the kernel was 85 KB of straight-line
 // code that every wavefront fetched exactly once (instruction-fetch bound, slower than the cooperative kernel).
 template <int NB, int VW>
-__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, unsigned long long *plan_stamp)
+__global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *plan_det, int32_t *plan, int plan_groups, unsigned long long *plan_stamp)
 {
-    const CnStampScope stamp_scope((plan && blockIdx.x == 0) ? plan_stamp : s.stamp); // the plan builder's wavefront has its own slot
-    // one extra workgroup builds the row plan of the policy's human-human kernel for the observation that was just written
-    // (row_plan.h): it only needs the detected-human counts, and this kernel is on the step's critical path anyway
-    __shared__ rowplan::Lds rp_lds;
-    // (workgroup 0: dispatched first; its single wavefront is the longest chain of the launch, so it also takes the issue priority)
-    if (plan && blockIdx.x == 0) {
+    const CnStampScope stamp_scope((plan && (int)blockIdx.x < plan_groups) ? plan_stamp : s.stamp); // the plan builders' wavefronts have their own slot
+    // the first workgroups (one wavefront each, rp_groups(E) of them) build the row plan of the policy's human-human kernel for the observation
+    // that was just written (row_plan.h): they only need the detected-human counts, and this kernel is on the step's critical path anyway
+    // (a builder's tables and the agents' line table below share one buffer: a workgroup is one or the other)
+    constexpr int RAW = (int)sizeof(rowplan::Lds) > NB * 64 * 16 ? (int)sizeof(rowplan::Lds) : NB * 64 * 16;
+    __shared__ __attribute__((aligned(16))) char s_raw[RAW];
+    // (dispatched first; a builder is the longest chain of the launch, so it also takes the issue priority)
+    if (plan && (int)blockIdx.x < plan_groups) {
         __builtin_amdgcn_s_setprio(3);
-        rowplan::build(s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, rp_lds);
+        rowplan::build((int)blockIdx.x, plan_groups, s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, *reinterpret_cast<rowplan::Lds *>(s_raw));
         return;
     }
-    const int blk = (int)blockIdx.x - (plan ? 1 : 0);
+    const int blk = (int)blockIdx.x - (plan ? plan_groups : 0);
     typedef typename LaneVec<VW>::f vec;
     const int agent = blk * 64 + threadIdx.x;
     const int H = s.H;
@@ -524,7 +656,9 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     const cn_env_config &c = s.cfg;
     // the agent records of the 1 + 63/H (+1) envs this wavefront's lanes belong to, staged once: every later access -- uniform in
     // pass 1, a per-lane gather in pass 2 -- is an LDS read instead of an L2 round trip (the kernel is a chain of dependent loads)
-    __shared__ double s_px[128], s_py[128], s_vx[128], s_vy[128], s_rad[128], s_rob[65][4];
+    // (the kernel for NB slots serves crowds of more than NB' agents, NB' the next smaller network: at most 63 / (NB' - 1) + 2 envs per wavefront)
+    constexpr int NENV = NB == 8 ? 65 : (NB == 20 ? 10 : 5);
+    __shared__ double s_px[128], s_py[128], s_vx[128], s_vy[128], s_rad[128], s_rob[NENV][4];
     {
         const int a0 = blk * 64;
         const int e0 = a0 / H, e1 = (min(a0 + 63, s.E * H - 1)) / H;
@@ -599,9 +733,14 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     int nmax = nn; // wave-uniform loop bound
     for (int off = 32; off >= 1; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
-    // pass 2: the ORCA half-plane of the k-th nearest neighbour (Agent::computeNewVelocity)
-    const float th = (float)c.orca_time_horizon, dt = (float)c.time_step;
-    vec Lpx, Lpy, Ldx, Ldy;
+    // pass 2: the ORCA half-plane of the k-th nearest neighbour (Agent::computeNewVelocity), kept in LDS as s_line[k][lane]: the
+    // linear program below reads lines of OTHER lanes' agents at per-lane line numbers, which registers cannot do.
+    // The three cases of RVO2 (cut-off circle, legs, collision) go through ONE sqrtf and ONE division whose operands are selected per
+    // case -- the same operations on the same operands as the branchy form (no contraction in this file), so the same bits, but no
+    // divergence: with 64 agents in a wavefront every branch was taken by somebody.
+    const float invTH = 1.0f / (float)c.orca_time_horizon, invDT = 1.0f / (float)c.time_step;
+    float4 *const s_line = reinterpret_cast<float4 *>(s_raw);
+    const int tid = threadIdx.x;
 #pragma unroll 1
     for (int k = 0; k < nmax; ++k) {
         float o_px = 0.0f, o_py = 0.0f, o_dx = 1.0f, o_dy = 0.0f;
@@ -623,45 +762,27 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
             const float distSq = rpx * rpx + rpy * rpy;
             const float cr = self_r + orad;
             const float crSq = cr * cr;
-            float ldx, ldy, ux, uy;
-            if (distSq > crSq) {
-                const float invTH = 1.0f / th;
-                const float wx = rvx - invTH * rpx, wy = rvy - invTH * rpy;
-                const float wLenSq = wx * wx + wy * wy;
-                const float dot1 = wx * rpx + wy * rpy;
-                if (dot1 < 0.0f && dot1 * dot1 > crSq * wLenSq) {
-                    const float wLen = sqrtf(wLenSq);
-                    const float inv = 1.0f / wLen;
-                    const float uwx = wx * inv, uwy = wy * inv;
-                    ldx = uwy; ldy = -uwx;
-                    const float sc = cr * invTH - wLen;
-                    ux = sc * uwx; uy = sc * uwy;
-                } else {
-                    const float leg = sqrtf(distSq - crSq);
-                    const float invD = 1.0f / distSq;
-                    if (rpx * wy - rpy * wx > 0.0f) {
-                        ldx = (rpx * leg - rpy * cr) * invD;
-                        ldy = (rpx * cr + rpy * leg) * invD;
-                    } else {
-                        ldx = -((rpx * leg + rpy * cr) * invD);
-                        ldy = -((-rpx * cr + rpy * leg) * invD);
-                    }
-                    const float dot2 = rvx * ldx + rvy * ldy;
-                    ux = dot2 * ldx - rvx; uy = dot2 * ldy - rvy;
-                }
-            } else {
-                const float invDT = 1.0f / dt;
-                const float wx = rvx - invDT * rpx, wy = rvy - invDT * rpy;
-                const float wLen = sqrtf(wx * wx + wy * wy);
-                const float inv = 1.0f / wLen;
-                const float uwx = wx * inv, uwy = wy * inv;
-                ldx = uwy; ldy = -uwx;
-                const float sc = cr * invDT - wLen;
-                ux = sc * uwx; uy = sc * uwy;
-            }
+            const bool collide = !(distSq > crSq);
+            const float invT = collide ? invDT : invTH;
+            const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
+            const float wLenSq = wx * wx + wy * wy;
+            const float dot1 = wx * rpx + wy * rpy;
+            const bool circle = collide || (dot1 < 0.0f && dot1 * dot1 > crSq * wLenSq); // project on the cut-off circle
+            const float sq = sqrtf(circle ? wLenSq : distSq - crSq);                        // wLen, or the leg length
+            const float inv = 1.0f / (circle ? sq : distSq);                                // 1 / wLen, or 1 / distSq
+            // cut-off circle (time horizon, or the time step on collision)
+            const float uwx = wx * inv, uwy = wy * inv;
+            const float sc = cr * invT - sq;
+            // legs
+            const bool left = rpx * wy - rpy * wx > 0.0f;
+            const float lgx = left ? (rpx * sq - rpy * cr) * inv : -((rpx * sq + rpy * cr) * inv);
+            const float lgy = left ? (rpx * cr + rpy * sq) * inv : -((-rpx * cr + rpy * sq) * inv);
+            const float dot2 = rvx * lgx + rvy * lgy;
+            const float ldx = circle ? uwy : lgx, ldy = circle ? -uwx : lgy;
+            const float ux = circle ? sc * uwx : dot2 * lgx - rvx, uy = circle ? sc * uwy : dot2 * lgy - rvy;
             o_px = fvx + 0.5f * ux; o_py = fvy + 0.5f * uy; o_dx = ldx; o_dy = ldy;
         }
-        Lpx[k] = o_px; Lpy[k] = o_py; Ldx[k] = o_dx; Ldy[k] = o_dy;
+        s_line[k * 64 + tid] = make_float4(o_px, o_py, o_dx, o_dy);
     }
     // preferred velocity: orca.py:97-100
     double gvx = sgx - spx, gvy = sgy - spy;
@@ -676,30 +797,63 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     } else {
         rx = optx; ry = opty;
     }
+    // linearProgram1 of a violated line li cuts it against every earlier line lj < li of the same agent.  An agent violates ~1.2 of
+    // its lines, but some agent of the 64 violates almost every line: a loop over lj run by the whole wavefront did 80 iterations per
+    // wavefront for a handful of agents each time.  Instead the (violating agent, earlier line) pairs of a line are dealt to the 64
+    // lanes, and the bounds of an agent are combined in LDS with integer min / max on order-preserving keys (min and max do not
+    // depend on the order of their operands: the same tLeft / tRight as the sequential loop).
+    // (their four 256-byte tables sit in row NB - 1 of the line table: an agent has at most NB - 1 neighbours.  The static LDS of a workgroup
+    // stays below 1/6 of the CU's: five per CU would leave the 1281st workgroup of a 4096 x 20 batch waiting for a whole generation)
+    unsigned *const s_tl = reinterpret_cast<unsigned *>(s_line + (NB - 1) * 64), *const s_tr = s_tl + 64;
+    int *const s_pf = reinterpret_cast<int *>(s_tr + 64), *const s_vl = s_pf + 64;
+    auto okey = [](float f) { const unsigned u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); };
+    auto okey_inv = [](unsigned o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu)); };
     bool failed = false;
     int line_fail = 0;
 #pragma unroll 1
     for (int li = 0; li < nmax; ++li) {
-        const float ipx = Lpx[li], ipy = Lpy[li], idx_ = Ldx[li], idy = Ldy[li];
+        const float4 Li = s_line[li * 64 + tid];
+        const float ipx = Li.x, ipy = Li.y, idx_ = Li.z, idy = Li.w;
         const bool viol = li < nn && !failed && idx_ * (ipy - ry) - idy * (ipx - rx) > 0.0f;
-        if (__ballot(viol) == 0ull) continue; // wave-uniform: nobody has to re-optimise on this line
-        // linearProgram1 on line li against the disc and the earlier lines
+        const unsigned long long vm = __ballot(viol);
+        if (vm == 0ull) continue; // wave-uniform: nobody has to re-optimise on this line
+        // linearProgram1 on line li against the disc ...
         const float dotProduct = ipx * idx_ + ipy * idy;
         const float discriminant = dotProduct * dotProduct + radius * radius - (ipx * ipx + ipy * ipy);
         bool ok = !(discriminant < 0.0f);
         const float sq = sqrtf(discriminant);
         float tLeft = -dotProduct - sq, tRight = -dotProduct + sq;
         bool pfail = false;
+        // ... and against the earlier lines
+        const int npairs = __popcll(vm) * li;
+        if (npairs > 0) {
+            if (viol) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                s_vl[rank] = tid; s_tl[tid] = okey(tLeft); s_tr[tid] = okey(tRight); s_pf[tid] = 0;
+            }
+            __syncthreads(); // (one wavefront: orders the LDS traffic, costs a waitcnt)
+            const unsigned inv20 = ((1u << 20) + (unsigned)li - 1u) / (unsigned)li; // p / li = p * inv20 >> 20 for p (li - 1) < 2^20
 #pragma unroll 1
-        for (int lj = 0; lj < li; ++lj) {
-            const float jpx = Lpx[lj], jpy = Lpy[lj], jdx = Ldx[lj], jdy = Ldy[lj];
-            const float denominator = idx_ * jdy - idy * jdx;
-            const float numerator = jdx * (ipy - jpy) - jdy * (ipx - jpx);
-            const bool parallel = fabsf(denominator) <= RVO_EPS;
-            pfail = pfail || (parallel && numerator < 0.0f);
-            const float t = numerator / denominator;
-            if (!parallel && denominator >= 0.0f) tRight = fminf(tRight, t);
-            if (!parallel && denominator < 0.0f) tLeft = fmaxf(tLeft, t);
+            for (int p0 = 0; p0 < npairs; p0 += 64) {
+                const int p = p0 + tid;
+                const bool on = p < npairs;
+                const int r = on ? (int)(((unsigned)p * inv20) >> 20) : 0;
+                const int lj = on ? p - r * li : 0;
+                const int a = s_vl[r];
+                const float4 A = s_line[li * 64 + a], B = s_line[lj * 64 + a];
+                const float denominator = A.z * B.w - A.w * B.z;
+                const float numerator = B.z * (A.y - B.y) - B.w * (A.x - B.x);
+                const bool parallel = fabsf(denominator) <= RVO_EPS;
+                const float t = numerator / denominator;
+                if (on) {
+                    if (parallel) { if (numerator < 0.0f) s_pf[a] = 1; }
+                    else if (denominator >= 0.0f) atomicMin(&s_tr[a], okey(t));
+                    else atomicMax(&s_tl[a], okey(t));
+                }
+            }
+            __syncthreads();
+            if (viol) { tLeft = okey_inv(s_tl[tid]); tRight = okey_inv(s_tr[tid]); pfail = s_pf[tid] != 0; }
+            __syncthreads(); // the slots are rewritten by the next violated line
         }
         // (sequential RVO2 fails at the first prefix that crosses; the bounds are monotone, so this is the same decision)
         ok = ok && !pfail && !(tLeft > tRight);
@@ -729,27 +883,30 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     if (__ballot(slot >= 0) != 0ull) {
 #pragma unroll 1
         for (int k = 0; k < nmax; ++k) {
-            const float4 ln = make_float4(Lpx[k], Lpy[k], Ldx[k], Ldy[k]);
+            const float4 ln = s_line[k * 64 + tid];
             if (slot >= 0 && k < nn) s.lp3_lines[(size_t)slot * 32 + k] = ln;
         }
     }
 }
 
-// the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): one wavefront each, lane k = line k
+// the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): two per wavefront, lane k of a half = line k
 __global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
 {
     const CnStampScope stamp_scope(s.stamp);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int total = *s.lp3_cnt;
+    const int pairs = (total + 1) >> 1;
     const int H = s.H;
-    for (int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); k < total; k += gridDim.x * 4) {
+    for (int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); p < pairs; p += gridDim.x * 4) {
+        const bool act = 2 * p + half < total;
+        const int k = act ? 2 * p + half : 2 * p; // (an odd list: the upper half of the last wavefront idles on a copy of the lower one's data)
         const Lp3Hdr hd = s.lp3_hdr[k];
-        const float4 ln = lane < hd.nn ? s.lp3_lines[(size_t)k * 32 + lane] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        const float4 ln = hl < hd.nn ? s.lp3_lines[(size_t)k * 32 + hl] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         LpLine L;
         L.px = ln.x; L.py = ln.y; L.dx = ln.z; L.dy = ln.w;
         float rx = hd.rx, ry = hd.ry;
-        lp3_wave(L, hd.nn, hd.line_fail, hd.radius, lane, rx, ry);
-        if (lane == 0) {
+        lp3_pair(L, hd.nn, hd.line_fail, hd.radius, act, lane, rx, ry);
+        if (act && hl == 0) {
             const int e = hd.agent / H, i = hd.agent - e * H;
             s.hact[(size_t)e * 2 * H + i] = rx;
             s.hact[(size_t)e * 2 * H + H + i] = ry;
@@ -898,7 +1055,9 @@ __device__ __forceinline__ void rng_store(Rng &R, const EnvDev &s, int e, int la
 __device__ __forceinline__ void rng_seed(Rng &R, uint32_t seed, int lane)
 {
     __syncthreads();
-    uint32_t sd = seed;
+    // (the seed comes out of vector loads: without this the 624-step chain runs on the vector ALU -- shift, xor, a quarter-rate 32-bit
+    // multiply and an add per step, ~13 us -- instead of four scalar instructions)
+    uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed);
     for (int base = 0; base < MT_N; base += 64) {
         uint32_t mine = 0;
         for (int t = 0; t < 64; ++t) {
@@ -1007,6 +1166,16 @@ struct Lane {
 struct Robot { double px, py, vx, vy, gx, gy, theta, pot; };
 
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
+// norm2(x, y) < d, decided without the square root whenever the squared distance is not within a few ulps of d * d: sqrt is correctly
+// rounded and monotone, so outside that band the comparison of the squares gives the same answer; inside it (practically never) the
+// reference expression itself is evaluated.  d >= 0.
+__device__ __forceinline__ bool closer_than(double x, double y, double d)
+{
+    const double q = x * x + y * y, dd = d * d;
+    if (q < dd * (1.0 - 0x1p-48)) return true;
+    if (q > dd * (1.0 + 0x1p-48)) return false;
+    return sqrt(q) < d;
+}
 
 // crowd_sim_var_num.py:116-146 generate_circle_crossing_human (+ Agent.__init__/sample_random_attributes draws).
 // All lanes compute the candidate position identically; the min-distance test against the existing agents is
@@ -1031,9 +1200,9 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
         py = c.circle_radius * sn + py_noise;
         // :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal
         const double md_r = c.kinematics == CN_KIN_UNICYCLE ? c.circle_radius / 2.0 : radius + c.robot_radius + c.discomfort_dist;
-        const bool coll_r = norm2(px - rb.px, py - rb.py) < md_r || norm2(px - rb.gx, py - rb.gy) < md_r;
+        const bool coll_r = closer_than(px - rb.px, py - rb.py, md_r) || closer_than(px - rb.gx, py - rb.gy, md_r);
         const double md = radius + h.rad + c.discomfort_dist;
-        const bool coll_h = lane < n_existing && (norm2(px - h.px, py - h.py) < md || norm2(px - h.gx, py - h.gy) < md);
+        const bool coll_h = lane < n_existing && (closer_than(px - h.px, py - h.py, md) || closer_than(px - h.gx, py - h.gy, md));
         if (!(coll_r || wv_any(coll_h)) || attempt >= (c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS)) break;
     }
     if (lane == slot) {
@@ -1922,12 +2091,13 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
         // beside it (see orca_lane_kernel), and a same-stream hand-over costs ~3 us where an event across streams costs 10-20
         int32_t *plan = (plan_det && env->plan_ok && ((uintptr_t)plan_det & 15u) == 0) ? row_plan : nullptr;
         if (plan) row_plan = nullptr; // built below
-        const dim3 grid((agents + 63) / 64 + (plan ? 1 : 0)), blk(64);
+        const int pg = plan ? rp_groups(env->d.E) : 0;
+        const dim3 grid((agents + 63) / 64 + pg), blk(64);
         const EnvDev dl = stamped(env->d, CN_K_ORCA_LANE);
         unsigned long long *pst = cn_stamp_slot(CN_K_ROW_PLAN);
-        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
-        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pst);
+        if (slots <= 8) hipLaunchKernelGGL((orca_lane_kernel<8, 8>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
+        else if (slots <= 20) hipLaunchKernelGGL((orca_lane_kernel<20, 32>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
+        else hipLaunchKernelGGL((orca_lane_kernel<32, 32>), grid, blk, 0, main, dl, plan_det, plan, pg, pst);
         CN_CHECK_LAUNCH();
     }
     // a caller's plan buffer that this step does not fill must not keep the previous observation's plan
