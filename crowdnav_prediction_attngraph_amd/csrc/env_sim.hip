@@ -1177,6 +1177,93 @@ __device__ __forceinline__ bool closer_than(double x, double y, double d)
     return sqrt(q) < d;
 }
 
+__device__ __forceinline__ double wv_readlane_d(double v, int lane_uniform)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), lane_uniform);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane_uniform);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// The reference's placement loops (crowd_sim_var_num.py:116-146 positions, crowd_sim.py:415-485 goals) are rejection sampling: candidate k
+// is made of the stream's next three doubles (angle, x noise, y noise), and the first candidate that keeps its distance from the robot
+// and from every human of the list is taken.  One candidate costs six words of the MT19937 stream whatever its fate, so candidate k of a
+// loop that starts at stream position p reads the words p + 6 k .. p + 6 k + 5: the candidates inside the current 624-word block are
+// evaluated 64 AT A TIME, one per lane (each lane walks the human list itself: human j's state comes out of lane j by v_readlane), and
+// the first accepted one in stream order wins -- the same candidate, the same stream position afterwards, as the one-at-a-time loop.
+// A candidate whose six words straddle the end of the block is evaluated the old way (all lanes the same candidate), which also
+// regenerates the block.  In crowds of ~50 randomised humans these loops run for 10^2 .. 10^5 candidates (BASELINE configs[4]).
+//   kind 0: position of a new human (noise = u * 2),  kind 1: new goal (noise = (u - 0.5) * vp)
+//   humans 0 .. n_list - 1 except `skip` are tested with md = radius + rad_j + discomfort_dist against their position and their goal
+__device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int lane, int kind, double radius, double vp, double md_r, int n_list, int skip,
+                                                   const Robot &rb, const Lane &h, double &out_x, double &out_y)
+{
+    const cn_env_config &c = s.cfg;
+    const int max_att = c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS;
+    auto make = [&](double u0, double u1, double u2, double &x, double &y) {
+        const double angle = u0 * M_PI * 2.0;
+        const double nx = kind == 0 ? (0.0 + (1.0 - 0.0) * u1) * 2.0 : (u1 - 0.5) * vp;
+        const double ny = kind == 0 ? (0.0 + (1.0 - 0.0) * u2) * 2.0 : (u2 - 0.5) * vp;
+        double sn, cs;
+        det_sincos(angle, sn, cs);
+        x = c.circle_radius * cs + nx;
+        y = c.circle_radius * sn + ny;
+    };
+    // does candidate (x, y) of this lane collide?  `live`: lanes whose answer matters (the walk ends once all of them have collided)
+    auto collides = [&](double x, double y, bool live) {
+        bool coll = closer_than(x - rb.px, y - rb.py, md_r) || closer_than(x - rb.gx, y - rb.gy, md_r);
+        for (int j = 0; j < n_list; ++j) {
+            if (__ballot(live && !coll) == 0ull) break;
+            if (j == skip) continue;
+            const double jx = wv_readlane_d(h.px, j), jy = wv_readlane_d(h.py, j), jgx = wv_readlane_d(h.gx, j), jgy = wv_readlane_d(h.gy, j);
+            const double md = radius + wv_readlane_d(h.rad, j) + c.discomfort_dist;
+            coll = coll || closer_than(x - jx, y - jy, md) || closer_than(x - jgx, y - jgy, md);
+        }
+        return coll;
+    };
+    int attempt = 0; // number of the next candidate
+    for (;;) {
+        const int avail = (MT_N - R.pos) / 6;
+        if (avail == 0) {
+            const double u0 = rng_double(R, lane), u1 = rng_double(R, lane), u2 = rng_double(R, lane);
+            double x, y;
+            make(u0, u1, u2, x, y);
+            const bool coll = collides(x, y, true);
+            if (!coll || attempt >= max_att) { out_x = x; out_y = y; return; }
+            ++attempt;
+            continue;
+        }
+        const int nb = avail < 64 ? avail : 64;
+        const bool live = lane < nb;
+        const uint32_t *w = g_mt_lds + R.pos + 6 * (live ? lane : 0);
+        const uint32_t a0 = mt_temper(w[0]) >> 5, b0 = mt_temper(w[1]) >> 6, a1 = mt_temper(w[2]) >> 5, b1 = mt_temper(w[3]) >> 6,
+                       a2 = mt_temper(w[4]) >> 5, b2 = mt_temper(w[5]) >> 6;
+        const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
+        const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
+        const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+        double x, y;
+        make(u0, u1, u2, x, y);
+        const bool coll = collides(x, y, live);
+        const uint64_t take = __ballot(live && (!coll || attempt + lane >= max_att));
+        if (take) {
+            const int f = __ffsll((unsigned long long)take) - 1;
+            out_x = wv_readlane_d(x, f); out_y = wv_readlane_d(y, f);
+            R.pos += 6 * (f + 1);
+            return;
+        }
+        R.pos += 6 * nb;
+        attempt += nb;
+    }
+}
+
 // crowd_sim_var_num.py:116-146 generate_circle_crossing_human (+ Agent.__init__/sample_random_attributes draws).
 // All lanes compute the candidate position identically; the min-distance test against the existing agents is
 // lane-parallel.  n_existing = number of humans currently in self.humans (slot itself included on respawn, :455).
@@ -1190,21 +1277,10 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
         radius = rng_uniform(R, lane, 0.3, 0.5);     // agent.py:50
     }
     double px, py;
-    for (int attempt = 0;; ++attempt) { // unbounded in the reference: see CN_MAX_PLACEMENT_ATTEMPTS
-        const double angle = rng_double(R, lane) * M_PI * 2.0;
-        const double px_noise = rng_uniform(R, lane, 0.0, 1.0) * 2.0;
-        const double py_noise = rng_uniform(R, lane, 0.0, 1.0) * 2.0;
-        double sn, cs;
-        det_sincos(angle, sn, cs);
-        px = c.circle_radius * cs + px_noise;
-        py = c.circle_radius * sn + py_noise;
-        // :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal
-        const double md_r = c.kinematics == CN_KIN_UNICYCLE ? c.circle_radius / 2.0 : radius + c.robot_radius + c.discomfort_dist;
-        const bool coll_r = closer_than(px - rb.px, py - rb.py, md_r) || closer_than(px - rb.gx, py - rb.gy, md_r);
-        const double md = radius + h.rad + c.discomfort_dist;
-        const bool coll_h = lane < n_existing && (closer_than(px - h.px, py - h.py, md) || closer_than(px - h.gx, py - h.gy, md));
-        if (!(coll_r || wv_any(coll_h)) || attempt >= (c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS)) break;
-    }
+    // (unbounded in the reference: see CN_MAX_PLACEMENT_ATTEMPTS)
+    // :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal
+    const double md_r = c.kinematics == CN_KIN_UNICYCLE ? c.circle_radius / 2.0 : radius + c.robot_radius + c.discomfort_dist;
+    place_by_rejection(s, R, lane, 0, radius, 0.0, md_r, n_existing, -1, rb, h, px, py);
     if (lane == slot) {
         h.px = px; h.py = py; h.gx = -px; h.gy = -py; h.vx = 0.0; h.vy = 0.0; h.rad = radius; h.vpref = vpref;
         h.simv = 0; // new Human -> new ORCA object, sim rebuilt on next use
@@ -1224,20 +1300,7 @@ __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, 
         if (vp_i == 0.0) vp_i = 1.0;
         if (rng_double(R, lane) <= (only >= 0 ? c.end_goal_change_chance : c.goal_change_chance)) {
             double gx, gy;
-            for (int attempt = 0;; ++attempt) {
-                const double angle = rng_double(R, lane) * M_PI * 2.0;
-                const double gx_noise = (rng_double(R, lane) - 0.5) * vp_i;
-                const double gy_noise = (rng_double(R, lane) - 0.5) * vp_i;
-                double sn, cs;
-                det_sincos(angle, sn, cs);
-                gx = c.circle_radius * cs + gx_noise;
-                gy = c.circle_radius * sn + gy_noise;
-                const double md_r = rad_i + c.robot_radius + c.discomfort_dist;
-                const bool coll_r = norm2(gx - rb.px, gy - rb.py) < md_r || norm2(gx - rb.gx, gy - rb.gy) < md_r;
-                const double md = rad_i + h.rad + c.discomfort_dist;
-                const bool coll_h = lane < H && lane != i && (norm2(gx - h.px, gy - h.py) < md || norm2(gx - h.gx, gy - h.gy) < md);
-                if (!(coll_r || wv_any(coll_h)) || attempt >= (c.max_placement_attempts > 0 ? c.max_placement_attempts : CN_MAX_PLACEMENT_ATTEMPTS)) break;
-            }
+            place_by_rejection(s, R, lane, 1, rad_i, vp_i, rad_i + c.robot_radius + c.discomfort_dist, H, i, rb, h, gx, gy);
             if (lane == i) { h.gx = gx; h.gy = gy; }
         }
     }
