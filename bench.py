@@ -159,6 +159,39 @@ def pmc_traffic_live(argv_tail, timeout_s=170):
     return res
 
 
+def other_configs_leg(timeout_s=150):
+    """The single-GPU shares of BASELINE configs[2], [3], [4] (extra keys, after the headline): each a short child run of this script on
+    this box and build (a separate process: its own simulator batch, policy and -- configs[3] -- the GST predictor + VecPretextNormalize
+    in the loop), env-steps/s, ms per step and the per-kernel medians of its step."""
+    import subprocess
+    common = ["--gpus", "1", "--no-cpu-baseline", "--no-ppo", "--no-worst-case", "--no-dropin", "--no-pmc-traffic", "--no-other-configs"]
+    legs = [
+        ("configs[2]: CrowdSimPred-v0, 20 humans, const_vel predictor, 4096 envs per GPU", ["--env-name", "CrowdSimPred-v0", "--envs", "4096", "--steps", "60", "--warmup", "20"]),
+        ("configs[3]: CrowdSimPredRealGST-v0, 20 humans, GST predictor + wrapper in the loop, 2048 envs per GPU",
+         ["--env-name", "CrowdSimPredRealGST-v0", "--envs", "2048", "--steps", "60", "--warmup", "20"]),
+        ("configs[4]: CrowdSimVarNum-v0, 50 randomised humans, random_goal_changing, 8192 envs per GPU, default placement bound",
+         ["--humans", "50", "--randomized", "--envs", "8192", "--steps", "40", "--warmup", "10", "--dephase", "120"]),
+    ]
+    out = []
+    for name, extra in legs:
+        rec = {"config": name, "argv": " ".join(extra)}
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=timeout_s)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError("exit %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+            d = json.loads(lines[-1])
+            rec.update({"env_steps_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "hh_kernel": d["roofline"]["kernel"].split(":")[0].split(" (")[0], "hh_launch_ms": d["roofline"]["launch_ms"], "hh_frac": d["roofline"]["frac"],
+                        "mean_detected_humans": d["roofline"]["mean_detected_humans"],
+                        "kernel_median_us": (d.get("step_decomposition") or {}).get("median_us"),
+                        "device_step_interval_us": (d.get("device_step_interval_us") or {}).get("median")})
+        except Exception as exc:
+            rec["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
+        out.append(rec)
+    return out
+
+
 def dropin_leg(E, H, env_name, steps=24):
     """The rollout loop in the shape the reference's train.py runs it (train.py:152-189), through the reference-compatible interfaces
     (make_vec_envs / Policy.act / envs.step -> CPU rewards, numpy dones, infos list / RolloutStorage.insert) at this bench's batch size.
@@ -256,6 +289,8 @@ def main():
                          "constant of the same kernel source is printed instead when there is one")
     ap.add_argument("--no-dropin", action="store_true", help="skip the leg that times the reference-shaped rollout loop through the drop-in interfaces")
     ap.add_argument("--no-ppo", action="store_true", help="skip the PPO samples/sec leg (rollout + update, 3 updates of T=30)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the legs that time the single-GPU shares of BASELINE configs[2], [3], [4] (three short child runs of this script, ~1 min)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: put every rank on GPU 0 (use with --dist-backend gloo)")
     ap.add_argument("--gemm", choices=["fused", "bf16x3", "fp32"], default="fused",
@@ -403,6 +438,7 @@ def main():
     hh_starts = [a_ for (_, k_, a_, _) in stamps.table() if k_ == "hh_fused"]
     step_intervals = [round(b_ - a_, 1) for a_, b_ in zip(hh_starts[:-1], hh_starts[1:])]     # us between consecutive human-human launches
     it += args.steps            # the hxs / masks ping-pong follows the step index: advance by exactly the steps taken
+    plan_hdr = env.row_plan[:8].tolist() if (gst is None and env.row_plan.numel() >= 8) else None   # [1] workgroups [6] tiles of the last planned launch
     per_rank = None
     if dist is not None:
         tdev0 = "cuda" if args.dist_backend == "nccl" else "cpu"
@@ -567,7 +603,7 @@ def main():
     split = args.gemm in ("bf16x3", "fused")
     # the split runs 3 bf16 MFMA passes per algorithmic product, so its attainable algorithmic rate is the bf16 peak / 3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    kname = ("hh_fused_kernel (v_mfma_f32_16x16x32_bf16, 3 passes hi*hi+hi*lo+lo*hi): embedding -> q|k|v -> attention -> out_proj∘spatial_linear in one launch" if fused else
+    kname = (("hh_fused_wide_kernel" if H > 48 else "hh_fused_kernel") + " (v_mfma_f32_16x16x32_bf16, 3 passes hi*hi+hi*lo+lo*hi): embedding -> q|k|v -> attention -> out_proj∘spatial_linear in one launch" if fused else
              "gemm3_nt_kernel<128,NONE> (v_mfma_f32_32x32x16_bf16, 3 passes hi*hi+hi*lo+lo*hi): folded q|k|v projection" if split
              else "gemm_nt_kernel<128,NONE> (v_mfma_f32_32x32x2_f32): folded q|k|v projection")
     # HBM traffic of the dominant kernel: bench.py cannot run rocprofv3 on itself, so the number comes from the committed PMC passes of
@@ -578,7 +614,7 @@ def main():
     if fused and world == 1 and not args.no_pmc_traffic:
         try:
             child = ["--gpus", "1", "--steps", "10", "--warmup", "10", "--dephase", str(args.dephase), "--envs", str(E), "--humans", str(H), "--env-name", args.env_name,
-                     "--no-cpu-baseline", "--no-ppo", "--no-worst-case", "--no-dropin", "--no-pmc-traffic", "--tail", args.tail] + (["--randomized"] if args.randomized else [])
+                     "--no-cpu-baseline", "--no-ppo", "--no-worst-case", "--no-dropin", "--no-pmc-traffic", "--no-other-configs", "--tail", args.tail] + (["--randomized"] if args.randomized else [])
             tl = pmc_traffic_live(child)
             traffic = tl["hbm_bytes_per_launch"]
             rows_c = tl["child_live_rows"] or M
@@ -640,6 +676,31 @@ def main():
                                             "(padded humans are not computed and affine pairs are folded)"}},
     }
     line["config"]["dephase_steps"] = args.dephase
+    if fused:
+        rl = line["roofline"]
+        step_s = elapsed / args.steps
+        rn_flops = 0.79e6 * E                                  # robot-node kernel: 0.79 MFLOP per env
+        rl["frac_of_dense_bf16_algorithmic"] = round(achieved / PEAK_BF16_MFMA_TFLOPS, 4)
+        rl["whole_step_frac"] = round((qkv_flops + rn_flops) / step_s / 1e12 / peak, 4)
+        rl["fractions_note"] = ("frac = dominant kernel against the three-pass ceiling (dense bf16 / 3); frac_of_dense_bf16_algorithmic = the same algorithmic rate "
+                                "against the dense bf16 peak itself (%.0f TFLOP/s); whole_step_frac = (human-human + robot-node FLOPs of a step) / ms_per_step "
+                                "against the three-pass ceiling: the simulator kernels and the launch gaps of the step count as time, not as work" % PEAK_BF16_MFMA_TFLOPS)
+        if plan_hdr is not None and plan_hdr[0] == 0x52504C4E and qkv_ms > 0:
+            tiles = int(plan_hdr[6])
+            rl["l2_weight_stream_TBps"] = round(tiles * 3932160 / (qkv_ms * 1e-3) / 1e12, 2)
+            rl["l2_weight_stream_note"] = "%d tiles of the last planned launch x the 3.93 MB weight image each tile streams L2 -> registers / launch time" % tiles
+        if decomp is not None:
+            rl["step_decomposition_us"] = dict(decomp.get("median_us", {}), **{"gap_" + k: v for k, v in decomp.get("median_gap_us", {}).items()})
+            if "median_step_us" in decomp:
+                rl["step_decomposition_us"]["step"] = decomp["median_step_us"]
+    if world > 1:
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        line["collectives"] = {"backend": args.dist_backend, "rccl_ranks": world if args.dist_backend == "nccl" else 0, "rccl_version": ver,
+                               "rollout": "none (envs sharded by global index)", "update": "one 3-double all-reduce + ONE flat fp32 gradient all-reduce per optimiser step",
+                               "grad_allreduce_ms_per_step": (ppo or {}).get("grad_allreduce_ms_per_step")}
     line["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1e3, 4)   # Python + launch cost of one step; the device needs ms_per_step
     if step_intervals:
         si = sorted(step_intervals)
@@ -657,6 +718,8 @@ def main():
         line["worst_case_all_detected"] = worst
     if ppo is not None:
         line["ppo"] = ppo
+    if not args.no_other_configs and world == 1 and (args.env_name, H, E, args.randomized) == ("CrowdSimVarNum-v0", 20, 4096, False):
+        line["other_baseline_configs_1gpu"] = other_configs_leg()
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline_threads(H, args.env_name, args.cpu_threads)
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)

@@ -39,3 +39,24 @@ soak(dict(human_num=15, human_num_range=5, randomize_attributes=1, random_goal_c
 soak(dict(human_num=6, human_num_range=5, kinematics=1, randomize_attributes=1), 2048, 600, 24)
 soak(dict(human_num=20, humans_policy=1, robot_visible=1), 2048, 500, 24)
 soak(dict(human_num=20, env_kind=1, predict_truth=1), 1024, 400, 16)
+
+
+def soak_update(E, T, updates):
+    """The training loop (rollout + GAE + PPO.update) `updates` times, twice from the same seed: losses and every weight bit-identical --
+    the update path's counterpart of the simulator soak above (a size-dependent scratch overrun in cn_rn_seq_bwd showed up 1-in-8 in round 4)."""
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.trainer import train
+    t0 = time.time()
+    runs = []
+    for _ in range(2):
+        hist, pol = train("CrowdSimVarNum-v0", num_processes=E, num_steps=T, num_updates=updates, seed=31, config=C.non_randomized(), log=None)
+        runs.append(({k: v.detach().clone() for k, v in pol.state_dict().items()}, [(r["value_loss"], r["action_loss"]) for r in hist]))
+    assert runs[0][1] == runs[1][1], "losses differ between two runs from the same seed"
+    for k, v in runs[0][0].items():
+        assert torch.equal(v, runs[1][0][k]), k
+    print("soak update: E=%d T=%d, %d updates twice, bit-identical (%.1f s)" % (E, T, updates, time.time() - t0))
+
+
+soak_update(8, 5, 50)
+soak_update(64, 8, 50)
+soak_update(4096, 30, 50)

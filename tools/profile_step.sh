@@ -7,13 +7,13 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 60 --no-cpu-baseline --no-ppo --no-worst-case --no-dropin --no-pmc-traffic"
+ARGS="--steps 100 --warmup 60 --no-cpu-baseline --no-ppo --no-worst-case --no-dropin --no-pmc-traffic --no-other-configs"
 cd /tmp; rm -rf /tmp/prof
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 DB=$(find /tmp/prof -name "*.db" | head -1)
 python $GRAFT_REPO_ROOT/profiles/summarize.py $DB "rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (240 de-phase + 60 warm-up + 100 timed steps)" > $OUT/kernel_trace.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/step_timeline.py $DB > $OUT/timeline.txt 2>&1
-PARGS="--steps 20 --warmup 20 --no-cpu-baseline --no-ppo --no-worst-case --no-dropin --no-pmc-traffic"
+PARGS="--steps 20 --warmup 20 --no-cpu-baseline --no-ppo --no-worst-case --no-dropin --no-pmc-traffic --no-other-configs"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
   i=$((i+1)); rm -rf /tmp/pmcout
