@@ -26,6 +26,7 @@
 #include "row_plan.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -699,6 +700,28 @@ __global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, con
 }
 
 // test tap: scatter the compacted [rows,256] activations back to [E,H,256] (zeros on padded humans)
+// args.sort_humans = False: the visible humans of a sample moved to the front (stable), the others behind them; detected = max(1, visible)
+// (an all-invisible sample keeps human 0: selfAttn_srnn_temp_node.py:381-383).  One wavefront per sample, lane = human.
+__global__ __launch_bounds__(64) void compact_visible_kernel(int B, int H, int D, const float *__restrict__ se, const uint8_t *__restrict__ vis,
+                                                             float *__restrict__ out, float *__restrict__ det)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const bool isH = lane < H;
+    unsigned long long m = __ballot(isH && vis[(size_t)b * H + (isH ? lane : 0)] != 0);
+    if (m == 0ull) m = 1ull;
+    const unsigned long long valid = H >= 64 ? ~0ull : ((1ull << H) - 1ull);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int cnt = __popcll(m);
+    const bool v = (m >> lane) & 1ull;
+    const int rank = v ? __popcll(m & below) : cnt + __popcll(~m & valid & below);
+    if (isH) {
+        const float *src = se + ((size_t)b * H + lane) * D;
+        float *dst = out + ((size_t)b * H + rank) * D;
+        for (int d = 0; d < D; ++d) dst[d] = src[d];
+    }
+    if (lane == 0) det[b] = (float)cnt;
+}
+
 __global__ __launch_bounds__(256) void scatter_rows_kernel(int E, int H, const float *__restrict__ src, const int *__restrict__ row_off,
                                                            float *__restrict__ dst)
 {
@@ -951,6 +974,7 @@ struct cn_policy {
     float *emb1, *emb2, *qkv, *attn, *out_sp;
     __bf16 *emb2_hi, *emb2_lo, *qkv_hi, *qkv_lo, *os_hi, *os_lo; // split copies of the three big weight matrices
     float *r_te, *r_whh, *r_edge, *r_wih, *r_ac0, *r_a2, *r_c2; // MFMA-fragment images of the robot-node weights (rn_fused.hip)
+    bool self_attn = true;       // args.use_self_attn: false = spatial_linear is a two-layer MLP on the spatial edges (cn_policy_set_self_attention)
     bool taps_on;                // fused mode: write the test taps (robot_emb, hr_attn, hr_out, actor_feat) of every forward
     void *f_emb2, *f_qkv, *f_os; // MFMA-fragment images of the three big weight matrices for the fused human-human kernel
     int gemm_mode; // 0 = exact fp32 MFMA, 1 = bf16x3 split as separate launches, 2 = bf16x3 split, fused human-human kernel (default)
@@ -1088,11 +1112,22 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
 {
     CN_REQUIRE(p && w, "cn_policy_set_weights: null argument");
     const float *const *ptrs = reinterpret_cast<const float *const *>(w);
-    for (size_t i = 0; i < sizeof(cn_policy_weights) / sizeof(const float *); ++i)
+    const size_t attn_first = offsetof(cn_policy_weights, emb2_w) / sizeof(const float *), attn_last = offsetof(cn_policy_weights, out_proj_b) / sizeof(const float *);
+    for (size_t i = 0; i < sizeof(cn_policy_weights) / sizeof(const float *); ++i) {
+        if (!p->self_attn && i >= attn_first && i <= attn_last) continue; // no human-human attention: those layers do not exist
         CN_REQUIRE(ptrs[i] != nullptr, "cn_policy_set_weights: weight pointer #%zu is null", i);
+    }
     hipStream_t st = (hipStream_t)stream;
     const int D = p->D;
     CN_D2D(p->emb0_w, w->emb0_w, 128 * D); CN_D2D(p->emb0_b, w->emb0_b, 128);
+    if (!p->self_attn) {
+        // use_self_attn = False: out_sp = relu(W2 relu(W0 x + b0) + b2); W2 = spatial_linear.2 [256,128] takes the place of the folded
+        // out_proj o spatial_linear image (fp32 + bf16 hi / lo planes)
+        CN_D2D(p->os_w, w->spatial_linear_w, 256 * 128); CN_D2D(p->os_b, w->spatial_linear_b, 256);
+        const size_t n = 256 * 128;
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p->os_w, p->os_hi, p->os_lo);
+        CN_CHECK_LAUNCH();
+    } else {
     CN_D2D(p->emb2_w, w->emb2_w, 512 * 128); CN_D2D(p->emb2_b, w->emb2_b, 512);
     // fold (q|k|v)_linear into in_proj:  y = W_in (W_x e + b_x) + b_in ; q additionally scaled by 1/sqrt(head_dim) = 0.125
     const float *xw[3] = {w->q_w, w->k_w, w->v_w}, *xb[3] = {w->q_b, w->k_b, w->v_b};
@@ -1120,6 +1155,7 @@ extern "C" int cn_policy_set_weights(cn_policy *p, const cn_policy_weights *w, v
         }
     }
     if (int rc = hh_fused_bake(p->emb2_w, p->qkv_w, p->os_w, p->f_emb2, p->f_qkv, p->f_os, st)) return rc;
+    } // self_attn
     CN_D2D(p->as_w, w->attn_spatial_w, 64 * 256); CN_D2D(p->as_b, w->attn_spatial_b, 64);
     CN_D2D(p->at_w, w->attn_temporal_w, 64 * 256); CN_D2D(p->at_b, w->attn_temporal_b, 64);
     CN_D2D(p->rl_w, w->robot_linear_w, 256 * 9); CN_D2D(p->rl_b, w->robot_linear_b, 256);
@@ -1175,6 +1211,20 @@ static int harvest_profile(cn_policy *p, bool all)
     return CN_OK;
 }
 
+// use_self_attn = False (selfAttn_srnn_temp_node.py:342-345, :404-408): out_sp = relu(W2 relu(W0 x + b0) + b2) on the live rows
+// (row offsets already built).  Two launches: the D -> 128 layer (embed0_kernel, exact fp32) and the 128 -> 256 layer on the large-GEMM
+// kernels in the policy's arithmetic mode (bf16x3 split, or exact fp32 MFMA in mode 0).
+static int spatial_mlp_forward(cn_policy *p, int E, const cn_obs *obs, hipStream_t st)
+{
+    const int H = p->H, D = p->D, M = E * H;
+    const int *m_dev = p->row_off + E;
+    const int blocks = E < 4096 ? E : 4096;
+    hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(128), 0, st, E, H, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->row_off, p->emb1);
+    CN_CHECK_LAUNCH();
+    if (p->gemm_mode != 0) return launch_gemm3<128, ACT_RELU>(M, 256, 128, p->emb1, 128, p->os_hi, p->os_lo, p->os_b, p->out_sp, 256, st, m_dev);
+    return launch_gemm<128, ACT_RELU>(M, 256, 128, p->emb1, 128, p->os_w, p->os_b, p->out_sp, 256, st, m_dev);
+}
+
 static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *hxs_in, const float *masks, const float *eps,
                           float *value, float *action, float *logp, float *hxs_out, hipStream_t st)
 {
@@ -1192,6 +1242,12 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
         static int hh_prio = -1;
         if (hh_prio < 0) { const char *v = getenv("CN_HH_PRIO"); hh_prio = v ? atoi(v) : 1; }
         HhFusedWeights fw{p->f_emb2, p->f_qkv, p->f_os, p->emb0_w, p->emb0_b, p->emb2_b, p->qkv_b, p->os_b, hh_prio, 1.0f, nullptr, nullptr, nullptr, nullptr};
+        if (!p->self_attn) {
+            hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
+                               p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
+            CN_CHECK_LAUNCH();
+            if ((rc = spatial_mlp_forward(p, E, obs, st))) return rc;
+        } else
         if ((rc = hh_fused_forward(E, H, D, obs->spatial_edges, obs->detected_human_num, p->row_off,
                                    p->profiling ? p->live_total : (unsigned long long *)nullptr, fw, p->out_sp, st, obs->row_plan))) return rc;
         if (p->profiling) { CN_HIP(hipEventRecord(p->ev[p->ev_head][1], st)); p->ev_head = (p->ev_head + 1) % cn_policy::PROF_RING; }
@@ -1225,7 +1281,9 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
                            p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
     CN_CHECK_LAUNCH();
-    {
+    if (!p->self_attn) {
+        if ((rc = spatial_mlp_forward(p, E, obs, st))) return rc;
+    } else {
     {
         int blocks = E < 4096 ? E : 4096;
         hipLaunchKernelGGL(embed0_kernel, dim3(blocks), dim3(128), 0, st, E, H, D, obs->spatial_edges, p->emb0_w, p->emb0_b, p->row_off, p->emb1);
@@ -1311,6 +1369,13 @@ extern "C" int cn_policy_set_gemm_mode(cn_policy *p, int mode)
     return CN_OK;
 }
 
+extern "C" int cn_policy_set_self_attention(cn_policy *p, int enabled)
+{
+    CN_REQUIRE(p, "cn_policy_set_self_attention: null handle");
+    if (p->self_attn != (enabled != 0)) { p->self_attn = enabled != 0; p->weights_set = false; }
+    return CN_OK;
+}
+
 extern "C" int cn_policy_set_post_hh_hook(cn_policy *p, int (*fn)(void *arg, void *stream), void *arg)
 {
     CN_REQUIRE(p, "cn_policy_set_post_hh_hook: null handle");
@@ -1385,6 +1450,18 @@ extern "C" int cn_hh_block_fwd(int B, int H, int D, const float *spatial_edges, 
 }
 
 // ---- stand-alone attention core (training path: autograd Function in the host mirror) ----
+extern "C" int cn_obs_compact_visible(int B, int H, int D, const float *spatial_edges, const uint8_t *visible_masks, float *out_edges, float *out_detected,
+                                      void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(B >= 1 && H >= 1 && H <= CN_MAX_HUMANS && D >= 1 && spatial_edges && visible_masks && out_edges && out_detected,
+               "cn_obs_compact_visible: bad argument");
+    CN_REQUIRE(out_edges != spatial_edges, "cn_obs_compact_visible: out_edges must not alias spatial_edges");
+    hipLaunchKernelGGL(compact_visible_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, H, D, spatial_edges, visible_masks, out_edges, out_detected);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 extern "C" int64_t cn_hh_attention_workspace_ints(int B) { return B > 0 ? 4 + 4 * (int64_t)B : 0; }
 
 // cls (optional, cn_hh_attention_workspace_ints(B) ints): when given, the size-class lists are built here and each class launch walks

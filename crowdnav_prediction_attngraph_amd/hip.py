@@ -217,11 +217,25 @@ class HipPolicy:
         except Exception:
             pass
 
+    def set_self_attention(self, enabled):
+        """args.use_self_attn (cn_policy_set_self_attention): False = no human-human attention, spatial_linear is the two-layer MLP
+        Linear(D, 128) - ReLU - Linear(128, 256) - ReLU on the spatial edges.  Call before set_weights."""
+        A.check(A.lib().cn_policy_set_self_attention(self._h, int(bool(enabled))), "cn_policy_set_self_attention")
+        self._self_attn = bool(enabled)
+
     def set_weights(self, state_dict):
         """state_dict: reference key -> float32 device tensor (the library snapshots + folds them)."""
         w = A.PolicyWeights()
         keep = []
+        no_attn = not getattr(self, "_self_attn", True)
+        # use_self_attn = False: the state dict has no spatial_attn.* tensors and spatial_linear is [.0: 128 x D, .2: 256 x 128]
+        remap = {"emb0_w": "base.spatial_linear.0.weight", "emb0_b": "base.spatial_linear.0.bias",
+                 "spatial_linear_w": "base.spatial_linear.2.weight", "spatial_linear_b": "base.spatial_linear.2.bias"} if no_attn else {}
         for field, key in A.POLICY_WEIGHT_KEYS:
+            if no_attn and field not in remap and key.startswith("base.spatial_attn."):
+                setattr(w, field, None)
+                continue
+            key = remap.get(field, key)
             t = state_dict[key].detach()
             if t.dtype != torch.float32 or not t.is_cuda:
                 t = t.to(device=self.device, dtype=torch.float32)
@@ -312,6 +326,19 @@ class HipPolicy:
     def reset_profile(self):
         """Drop the samples and sums collected so far, keep the stride (the events stay warm)."""
         A.check(A.lib().cn_policy_reset_profile(self._h), "cn_policy_reset_profile")
+
+
+def compact_visible(spatial_edges, visible_masks):
+    """args.sort_humans = False: (spatial_edges [B,H,D] with the visible humans moved to the front, detected [B,1] = max(1, visible)) --
+    cn_obs_compact_visible; see include/crowdnav_hip.h for why this equals the reference's mask-based attention."""
+    B, H, D = spatial_edges.shape
+    se = spatial_edges.detach().to(torch.float32).contiguous()
+    vm = visible_masks.detach().reshape(B, H).to(torch.uint8).contiguous()
+    out = torch.empty_like(se)
+    det = torch.empty(B, 1, device=se.device)
+    with torch.cuda.device(se.device):
+        A.check(A.lib().cn_obs_compact_visible(B, H, D, A.ptr(se), A.ptr(vm), A.ptr(out), A.ptr(det), A.stream_ptr()), "cn_obs_compact_visible")
+    return out, det
 
 
 class StepStamps:

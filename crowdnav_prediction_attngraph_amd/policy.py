@@ -140,8 +140,10 @@ class AttnGraphBase(nn.Module):
         attention_size = _arg(args, "attention_size", 64)
         if (self.human_node_rnn_size, self.human_human_edge_rnn_size, self.output_size, emb, attention_size) != (128, 256, 256, 64, 64):
             raise NotImplementedError("the HIP kernels are specialised to the reference's network sizes (128/256/256/64/64)")
-        if not _arg(args, "use_self_attn", True) or not _arg(args, "sort_humans", True):
-            raise NotImplementedError("only use_self_attn=True, sort_humans=True (the configuration of every BASELINE config) is implemented")
+        # arguments.py:189, :206.  use_self_attn = False: no human-human attention, spatial_linear embeds the raw edges
+        # (selfAttn_srnn_temp_node.py:340-345); sort_humans = False: attention masks from `visible_masks` instead of the detected count (:378-383)
+        self.use_self_attn = bool(_arg(args, "use_self_attn", True))
+        self.sort_humans = bool(_arg(args, "sort_humans", True))
         env_name = _arg(args, "env_name", None)
         expect = {"CrowdSimVarNum-v0": 2, "CrowdSimPred-v0": 12, "CrowdSimPredRealGST-v0": 12}.get(env_name)
         if expect is not None and _arg(args, "predict_steps", 5) == 5 and expect != self.edge_width:
@@ -156,8 +158,11 @@ class AttnGraphBase(nn.Module):
         self.critic_linear = _ortho(nn.Linear(h, 1), gain)
         self.robot_linear = nn.Sequential(_ortho(nn.Linear(9, 256), gain), nn.ReLU())
         self.human_node_final_linear = _ortho(nn.Linear(self.output_size, 2), gain)
-        self.spatial_attn = _SpatialSelfAttn(self.edge_width)
-        self.spatial_linear = nn.Sequential(_ortho(nn.Linear(512, 256), gain), nn.ReLU())
+        if self.use_self_attn:
+            self.spatial_attn = _SpatialSelfAttn(self.edge_width)
+            self.spatial_linear = nn.Sequential(_ortho(nn.Linear(512, 256), gain), nn.ReLU())
+        else:
+            self.spatial_linear = nn.Sequential(_ortho(nn.Linear(self.edge_width, 128), gain), nn.ReLU(), _ortho(nn.Linear(128, 256), gain), nn.ReLU())
 
     # ---- training-time forward in torch ops (autograd) ----
     # arithmetic of the three large human-human Linear layers in the PPO update on the GPU: 'bf16x3' = split-precision MFMA
@@ -168,6 +173,29 @@ class AttnGraphBase(nn.Module):
     # everything behind the human-human block (robot node, robot-human attention, GRU sequence, trunks, heads, log-prob) as ONE call forward and
     # ONE backward (hip.RnSequence: cn_rn_seq_fwd / cn_rn_seq_bwd) instead of torch modules with HIP Functions spliced in
     train_fused_rn = os.environ.get("CN_TRAIN_FUSED_RN", "1") != "0"   # (the environment switch is for A/B timing: bench.py's PPO leg)
+
+    def counted_inputs(self, inputs):
+        """sort_humans = True: the inputs as they are.  sort_humans = False (selfAttn_srnn_temp_node.py:378-383, :410-414): both attention modules
+        mask by `visible_masks` (an all-invisible sample keeps human 0).  They are permutation-equivariant over the humans, and masked humans
+        contribute exactly nothing (their keys are excluded, their rows meet an exactly-zero robot-human weight), so the masked form equals
+        the counted form on the observation with the visible humans moved to the front -- stable, so that equal inputs give equal outputs."""
+        if self.sort_humans:
+            return inputs
+        se = inputs["spatial_edges"]
+        B = se.shape[0]
+        se = se.reshape(B, self.human_num, self.edge_width)
+        vm = inputs["visible_masks"].reshape(B, self.human_num)
+        out = dict(inputs)
+        if se.is_cuda:
+            from .hip import compact_visible
+            out["spatial_edges"], out["detected_human_num"] = compact_visible(se, vm)
+        else:
+            m = vm.to(torch.bool).clone()
+            m[~m.any(1), 0] = True
+            order = torch.argsort((~m).to(torch.int8), dim=1, stable=True)
+            out["spatial_edges"] = torch.gather(se, 1, order.unsqueeze(-1).expand(-1, -1, self.edge_width))
+            out["detected_human_num"] = m.sum(1, keepdim=True).to(se.dtype)
+        return out
 
     def fused_rn_shapes_ok(self):
         """hip.RnSequence hard-codes every layer shape of the robot-node sequence (_abi.RN_WEIGHT_SHAPES) and computes its products as bf16x3
@@ -232,12 +260,26 @@ class AttnGraphBase(nn.Module):
         identical to the dense computation while the dominant GEMMs shrink by H / mean(det) (~3.4x at 20 humans).
         The tiny per-env attention itself runs on zero-padded [B,8,H,64] tensors."""
         B, H, D = spatial_edges.shape
-        sa = self.spatial_attn
+        sa = self.spatial_attn if self.use_self_attn else None
         det = det.clamp(1, H)   # every sample has 1..H rows, as the env guarantees (crowd_sim_var_num.py:290-292) and the kernels assume
         valid = torch.arange(H, device=spatial_edges.device).view(1, H) < det.view(B, 1)     # key padding mask
         idx = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)                            # live (sample, human) rows
-        emb0, emb2 = sa.embedding_layer[0], sa.embedding_layer[2]
         x_live = spatial_edges.reshape(B * H, D).index_select(0, idx)
+        if not self.use_self_attn:
+            # selfAttn_srnn_temp_node.py:404-408 with use_self_attn = False: output_spatial = spatial_linear(spatial_edges), a two-layer MLP per
+            # human; only the live rows are computed (the others only ever meet an exactly-zero robot-human weight)
+            l0, l2 = self.spatial_linear[0], self.spatial_linear[2]
+            if x_live.is_cuda and D <= 16:
+                from .hip import Embed0
+                e0 = Embed0.apply(x_live, l0.weight, l0.bias)
+            else:
+                e0 = F.relu(l0(x_live))
+            o = self._big_linear(e0, l2.weight, l2.bias, relu=True)
+            if o.is_cuda:
+                nd = det.to(torch.int32)
+                return o, torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
+            return o.new_zeros(B * H, o.shape[1]).index_copy(0, idx, o).view(B, H, -1), valid
+        emb0, emb2 = sa.embedding_layer[0], sa.embedding_layer[2]
         if x_live.is_cuda and self.train_gemm_mode == "bf16x3" and self.train_fused_hh and H <= 48 and D <= 16 and emb0.weight.shape[0] == 128:
             # ONE launch for the whole block (the rollout's fused kernel on the training weights, writing the activations the backward
             # needs); the affine pairs are composed exactly as below, so both factors still receive their exact gradients
@@ -315,6 +357,7 @@ class AttnGraphBase(nn.Module):
         Returns value [T*N,1], actor features [T*N,256], h_T [N,128].  Masking h at every step is arithmetically the
         reference's split-at-done trick (rl/networks/srnn_model.py:52-104)."""
         B = T * N
+        inputs = self.counted_inputs(inputs)
         robot_in = torch.cat((inputs["temporal_edges"].reshape(B, 2), inputs["robot_node"].reshape(B, 7)), dim=-1)
         robot_states = self.robot_linear(robot_in)
         det = inputs["detected_human_num"].reshape(B).to(torch.int64).clamp(min=1)
@@ -386,6 +429,7 @@ class Policy(nn.Module):
         from .hip import HipPolicy
         if self._hip is None or self._hip.maxE < E or self._hip.device != device:
             self._hip = HipPolicy(self.base.human_num, self.base.edge_width, E, device=device)
+            self._hip.set_self_attention(self.base.use_self_attn)
             self._hip.set_taps(False)          # rollout path: nobody reads the test taps
             self._hip_version = None
             self._hip_mode = None
@@ -409,8 +453,8 @@ class Policy(nn.Module):
             self._zero_edge = {key: torch.zeros(1, 1, 1, device=device).expand(E, self.base.human_num + 1, self.base.human_human_edge_rnn_size)}
         return self._zero_edge[key]
 
-    @staticmethod
-    def _obs32(inputs):
+    def _obs32(self, inputs):
+        inputs = self.base.counted_inputs(inputs)      # sort_humans = False: visible humans first + their count (cn_obs_compact_visible)
         return {k: (v if v.dtype == torch.float32 else v.float()).contiguous() for k, v in inputs.items() if k != "visible_masks"}
 
     def act(self, inputs, rnn_hxs, masks, deterministic=False):
@@ -454,6 +498,7 @@ class Policy(nn.Module):
         if inputs["robot_node"].is_cuda and base.train_fused_rn and base.train_gemm_mode == "bf16x3" and base.fused_rn_shapes_ok():
             # train-mode forward as two boundary calls: the human-human block (cn_hh_block_fwd behind _hh_block) and the robot-node sequence
             # (cn_rn_seq_fwd), each with ONE backward entry
+            inputs = base.counted_inputs(inputs)
             det = inputs["detected_human_num"].reshape(B).to(torch.int64).clamp(min=1)
             out_sp, row_off = base._hh_block(inputs["spatial_edges"].reshape(B, base.human_num, base.edge_width), det)
             value, logp, h = base.rn_sequence(inputs, out_sp, row_off, rnn_hxs["human_node_rnn"], masks, action, T, N, self.dist)

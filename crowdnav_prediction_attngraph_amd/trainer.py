@@ -62,11 +62,15 @@ def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
     # the simulator writes a row plan beside every observation (hip.HipEnvBatch.row_plan): row t of the storage IS the newest observation of
     # `env` at every t of this loop (row 0: the last one of the previous rollout, or the reset), so the plan in the buffer is the one made
     # for it.  Not through the GST wrapper, which post-processes the observation.
-    plan = env.row_plan if envs._pretext is None else None
+    base = actor_critic.base
+    plan = env.row_plan if (envs._pretext is None and base.use_self_attn and base.sort_humans) else None
     for t in range(T):
         obs_t = {k: rollouts.obs[k][t] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
         out = dict(value=rollouts.value_preds[t], action=rollouts.actions[t], logp=rollouts.action_log_probs[t], hxs=hx[t + 1])
-        pol.act(obs_t, hx[t], rollouts.masks[t], eps=eps[t], out=out, row_plan=plan)
+        pol_obs = obs_t
+        if not base.sort_humans:   # args.sort_humans = False: attention masked by visible_masks -> visible humans first + their count
+            pol_obs = base.counted_inputs(dict(obs_t, visible_masks=rollouts.obs["visible_masks"][t]))
+        pol.act(pol_obs, hx[t], rollouts.masks[t], eps=eps[t], out=out, row_plan=plan)
         obs_n = {k: rollouts.obs[k][t + 1] for k in obs_t}
         obs_n["visible_masks"] = None
         if "visible_masks" in rollouts.obs:
@@ -90,7 +94,7 @@ def collect_rollout(envs, actor_critic, rollouts, stats=None, generator=None):
 
 
 def bootstrap_value(actor_critic, rollouts):
-    obs = {k: rollouts.obs[k][-1] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+    obs = {k: rollouts.obs[k][-1] for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "visible_masks") if k in rollouts.obs}
     hxs = {"human_node_rnn": rollouts.recurrent_hidden_states["human_node_rnn"][-1]}
     return actor_critic.get_value(obs, hxs, rollouts.masks[-1])
 

@@ -145,7 +145,7 @@ typedef struct cn_policy cn_policy;
 
 /* Bumped whenever a struct layout, a signature or the snapshot format changes (round 4: cn_obs.row_plan, cn_env_config.robot_fov /
  * human_fov, the profiling entry points, snapshot layout CNENV004); the ctypes binding refuses a library that reports another number. */
-#define CN_ABI_VERSION 401
+#define CN_ABI_VERSION 402
 const char *cn_last_error(void);
 int cn_version(void);
 int cn_device_count(void);
@@ -274,6 +274,23 @@ int cn_policy_set_post_hh_hook(cn_policy *p, int (*fn)(void *arg, void *stream),
  *   0           = exact fp32 on v_mfma_f32_32x32x2_f32, separate launches.
  * Everything outside the three large GEMMs always runs in exact fp32. */
 int cn_policy_set_gemm_mode(cn_policy *p, int mode);
+/* args.use_self_attn (arguments.py:189; selfAttn_srnn_temp_node.py:340-345, :402-414).  enabled = 1 (default): the human-human block is
+ * SpatialEdgeSelfAttn + spatial_linear.  enabled = 0: no human-human attention -- spatial_linear is Sequential(Linear(D, 128), ReLU,
+ * Linear(128, 256), ReLU) applied to the spatial edges themselves; cn_policy_set_weights then reads
+ *   emb0_w / emb0_b               = base.spatial_linear.0 [128,D]
+ *   spatial_linear_w / _b         = base.spatial_linear.2 [256,128]
+ * and ignores emb2_*, q_*, k_*, v_*, in_proj_*, out_proj_* (they may be NULL).  Call before cn_policy_set_weights; changing it
+ * invalidates the weight snapshot.  The robot-node part (robot-human attention, GRU, heads) is the same in both variants. */
+int cn_policy_set_self_attention(cn_policy *p, int enabled);
+/* args.sort_humans = False (arguments.py:206; selfAttn_srnn_temp_node.py:378-383, :402-414): the observation's humans are NOT sorted by
+ * distance and both attention modules mask by `visible_masks` instead of by the detected count (all-invisible samples keep human 0).  Both
+ * modules are permutation-equivariant over the humans and masked humans contribute exactly nothing, so the masked form equals the counted
+ * form on the observation with the visible humans moved to the front (stable), which is what this entry point produces:
+ *   spatial_edges [B,H,D], visible_masks [B,H] (bytes, non-zero = visible)  ->  out_edges [B,H,D] (visible rows first, the others behind
+ *   them, each group in index order), out_detected [B] (float: max(1, number visible))
+ * feed those to cn_policy_act / cn_hh_block_fwd / cn_rn_seq_fwd in place of the raw observation.  One wavefront per sample, H <= 64. */
+int cn_obs_compact_visible(int B, int H, int D, const float *spatial_edges, const uint8_t *visible_masks, float *out_edges, float *out_detected,
+                           void *stream);
 /* Dominant-kernel timing support for bench.py: `every` = 0 switches it off, n >= 1 brackets every n-th forward's dominant kernel
  * (the fused human-human kernel, or the QKV projection of the separate-launch modes) with a pair of hipEvents on `stream`;
  * cn_policy_get_profile returns the accumulated device time [0], the bracketed launches [0] and their live rows [1].  An event

@@ -97,6 +97,63 @@ def policy_case(tag, env_name, E, H, D):
                                                                    os.path.getsize(path) / 1024))
 
 
+def variant_obs(E, H, D, seed, unsorted):
+    """synth_obs, and for sort_humans = False: humans in random order with the visibility as a mask (one sample with nobody visible)."""
+    ob = PU.synth_obs(E, H, D, seed=seed)
+    rs = np.random.RandomState(seed + 17)
+    det = ob["detected_human_num"].reshape(E).astype(int)
+    vm = np.arange(H)[None, :] < det[:, None]
+    if unsorted:
+        for e in range(E):
+            perm = rs.permutation(H)
+            ob["spatial_edges"][e] = ob["spatial_edges"][e][perm]
+            vm[e] = vm[e][perm]
+        vm[E // 2] = False                       # nobody visible: the reference then keeps human 0 (selfAttn_srnn_temp_node.py:381-383)
+        ob["detected_human_num"] = np.maximum(vm.sum(1), 1).astype(np.float32).reshape(E, 1)
+    ob["visible_masks"] = vm
+    return ob
+
+
+def variant_case(tag, env_name, N, H, D, T, use_self_attn, sort_humans):
+    """args.use_self_attn = False and / or args.sort_humans = False (arguments.py:189, :206): act on N envs and evaluate_actions on a [T, N]
+    slice, by the reference's own modules."""
+    import torch
+    from rl.networks.model import Policy
+    args = ref_args(env_name, N, 1, T)
+    args.use_self_attn, args.sort_humans = use_self_attn, sort_humans
+    ob_space, act_space = spaces(H, D)
+    torch.manual_seed(0)
+    pol = Policy(ob_space.spaces, act_space, base_kwargs=args, base="selfAttn_merge_srnn")
+    init_sum = {k: float(v.double().abs().sum()) for k, v in pol.state_dict().items()}      # seeded-init parity of the variant's modules
+    shapes = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    pol.load_state_dict({k: torch.from_numpy(v) for k, v in PU.formula_state_dict(shapes).items()})
+    rs = np.random.RandomState(9)
+    obs_seq = variant_obs(T * N, H, D, 4000 + H + 10 * D, not sort_humans)
+    hxs = {"human_node_rnn": rs.uniform(-1, 1, (N, 1, 128)).astype(np.float32), "human_human_edge_rnn": np.zeros((N, H + 1, 256), np.float32)}
+    masks_seq = (rs.uniform(size=(T * N, 1)) > 0.2).astype(np.float32)
+    actions = rs.uniform(-1.5, 1.5, (T * N, 2)).astype(np.float32)
+    taps = {}
+    hooks = [pol.base.spatial_linear.register_forward_hook(lambda m, i, o: taps.__setitem__("spatial_lin", o.detach().numpy().copy())),
+             pol.base.attn.register_forward_hook(lambda m, i, o: taps.update(hr_out=o[0].detach().numpy().copy(), hr_attn=o[1].detach().numpy().copy()))]
+    with torch.no_grad():
+        first = {k: t(v[:N]) for k, v in obs_seq.items()}
+        value, action, logp, hx_out = pol.act(first, {k: t(v) for k, v in hxs.items()}, t(masks_seq[:N]), deterministic=True)
+        act_taps = dict(taps)
+        ev_value, ev_logp, ev_ent, ev_hx = pol.evaluate_actions({k: t(v) for k, v in obs_seq.items()}, {k: t(v) for k, v in hxs.items()}, t(masks_seq), t(actions))
+    for h in hooks:
+        h.remove()
+    out = {"obs_" + k: v for k, v in obs_seq.items()}
+    out.update(hxs_node=hxs["human_node_rnn"], masks=masks_seq, actions=actions, value=value.numpy(), action=action.numpy(), logp=logp.numpy(),
+               hx_out=hx_out["human_node_rnn"].numpy(), spatial_lin=act_taps["spatial_lin"].reshape(N, H, 256), hr_out=act_taps["hr_out"].reshape(N, 256),
+               hr_attn=act_taps["hr_attn"].reshape(N, H), ev_value=ev_value.numpy(), ev_logp=ev_logp.numpy(), ev_entropy=np.float32(ev_ent.item()),
+               ev_hx=ev_hx["human_node_rnn"].numpy(),
+               meta=np.array(json.dumps(dict(env_name=env_name, N=N, H=H, D=D, T=T, use_self_attn=use_self_attn, sort_humans=sort_humans,
+                                             shapes={k: list(v) for k, v in shapes.items()}, init_abs_sum=init_sum))))
+    path = os.path.join(HERE, "polvar_%s.npz" % tag)
+    np.savez_compressed(path, **out)
+    print("variant %-22s value[0]=%.5f -> %s (%.0f KB)" % (tag, out["value"][0, 0], os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 def rollout_case(tag, env_name, E, H, D, T, nmb):
     """A synthetic rollout pushed through the reference RolloutStorage / compute_returns / PPO.update."""
     import torch
@@ -190,8 +247,14 @@ def init_case():
 
 
 def main():
+    flags = set(sys.argv[1:])          # (install() rewrites sys.argv for the reference's config module)
     R.install()
-    if "--rollouts-only" in sys.argv:
+    if "--variants-only" in flags:
+        variant_case("varnum_h20_noattn", "CrowdSimVarNum-v0", 4, 20, 2, 3, False, True)
+        variant_case("varnum_h20_unsorted", "CrowdSimVarNum-v0", 4, 20, 2, 3, True, False)
+        variant_case("pred_h10_noattn_unsorted", "CrowdSimPred-v0", 3, 10, 12, 4, False, False)
+        return
+    if "--rollouts-only" in flags:
         rollout_case("varnum_e4_h5_t6", "CrowdSimVarNum-v0", 4, 5, 2, 6, 2)
         rollout_case("pred_e4_h20_t5", "CrowdSimPred-v0", 4, 20, 12, 5, 2)
         return

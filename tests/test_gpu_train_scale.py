@@ -47,7 +47,7 @@ def test_default_training_path_matches_the_cpu_graph_in_fp64_at_training_sizes(N
     assert pol_g.base.train_fused_hh and pol_g.base.train_fused_rn and pol_g.base.train_gemm_mode == "bf16x3"
     obs, h0, masks, actions = _synth_batch(T, N, H, D, seed=100 + N)
     B = T * N
-    wv = torch.linspace(-1, 1, B).view(-1, 1)
+    wv = torch.linspace(-0.5, 1.5, B).view(-1, 1)
 
     def run(pol, dev, dt):
         o = {k: v.to(dev, dt) for k, v in obs.items()}
@@ -70,7 +70,7 @@ def test_default_training_path_matches_the_cpu_graph_in_fp64_at_training_sizes(N
         err = float((g_c[k] - g_g[k]).abs().max())
         if err / scale > worst[1]:
             worst = (k, err / scale)
-        assert err <= 3e-4 * scale + 1e-9, (k, err, scale)
+        assert err <= 3e-4 * scale + 1e-7, (k, err, scale)
     # the run is deterministic: a second pass over the same batch gives bit-identical gradients
     _, _, _, g_g2 = run(pol_g, "cuda", torch.float32)
     for k in g_g:
