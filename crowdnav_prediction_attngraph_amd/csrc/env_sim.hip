@@ -890,29 +890,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
 }
 
 // the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): two per wavefront, lane k of a half = line k
-__global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
-{
-    const CnStampScope stamp_scope(s.stamp);
-    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
-    const int total = *s.lp3_cnt;
-    const int pairs = (total + 1) >> 1;
-    const int H = s.H;
-    for (int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); p < pairs; p += gridDim.x * 4) {
-        const bool act = 2 * p + half < total;
-        const int k = act ? 2 * p + half : 2 * p; // (an odd list: the upper half of the last wavefront idles on a copy of the lower one's data)
-        const Lp3Hdr hd = s.lp3_hdr[k];
-        const float4 ln = hl < hd.nn ? s.lp3_lines[(size_t)k * 32 + hl] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-        LpLine L;
-        L.px = ln.x; L.py = ln.y; L.dx = ln.z; L.dy = ln.w;
-        float rx = hd.rx, ry = hd.ry;
-        lp3_pair(L, hd.nn, hd.line_fail, hd.radius, act, lane, rx, ry);
-        if (act && hl == 0) {
-            const int e = hd.agent / H, i = hd.agent - e * H;
-            s.hact[(size_t)e * 2 * H + i] = rx;
-            s.hact[(size_t)e * 2 * H + H + i] = ry;
-        }
-    }
-}
+// (orca_lp3_kernel: defined behind the episode generator it hosts, see below)
 
 // calc_human_future_traj(method='truth') (crowd_sim_var_num.py:152-206), one roll per launch: every human acts with its own
 // ORCA policy (act_joint_state -> ORCA.predict on its private simulator: frozen radii / neighbour distance) on the states
@@ -1027,34 +1005,42 @@ __global__ __launch_bounds__(256) void orca_solve_kernel(int B, int n_other, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// MT19937 (numpy legacy RandomState) staged in LDS, wave-uniform draws.  The block is exactly one wavefront, so
-// __syncthreads() is a wave barrier.
+// MT19937 (numpy legacy RandomState) staged in LDS, wave-uniform draws.  The state belongs to ONE wavefront (R.mt: the block's array in the
+// one-wavefront kernels, a per-wavefront slice in the ORCA tail kernel that also hosts the episode generator), so everything that orders its
+// LDS traffic is wave-level: LDS operations of a wavefront are executed in issue order, the fence only keeps the compiler from moving them.
 // ------------------------------------------------------------------------------------------------------------------
-__shared__ uint32_t g_mt_lds[MT_N]; // the block's (= the wavefront's) staged MT19937 state
+__shared__ uint32_t g_mt_lds[MT_N]; // the staged MT19937 state of a one-wavefront block
 struct Rng {
     int pos;
     bool loaded;
+    uint32_t *mt = g_mt_lds;
 };
+__device__ __forceinline__ void rng_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
 
 __device__ __forceinline__ void rng_load(Rng &R, const EnvDev &s, int e, int lane)
 {
     if (R.loaded) return;
-    for (int k = lane; k < MT_N; k += 64) g_mt_lds[k] = s.mt[(size_t)e * MT_N + k];
+    for (int k = lane; k < MT_N; k += 64) R.mt[k] = s.mt[(size_t)e * MT_N + k];
     R.pos = s.mt_pos[e];
     R.loaded = true;
-    __syncthreads();
+    rng_sync();
 }
 __device__ __forceinline__ void rng_store(Rng &R, const EnvDev &s, int e, int lane)
 {
     if (!R.loaded) return;
-    __syncthreads();
-    for (int k = lane; k < MT_N; k += 64) s.mt[(size_t)e * MT_N + k] = g_mt_lds[k];
+    rng_sync();
+    for (int k = lane; k < MT_N; k += 64) s.mt[(size_t)e * MT_N + k] = R.mt[k];
     if (lane == 0) s.mt_pos[e] = R.pos;
 }
 // np.random.seed(int) == init_genrand: serial recurrence, computed redundantly by all lanes (wave-uniform)
 __device__ __forceinline__ void rng_seed(Rng &R, uint32_t seed, int lane)
 {
-    __syncthreads();
+    rng_sync();
     // (the seed comes out of vector loads: without this the 624-step chain runs on the vector ALU -- shift, xor, a quarter-rate 32-bit
     // multiply and an add per step, ~13 us -- instead of four scalar instructions)
     uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed);
@@ -1067,11 +1053,11 @@ __device__ __forceinline__ void rng_seed(Rng &R, uint32_t seed, int lane)
                 sd = 1812433253u * (sd ^ (sd >> 30)) + (uint32_t)pos + 1u;
             }
         }
-        if (base + lane < MT_N) g_mt_lds[base + lane] = mine;
+        if (base + lane < MT_N) R.mt[base + lane] = mine;
     }
     R.pos = MT_N;
     R.loaded = true;
-    __syncthreads();
+    rng_sync();
 }
 __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -1082,34 +1068,34 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c)
 // processed in order reproduce the sequential recurrence exactly.
 __device__ __forceinline__ void rng_twist(Rng &R, int lane)
 {
-    uint32_t *k = g_mt_lds;
-    __syncthreads();
+    uint32_t *k = R.mt;
+    rng_sync();
     for (int base = 0; base < 227; base += 64) {
         const int i = base + lane;
         const bool act = i < 227;
         uint32_t a = 0, b = 0, c = 0;
         if (act) { a = k[i]; b = k[i + 1]; c = k[i + 397]; }
-        __syncthreads();
+        rng_sync();
         if (act) k[i] = mt_mix(a, b, c);
-        __syncthreads();
+        rng_sync();
     }
     for (int base = 227; base < 623; base += 64) {
         const int i = base + lane;
         const bool act = i < 623;
         uint32_t a = 0, b = 0, c = 0;
         if (act) { a = k[i]; b = k[i + 1]; c = k[i - 227]; }
-        __syncthreads();
+        rng_sync();
         if (act) k[i] = mt_mix(a, b, c);
-        __syncthreads();
+        rng_sync();
     }
     if (lane == 0) k[623] = mt_mix(k[623], k[0], k[396]);
-    __syncthreads();
+    rng_sync();
     R.pos = 0;
 }
 __device__ __forceinline__ uint32_t rng_u32(Rng &R, int lane)
 {
     if (R.pos == MT_N) rng_twist(R, lane);
-    uint32_t y = g_mt_lds[R.pos++];
+    uint32_t y = R.mt[R.pos++];
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
@@ -1245,29 +1231,35 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
     const bool listed = lane < n_list && lane != skip;
     const double hp2 = h.px * h.px + h.py * h.py, hg2 = h.gx * h.gx + h.gy * h.gy;
     const uint64_t pos_mask = __ballot(listed && hp2 > in2 && hp2 < out2), goal_mask = __ballot(listed && hg2 > in2 && hg2 < out2);
+    // The verdicts are kept as two running minima instead of lane masks (a mask update per test is a dozen scalar instructions; a
+    // v_min_f64 is one): with d = q - lo,  closer  <=>  d < 0  (an IEEE difference has the sign of the comparison), and
+    // inside the band  <=>  lo <= q <= hi  <=>  max(-d, q - hi) <= 0.
     auto collides = [&](double x, double y, bool live) {
         double ax = x - rb.px, ay = y - rb.py, bx = x - rb.gx, by = y - rb.gy;
         double q1 = ax * ax + ay * ay, q2 = bx * bx + by * by;
-        bool coll = q1 < lo_r || q2 < lo_r;
-        bool unsure = (!(q1 < lo_r) && !(q1 > hi_r)) || (!(q2 < lo_r) && !(q2 > hi_r));
+        double d1 = q1 - lo_r, d2 = q2 - lo_r;
+        double cmin = fmin(d1, d2);
+        double bmin = fmin(fmax(-d1, q1 - hi_r), fmax(-d2, q2 - hi_r));
         for (uint64_t m = goal_mask; m; m &= m - 1) {
-            if (__ballot(live && !coll) == 0ull) break;
             const int j = __ffsll((unsigned long long)m) - 1;
             const double jx = wv_readlane_d(h.gx, j), jy = wv_readlane_d(h.gy, j), lo = wv_readlane_d(lo_l, j), hi = wv_readlane_d(hi_l, j);
             ax = x - jx; ay = y - jy;
             q1 = ax * ax + ay * ay;
-            coll = coll || q1 < lo;
-            unsure = unsure || (!(q1 < lo) && !(q1 > hi));
+            d1 = q1 - lo;
+            cmin = fmin(cmin, d1);
+            bmin = fmin(bmin, fmax(-d1, q1 - hi));
         }
         for (uint64_t m = pos_mask; m; m &= m - 1) {
-            if (__ballot(live && !coll) == 0ull) break;
             const int j = __ffsll((unsigned long long)m) - 1;
             const double jx = wv_readlane_d(h.px, j), jy = wv_readlane_d(h.py, j), lo = wv_readlane_d(lo_l, j), hi = wv_readlane_d(hi_l, j);
             ax = x - jx; ay = y - jy;
             q1 = ax * ax + ay * ay;
-            coll = coll || q1 < lo;
-            unsure = unsure || (!(q1 < lo) && !(q1 > hi));
+            d1 = q1 - lo;
+            cmin = fmin(cmin, d1);
+            bmin = fmin(bmin, fmax(-d1, q1 - hi));
         }
+        bool coll = cmin < 0.0;
+        const bool unsure = bmin <= 0.0;
         if (__ballot(live && unsure && !coll) != 0ull) { // some square sat inside the band: the reference expression decides (all lanes walk again)
             const bool exact = collides_exact(x, y);
             if (unsure && !coll) coll = exact;
@@ -1288,7 +1280,7 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
         }
         const int nb = avail < 64 ? avail : 64;
         const bool live = lane < nb;
-        const uint32_t *w = g_mt_lds + R.pos + 6 * (live ? lane : 0);
+        const uint32_t *w = R.mt + R.pos + 6 * (live ? lane : 0);
         const uint32_t a0 = mt_temper(w[0]) >> 5, b0 = mt_temper(w[1]) >> 6, a1 = mt_temper(w[2]) >> 5, b1 = mt_temper(w[3]) >> 6,
                        a2 = mt_temper(w[4]) >> 5, b2 = mt_temper(w[5]) >> 6;
         const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
@@ -1532,11 +1524,11 @@ __device__ __forceinline__ void do_reset(const EnvDev &s, Rng &R, int e, int lan
         const double *r = s.nx_rob + (size_t)e * 8;
         rb.px = r[R_PX]; rb.py = r[R_PY]; rb.vx = 0.0; rb.vy = 0.0; rb.gx = r[R_GX]; rb.gy = r[R_GY]; rb.theta = r[R_THETA]; rb.pot = r[R_POT];
         shared_nd = s.nx_shared_nd[e];
-        __syncthreads();
-        for (int k = lane; k < MT_N; k += 64) g_mt_lds[k] = s.nx_mt[(size_t)e * MT_N + k];
+        rng_sync();
+        for (int k = lane; k < MT_N; k += 64) R.mt[k] = s.nx_mt[(size_t)e * MT_N + k];
         R.pos = s.nx_mt_pos[e];
         R.loaded = true;
-        __syncthreads();
+        rng_sync();
         if (lane == 0) s.nx_ready[e] = 0;
     } else {
         gen_episode(s, R, e, lane, rb, h, shared_nd, n);
@@ -1599,17 +1591,14 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int 
 // `budget` ticks of the 100 MHz clock saves where it is -- the staging arrays hold exactly the state between two humans -- and the
 // next launch resumes there.  The episode is the same whichever way it is cut; an env that resets before its staging is complete
 // generates in place, as it always could, and the stale staging is restarted (nx_case).
-__global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budget)
+// (the body: one wavefront, one env; R.mt = that wavefront's 624-word LDS slice)
+__device__ __forceinline__ void pregen_env(const EnvDev &s, int e, int lane, long long budget, Rng &R)
 {
-    const CnStampScope stamp_scope(s.stamp);
-    const int lane = threadIdx.x;
-    const int e = blockIdx.x;
     if (s.nx_ready[e]) return;
     const long long t0 = wall_clock64();
     const int H = s.H;
     int prog = s.nx_prog[e];
     if (prog > 0 && s.nx_case[e] != s.case_counter[e]) prog = 0;
-    Rng R{MT_N, false};
     Robot rb{};
     Lane h{};
     h.rad = s.cfg.human_radius;
@@ -1628,11 +1617,11 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budg
         rb.px = r[R_PX]; rb.py = r[R_PY]; rb.gx = r[R_GX]; rb.gy = r[R_GY]; rb.theta = r[R_THETA];
         shared_nd = s.nx_shared_nd[e];
         n = s.nx_nh ? s.nx_nh[e] : H;
-        __syncthreads();
-        for (int k = lane; k < MT_N; k += 64) g_mt_lds[k] = s.nx_mt[(size_t)e * MT_N + k];
+        rng_sync();
+        for (int k = lane; k < MT_N; k += 64) R.mt[k] = s.nx_mt[(size_t)e * MT_N + k];
         R.pos = s.nx_mt_pos[e];
         R.loaded = true;
-        __syncthreads();
+        rng_sync();
     }
     bool complete = true;
     for (int i = prog - 1; i < n; ++i) {
@@ -1653,10 +1642,60 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budg
         if (s.nx_nh) s.nx_nh[e] = n;
         s.nx_prog[e] = complete ? 0 : prog;
     }
-    __syncthreads();
-    for (int k = lane; k < MT_N; k += 64) s.nx_mt[(size_t)e * MT_N + k] = g_mt_lds[k];
-    __syncthreads();
+    rng_sync();
+    for (int k = lane; k < MT_N; k += 64) s.nx_mt[(size_t)e * MT_N + k] = R.mt[k];
+    __threadfence(); // the staging is complete before the flag says so (the flag's readers run in later launches; belt and braces)
     if (lane == 0 && complete) s.nx_ready[e] = 1;
+}
+
+__global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budget)
+{
+    const CnStampScope stamp_scope(s.stamp);
+    Rng R{MT_N, false};
+    pregen_env(s, blockIdx.x, threadIdx.x, budget, R);
+}
+
+// `pregen_blocks` > 0: the first blocks of the launch are the episode pre-generation (one wavefront per env, four per block, each with its
+// own MT19937 slice: pregen_env) and the linearProgram3 pairs follow.  Why in THIS launch: the generator's ~60 working wavefronts per
+// step hold registers on ~60 CUs for up to its 55 us budget, and the policy's human-human kernel needs whole CUs -- launched beside the lane
+// kernel (rounds 2 .. 4) the generator was still running when that kernel started, a quarter of its workgroups waited ~22 us for their CUs
+// and the launch ended that much later (stamped per workgroup: profiles/r05_step_timeline*.txt).  This kernel is queued behind the
+// human-human kernel's arrival anyway (it gets its CUs as that kernel's workgroups retire), runs beside the robot-node kernel, and the
+// next simulator step already waits for it.
+__global__ __launch_bounds__(256, 8) void orca_lp3_kernel(EnvDev s, int pregen_blocks, long long budget, unsigned long long *pregen_stamp)
+{
+    __shared__ uint32_t mt4[4][MT_N];
+    if ((int)blockIdx.x < pregen_blocks) {
+        const CnStampScope stamp_scope(pregen_stamp);
+        const int w = threadIdx.x >> 6;
+        const int e = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + w);
+        if (e < s.E) {
+            Rng R{MT_N, false, mt4[w]};
+            pregen_env(s, e, threadIdx.x & 63, budget, R);
+        }
+        return;
+    }
+    const CnStampScope stamp_scope(s.stamp);
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int total = *s.lp3_cnt;
+    const int pairs = (total + 1) >> 1;
+    const int H = s.H;
+    const int b0 = (int)blockIdx.x - pregen_blocks, nb = (int)gridDim.x - pregen_blocks;
+    for (int p = __builtin_amdgcn_readfirstlane(b0 * 4 + (threadIdx.x >> 6)); p < pairs; p += nb * 4) {
+        const bool act = 2 * p + half < total;
+        const int k = act ? 2 * p + half : 2 * p; // (an odd list: the upper half of the last wavefront idles on a copy of the lower one's data)
+        const Lp3Hdr hd = s.lp3_hdr[k];
+        const float4 ln = hl < hd.nn ? s.lp3_lines[(size_t)k * 32 + hl] : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        LpLine L;
+        L.px = ln.x; L.py = ln.y; L.dx = ln.z; L.dy = ln.w;
+        float rx = hd.rx, ry = hd.ry;
+        lp3_pair(L, hd.nn, hd.line_fail, hd.radius, act, lane, rx, ry);
+        if (act && hl == 0) {
+            const int e = hd.agent / H, i = hd.agent - e * H;
+            s.hact[(size_t)e * 2 * H + i] = rx;
+            s.hact[(size_t)e * 2 * H + H + i] = ry;
+        }
+    }
 }
 
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
@@ -1710,7 +1749,7 @@ __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
 // SPLIT = true: first half only (everything up to the kinematics and the reset bookkeeping); env_obs_kernel finishes the step after
 // the roll-out kernels.
 template <bool SPLIT>
-__global__ __launch_bounds__(64) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
+__global__ __launch_bounds__(64, 4) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
                                                       uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
     const CnStampScope stamp_scope(s.stamp);
@@ -2120,6 +2159,15 @@ static bool lane_path_of(const cn_env_batch *env)
 // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial fp64
 // work per such env).  It only depends on the step that just ran; nothing needs it before those envs finish their NEXT episode.
 // Budget (ticks of 10 ns; cn_env_set_pregen_budget): see cn_env_set_pregen_budget in the header.
+// does the episode pre-generation ride in the ORCA tail's launch (lane path, tail launched by the step itself)?  CN_PREGEN_SEPARATE=1
+// keeps the round-4 placement (own launch beside the lane kernel) for A/B measurements
+static bool pregen_in_tail(const cn_env_batch *env)
+{
+    static int separate = -1;
+    if (separate < 0) { const char *v = getenv("CN_PREGEN_SEPARATE"); separate = v ? atoi(v) : 0; }
+    return !separate && lane_path_of(env) && !env->defer_tail;
+}
+
 static int launch_pregen(cn_env_batch *env, hipStream_t on)
 {
     hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
@@ -2151,7 +2199,11 @@ static int launch_tail(cn_env_batch *env, hipStream_t main)
             // wavefronts exit at once, longer lists are walked with a stride) keeps enough wavefronts in flight to hide the latency
             // of the cooperative routine
             const int blocks = (agents + 15) / 16;
-            hipLaunchKernelGGL(orca_lp3_kernel, dim3(blocks), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3));
+            // inline mode: the episode pre-generation rides in front of the linearProgram3 pairs (see orca_lp3_kernel); deferred mode keeps
+            // its own launch on side2
+            const int pg_blocks = pregen_in_tail(env) ? (env->d.E + 3) / 4 : 0;
+            hipLaunchKernelGGL(orca_lp3_kernel, dim3(pg_blocks + blocks), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3), pg_blocks, env->pregen_ticks,
+                               cn_stamp_slot(CN_K_PREGEN));
             CN_CHECK_LAUNCH();
         } else {
             hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3));
@@ -2183,7 +2235,8 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
     const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0);
     const bool lane_path = lane_path_of(env);
     const bool defer = env->defer_tail && lane_path;
-    if (!defer) {
+    if (!defer && !pregen_in_tail(env)) {
+        // (configurations without a lane kernel, and CN_PREGEN_SEPARATE=1)
         // beside the lane kernel, before the policy kernels take the whole LDS of every CU.  Budget: the lane kernel below takes ~50 us at
         // 4096 envs x 20 humans and the policy comes right behind it.  55 us cuts the long tail of the rejection sampling (up to 150 us)
         // and still lets the usual 60-odd new episodes of a step finish in one go.  Measured inside one box, human-human kernel of the
