@@ -59,17 +59,18 @@ unsigned long long *cn_stamp_slot(int kernel_id); // host: the current step's sl
 #ifdef __HIPCC__
 struct CnStampScope {
     unsigned long long *s;
-    __device__ __forceinline__ explicit CnStampScope(unsigned long long *slot) : s(slot)
+    unsigned blk;   // the block's index within ITS part of the launch (a launch that hosts two kernels' work stamps each part from 0)
+    __device__ __forceinline__ explicit CnStampScope(unsigned long long *slot, int block = -1) : s(slot), blk(block < 0 ? blockIdx.x : (unsigned)block)
     {
         if (s && threadIdx.x == 0) {
             const unsigned long long now = (unsigned long long)wall_clock64();
-            if (blockIdx.x < 64) atomicMin(s + blockIdx.x * 16, now);
-            atomicMax(s + (blockIdx.x & 63) * 16 + 8, now);   // latest first instruction among the workgroups b with b & 63 == slot
+            if (blk < 64) atomicMin(s + blk * 16, now);
+            atomicMax(s + (blk & 63) * 16 + 8, now);   // latest first instruction among the workgroups b with b & 63 == slot
         }
     }
     __device__ __forceinline__ ~CnStampScope()
     {
-        if (s && (threadIdx.x & 63) == 0) atomicMax(s + (64 + (blockIdx.x & 63)) * 16, (unsigned long long)wall_clock64());
+        if (s && (threadIdx.x & 63) == 0) atomicMax(s + (64 + (blk & 63)) * 16, (unsigned long long)wall_clock64());
     }
 };
 #endif

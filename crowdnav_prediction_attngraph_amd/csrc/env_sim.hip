@@ -1655,8 +1655,8 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budg
     pregen_env(s, blockIdx.x, threadIdx.x, budget, R);
 }
 
-// `pregen_blocks` > 0: the first blocks of the launch are the episode pre-generation (one wavefront per env, four per block, each with its
-// own MT19937 slice: pregen_env) and the linearProgram3 pairs follow.  Why in THIS launch: the generator's ~60 working wavefronts per
+// `pregen_blocks` > 0: the first blocks of the launch are the episode pre-generation (one wavefront per env, one working wavefront per block:
+// pregen_env) and the linearProgram3 pairs follow.  Why in THIS launch: the generator's ~60 working wavefronts per
 // step hold registers on ~60 CUs for up to its 55 us budget, and the policy's human-human kernel needs whole CUs -- launched beside the lane
 // kernel (rounds 2 .. 4) the generator was still running when that kernel started, a quarter of its workgroups waited ~22 us for their CUs
 // and the launch ended that much later (stamped per workgroup: profiles/r05_step_timeline*.txt).  This kernel is queued behind the
@@ -1664,23 +1664,24 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budg
 // next simulator step already waits for it.
 __global__ __launch_bounds__(256, 8) void orca_lp3_kernel(EnvDev s, int pregen_blocks, long long budget, unsigned long long *pregen_stamp)
 {
-    __shared__ uint32_t mt4[4][MT_N];
+    // ONE generator wavefront per block (the other three of a generator block leave at once): the block's static LDS is what EVERY block
+    // of this launch allocates, and the robot-node kernel that starts beside this one needs 132 of a CU's 160 KB -- with a 624-word
+    // slice per wavefront (10 KB per block, 16 blocks per CU) that kernel found no CU with room until the tail had drained (measured:
+    // its start 22 us late, the step 4 % slower); 2.5 KB per block leaves it 140 KB.
+    __shared__ uint32_t mt1[MT_N];
     if ((int)blockIdx.x < pregen_blocks) {
+        if (threadIdx.x >= 64) return;
         const CnStampScope stamp_scope(pregen_stamp);
-        const int w = threadIdx.x >> 6;
-        const int e = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + w);
-        if (e < s.E) {
-            Rng R{MT_N, false, mt4[w]};
-            pregen_env(s, e, threadIdx.x & 63, budget, R);
-        }
+        Rng R{MT_N, false, mt1};
+        pregen_env(s, (int)blockIdx.x, threadIdx.x, budget, R);
         return;
     }
-    const CnStampScope stamp_scope(s.stamp);
+    const int b0 = (int)blockIdx.x - pregen_blocks, nb = (int)gridDim.x - pregen_blocks;
+    const CnStampScope stamp_scope(s.stamp, b0);
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int total = *s.lp3_cnt;
     const int pairs = (total + 1) >> 1;
     const int H = s.H;
-    const int b0 = (int)blockIdx.x - pregen_blocks, nb = (int)gridDim.x - pregen_blocks;
     for (int p = __builtin_amdgcn_readfirstlane(b0 * 4 + (threadIdx.x >> 6)); p < pairs; p += nb * 4) {
         const bool act = 2 * p + half < total;
         const int k = act ? 2 * p + half : 2 * p; // (an odd list: the upper half of the last wavefront idles on a copy of the lower one's data)
@@ -2201,7 +2202,7 @@ static int launch_tail(cn_env_batch *env, hipStream_t main)
             const int blocks = (agents + 15) / 16;
             // inline mode: the episode pre-generation rides in front of the linearProgram3 pairs (see orca_lp3_kernel); deferred mode keeps
             // its own launch on side2
-            const int pg_blocks = pregen_in_tail(env) ? (env->d.E + 3) / 4 : 0;
+            const int pg_blocks = pregen_in_tail(env) ? env->d.E : 0;
             hipLaunchKernelGGL(orca_lp3_kernel, dim3(pg_blocks + blocks), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3), pg_blocks, env->pregen_ticks,
                                cn_stamp_slot(CN_K_PREGEN));
             CN_CHECK_LAUNCH();
