@@ -890,8 +890,6 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
 }
 
 // the agents orca_lane_kernel could not finish (infeasible program -> linearProgram3): two per wavefront, lane k of a half = line k
-// (orca_lp3_kernel: defined behind the episode generator it hosts, see below)
-
 // calc_human_future_traj(method='truth') (crowd_sim_var_num.py:152-206), one roll per launch: every human acts with its own
 // ORCA policy (act_joint_state -> ORCA.predict on its private simulator: frozen radii / neighbour distance) on the states
 // predicted by roll k-1 and is stepped by one_step_lookahead (agent.py:185-192).  The other humans' states are passed as
@@ -1655,34 +1653,18 @@ __global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budg
     pregen_env(s, blockIdx.x, threadIdx.x, budget, R);
 }
 
-// `pregen_blocks` > 0: the first blocks of the launch are the episode pre-generation (one wavefront per env, one working wavefront per block:
-// pregen_env) and the linearProgram3 pairs follow.  Why in THIS launch: the generator's ~60 working wavefronts per
-// step hold registers on ~60 CUs for up to its 55 us budget, and the policy's human-human kernel needs whole CUs -- launched beside the lane
-// kernel (rounds 2 .. 4) the generator was still running when that kernel started, a quarter of its workgroups waited ~22 us for their CUs
-// and the launch ended that much later (stamped per workgroup: profiles/r05_step_timeline*.txt).  This kernel is queued behind the
-// human-human kernel's arrival anyway (it gets its CUs as that kernel's workgroups retire), runs beside the robot-node kernel, and the
-// next simulator step already waits for it.
-__global__ __launch_bounds__(256, 8) void orca_lp3_kernel(EnvDev s, int pregen_blocks, long long budget, unsigned long long *pregen_stamp)
+// (Round 5 measured this generator INSIDE the ORCA tail's launch, i.e. behind the human-human kernel instead of beside the lane kernel, so
+// that it no longer holds ~60 CUs when that kernel starts: the kernel got 17 us shorter (all its workgroups start within 8 us) and the
+// step 4 % LONGER -- its workgroups then end together, and the 20 us in which the tail used to run on the CUs of the early finishers are
+// gone; profiles/HISTORY.md section 10.)
+__global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
 {
-    // ONE generator wavefront per block (the other three of a generator block leave at once): the block's static LDS is what EVERY block
-    // of this launch allocates, and the robot-node kernel that starts beside this one needs 132 of a CU's 160 KB -- with a 624-word
-    // slice per wavefront (10 KB per block, 16 blocks per CU) that kernel found no CU with room until the tail had drained (measured:
-    // its start 22 us late, the step 4 % slower); 2.5 KB per block leaves it 140 KB.
-    __shared__ uint32_t mt1[MT_N];
-    if ((int)blockIdx.x < pregen_blocks) {
-        if (threadIdx.x >= 64) return;
-        const CnStampScope stamp_scope(pregen_stamp);
-        Rng R{MT_N, false, mt1};
-        pregen_env(s, (int)blockIdx.x, threadIdx.x, budget, R);
-        return;
-    }
-    const int b0 = (int)blockIdx.x - pregen_blocks, nb = (int)gridDim.x - pregen_blocks;
-    const CnStampScope stamp_scope(s.stamp, b0);
+    const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int total = *s.lp3_cnt;
     const int pairs = (total + 1) >> 1;
     const int H = s.H;
-    for (int p = __builtin_amdgcn_readfirstlane(b0 * 4 + (threadIdx.x >> 6)); p < pairs; p += nb * 4) {
+    for (int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); p < pairs; p += gridDim.x * 4) {
         const bool act = 2 * p + half < total;
         const int k = act ? 2 * p + half : 2 * p; // (an odd list: the upper half of the last wavefront idles on a copy of the lower one's data)
         const Lp3Hdr hd = s.lp3_hdr[k];
@@ -2160,15 +2142,6 @@ static bool lane_path_of(const cn_env_batch *env)
 // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial fp64
 // work per such env).  It only depends on the step that just ran; nothing needs it before those envs finish their NEXT episode.
 // Budget (ticks of 10 ns; cn_env_set_pregen_budget): see cn_env_set_pregen_budget in the header.
-// does the episode pre-generation ride in the ORCA tail's launch (lane path, tail launched by the step itself)?  CN_PREGEN_SEPARATE=1
-// keeps the round-4 placement (own launch beside the lane kernel) for A/B measurements
-static bool pregen_in_tail(const cn_env_batch *env)
-{
-    static int separate = -1;
-    if (separate < 0) { const char *v = getenv("CN_PREGEN_SEPARATE"); separate = v ? atoi(v) : 0; }
-    return !separate && lane_path_of(env) && !env->defer_tail;
-}
-
 static int launch_pregen(cn_env_batch *env, hipStream_t on)
 {
     hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
@@ -2200,11 +2173,7 @@ static int launch_tail(cn_env_batch *env, hipStream_t main)
             // wavefronts exit at once, longer lists are walked with a stride) keeps enough wavefronts in flight to hide the latency
             // of the cooperative routine
             const int blocks = (agents + 15) / 16;
-            // inline mode: the episode pre-generation rides in front of the linearProgram3 pairs (see orca_lp3_kernel); deferred mode keeps
-            // its own launch on side2
-            const int pg_blocks = pregen_in_tail(env) ? env->d.E : 0;
-            hipLaunchKernelGGL(orca_lp3_kernel, dim3(pg_blocks + blocks), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3), pg_blocks, env->pregen_ticks,
-                               cn_stamp_slot(CN_K_PREGEN));
+            hipLaunchKernelGGL(orca_lp3_kernel, dim3(blocks), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3));
             CN_CHECK_LAUNCH();
         } else {
             hipLaunchKernelGGL(orca_kernel, dim3((agents + 3) / 4), dim3(256), 0, env->side, stamped(env->d, CN_K_ORCA_LP3));
@@ -2236,8 +2205,7 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
     const int slots = env->d.H + (env->d.cfg.robot_visible ? 1 : 0);
     const bool lane_path = lane_path_of(env);
     const bool defer = env->defer_tail && lane_path;
-    if (!defer && !pregen_in_tail(env)) {
-        // (configurations without a lane kernel, and CN_PREGEN_SEPARATE=1)
+    if (!defer) {
         // beside the lane kernel, before the policy kernels take the whole LDS of every CU.  Budget: the lane kernel below takes ~50 us at
         // 4096 envs x 20 humans and the policy comes right behind it.  55 us cuts the long tail of the rejection sampling (up to 150 us)
         // and still lets the usual 60-odd new episodes of a step finish in one go.  Measured inside one box, human-human kernel of the
