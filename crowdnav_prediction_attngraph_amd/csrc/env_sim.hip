@@ -1183,8 +1183,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 // loop that starts at stream position p reads the words p + 6 k .. p + 6 k + 5: the candidates inside the current 624-word block are
 // evaluated 64 AT A TIME, one per lane (each lane walks the human list itself: human j's state comes out of lane j by v_readlane), and
 // the first accepted one in stream order wins -- the same candidate, the same stream position afterwards, as the one-at-a-time loop.
-// A candidate whose six words straddle the end of the block is evaluated the old way (all lanes the same candidate), which also
-// regenerates the block.  In crowds of ~50 randomised humans these loops run for 10^2 .. 10^5 candidates (BASELINE configs[4]).
+// A candidate whose six words straddle the end of the block rides as lane 0 of the first pass over the regenerated block.  In crowds of ~50 randomised humans these loops run for 10^2 .. 10^5 candidates (BASELINE configs[4]).
 //   kind 0: position of a new human (noise = u * 2),  kind 1: new goal (noise = (u - 0.5) * vp)
 //   humans 0 .. n_list - 1 except `skip` are tested with md = radius + rad_j + discomfort_dist against their position and their goal
 __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int lane, int kind, double radius, double vp, double md_r, int n_list, int skip,
@@ -1232,7 +1231,7 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
     // The verdicts are kept as two running minima instead of lane masks (a mask update per test is a dozen scalar instructions; a
     // v_min_f64 is one): with d = q - lo,  closer  <=>  d < 0  (an IEEE difference has the sign of the comparison), and
     // inside the band  <=>  lo <= q <= hi  <=>  max(-d, q - hi) <= 0.
-    auto collides = [&](double x, double y, bool live) {
+    auto collides64 = [&](double x, double y, bool live) {
         double ax = x - rb.px, ay = y - rb.py, bx = x - rb.gx, by = y - rb.gy;
         double q1 = ax * ax + ay * ay, q2 = bx * bx + by * by;
         double d1 = q1 - lo_r, d2 = q2 - lo_r;
@@ -1264,23 +1263,84 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
         }
         return coll;
     };
+    // fp32 SCREEN in front of that walk.  A capped loop of a dense crowd is 65 536 candidates x ~100 points, and the walk above costs ~24
+    // instructions per (candidate, point) of the one wavefront an env has.  In fp32, with a human's goal and position as the two halves of
+    // packed instructions, a pair of tests costs ~20: candidate and points rounded to float (|coordinate| < 32: 2^-20 absolute), the
+    // square from a packed multiply + fma, compared with thresholds moved apart by 2e-5 relative -- several times what the roundings can
+    // move a square near md^2 (|q32 - q| <= 2 |d| 3e-6 + 3e-7 q: 4e-6 relative at |d| ~ 1).  A candidate with some square below the lower
+    // threshold collides, one with every square above the upper ones does not; anything else (a few candidates per million) sends the
+    // batch through the fp64 walk.  Rounding of the thresholds themselves: 6e-8 relative, inside the 2e-5.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float gx32 = (float)h.gx, gy32 = (float)h.gy, px32 = (float)h.px, py32 = (float)h.py;
+    const float lo32 = (float)(dd_l * (1.0 - 2e-5)), hi32 = (float)(dd_l * (1.0 + 2e-5));
+    const float lor32 = (float)(ddr * (1.0 - 2e-5)), hir32 = (float)(ddr * (1.0 + 2e-5));
+    const float rpx32 = (float)rb.px, rpy32 = (float)rb.py, rgx32 = (float)rb.gx, rgy32 = (float)rb.gy;
+    const uint64_t pair_mask = goal_mask | pos_mask;
+    auto collides = [&](double x, double y, bool live) {
+        const float xf = (float)x, yf = (float)y;
+        f2 ax = f2{xf - rgx32, xf - rpx32}, ay = f2{yf - rgy32, yf - rpy32};
+        f2 q = ax * ax + ay * ay;
+        float m1 = fminf(q.x, q.y) - lor32;          // min over the tests of (square - lower threshold): < 0 -> collides for certain
+        float m2 = fminf(q.x, q.y) - hir32;          // min over the tests of (square - upper threshold): > 0 -> free for certain
+        for (uint64_t m = pair_mask; m; m &= m - 1) {
+            const int j = __ffsll((unsigned long long)m) - 1;
+            const float jgx = wv_readlane(gx32, j), jgy = wv_readlane(gy32, j), jpx = wv_readlane(px32, j), jpy = wv_readlane(py32, j);
+            const float lo = wv_readlane(lo32, j), hi = wv_readlane(hi32, j);
+            ax = f2{xf - jgx, xf - jpx}; ay = f2{yf - jgy, yf - jpy};
+            q = ax * ax + ay * ay;
+            const float qm = fminf(q.x, q.y);
+            m1 = fminf(m1, qm - lo);
+            m2 = fminf(m2, qm - hi);
+        }
+        const bool hit = m1 < 0.0f, open = m2 > 0.0f;
+        if (__ballot(live && !hit && !open) != 0ull) { // a square between the moved thresholds: fp64 decides (rare; all lanes walk)
+            const bool c64 = collides64(x, y, live);
+            return (hit || open) ? hit : c64;
+        }
+        return hit;
+    };
     int attempt = 0; // number of the next candidate
     for (;;) {
-        const int avail = (MT_N - R.pos) / 6;
-        if (avail == 0) {
-            const double u0 = rng_double(R, lane), u1 = rng_double(R, lane), u2 = rng_double(R, lane);
-            double x, y;
-            make(u0, u1, u2, x, y);
-            const bool coll = collides(x, y, true);
-            if (!coll || attempt >= max_att) { out_x = x; out_y = y; return; }
-            ++attempt;
-            continue;
+        const int left = MT_N - R.pos; // unread words of the current block
+        int nb, first;                 // candidates of this pass; word index (in the block R.mt holds at evaluation time) of lane 1's / lane 0's first word
+        uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0; // the straddling candidate's words of the OLD block (raw, wave-uniform)
+        int nt = 0;                                        // ... and how many there are
+        if (left >= 6) {
+            nb = left / 6 < 64 ? left / 6 : 64;
+            first = R.pos;
+        } else {
+            // fewer than six words left: the next candidate straddles the end of the block (or starts the next one).  Its words of this
+            // block are kept in registers, the block is regenerated, and the candidate is lane 0 of a pass whose other lanes take whole
+            // candidates of the new block (as a pass of its own it cost a full walk for ONE candidate, every 104 candidates).
+            nt = left;
+            if (nt > 0) t0 = R.mt[R.pos];
+            if (nt > 1) t1 = R.mt[R.pos + 1];
+            if (nt > 2) t2 = R.mt[R.pos + 2];
+            if (nt > 3) t3 = R.mt[R.pos + 3];
+            if (nt > 4) t4 = R.mt[R.pos + 4];
+            rng_twist(R, lane); // (R.pos = 0)
+            nb = 64;            // 1 + (624 - 6) / 6 >= 64
+            first = -1;
         }
-        const int nb = avail < 64 ? avail : 64;
         const bool live = lane < nb;
-        const uint32_t *w = R.mt + R.pos + 6 * (live ? lane : 0);
-        const uint32_t a0 = mt_temper(w[0]) >> 5, b0 = mt_temper(w[1]) >> 6, a1 = mt_temper(w[2]) >> 5, b1 = mt_temper(w[3]) >> 6,
-                       a2 = mt_temper(w[4]) >> 5, b2 = mt_temper(w[5]) >> 6;
+        const int need = 6 - nt; // words of the new block that complete the straddling candidate
+        uint32_t wd[6];
+        if (first >= 0) {
+            const uint32_t *w = R.mt + first + 6 * (live ? lane : 0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wd[k] = w[k];
+        } else {
+            const uint32_t tl[5] = {t0, t1, t2, t3, t4};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                // lane 0: tail words, then words 0 .. need - 1 of the new block; lane a >= 1: words need + 6 (a - 1) + k
+                const int idx = lane == 0 ? (k < nt ? 0 : k - nt) : need + 6 * (lane - 1) + k;
+                const uint32_t v = R.mt[idx];
+                wd[k] = (lane == 0 && k < nt) ? tl[k < 5 ? k : 4] : v;
+            }
+        }
+        const uint32_t a0 = mt_temper(wd[0]) >> 5, b0 = mt_temper(wd[1]) >> 6, a1 = mt_temper(wd[2]) >> 5, b1 = mt_temper(wd[3]) >> 6,
+                       a2 = mt_temper(wd[4]) >> 5, b2 = mt_temper(wd[5]) >> 6;
         const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
         const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
         const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
@@ -1288,13 +1348,14 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
         make(u0, u1, u2, x, y);
         const bool coll = collides(x, y, live);
         const uint64_t take = __ballot(live && (!coll || attempt + lane >= max_att));
+        // stream position behind candidate f of this pass
         if (take) {
             const int f = __ffsll((unsigned long long)take) - 1;
             out_x = wv_readlane_d(x, f); out_y = wv_readlane_d(y, f);
-            R.pos += 6 * (f + 1);
+            R.pos = first >= 0 ? first + 6 * (f + 1) : need + 6 * f;
             return;
         }
-        R.pos += 6 * nb;
+        R.pos = first >= 0 ? first + 6 * nb : need + 6 * (nb - 1);
         attempt += nb;
     }
 }

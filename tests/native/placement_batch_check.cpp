@@ -18,22 +18,30 @@ static void serial(Rng &R, int max_att, double &ox, double &oy) {
     for (int attempt = 0;; ++attempt) { double u0 = dbl(R), u1 = dbl(R), u2 = dbl(R); double x, y; make(u0, u1, u2, x, y); if (!collides(x, y) || attempt >= max_att) { ox = x; oy = y; return; } }
 }
 static void batch(Rng &R, int max_att, double &ox, double &oy) {
+    // the device loop of place_by_rejection (csrc/env_sim.hip): passes of up to 64 candidates inside the current block; a candidate whose
+    // six words straddle the end of the block is lane 0 of the first pass over the regenerated block
     int attempt = 0;
     for (;;) {
-        const int avail = (MT_N - R.pos) / 6;
-        if (avail == 0) { double u0 = dbl(R), u1 = dbl(R), u2 = dbl(R); double x, y; make(u0, u1, u2, x, y); if (!collides(x, y) || attempt >= max_att) { ox = x; oy = y; return; } ++attempt; continue; }
-        const int nb = avail < 64 ? avail : 64;
+        const int left = MT_N - R.pos;
+        int nb, first, nt = 0;
+        uint32_t tl[5] = {0, 0, 0, 0, 0};
+        if (left >= 6) { nb = left / 6 < 64 ? left / 6 : 64; first = R.pos; }
+        else { nt = left; for (int k = 0; k < nt; ++k) tl[k] = R.k[R.pos + k]; twist(R); nb = 64; first = -1; }
+        const int need = 6 - nt;
         int f = -1; double fx = 0, fy = 0;
         for (int lane = 0; lane < 64; ++lane) {
             const bool live = lane < nb;
-            const uint32_t *w = R.k + R.pos + 6 * (live ? lane : 0);
-            const uint32_t a0 = temper(w[0]) >> 5, b0 = temper(w[1]) >> 6, a1 = temper(w[2]) >> 5, b1 = temper(w[3]) >> 6, a2 = temper(w[4]) >> 5, b2 = temper(w[5]) >> 6;
+            uint32_t wd[6];
+            if (first >= 0) { const uint32_t *w = R.k + first + 6 * (live ? lane : 0); for (int k = 0; k < 6; ++k) wd[k] = w[k]; }
+            else for (int k = 0; k < 6; ++k) { const int idx = lane == 0 ? (k < nt ? 0 : k - nt) : need + 6 * (lane - 1) + k; const uint32_t v = R.k[idx]; wd[k] = (lane == 0 && k < nt) ? tl[k < 5 ? k : 4] : v; }
+            const uint32_t a0 = temper(wd[0]) >> 5, b0 = temper(wd[1]) >> 6, a1 = temper(wd[2]) >> 5, b1 = temper(wd[3]) >> 6, a2 = temper(wd[4]) >> 5, b2 = temper(wd[5]) >> 6;
             const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0, u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0, u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
             double x, y; make(u0, u1, u2, x, y);
             if (live && (!collides(x, y) || attempt + lane >= max_att) && f < 0) { f = lane; fx = x; fy = y; }
         }
-        if (f >= 0) { ox = fx; oy = fy; R.pos += 6 * (f + 1); return; }
-        R.pos += 6 * nb; attempt += nb;
+        if (f >= 0) { ox = fx; oy = fy; R.pos = first >= 0 ? first + 6 * (f + 1) : need + 6 * f; return; }
+        R.pos = first >= 0 ? first + 6 * nb : need + 6 * (nb - 1);
+        attempt += nb;
     }
 }
 int main() {
