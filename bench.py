@@ -281,7 +281,7 @@ def main():
                          "itself (default, fastest: 0.287 ms per step), 'deferred' = right behind the policy's human-human kernel (cn_env_set_tail_deferral + "
                          "cn_policy_set_post_hh_hook: every kernel runs undisturbed and 5-12 us shorter, but the cross-stream event that releases the "
                          "tail costs 15-25 us and its chain ends after the robot-node kernel: 0.325-0.33 ms per step, profiles/HISTORY.md)")
-    ap.add_argument("--pregen-budget-us", type=float, default=None, help="time budget of one launch of the episode pre-generation kernel (library default 55)")
+    ap.add_argument("--pregen-budget-us", type=float, default=None, help="time budget of one launch of the episode pre-generation kernel (library default 40)")
     ap.add_argument("--timeline-out", default=None, help="write the stamped timeline of the decomposition window (all kernels of 24 steps) to this file")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the second timed window with every human detected (all H rows live)")
     ap.add_argument("--no-pmc-traffic", action="store_true",

@@ -2290,6 +2290,11 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
     const bool lane_path = lane_path_of(env);
     const bool defer = env->defer_tail && lane_path;
     if (!defer) {
+        // Round 5: 40 us.  With the placement loops 64 candidates at a time an episode is generated in ~30 us, and the lane kernel in front of
+        // the policy got shorter (42 us): same box, 200 steps each -- 55 us 0.2866 / 0.2860 ms per step (human-human kernel 153 us on its own
+        // clock: a quarter of its workgroups wait for this kernel's CUs), 45 us 0.2825, 40 us 0.2799 (139 us), 35 us 0.2903, 30 us 0.3001 (the
+        // ORCA tail then reaches the CUs early); env_step stays at 25 us down to 30 us: no env runs out of staged episodes any more.
+        // Rounds 3-4 (notes kept):
         // beside the lane kernel, before the policy kernels take the whole LDS of every CU.  Budget: the lane kernel below takes ~50 us at
         // 4096 envs x 20 humans and the policy comes right behind it.  55 us cuts the long tail of the rejection sampling (up to 150 us)
         // and still lets the usual 60-odd new episodes of a step finish in one go.  Measured inside one box, human-human kernel of the
@@ -2461,7 +2466,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     // the row plan is built by the lane kernel's extra workgroup: only configs that run that kernel have one (and the consumer, the
     // two-team human-human kernel, takes crowds of <= 48 humans)
     b->plan_ok = lane_orca && HM <= RP_HMAX && num_envs <= RP_EMAX;
-    b->pregen_ticks = 5500;
+    b->pregen_ticks = 4000; // 40 us: see prefetch_orca
     *out = b;
     return CN_OK;
 }

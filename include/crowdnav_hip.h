@@ -158,7 +158,7 @@ int cn_env_destroy(cn_env_batch *env);
 int cn_env_obs_width(const cn_env_config *cfg);
 /* Episodes are generated ahead of the reset that needs them (crowd_sim_var_num.py:303-363: seed, robot, humans by rejection sampling), on a
  * side stream beside the ORCA kernel.  One launch of that generator works for at most `ticks_10ns` x 10 ns per env and resumes in the next
- * step (default 5500 = 55 us): its wavefronts hold registers the policy's kernel, next on the caller's stream, needs.  The episodes do not
+ * step (default 4000 = 40 us): its wavefronts hold registers the policy's kernel, next on the caller's stream, needs.  The episodes do not
  * depend on the budget (0 = one human per launch); an env that resets before its next episode is complete generates it in place. */
 int cn_env_set_pregen_budget(cn_env_batch *env, int64_t ticks_10ns);
 /* Deferred tail.  A step leaves two pieces of work for its successor on the library's side stream: the ORCA programs the lane kernel could not
