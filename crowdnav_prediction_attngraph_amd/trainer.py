@@ -161,7 +161,7 @@ def update_flops(live_rows, samples, ppo_epoch):
 
 def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_updates=10, seed=425, config=None, ppo_epoch=5,
           num_mini_batch=2, lr=4e-5, eps=1e-5, clip_param=0.2, value_loss_coef=0.5, entropy_coef=0.0, max_grad_norm=0.5, gamma=0.99,
-          gae_lambda=0.95, log=print, device=None, save_dir=None, save_interval=0, resume=None):
+          gae_lambda=0.95, log=print, device=None, save_dir=None, save_interval=0, resume=None, use_self_attn=True, sort_humans=None):
     """Returns a list of per-update dicts (losses, timings, episode stats).  Works single- or multi-GPU (one process per
     GPU, torch.distributed initialised by the caller).  save_dir / save_interval: write checkpoints like train.py:213-219 (every
     `save_interval` updates and after the last one); resume = path of a `NNNNN.pt` written by this function: continue that run
@@ -169,7 +169,11 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
     device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(seed)
     envs = make_vec_envs(env_name, seed, num_processes, gamma, None, device, False, config=config, phase="train")
-    base_kwargs = dict(env_name=env_name, num_processes=num_processes, num_mini_batch=num_mini_batch, seq_length=num_steps)
+    # arguments.py:189, :206: use_self_attn, and sort_humans -- by default whatever the config's args say (it also decides the simulator's row order)
+    if sort_humans is None:
+        sort_humans = bool(getattr(getattr(config, "args", None), "sort_humans", True))
+    base_kwargs = dict(env_name=env_name, num_processes=num_processes, num_mini_batch=num_mini_batch, seq_length=num_steps, use_self_attn=use_self_attn,
+                       sort_humans=sort_humans)
     actor_critic = Policy(envs.observation_space.spaces, envs.action_space, base_kwargs=base_kwargs, base="selfAttn_merge_srnn").to(device)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         # identical weights on every rank (seeded above), but each env shard explores with its own action noise

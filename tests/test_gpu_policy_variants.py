@@ -92,3 +92,18 @@ def test_compact_visible_kernel_matches_the_torch_form():
         order = torch.argsort((~m).to(torch.int8), dim=1, stable=True)
         want = torch.gather(se, 1, order.unsqueeze(-1).expand(-1, -1, D))
         assert torch.equal(out.cpu(), want) and torch.equal(det.cpu().reshape(-1), m.sum(1).float())
+
+
+@pytest.mark.parametrize("use_self_attn,sort_humans", [(False, True), (True, False), (False, False)])
+def test_variants_train_end_to_end_on_the_device(use_self_attn, sort_humans):
+    """Fused rollout (the simulator's UNSORTED observation + visible_masks through cn_obs_compact_visible when sort_humans = False) + GAE +
+    PPO.update for two updates through trainer.train: the switches reach the policy and the losses are finite."""
+    from types import SimpleNamespace
+    from crowdnav_prediction_attngraph_amd import config as C
+    from crowdnav_prediction_attngraph_amd.trainer import train
+    cfg = C.non_randomized(**{"sim.human_num": 8})
+    cfg.args = SimpleNamespace(**dict(vars(cfg.args), sort_humans=sort_humans))
+    hist, pol = train("CrowdSimVarNum-v0", num_processes=32, num_steps=10, num_updates=2, seed=9, config=cfg, log=None, use_self_attn=use_self_attn)
+    assert pol.base.use_self_attn == use_self_attn and pol.base.sort_humans == sort_humans
+    for r in hist:
+        assert all(np.isfinite([r["value_loss"], r["action_loss"], r["entropy"]]))
