@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CN_HIP_LIB") or os.path.join(_PKG, "libcrowdnav_hip.so")   # CN_HIP_LIB: another build of the same ABI (A/B measurements)
 
 CN_MAX_HUMANS = 64
-ABI_VERSION = 402          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against
+ABI_VERSION = 403          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against
 PROF_KERNELS, PROF_SLOT_WORDS = 8, 2048
 PROF_KERNEL_IDS = {"env_step": 0, "orca_lane": 1, "hh_fused": 2, "rn_fused": 3, "orca_lp3": 4, "env_pregen": 5, "row_plan": 6, "other": 7}
 ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2, "CrowdSimVarNumCollect-v0": 3}
@@ -126,7 +126,7 @@ ABI_SYMBOLS = [
     "cn_policy_create", "cn_policy_destroy", "cn_policy_set_weights", "cn_policy_act", "cn_policy_get_value",
     "cn_policy_get_taps", "cn_policy_set_gemm_mode", "cn_policy_set_self_attention", "cn_obs_compact_visible", "cn_policy_set_taps", "cn_policy_set_profiling", "cn_policy_get_profile",
     "cn_policy_get_profile_samples", "cn_policy_reset_profile", "cn_prof_set_stamps", "cn_prof_next_step", "cn_hh_block_workspace_bytes", "cn_hh_block_fwd", "cn_rn_seq_workspace_floats", "cn_rn_seq_fwd_workspace_floats", "cn_rn_seq_fwd", "cn_rn_seq_bwd", "cn_hh_attention_workspace_ints", "cn_hh_attention_fwd", "cn_hh_attention_bwd", "cn_hr_attention_fwd", "cn_hr_attention_bwd", "cn_gru_cell_fwd", "cn_gru_cell_bwd", "cn_gru_seq_fwd", "cn_gru_seq_bwd", "cn_embed0_fwd", "cn_embed0_bwd",
-    "cn_split_bf16", "cn_split_bf16_padded", "cn_linear_fwd", "cn_linear_fwd_act", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
+    "cn_split_bf16", "cn_split_bf16_padded", "cn_linear_fwd", "cn_linear_fwd_act", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_small_mm", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gst_wrapper_set_interval", "cn_gst_wrapper_history_len", "cn_gst_wrapper_save", "cn_gst_wrapper_load", "cn_gae", "cn_adv_stats", "cn_adv_normalize", "cn_episode_stats_update",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
 ]
@@ -213,6 +213,7 @@ def lib():
         L.cn_split_bf16_padded.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
         L.cn_linear_fwd_act.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, i32, vp]
         L.cn_linear_wgrad_splits.argtypes = [i32, i32, i32]
+        L.cn_small_mm.argtypes = [i32, i32, i32, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64, vp, vp]
         L.cn_linear_wgrad.argtypes = [i32, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
         L.cn_gst_create.argtypes = [i32, i32, C.POINTER(vp)]
         L.cn_gst_destroy.argtypes = [vp]

@@ -568,3 +568,55 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
     }
     return CN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small weight-by-weight products of the update (the folds of policy.py: (q|k|v)_linear o in_proj, out_proj o spatial_linear,
+// Ws^T Wt, (actor.0 ; critic.0) o output_linear, their bias images, and the backward of each): C[M,N] = A . B in exact fp32 with
+// GENERAL strides for both operands, so that every transposed form of the chain rule is the same launch (dA = dC B^T, dB = A^T dC)
+// and a matrix-vector product is the N = 1 case.  At most 512 x 512 x 512 per call, ~40 calls per optimiser step: a 32 x 32 tile per
+// workgroup with K tiles of 32 through LDS.  Fixed summation order (k ascending inside a tile, tiles ascending): deterministic.
+// (Round 4 left these on the library's GEMM / GEMV kernels -- the only library products on the training path.)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void small_mm_kernel(int M, int N, int K, const float *__restrict__ A, long long sam, long long sak,
+                                                       const float *__restrict__ B, long long sbk, long long sbn, float *__restrict__ C)
+{
+    __shared__ float As[32][33], Bs[32][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4; // 16 x 16 threads, 2 x 2 outputs each
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            const int r = i >> 5, q = i & 31;
+            const int m = m0 + r, k = k0 + q;
+            As[r][q] = (m < M && k < K) ? A[(long long)m * sam + (long long)k * sak] : 0.0f;
+            const int kb = k0 + r, n = n0 + q;
+            Bs[r][q] = (kb < K && n < N) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = As[2 * ty][k], a1 = As[2 * ty + 1][k], b0 = Bs[k][2 * tx], b1 = Bs[k][2 * tx + 1];
+            c00 = fmaf(a0, b0, c00); c01 = fmaf(a0, b1, c01); c10 = fmaf(a1, b0, c10); c11 = fmaf(a1, b1, c11);
+        }
+        __syncthreads();
+    }
+    const int m = m0 + 2 * ty, n = n0 + 2 * tx;
+    if (m < M && n < N) C[(size_t)m * N + n] = c00;
+    if (m < M && n + 1 < N) C[(size_t)m * N + n + 1] = c01;
+    if (m + 1 < M && n < N) C[(size_t)(m + 1) * N + n] = c10;
+    if (m + 1 < M && n + 1 < N) C[(size_t)(m + 1) * N + n + 1] = c11;
+}
+} // namespace
+
+extern "C" int cn_small_mm(int M, int N, int K, const float *A, int64_t a_stride_m, int64_t a_stride_k, const float *B, int64_t b_stride_k, int64_t b_stride_n,
+                           float *C, void *stream)
+{
+    if (int rc = cn_require_device()) return rc;
+    CN_REQUIRE(M >= 1 && N >= 1 && K >= 1 && A && B && C, "cn_small_mm: bad argument");
+    CN_REQUIRE(M <= 4096 && N <= 4096 && K <= 4096, "cn_small_mm: M=%d N=%d K=%d -- meant for weight-sized operands (<= 4096 per dimension)", M, N, K);
+    hipLaunchKernelGGL(small_mm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, M, N, K, A, (long long)a_stride_m,
+                       (long long)a_stride_k, B, (long long)b_stride_k, (long long)b_stride_n, C);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

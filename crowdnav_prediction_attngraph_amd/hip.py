@@ -683,6 +683,49 @@ def wgrad(dy, x):
     return dw, db
 
 
+def _small_mm(a, b):
+    """a [M,K] @ b [K,N] (any strides, fp32, on the GPU) through cn_small_mm -> contiguous [M,N]."""
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):
+        A.check(A.lib().cn_small_mm(M, N, K, A.ptr(a), a.stride(0), a.stride(1), A.ptr(b), b.stride(0), b.stride(1), A.ptr(out), A.stream_ptr()), "cn_small_mm")
+    return out
+
+
+class SmallMM(torch.autograd.Function):
+    """a @ b for WEIGHT-sized operands (the affine folds of the update and their backward): forward and both gradients are cn_small_mm
+    launches -- transposes are strides, a vector operand is an [n, 1] matrix.  Replaces the library's GEMM / GEMV kernels on the training path."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        vec = b.dim() == 1
+        b2 = b.unsqueeze(1) if vec else b
+        a32, b32 = a.detach().float(), b2.detach().float()
+        ctx.save_for_backward(a32, b32)
+        ctx.vec = vec
+        out = _small_mm(a32, b32)
+        return out.squeeze(1) if vec else out
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = (dc.unsqueeze(1) if ctx.vec else dc).float()
+        da = _small_mm(dc, b.t()) if ctx.needs_input_grad[0] else None
+        db = _small_mm(a.t(), dc) if ctx.needs_input_grad[1] else None
+        if db is not None and ctx.vec:
+            db = db.squeeze(1)
+        return da, db
+
+
+def weight_mm(a, b):
+    """a @ b between parameters / their slices: cn_small_mm on the GPU (fp32), torch on the CPU."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32:
+        return SmallMM.apply(a, b)
+    return a @ b
+
+
 class RightMatmul(torch.autograd.Function):
     """t @ w for a tall t [M,N] and a small w [N,K]: the weight gradient t^T d(out) (a reduction over all M rows) on the split-K
     TN kernel; forward and d(t) are ordinary library products."""

@@ -216,11 +216,12 @@ class AttnGraphBase(nn.Module):
         from .hip import RnSequence
         B = T * N
         sl, tl, rnn = self.attn.spatial_edge_layer[0], self.attn.temporal_edge_layer[0], self.humanNodeRNN
-        te_w = torch.cat([sl.weight.t() @ tl.weight, rnn.encoder_linear.weight], 0)
-        te_b = torch.cat([sl.weight.t() @ tl.bias + 0.0 * sl.bias.sum(), rnn.encoder_linear.bias], 0)
+        from .hip import weight_mm as mm     # weight-by-weight products: cn_small_mm forward and backward (no library GEMM / GEMV)
+        te_w = torch.cat([mm(sl.weight.t(), tl.weight), rnn.encoder_linear.weight], 0)
+        te_b = torch.cat([mm(sl.weight.t(), tl.bias) + 0.0 * sl.bias.sum(), rnn.encoder_linear.bias], 0)
         w0 = torch.cat([self.actor[0].weight, self.critic[0].weight], 0)
-        ac0_w = w0 @ rnn.output_linear.weight
-        ac0_b = w0 @ rnn.output_linear.bias + torch.cat([self.actor[0].bias, self.critic[0].bias], 0)
+        ac0_w = mm(w0, rnn.output_linear.weight)
+        ac0_b = mm(w0, rnn.output_linear.bias) + torch.cat([self.actor[0].bias, self.critic[0].bias], 0)
         g = rnn.gru
         return RnSequence.apply(inputs["robot_node"].reshape(B, 7), inputs["temporal_edges"].reshape(B, 2), out_sp, row_off, h0.reshape(N, -1), masks.reshape(B),
                                 actions.reshape(B, 2), T, N, self.human_num,
@@ -286,13 +287,14 @@ class AttnGraphBase(nn.Module):
             from .hip import HHBlockFused
             W, b = sa.multihead_attn.in_proj_weight, sa.multihead_attn.in_proj_bias
             lins = (sa.q_linear, sa.k_linear, sa.v_linear)
-            Wc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].weight for i in range(3)], 0)
-            bc = torch.cat([W[i * 512:(i + 1) * 512] @ lins[i].bias + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
+            from .hip import weight_mm as mm     # the folds and their backward as cn_small_mm launches
+            Wc = torch.cat([mm(W[i * 512:(i + 1) * 512], lins[i].weight) for i in range(3)], 0)
+            bc = torch.cat([mm(W[i * 512:(i + 1) * 512], lins[i].bias) + b[i * 512:(i + 1) * 512] for i in range(3)], 0)
             op, sl = sa.multihead_attn.out_proj, self.spatial_linear[0]
             nd = det.clamp(1, H).to(torch.int32)   # 1..H rows per sample, like the rollout kernels (crowd_sim_var_num.py:290-292)
             row_off = torch.cat([nd.new_zeros(1), nd.cumsum(0, dtype=torch.int32)])
             o = HHBlockFused.apply(spatial_edges, x_live, row_off, emb0.weight, emb0.bias, emb2.weight, emb2.bias, Wc, bc,
-                                   sl.weight @ op.weight, sl.weight @ op.bias + sl.bias)
+                                   mm(sl.weight, op.weight), mm(sl.weight, op.bias) + sl.bias)
             return o, row_off
         if x_live.is_cuda and D <= 16 and emb0.weight.shape[0] == 128:
             from .hip import Embed0

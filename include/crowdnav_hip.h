@@ -145,7 +145,7 @@ typedef struct cn_policy cn_policy;
 
 /* Bumped whenever a struct layout, a signature or the snapshot format changes (round 4: cn_obs.row_plan, cn_env_config.robot_fov /
  * human_fov, the profiling entry points, snapshot layout CNENV004); the ctypes binding refuses a library that reports another number. */
-#define CN_ABI_VERSION 402
+#define CN_ABI_VERSION 403
 const char *cn_last_error(void);
 int cn_version(void);
 int cn_device_count(void);
@@ -458,6 +458,12 @@ int cn_split_bf16_padded(const float *w, int rows, int cols, int transpose, int 
 int cn_linear_fwd_act(int M, int N, int K, const float *X, int ldx, const void *Whi, const void *Wlo, const float *bias, int act,
                       const float *aux, int ldaux, int relu_from, float *Y, int ldy, void *stream);
 int cn_linear_wgrad_splits(int M, int N, int K);
+/* C[M,N] (contiguous) = A . B in exact fp32, A and B addressed through element strides (A[m,k] = A[m * a_stride_m + k * a_stride_k], B[k,n] likewise):
+ * the small weight-by-weight products of the update -- the affine folds of the mirror (policy.py: (q|k|v)_linear o in_proj, out_proj o
+ * spatial_linear, Ws^T Wt, (actor.0 ; critic.0) o output_linear; selfAttn_srnn_temp_node.py:63-91, :160-163, :262-268 compute the unfolded
+ * chains) and their backward, every transposed form being a choice of strides; N = 1 is a matrix-vector product.  Dimensions <= 4096. */
+int cn_small_mm(int M, int N, int K, const float *A, int64_t a_stride_m, int64_t a_stride_k, const float *B, int64_t b_stride_k, int64_t b_stride_n,
+                float *C, void *stream);
 int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, const float *relu_gate, const float *X, int ldx, int splits,
                     float *partials, float *db_partials, float *dW, float *db, void *stream);
 

@@ -153,3 +153,35 @@ def test_training_reruns_are_bit_identical(E, T, updates):
     assert runs[0][1] == runs[1][1]
     for k, v in runs[0][0].items():
         assert torch.equal(v, runs[1][0][k]), k
+
+
+@pytest.mark.parametrize("M,K,N,ta,tb", [(512, 512, 512, False, False), (256, 64, 256, True, False), (512, 256, 128, False, False), (512, 512, 1, False, False),
+                                          (256, 64, 1, True, False), (33, 70, 45, False, True)])
+def test_small_mm_forward_and_both_gradients_match_fp64(M, K, N, ta, tb):
+    """cn_small_mm behind hip.weight_mm (the affine folds of the update and their backward: strided operands, slices of a larger matrix,
+    vector right-hand sides) against fp64: 1e-6 of the largest entry (exact fp32 products, fixed summation order)."""
+    from crowdnav_prediction_attngraph_amd import hip
+    g = torch.Generator().manual_seed(M + 3 * K + 7 * N)
+    big = torch.randn(3 * (K if ta else M), (M if ta else K) + 5, generator=g)
+    a0 = big[(K if ta else M):2 * (K if ta else M), 2:2 + (M if ta else K)]      # a slice: non-contiguous rows
+    b0 = torch.randn(*((N, K) if tb else (K, N)), generator=g)
+    vec = N == 1 and not tb
+    if vec:
+        b0 = b0[:, 0]
+    dc = torch.randn(M, generator=g) if vec else torch.randn(M, N, generator=g)
+
+    def run(dev, dt):
+        a_ = a0.to(dev, dt).requires_grad_()
+        b_ = b0.to(dev, dt).requires_grad_()
+        aa = a_.t() if ta else a_
+        bb = b_.t() if tb else b_
+        c = hip.weight_mm(aa, bb) if dev == "cuda" else aa @ bb
+        c.backward(dc.to(dev, dt))
+        return c.detach().cpu().double(), a_.grad.cpu().double(), b_.grad.cpu().double()
+
+    got, ref = run("cuda", torch.float32), run("cpu", torch.float64)
+    for x, y, what in zip(got, ref, ("c", "da", "db")):
+        assert x.shape == y.shape, what
+        assert float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1.0), (what, float((x - y).abs().max()))
+    c2 = run("cuda", torch.float32)
+    assert all(torch.equal(p, q) for p, q in zip(got, c2))
