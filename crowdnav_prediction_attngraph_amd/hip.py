@@ -688,9 +688,13 @@ def _small_mm(a, b):
     M, K = a.shape
     K2, N = b.shape
     assert K == K2
+    if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
+        raise A.CnError("cn_small_mm: float32 tensors on the GPU expected")
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):
-        A.check(A.lib().cn_small_mm(M, N, K, A.ptr(a), a.stride(0), a.stride(1), A.ptr(b), b.stride(0), b.stride(1), A.ptr(out), A.stream_ptr()), "cn_small_mm")
+        # (raw pointers + element strides: the operands are views -- transposes, row slices of in_proj_weight -- by design)
+        A.check(A.lib().cn_small_mm(M, N, K, C.c_void_p(a.data_ptr()), a.stride(0), a.stride(1), C.c_void_p(b.data_ptr()), b.stride(0), b.stride(1),
+                                    A.ptr(out), A.stream_ptr()), "cn_small_mm")
     return out
 
 
