@@ -587,11 +587,14 @@ __global__ __launch_bounds__(256) void small_mm_kernel(int M, int N, int K, cons
     float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
     for (int k0 = 0; k0 < K; k0 += 32) {
         for (int i = threadIdx.x; i < 1024; i += 256) {
-            const int r = i >> 5, q = i & 31;
-            const int m = m0 + r, k = k0 + q;
-            As[r][q] = (m < M && k < K) ? A[(long long)m * sam + (long long)k * sak] : 0.0f;
-            const int kb = k0 + r, n = n0 + q;
-            Bs[r][q] = (kb < K && n < N) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
+            // consecutive lanes walk the operand's unit-stride dimension (a transposed view has it on the other index)
+            const int hi = i >> 5, lo = i & 31;
+            const int ar = sak == 1 ? hi : lo, aq = sak == 1 ? lo : hi; // (row m, column k) of the A tile
+            const int m = m0 + ar, k = k0 + aq;
+            As[ar][aq] = (m < M && k < K) ? A[(long long)m * sam + (long long)k * sak] : 0.0f;
+            const int br = sbn == 1 ? hi : lo, bq = sbn == 1 ? lo : hi; // (row k, column n) of the B tile
+            const int kb = k0 + br, n = n0 + bq;
+            Bs[br][bq] = (kb < K && n < N) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
         }
         __syncthreads();
 #pragma unroll 8
