@@ -585,18 +585,31 @@ __global__ __launch_bounds__(256) void small_mm_kernel(int M, int N, int K, cons
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4; // 16 x 16 threads, 2 x 2 outputs each
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        for (int i = threadIdx.x; i < 1024; i += 256) {
-            // consecutive lanes walk the operand's unit-stride dimension (a transposed view has it on the other index)
-            const int hi = i >> 5, lo = i & 31;
-            const int ar = sak == 1 ? hi : lo, aq = sak == 1 ? lo : hi; // (row m, column k) of the A tile
-            const int m = m0 + ar, k = k0 + aq;
-            As[ar][aq] = (m < M && k < K) ? A[(long long)m * sam + (long long)k * sak] : 0.0f;
-            const int br = sbn == 1 ? hi : lo, bq = sbn == 1 ? lo : hi; // (row k, column n) of the B tile
-            const int kb = k0 + br, n = n0 + bq;
-            Bs[br][bq] = (kb < K && n < N) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
+    // this thread's four elements of each 32 x 32 operand tile; consecutive lanes walk the operand's unit-stride dimension (a transposed
+    // view has it on the other index)
+    int ar[4], aq[4], br[4], bq[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = threadIdx.x + 256 * p, hi = i >> 5, lo = i & 31;
+        ar[p] = sak == 1 ? hi : lo; aq[p] = sak == 1 ? lo : hi; // (row m, column k) of the A tile
+        br[p] = sbn == 1 ? hi : lo; bq[p] = sbn == 1 ? lo : hi; // (row k, column n) of the B tile
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) { // the tile at k0 -> registers (the next tile travels while the current one is multiplied)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + ar[p], k = k0 + aq[p];
+            ra[p] = (m < M && k < K) ? A[(long long)m * sam + (long long)k * sak] : 0.0f;
+            const int kb = k0 + br[p], n = n0 + bq[p];
+            rb[p] = (kb < K && n < N) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { As[ar[p]][aq[p]] = ra[p]; Bs[br[p]][bq[p]] = rb[p]; }
         __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) {
             const float a0 = As[2 * ty][k], a1 = As[2 * ty + 1][k], b0 = Bs[k][2 * tx], b1 = Bs[k][2 * tx + 1];

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r5j; mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_train_scale.py tests/test_gpu_ppo.py tests/test_gpu_train.py tests/test_gpu_policy_variants.py tests/test_gpu_dist.py tests/test_gpu_boundary.py -m gpu -x -q > $O/pytest1.log 2>&1; echo "pytest1 rc=$?"; tail -4 $O/pytest1.log
+timeout 900 python -m pytest tests/test_gpu_train_scale.py tests/test_gpu_ppo.py -m gpu -x -q > $O/pytest1.log 2>&1; echo "pytest1 rc=$?"; tail -4 $O/pytest1.log
 cd /tmp; rm -rf /tmp/prof
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o u -- python $GRAFT_REPO_ROOT/examples/train_ppo.py --updates 4 > $O/update.log 2>&1
 python $GRAFT_REPO_ROOT/profiles/summarize.py $(find /tmp/prof -name "*.db" | head -1) "rocprofv3 --kernel-trace --stats -- python examples/train_ppo.py --updates 4   (4 rollouts of 30 steps + 4 PPO updates = 40 optimiser steps, E=4096, H=20)" > $O/update_kernel_trace.txt 2>&1
