@@ -573,55 +573,64 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
 // Small weight-by-weight products of the update (the folds of policy.py: (q|k|v)_linear o in_proj, out_proj o spatial_linear,
 // Ws^T Wt, (actor.0 ; critic.0) o output_linear, their bias images, and the backward of each): C[M,N] = A . B in exact fp32 with
 // GENERAL strides for both operands, so that every transposed form of the chain rule is the same launch (dA = dC B^T, dB = A^T dC)
-// and a matrix-vector product is the N = 1 case.  At most 512 x 512 x 512 per call, ~40 calls per optimiser step: a 32 x 32 tile per
-// workgroup with K tiles of 32 through LDS.  Fixed summation order (k ascending inside a tile, tiles ascending): deterministic.
+// and a matrix-vector product is the N = 1 case.  At most 512 x 512 x 512 per call, ~40 calls per optimiser step: a 64 x 64 tile per
+// workgroup on the exact-fp32 matrix instruction, K tiles of 32 through LDS.  Fixed summation order: deterministic.
 // (Round 4 left these on the library's GEMM / GEMV kernels -- the only library products on the training path.)
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
+// 64 x 64 output tile per workgroup, four wavefronts 2 x 2, each a 32 x 32 block on v_mfma_f32_32x32x2_f32 (exact fp32, the k order of
+// gemm.h's kernel); both operands go through LDS as [row][k] whatever their strides.
 __global__ __launch_bounds__(256) void small_mm_kernel(int M, int N, int K, const float *__restrict__ A, long long sam, long long sak,
                                                        const float *__restrict__ B, long long sbk, long long sbn, float *__restrict__ C)
 {
-    __shared__ float As[32][33], Bs[32][33];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4; // 16 x 16 threads, 2 x 2 outputs each
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
-    // this thread's four elements of each 32 x 32 operand tile; consecutive lanes walk the operand's unit-stride dimension (a transposed
-    // view has it on the other index)
-    int ar[4], aq[4], br[4], bq[4];
+    constexpr int T = 64, KT = 32, LS = 36; // tile, K tile, LDS row stride (144 B: conflict-free 16-byte fragment reads)
+    __shared__ __attribute__((aligned(16))) float As[T * LS], Bs[T * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    // this thread's eight elements of each 64 x 32 operand tile; consecutive lanes walk the operand's unit-stride dimension
+    int ar[8], ak[8], bn[8], bk[8];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int i = threadIdx.x + 256 * p, hi = i >> 5, lo = i & 31;
-        ar[p] = sak == 1 ? hi : lo; aq[p] = sak == 1 ? lo : hi; // (row m, column k) of the A tile
-        br[p] = sbn == 1 ? hi : lo; bq[p] = sbn == 1 ? lo : hi; // (row k, column n) of the B tile
+    for (int p = 0; p < 8; ++p) {
+        const int i = tid + 256 * p;                       // 0 .. 2047
+        if (sak == 1) { ar[p] = i >> 5; ak[p] = i & 31; } else { ar[p] = i & 63; ak[p] = i >> 6; }   // A tile: row m (64), column k (32)
+        if (sbk == 1) { bn[p] = i >> 5; bk[p] = i & 31; } else { bn[p] = i & 63; bk[p] = i >> 6; }   // B tile as [n (64)][k (32)]
     }
-    float ra[4], rb[4];
-    auto fetch = [&](int k0) { // the tile at k0 -> registers (the next tile travels while the current one is multiplied)
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int m = m0 + ar[p], k = k0 + aq[p];
-            ra[p] = (m < M && k < K) ? A[(long long)m * sam + (long long)k * sak] : 0.0f;
-            const int kb = k0 + br[p], n = n0 + bq[p];
-            rb[p] = (kb < K && n < N) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
+        for (int p = 0; p < 8; ++p) {
+            const int m = m0 + ar[p], ka = k0 + ak[p];
+            ra[p] = (m < M && ka < K) ? A[(long long)m * sam + (long long)ka * sak] : 0.0f;
+            const int n = n0 + bn[p], kb = k0 + bk[p];
+            rb[p] = (n < N && kb < K) ? B[(long long)kb * sbk + (long long)n * sbn] : 0.0f;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    f32x16 acc;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { As[ar[p]][aq[p]] = ra[p]; Bs[br[p]][bq[p]] = rb[p]; }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        __syncthreads(); // the previous tile is consumed
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { As[ar[p] * LS + ak[p]] = ra[p]; Bs[bn[p] * LS + bk[p]] = rb[p]; }
         __syncthreads();
-        if (k0 + 32 < K) fetch(k0 + 32);
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const float a0 = As[2 * ty][k], a1 = As[2 * ty + 1][k], b0 = Bs[k][2 * tx], b1 = Bs[k][2 * tx + 1];
-            c00 = fmaf(a0, b0, c00); c01 = fmaf(a0, b1, c01); c10 = fmaf(a1, b0, c10); c11 = fmaf(a1, b1, c11);
+        if (k0 + KT < K) fetch(k0 + KT); // the next tile travels while this one is multiplied
+#pragma unroll
+        for (int g = 0; g < KT / 8; ++g) {
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(&As[(wm * 32 + l31) * LS + g * 8 + half * 4]);
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(&Bs[(wn * 32 + l31) * LS + g * 8 + half * 4]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4], bf[s4], acc, 0, 0, 0);
         }
-        __syncthreads();
     }
-    const int m = m0 + 2 * ty, n = n0 + 2 * tx;
-    if (m < M && n < N) C[(size_t)m * N + n] = c00;
-    if (m < M && n + 1 < N) C[(size_t)m * N + n + 1] = c01;
-    if (m + 1 < M && n < N) C[(size_t)(m + 1) * N + n] = c10;
-    if (m + 1 < M && n + 1 < N) C[(size_t)(m + 1) * N + n + 1] = c11;
+    // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M && col < N) C[(size_t)row * N + col] = acc[r];
+    }
 }
 } // namespace
 
@@ -631,7 +640,7 @@ extern "C" int cn_small_mm(int M, int N, int K, const float *A, int64_t a_stride
     if (int rc = cn_require_device()) return rc;
     CN_REQUIRE(M >= 1 && N >= 1 && K >= 1 && A && B && C, "cn_small_mm: bad argument");
     CN_REQUIRE(M <= 4096 && N <= 4096 && K <= 4096, "cn_small_mm: M=%d N=%d K=%d -- meant for weight-sized operands (<= 4096 per dimension)", M, N, K);
-    hipLaunchKernelGGL(small_mm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, M, N, K, A, (long long)a_stride_m,
+    hipLaunchKernelGGL(small_mm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, N, K, A, (long long)a_stride_m,
                        (long long)a_stride_k, B, (long long)b_stride_k, (long long)b_stride_n, C);
     CN_CHECK_LAUNCH();
     return CN_OK;
