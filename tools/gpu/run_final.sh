@@ -7,6 +7,7 @@ bash tools/profile_step.sh r05 --with-update > gpurun_out/final/profile_step.log
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --timeline-out gpurun_out/final/step_timeline.txt > gpurun_out/final/bench_driver.json 2> gpurun_out/final/bench_driver.err; echo "bench driver rc=$?"
 timeout 400 python bench.py --no-ppo --no-cpu-baseline --no-dropin --no-pmc-traffic --no-other-configs > gpurun_out/final/bench_long.json 2> gpurun_out/final/bench_long.err; echo "bench long rc=$?"
 timeout 600 python bench.py --gpus 8 --same-gpu --dist-backend gloo --envs 512 --steps 20 --warmup 5 --no-cpu-baseline --no-worst-case --no-dropin --no-pmc-traffic --no-other-configs > gpurun_out/final/bench_8rank_gloo.json 2> gpurun_out/final/bench_8rank.err; echo "bench8 rc=$?"
+timeout 300 python examples/train_ppo.py --updates 60 > gpurun_out/final/train_60_updates.jsonl 2> gpurun_out/final/train_60.err; echo "train60 rc=$?"; tail -1 gpurun_out/final/train_60_updates.jsonl | cut -c1-300
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/final/pytest.log
 python - <<'PY'
 import json
