@@ -141,6 +141,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CnError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C crowdnav_prediction_attngraph_amd/csrc)" % LIB_PATH)
+        # ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; loaded first (import torch), the library's HIP symbols bind to
+        # that copy.  Loaded the other way round -- this library before torch, e.g. build() followed by smoke() in one interpreter -- the
+        # process ends up with /opt/rocm's runtime AND torch's, and the one behind this library sees no device (measured: cn_env_create
+        # "no HIP device visible" while torch.cuda.is_available() is True).
+        try:
+            import torch  # noqa: F401
+        except ImportError:      # the symbol / ABI checks of the CPU-only tests do not need it
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
         L.cn_last_error.restype = C.c_char_p
