@@ -634,6 +634,19 @@ static int launch_hh_attention_bwd(int B, const float *qkv, const int *row_off, 
 // [rows,256]x[256,64] projection of every human row (and its two backward products) is replaced by a [E,64]x[64,256]
 // product per env.  masked_fill(-1e9) + softmax gives padded humans exactly zero weight (exp underflows to 0), so the
 // softmax and the weighted sum run over the nd live rows only.
+// (both kernels: the rows of a sample are requested eight at a time ahead of the wave-wide reductions that consume them -- as a loop of
+// "load row j, reduce" every row paid its own memory round trip -- and the first eight stay in registers for the second pass: most samples
+// have no more.  Same operations in the same order as the plain loops: bit-identical results.)
+struct HrRows { float v[8][4]; };
+__device__ __forceinline__ void hr_load8(HrRows &r, const float *__restrict__ out_sp, int r0, int j0, int nd, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float *row = out_sp + (size_t)(r0 + max(min(j0 + q, nd - 1), 0)) * 256 + lane; // (rows past nd repeat the last one: loaded, never used)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r.v[q][c] = row[64 * c];
+    }
+}
 __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const float *__restrict__ u, int u_ld, const float *__restrict__ out_sp,
                                                            const int *__restrict__ row_off, float *__restrict__ hr_out, float *__restrict__ hr_attn)
 {
@@ -643,11 +656,25 @@ __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const f
     const int r0 = row_off[e], nd = row_off[e + 1] - r0;
     const float *ue = u + (size_t)e * u_ld;
     const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
+    const float temp = (float)H / 8.0f; // temperature = num_edges / sqrt(attention_size = 64)
     float s = -INFINITY; // lane j holds the score of human j
-    for (int j = 0; j < nd; ++j) {
-        const float *row = out_sp + (size_t)(r0 + j) * 256;
-        const float tot = wv_sum(u0 * row[lane] + u1 * row[64 + lane] + u2 * row[128 + lane] + u3 * row[192 + lane]);
-        if (lane == j) s = tot * ((float)H / 8.0f); // temperature = num_edges / sqrt(attention_size = 64)
+    HrRows k0;
+    hr_load8(k0, out_sp, r0, 0, nd, lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < nd) {
+            const float tot = wv_sum(u0 * k0.v[q][0] + u1 * k0.v[q][1] + u2 * k0.v[q][2] + u3 * k0.v[q][3]);
+            if (lane == q) s = tot * temp;
+        }
+    for (int j0 = 8; j0 < nd; j0 += 8) {
+        HrRows r;
+        hr_load8(r, out_sp, r0, j0, nd, lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < nd) {
+                const float tot = wv_sum(u0 * r.v[q][0] + u1 * r.v[q][1] + u2 * r.v[q][2] + u3 * r.v[q][3]);
+                if (lane == j0 + q) s = tot * temp;
+            }
     }
     const float mx = wv_max(s);
     const float p = lane < nd ? expf(s - mx) : 0.0f;
@@ -655,10 +682,21 @@ __global__ __launch_bounds__(256) void hr_attention_kernel(int E, int H, const f
     const float a = p / denom;
     if (hr_attn && lane < H) hr_attn[(size_t)e * H + lane] = a;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int j = 0; j < nd; ++j) {
-        const float aj = wv_readlane(a, j);
-        const float *row = out_sp + (size_t)(r0 + j) * 256;
-        o0 += aj * row[lane]; o1 += aj * row[64 + lane]; o2 += aj * row[128 + lane]; o3 += aj * row[192 + lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < nd) {
+            const float aj = wv_readlane(a, q);
+            o0 += aj * k0.v[q][0]; o1 += aj * k0.v[q][1]; o2 += aj * k0.v[q][2]; o3 += aj * k0.v[q][3];
+        }
+    for (int j0 = 8; j0 < nd; j0 += 8) {
+        HrRows r;
+        hr_load8(r, out_sp, r0, j0, nd, lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < nd) {
+                const float aj = wv_readlane(a, j0 + q);
+                o0 += aj * r.v[q][0]; o1 += aj * r.v[q][1]; o2 += aj * r.v[q][2]; o3 += aj * r.v[q][3];
+            }
     }
     float *o = hr_out + (size_t)e * 256;
     o[lane] = o0; o[64 + lane] = o1; o[128 + lane] = o2; o[192 + lane] = o3;
@@ -680,20 +718,42 @@ __global__ __launch_bounds__(256) void hr_attention_bwd_kernel(int B, int H, con
     const float g0 = g[lane], g1 = g[64 + lane], g2 = g[128 + lane], g3 = g[192 + lane];
     const float u0 = ue[lane], u1 = ue[64 + lane], u2 = ue[128 + lane], u3 = ue[192 + lane];
     float dp = 0.0f;
-    for (int j = 0; j < nd; ++j) {
-        const float *row = out_sp + (size_t)(r0 + j) * 256;
-        const float tot = wv_sum(g0 * row[lane] + g1 * row[64 + lane] + g2 * row[128 + lane] + g3 * row[192 + lane]);
-        if (lane == j) dp = tot;
+    HrRows k0;
+    hr_load8(k0, out_sp, r0, 0, nd, lane);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < nd) {
+            const float tot = wv_sum(g0 * k0.v[q][0] + g1 * k0.v[q][1] + g2 * k0.v[q][2] + g3 * k0.v[q][3]);
+            if (lane == q) dp = tot;
+        }
+    for (int j0 = 8; j0 < nd; j0 += 8) {
+        HrRows r;
+        hr_load8(r, out_sp, r0, j0, nd, lane);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < nd) {
+                const float tot = wv_sum(g0 * r.v[q][0] + g1 * r.v[q][1] + g2 * r.v[q][2] + g3 * r.v[q][3]);
+                if (lane == j0 + q) dp = tot;
+            }
     }
     const float dot = wv_sum(a * dp);
     const float gg = a * (dp - dot) * ((float)H / 8.0f);
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-    for (int j = 0; j < nd; ++j) {
-        const float aj = wv_readlane(a, j), gj = wv_readlane(gg, j);
-        const float *row = out_sp + (size_t)(r0 + j) * 256;
-        float *dor = d_o + (size_t)(r0 + j) * 256;
-        d0 += gj * row[lane]; d1 += gj * row[64 + lane]; d2 += gj * row[128 + lane]; d3 += gj * row[192 + lane];
-        dor[lane] = aj * g0 + gj * u0; dor[64 + lane] = aj * g1 + gj * u1; dor[128 + lane] = aj * g2 + gj * u2; dor[192 + lane] = aj * g3 + gj * u3;
+    auto second = [&](const HrRows &r, int j0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < nd) {
+                const float aj = wv_readlane(a, j0 + q), gj = wv_readlane(gg, j0 + q);
+                float *dor = d_o + (size_t)(r0 + j0 + q) * 256;
+                d0 += gj * r.v[q][0]; d1 += gj * r.v[q][1]; d2 += gj * r.v[q][2]; d3 += gj * r.v[q][3];
+                dor[lane] = aj * g0 + gj * u0; dor[64 + lane] = aj * g1 + gj * u1; dor[128 + lane] = aj * g2 + gj * u2; dor[192 + lane] = aj * g3 + gj * u3;
+            }
+    };
+    second(k0, 0);
+    for (int j0 = 8; j0 < nd; j0 += 8) {
+        HrRows r;
+        hr_load8(r, out_sp, r0, j0, nd, lane);
+        second(r, j0);
     }
     float *du = d_u + (size_t)e * du_ld;
     du[lane] = d0; du[64 + lane] = d1; du[128 + lane] = d2; du[192 + lane] = d3;
