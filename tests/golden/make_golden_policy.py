@@ -154,6 +154,61 @@ def variant_case(tag, env_name, N, H, D, T, use_self_attn, sort_humans):
     print("variant %-22s value[0]=%.5f -> %s (%.0f KB)" % (tag, out["value"][0, 0], os.path.basename(path), os.path.getsize(path) / 1024))
 
 
+def rollout_variant_case(tag, env_name, E, H, D, T, nmb, use_self_attn, sort_humans):
+    """One PPO.update of the reference with args.use_self_attn / args.sort_humans switched (arguments.py:189, :206): a rollout stored with its
+    visibility masks, three losses and every post-update tensor sampled at <= 256 positions."""
+    import torch
+    from rl.networks.model import Policy
+    from rl.networks.storage import RolloutStorage
+    from rl import ppo as ref_ppo
+    args = ref_args(env_name, E, nmb, T)
+    args.use_self_attn, args.sort_humans = use_self_attn, sort_humans
+    ob_space, act_space = spaces(H, D)
+    torch.manual_seed(0)
+    pol = Policy(ob_space.spaces, act_space, base_kwargs=args, base="selfAttn_merge_srnn")
+    shapes = {k: tuple(v.shape) for k, v in pol.state_dict().items()}
+    pol.load_state_dict({k: torch.from_numpy(v) for k, v in PU.formula_state_dict(shapes).items()})
+    rollouts = RolloutStorage(T, E, ob_space.spaces, act_space, 128, 256)
+    rs = np.random.RandomState(23)
+    obs_seq = [variant_obs(E, H, D, 700 + s, not sort_humans) for s in range(T + 1)]
+    dones = rs.uniform(size=(T, E)) < 0.15
+    rewards = rs.uniform(-1, 1, (T, E, 1)).astype(np.float32)
+    for k in rollouts.obs:
+        rollouts.obs[k][0].copy_(t(obs_seq[0][k]))
+    torch.manual_seed(123)
+    for s in range(T):
+        with torch.no_grad():
+            ob = {k: rollouts.obs[k][s] for k in rollouts.obs}
+            hx = {k: rollouts.recurrent_hidden_states[k][s] for k in rollouts.recurrent_hidden_states}
+            value, action, logp, hx_new = pol.act(ob, hx, rollouts.masks[s])
+        masks = t(np.where(dones[s], 0.0, 1.0).astype(np.float32).reshape(E, 1))
+        rollouts.insert({k: t(v) for k, v in obs_seq[s + 1].items()}, hx_new, action, logp, value, t(rewards[s]), masks, torch.ones(E, 1))
+    with torch.no_grad():
+        ob = {k: rollouts.obs[k][-1] for k in rollouts.obs}
+        hx = {k: rollouts.recurrent_hidden_states[k][-1] for k in rollouts.recurrent_hidden_states}
+        next_value = pol.get_value(ob, hx, rollouts.masks[-1]).detach()
+    rollouts.compute_returns(next_value, True, 0.99, 0.95, False)
+    out = dict(rewards=rewards, actions=rollouts.actions.numpy().copy(), logp=rollouts.action_log_probs.numpy().copy(), values=rollouts.value_preds.numpy().copy(),
+               next_value=next_value.numpy(), returns=rollouts.returns.numpy().copy(), masks=rollouts.masks.numpy().copy(),
+               hxs_node=rollouts.recurrent_hidden_states["human_node_rnn"].numpy().copy())
+    agent = ref_ppo.PPO(pol, 0.2, 2, nmb, 0.5, 0.0, lr=4e-5, eps=1e-5, max_grad_norm=0.5)
+    torch.manual_seed(321)
+    v_loss, a_loss, ent = agent.update(rollouts)
+    out["losses"] = np.array([v_loss, a_loss, ent], dtype=np.float64)
+    for k, v in pol.state_dict().items():
+        flat = v.detach().numpy().reshape(-1)
+        out["smp_" + k] = flat[np.linspace(0, flat.size - 1, min(flat.size, 256)).astype(np.int64)].copy()
+        out["chk_" + k] = np.array([float(flat.astype(np.float64).sum()), float(np.abs(flat.astype(np.float64)).sum())])
+    for s in range(T + 1):
+        for k, v in obs_seq[s].items():
+            out["obs%d_%s" % (s, k)] = v
+    out["meta"] = np.array(json.dumps(dict(env_name=env_name, E=E, N=E, H=H, D=D, T=T, nmb=nmb, use_self_attn=use_self_attn, sort_humans=sort_humans, update_seed=321,
+                                           ppo_epoch=2, shapes={k: list(v) for k, v in shapes.items()})))
+    path = os.path.join(HERE, "rollvar_%s.npz" % tag)
+    np.savez_compressed(path, **out)
+    print("rollout variant %-22s losses=%s -> %s (%.0f KB)" % (tag, out["losses"], os.path.basename(path), os.path.getsize(path) / 1024))
+
+
 def rollout_case(tag, env_name, E, H, D, T, nmb):
     """A synthetic rollout pushed through the reference RolloutStorage / compute_returns / PPO.update."""
     import torch
@@ -253,6 +308,8 @@ def main():
         variant_case("varnum_h20_noattn", "CrowdSimVarNum-v0", 4, 20, 2, 3, False, True)
         variant_case("varnum_h20_unsorted", "CrowdSimVarNum-v0", 4, 20, 2, 3, True, False)
         variant_case("pred_h10_noattn_unsorted", "CrowdSimPred-v0", 3, 10, 12, 4, False, False)
+        rollout_variant_case("varnum_e4_h8_t5_noattn_unsorted", "CrowdSimVarNum-v0", 4, 8, 2, 5, 2, False, False)
+        rollout_variant_case("pred_e4_h10_t4_unsorted", "CrowdSimPred-v0", 4, 10, 12, 4, 2, True, False)
         return
     if "--rollouts-only" in flags:
         rollout_case("varnum_e4_h5_t6", "CrowdSimVarNum-v0", 4, 5, 2, 6, 2)

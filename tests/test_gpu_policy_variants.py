@@ -107,3 +107,22 @@ def test_variants_train_end_to_end_on_the_device(use_self_attn, sort_humans):
     assert pol.base.use_self_attn == use_self_attn and pol.base.sort_humans == sort_humans
     for r in hist:
         assert all(np.isfinite([r["value_loss"], r["action_loss"], r["entropy"]]))
+
+
+from tests.test_policy_variants import ROLL, check_update_against_the_reference, filled_rollouts  # noqa: E402
+
+
+@pytest.mark.parametrize("path", ROLL, ids=lambda p: os.path.basename(p)[8:-4])
+def test_variant_ppo_update_reference_golden_through_the_hip_path(path):
+    """The reference's PPO.update with the switches set, replayed on the GPU (cn_obs_compact_visible / the spatial MLP in front of the fused
+    robot-node sequence, HIP losses, clip + Adam): 1e-5 relative like the default configuration's golden (tests/test_gpu_ppo.py)."""
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    ob_space, act_space = make_spaces(meta["H"], meta["D"])
+    pol = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn",
+                 base_kwargs=dict(env_name=meta["env_name"], num_processes=meta["E"], num_mini_batch=meta["nmb"], seq_length=meta["T"],
+                                  use_self_attn=meta["use_self_attn"], sort_humans=meta["sort_humans"]))
+    pol.load_state_dict({k: torch.from_numpy(v) for k, v in PU.formula_state_dict({k: tuple(v) for k, v in meta["shapes"].items()}).items()})
+    pol.cuda()
+    check_update_against_the_reference(z, meta, pol, filled_rollouts(z, meta, "cuda"), atol=2e-6, rtol=1e-5)
