@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CN_HIP_LIB") or os.path.join(_PKG, "libcrowdnav_hip.so")   # CN_HIP_LIB: another build of the same ABI (A/B measurements)
 
 CN_MAX_HUMANS = 64
-ABI_VERSION = 403          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against
+ABI_VERSION = 404          # CN_ABI_VERSION of include/crowdnav_hip.h this binding was written against
 PROF_KERNELS, PROF_SLOT_WORDS = 8, 2048
 PROF_KERNEL_IDS = {"env_step": 0, "orca_lane": 1, "hh_fused": 2, "rn_fused": 3, "orca_lp3": 4, "env_pregen": 5, "row_plan": 6, "other": 7}
 ENV_KINDS = {"CrowdSimVarNum-v0": 0, "CrowdSimPred-v0": 1, "CrowdSimPredRealGST-v0": 2, "CrowdSimVarNumCollect-v0": 3}
@@ -119,6 +119,18 @@ class PolicyWeights(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _ in POLICY_WEIGHT_KEYS]
 
 
+PPO_BATCH_TENSORS = ["env_idx", "robot_node", "temporal_edges", "spatial_edges", "detected_human_num", "h0", "masks", "actions", "value_preds", "returns",
+                     "old_logp", "adv"]     # pointer fields of cn_ppo_batch, in field order
+
+
+class PpoBatch(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("T", "N", "E", "H", "D")] + [(n, C.c_void_p) for n in PPO_BATCH_TENSORS]
+
+
+class PpoHyper(C.Structure):
+    _fields_ = [("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float), ("use_clipped_value_loss", C.c_int)]
+
+
 # every symbol include/crowdnav_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
     "cn_last_error", "cn_version", "cn_device_count", "cn_env_config_default", "cn_env_create", "cn_env_destroy",
@@ -129,6 +141,7 @@ ABI_SYMBOLS = [
     "cn_split_bf16", "cn_split_bf16_padded", "cn_linear_fwd", "cn_linear_fwd_act", "cn_linear_wgrad_splits", "cn_linear_wgrad", "cn_small_mm", "cn_gst_create", "cn_gst_destroy", "cn_gst_set_weights", "cn_gst_predict",
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gst_wrapper_set_interval", "cn_gst_wrapper_history_len", "cn_gst_wrapper_save", "cn_gst_wrapper_load", "cn_gae", "cn_adv_stats", "cn_adv_normalize", "cn_episode_stats_update",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
+    "cn_ppo_minibatch_workspace_bytes", "cn_ppo_row_totals", "cn_ppo_minibatch_step",
 ]
 
 _lib = None
@@ -242,6 +255,10 @@ def lib():
         L.cn_ppo_loss_fwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp]
         L.cn_ppo_loss_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp]
         L.cn_adam_clip_step.argtypes = [i64, vp, vp, vp, vp, f64, f64, f64, f64, f64, f64, i64, vp, vp, vp]
+        L.cn_ppo_minibatch_workspace_bytes.restype = C.c_int64
+        L.cn_ppo_minibatch_workspace_bytes.argtypes = [i32, i32, i32, i32, i64]
+        L.cn_ppo_row_totals.argtypes = [i32, i32, i32, vp, vp, vp]
+        L.cn_ppo_minibatch_step.argtypes = [C.POINTER(PpoBatch), i64, C.POINTER(PolicyWeights), C.POINTER(PolicyWeights), C.POINTER(PpoHyper), vp, i64, vp, vp, vp]
         _lib = L
     return _lib
 

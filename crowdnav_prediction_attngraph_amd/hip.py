@@ -990,3 +990,78 @@ def adv_stats(returns, values, n):
 def adv_normalize(returns, values, stats, n, out):
     A.check(A.lib().cn_adv_normalize(int(n), A.ptr(returns), A.ptr(values), A.ptr(stats), A.ptr(out), A.stream_ptr()), "cn_adv_normalize")
     return out
+
+
+class MinibatchStepper:
+    """One PPO minibatch -- gather from the rollout storage, train-mode forward, losses, backward, every parameter gradient written into the
+    caller's flat bucket -- as ONE boundary call (cn_ppo_minibatch_step; rl/networks/storage.py:184-253 + rl/networks/model.py:82-90 +
+    rl/ppo/ppo.py:66-88).  Built by ppo.PPO for the default network; the workspace is one cached byte tensor that grows with the row count."""
+
+    def __init__(self, policy):
+        self.policy = policy
+        self._ws = None
+        self._ptrs = None
+
+    @staticmethod
+    def supported(policy, rollouts):
+        base = policy.base
+        if not (base.use_self_attn and base.sort_humans and base.train_gemm_mode == "bf16x3" and base.train_fused_hh and base.train_fused_rn
+                and base.fused_rn_shapes_ok() and base.human_num <= 48 and base.edge_width <= 16):
+            return False
+        if tuple(base.spatial_attn.embedding_layer[0].weight.shape) != (128, base.edge_width):
+            return False
+        need = ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")
+        ts = [rollouts.obs.get(k) for k in need] + [rollouts.recurrent_hidden_states["human_node_rnn"], rollouts.masks, rollouts.actions,
+                                                    rollouts.value_preds, rollouts.returns, rollouts.action_log_probs]
+        return all(t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+
+    def _structs(self):
+        """Parameter / gradient pointer structs (views of the flat buckets ppo.PPO binds; re-read whenever a pointer moved)."""
+        named = dict(self.policy.named_parameters())
+        key = tuple((named[k].data_ptr(), named[k].grad.data_ptr()) for _, k in A.POLICY_WEIGHT_KEYS)
+        if self._ptrs is None or self._ptrs[0] != key:
+            w, g = A.PolicyWeights(), A.PolicyWeights()
+            for field, k in A.POLICY_WEIGHT_KEYS:
+                p = named[k]
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad is None:
+                    raise A.CnError("MinibatchStepper: parameter %s must be a contiguous float32 GPU tensor with a bound gradient" % k)
+                setattr(w, field, p.data_ptr())
+                setattr(g, field, p.grad.data_ptr())
+            self._ptrs = (key, w, g)
+        return self._ptrs[1], self._ptrs[2]
+
+    def row_totals(self, rollouts):
+        """[E] int64 on the HOST: the compacted rows every env contributes to a minibatch (one readback per update())."""
+        det = rollouts.obs["detected_human_num"]
+        T, E = rollouts.rewards.shape[0], rollouts.rewards.shape[1]
+        tot = torch.empty(E, dtype=torch.int32, device=det.device)
+        with torch.cuda.device(det.device):
+            A.check(A.lib().cn_ppo_row_totals(T, E, self.policy.base.human_num, A.ptr(det), A.ptr(tot), A.stream_ptr()), "cn_ppo_row_totals")
+        return tot.cpu().to(torch.int64)
+
+    def step(self, rollouts, advantages, env_idx, rows, hyper, losses_out, value_logp_out=None):
+        """env_idx [N] int32 on the device, rows = their row total, hyper = (clip, value_loss_coef, entropy_coef, use_clipped_value_loss),
+        losses_out [3] float32 on the device; value_logp_out (optional, tests): [2, T * N] float32 on the device."""
+        base = self.policy.base
+        T, E = rollouts.rewards.shape[0], rollouts.rewards.shape[1]
+        N, H, D = int(env_idx.numel()), base.human_num, base.edge_width
+        dev = rollouts.rewards.device
+        L = A.lib()
+        need = int(L.cn_ppo_minibatch_workspace_bytes(T, N, H, D, int(rows)))
+        if need <= 0:
+            raise A.CnError("cn_ppo_minibatch_workspace_bytes: unsupported shape T=%d N=%d H=%d D=%d rows=%d" % (T, N, H, D, rows))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None                       # free the old block first: the two do not need to coexist
+            self._ws = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=dev)
+        w, g = self._structs()
+        b = A.PpoBatch(T, N, E, H, D)
+        ts = dict(env_idx=env_idx, robot_node=rollouts.obs["robot_node"], temporal_edges=rollouts.obs["temporal_edges"],
+                  spatial_edges=rollouts.obs["spatial_edges"], detected_human_num=rollouts.obs["detected_human_num"],
+                  h0=rollouts.recurrent_hidden_states["human_node_rnn"], masks=rollouts.masks, actions=rollouts.actions,
+                  value_preds=rollouts.value_preds, returns=rollouts.returns, old_logp=rollouts.action_log_probs, adv=advantages)
+        for k in A.PPO_BATCH_TENSORS:
+            setattr(b, k, ts[k].data_ptr())
+        hy = A.PpoHyper(float(hyper[0]), float(hyper[1]), float(hyper[2]), int(bool(hyper[3])))
+        with torch.cuda.device(dev):
+            A.check(L.cn_ppo_minibatch_step(C.byref(b), int(rows), C.byref(w), C.byref(g), C.byref(hy), C.c_void_p(self._ws.data_ptr()), int(self._ws.numel()),
+                                            A.ptr(losses_out), A.ptr(value_logp_out), A.stream_ptr()), "cn_ppo_minibatch_step")

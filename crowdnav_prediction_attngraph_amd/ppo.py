@@ -140,6 +140,72 @@ class PPO():
             value_loss = 0.5 * (returns - values).pow(2).mean()
         return value_loss, action_loss
 
+    # ---- one boundary call per minibatch (default network on the GPU) -------------------------------------------------
+    # cn_ppo_minibatch_step gathers the minibatch from the storage by env index, runs the train-mode forward, the losses and the whole
+    # backward, and WRITES every parameter gradient into the flat bucket: no autograd graph, no framework kernel between the rollout
+    # storage and the Adam step.  use_minibatch_step = False (or CN_PPO_MINIBATCH_STEP=0) keeps the autograd-joined path below, which
+    # the non-default variants (use_self_attn / sort_humans off, fp32 arithmetic, CPU tensors) always take.
+    use_minibatch_step = True
+
+    def _fast_path(self, rollouts):
+        import os
+        if not self.use_minibatch_step or os.environ.get("CN_PPO_MINIBATCH_STEP", "1") == "0":
+            return False
+        if not self.actor_critic.is_recurrent or not hasattr(self.actor_critic, "base"):
+            return False
+        return hip.MinibatchStepper.supported(self.actor_critic, rollouts)
+
+    def _update_fast(self, rollouts, advantages, d):
+        flat = self._flat
+        if getattr(self, "_stepper", None) is None or self._stepper.policy is not self.actor_critic:
+            self._stepper = hip.MinibatchStepper(self.actor_critic)
+        stepper = self._stepper
+        for p, (_, gv, _, _) in zip(self._params(), flat["views"]):     # the bucket views must still be the gradients (checked once per update())
+            if p.grad is not gv and (p.grad is None or p.grad.data_ptr() != gv.data_ptr()):
+                p.grad = gv
+        E = rollouts.rewards.shape[1]
+        dev = rollouts.rewards.device
+        assert E >= self.num_mini_batch, (
+            "PPO requires the number of processes ({}) to be greater than or equal to the number of PPO mini batches ({}).".format(E, self.num_mini_batch))
+        npb = E // self.num_mini_batch
+        totals = stepper.row_totals(rollouts)                    # the ONE readback of update(): rows per env -> rows per minibatch on the host
+        starts = list(range(0, E, npb))
+        losses = torch.zeros(self.ppo_epoch * len(starts), 3, device=dev)
+        hyper = (self.clip_param, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
+        ar_events, k = [], 0
+        for e in range(self.ppo_epoch):
+            perm = torch.randperm(E)                             # storage.py:193: one permutation per epoch, same generator draw
+            for start in starts:
+                if start + npb > E:                              # storage.py:209-210 raises here, after the complete groups (see storage.py)
+                    raise IndexError("index {} is out of bounds for dimension 0 with size {}".format(E, E))
+                idx = perm[start:start + npb]
+                rows = int(totals[idx].sum())
+                stepper.step(rollouts, advantages, idx.to(device=dev, dtype=torch.int32), rows, hyper, losses[k])
+                scale = 1.0
+                if d is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                    d.all_reduce(flat["g"])                      # ONE collective per optimiser step (RCCL over xGMI)
+                    ev[1].record()
+                    ar_events.append(ev)
+                    scale = 1.0 / d.get_world_size()
+                g = self.optimizer.param_groups[0]
+                self._step += 1
+                hip.adam_clip_step(flat["p"], flat["g"], flat["m"], flat["v"], self._step, g["lr"], g["betas"], g["eps"],
+                                   self.max_grad_norm, grad_scale=scale, workspace=flat["ws"])
+                k += 1
+        self._weights_changed()
+        self._sync_optimizer_state()
+        if ar_events:
+            torch.cuda.synchronize()
+            self.last_allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+        sums = losses[:k].sum(0)
+        if d is not None:
+            d.all_reduce(sums)
+            sums /= d.get_world_size()
+        v, a, ent = (sums / (self.ppo_epoch * self.num_mini_batch)).tolist()   # single host sync per update()
+        return v, a, ent
+
     def update(self, rollouts):
         advantages = self._advantages(rollouts)
         dev = rollouts.rewards.device
@@ -151,6 +217,8 @@ class PPO():
         num_steps = 0
         ar_events = []
         self.last_allreduce_ms = None
+        if on_gpu and self._fast_path(rollouts):
+            return self._update_fast(rollouts, advantages, d)
         for e in range(self.ppo_epoch):
             if not self.actor_critic.is_recurrent:
                 raise NotImplementedError("feed-forward policies are out of scope")

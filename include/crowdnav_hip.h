@@ -145,7 +145,7 @@ typedef struct cn_policy cn_policy;
 
 /* Bumped whenever a struct layout, a signature or the snapshot format changes (round 4: cn_obs.row_plan, cn_env_config.robot_fov /
  * human_fov, the profiling entry points, snapshot layout CNENV004); the ctypes binding refuses a library that reports another number. */
-#define CN_ABI_VERSION 403
+#define CN_ABI_VERSION 404
 const char *cn_last_error(void);
 int cn_version(void);
 int cn_device_count(void);
@@ -550,6 +550,42 @@ int cn_adam_workspace_doubles(void);
 int cn_adam_clip_step(int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, double grad_scale,
                       double max_grad_norm, double lr, double beta1, double beta2, double eps, int64_t step, double *workspace,
                       float *grad_norm_out, void *stream);
+
+/* ---- one PPO minibatch step as ONE boundary call (rl/ppo/ppo.py:55-95 for one `sample` of the recurrent generator) ----
+ * Replaces, for the default network (use_self_attn, sort_humans; crowds of <= 48 humans, edge width <= 16), the statement sequence
+ *   sample = recurrent_generator(...)            rl/networks/storage.py:184-253  (gather of N whole env trajectories by index)
+ *   evaluate_actions(...)                        rl/networks/model.py:82-90
+ *   value_loss / action_loss / entropy           rl/ppo/ppo.py:66-86
+ *   optimizer.zero_grad(); total.backward()      rl/ppo/ppo.py:87-88
+ * by: gather -> affine folds -> cn_hh_block_fwd -> cn_rn_seq_fwd -> cn_ppo_loss_fwd/bwd -> cn_rn_seq_bwd -> the per-layer backward of
+ * the human-human block -> chain rule of the folds, all on `stream` (+ a library-owned side stream that carries weight-gradient
+ * products off the critical path and is joined before the call returns its last launch), with NO framework kernel in between: every
+ * parameter gradient is WRITTEN (not accumulated) to grads-><same field>; parameters the loss does not reach
+ * (attn.spatial_edge_layer.bias) get an exact zero.  The caller then runs its gradient all-reduce (data parallel) and
+ * cn_adam_clip_step on the flat bucket the pointers live in.
+ *
+ * storage tensors (float32, contiguous, device; T = num_steps, E = envs in storage):
+ *   robot_node [T+1,E,1,7], temporal_edges [T+1,E,1,2], spatial_edges [T+1,E,H,D], detected_human_num [T+1,E,1], h0 = recurrent_hidden_states
+ *   ['human_node_rnn'][0] [E,1,128], masks [T+1,E,1], actions [T,E,2], value_preds / returns [T+1,E,1], old_logp = action_log_probs [T,E,1],
+ *   adv = normalised advantages [T,E,1];  env_idx [N] int32 = perm[start : start + N] (storage.py:209-210).
+ * rows = sum over the minibatch of clamp(detected_human_num, 1, H) -- the caller knows it from cn_ppo_row_totals (one readback per
+ * update(), not per minibatch); the call fails with CN_ERR_INVALID if the workspace is smaller than cn_ppo_minibatch_workspace_bytes.
+ * losses_out [3] (device) = value_loss, action_loss, dist_entropy (ppo.py:66-86, the three numbers update() averages). */
+typedef struct {
+    int T, N, E, H, D;
+    const int32_t *env_idx;
+    const float *robot_node, *temporal_edges, *spatial_edges, *detected_human_num, *h0, *masks, *actions, *value_preds, *returns, *old_logp, *adv;
+} cn_ppo_batch;
+typedef struct {
+    float clip_param, value_loss_coef, entropy_coef;
+    int use_clipped_value_loss;
+} cn_ppo_hyper;
+int64_t cn_ppo_minibatch_workspace_bytes(int T, int N, int H, int D, int64_t rows);
+/* totals [E] int32 (device) = sum_t clamp(detected_human_num[t, e], 1, H) over t < T: the compacted rows env e contributes to a minibatch */
+int cn_ppo_row_totals(int T, int E, int H, const float *detected_human_num, int32_t *totals, void *stream);
+int cn_ppo_minibatch_step(const cn_ppo_batch *batch, int64_t rows, const cn_policy_weights *params, const cn_policy_weights *grads,
+                          const cn_ppo_hyper *hyper, void *workspace, int64_t workspace_bytes, float *losses_out,
+                          float *value_logp_out /* optional [2, T * N]: values, log-probs of the minibatch (tests) */, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,195 @@
+"""-m gpu: cn_ppo_minibatch_step -- one PPO minibatch (gather from the rollout storage, train-mode forward, losses, backward, every parameter
+gradient written into the flat bucket) as ONE boundary call, the default path of ppo.PPO.update on the GPU.
+
+  * against the autograd-joined path of the same build (same kernels for the big layers, same minibatch): every gradient, the three losses;
+  * at the size the bench runs it (T = 30, N = 2048 envs of 20 humans, ~400 k live rows: the 128 x 512-tile weight-gradient kernel with 64
+    splits, the multi-split reductions) against the torch-op graph on the CPU in fp64 -- values / log-probs on ALL samples, every parameter
+    gradient (tolerances of tests/test_gpu_train_scale.py);
+  * a whole PPO.update through it against the CPU update (the reference-golden update tests of test_gpu_ppo.py run through it as well).
+Reference: rl/networks/storage.py:184-253, rl/networks/model.py:82-90, rl/ppo/ppo.py:36-101."""
+import copy
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _setup(T, E, H, D, nmb, seed, env_name="CrowdSimVarNum-v0"):
+    from crowdnav_prediction_attngraph_amd.policy import Policy, make_spaces
+    from crowdnav_prediction_attngraph_amd.ppo import PPO
+    from tests.test_gpu_train_scale import _filled_rollouts
+    torch.manual_seed(seed)
+    ob_space, act_space = make_spaces(H, D)
+    pol_c = Policy(ob_space.spaces, act_space, base="selfAttn_merge_srnn", base_kwargs=dict(env_name=env_name, num_processes=E, num_mini_batch=nmb, seq_length=T))
+    pol_c.base.nenv = E
+    ro_c, next_value = _filled_rollouts(pol_c, T, E, H, D, seed=seed + 1)
+    pol_g = copy.deepcopy(pol_c).cuda()
+    ro_g = copy.deepcopy(ro_c)
+    ro_g.to(torch.device("cuda"))
+    ro_g.compute_returns(next_value.cuda(), True, 0.99, 0.95, False)
+    ro_c.compute_returns(next_value, True, 0.99, 0.95, False)
+    agent = PPO(pol_g, 0.2, 2, nmb, 0.5, 0.01, lr=4e-5, eps=1e-5, max_grad_norm=0.5)
+    return pol_c, ro_c, pol_g, ro_g, agent
+
+
+@pytest.mark.parametrize("H,D,env_name", [(20, 2, "CrowdSimVarNum-v0"), (5, 2, "CrowdSimVarNum-v0"), (20, 12, "CrowdSimPred-v0")])
+def test_minibatch_step_equals_the_autograd_joined_path(H, D, env_name):
+    """Same minibatch, same weights: gradients written by cn_ppo_minibatch_step vs the ones autograd accumulates through the per-call Functions
+    (HHBlockFused, RnSequence, PPOLoss, SmallMM).  The big layers run the same kernels on the same inputs in both; the folds and their
+    chain rule differ in summation order only (one grouped launch with two-segment sums vs separate products + adds): 2e-5 of the
+    tensor's largest entry.  The entropy coefficient is non-zero here so that its gradient path into dist.logstd is exercised."""
+    from crowdnav_prediction_attngraph_amd import hip
+    T, E, nmb = 30, 48, 2
+    _, _, pol, ro, agent = _setup(T, E, H, D, nmb, seed=21, env_name=env_name)
+    agent._bind_flat()
+    assert hip.MinibatchStepper.supported(pol, ro)
+    adv = agent._advantages(ro)
+    flat = agent._flat
+    # ---- autograd-joined path on the first minibatch of the generator ----
+    torch.manual_seed(77)
+    sample = next(ro.recurrent_generator(adv, nmb))
+    obs_b, hxs_b, act_b, vp_b, ret_b, m_b, olp_b, adv_b = sample
+    values, logp, ent, _ = pol.evaluate_actions(obs_b, hxs_b, m_b, act_b)
+    vl, al = agent._losses(values, logp, olp_b, adv_b, vp_b, ret_b)
+    total = vl * agent.value_loss_coef + al - ent * agent.entropy_coef
+    flat["g"].zero_()
+    total.backward()
+    g_ref = flat["g"].clone()
+    ref_losses = torch.stack([vl.detach(), al.detach(), ent.detach()]).cpu()
+    # ---- one boundary call on the same minibatch ----
+    torch.manual_seed(77)
+    perm = torch.randperm(E)
+    idx = perm[:E // nmb]
+    stepper = hip.MinibatchStepper(pol)
+    rows = int(stepper.row_totals(ro)[idx].sum())
+    det = ro.obs["detected_human_num"][:T, idx.cuda()].clamp(1, H)
+    assert rows == int(det.sum().item())
+    losses = torch.zeros(3, device="cuda")
+    vlp = torch.empty(2, T * (E // nmb), device="cuda")
+    flat["g"].fill_(float("nan"))                                   # the call must WRITE every gradient (no accumulation, no stale entry)
+    stepper.step(ro, adv, idx.to("cuda", torch.int32), rows, (agent.clip_param, agent.value_loss_coef, agent.entropy_coef, True), losses, vlp)
+    torch.cuda.synchronize()
+    assert torch.equal(vlp[0].view(-1, 1), values.detach()) and torch.equal(vlp[1].view(-1, 1), logp.detach())   # same forward kernels, same inputs
+    np.testing.assert_allclose(losses.cpu().numpy(), ref_losses.numpy(), rtol=1e-6, atol=1e-7)
+    off = 0
+    for name, p in pol.named_parameters():
+        k = p.numel()
+        got, want = flat["g"][off:off + k], g_ref[off:off + k]
+        off += (k + 3) // 4 * 4
+        if name.startswith("base.human_node_final_linear"):          # never reached by the loss (the reference leaves its .grad None)
+            continue
+        assert bool(torch.isfinite(got).all()), name
+        scale = max(float(want.abs().max()), 1e-8)
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * scale + 1e-9, (name, err, scale)
+
+
+def _cpu_grads_in_chunks(pol64, ro, adv, idx, T, H, clip, vcoef, chunk):
+    """fp64 torch-op graph on the CPU over the envs of `idx`, `chunk` envs at a time (every loss term is a mean over all B samples and the envs
+    are independent sequences: the gradients of the chunks add up exactly)."""
+    N = idx.numel()
+    B = T * N
+    for p in pol64.parameters():
+        p.grad = None
+    vs, lps = [], []
+    sums = torch.zeros(2, dtype=torch.float64)
+    for c0 in range(0, N, chunk):
+        ii = idx[c0:c0 + chunk]
+        n = ii.numel()
+
+        def take(x):
+            g = x[:T].index_select(1, ii).double()
+            return g.reshape(T * n, *g.shape[2:])
+        obs = {k: take(ro.obs[k]) for k in ("robot_node", "temporal_edges", "spatial_edges", "detected_human_num")}
+        h0 = ro.recurrent_hidden_states["human_node_rnn"][0].index_select(0, ii).double()
+        v, lp, ent, _ = pol64.evaluate_actions(obs, {"human_node_rnn": h0}, take(ro.masks), take(ro.actions))
+        olp, a, vp, ret = take(ro.action_log_probs), take(adv), take(ro.value_preds), take(ro.returns)
+        ratio = torch.exp(lp - olp)
+        al = -torch.min(ratio * a, torch.clamp(ratio, 1 - clip, 1 + clip) * a).sum() / B
+        vpc = vp + (v - vp).clamp(-clip, clip)
+        vl = 0.5 * torch.max((v - ret).pow(2), (vpc - ret).pow(2)).sum() / B
+        (vl * vcoef + al).backward()
+        sums += torch.stack([vl.detach(), al.detach()])
+        vs.append(v.detach().view(T, n)); lps.append(lp.detach().view(T, n))
+    grads = {k: p.grad for k, p in pol64.named_parameters() if p.grad is not None}
+    return torch.cat(vs, 1).reshape(B), torch.cat(lps, 1).reshape(B), sums, grads
+
+
+def test_minibatch_step_at_the_bench_size_matches_the_fp64_cpu_graph():
+    """T = 30, N = 2048 envs of 20 humans with simulator-like ragged detected counts (61 440 samples, ~400 k live rows: the minibatch shape of
+    bench.py's PPO leg and of real training at 4096 envs) through cn_ppo_minibatch_step vs the CPU torch graph in fp64: values and
+    log-probs of ALL samples at 1e-4, the two losses, and every parameter gradient within 5e-4 of its tensor's largest entry."""
+    from crowdnav_prediction_attngraph_amd import hip
+    T, E, H, D = 30, 2048, 20, 2
+    pol_c, ro_c, pol, ro, agent = _setup(T, E, H, D, 1, seed=31)
+    agent.entropy_coef = 0.0
+    agent._bind_flat()
+    adv = agent._advantages(ro)
+    idx = torch.randperm(E, generator=torch.Generator().manual_seed(5))
+    stepper = hip.MinibatchStepper(pol)
+    rows = int(stepper.row_totals(ro)[idx].sum())
+    assert rows > 300000, rows
+    losses = torch.zeros(3, device="cuda")
+    vlp = torch.empty(2, T * E, device="cuda")
+    flat = agent._flat
+    flat["g"].fill_(float("nan"))
+    stepper.step(ro, adv, idx.to("cuda", torch.int32), rows, (0.2, 0.5, 0.0, True), losses, vlp)
+    torch.cuda.synchronize()
+    g1 = flat["g"].clone()
+    stepper.step(ro, adv, idx.to("cuda", torch.int32), rows, (0.2, 0.5, 0.0, True), losses, vlp)   # deterministic: bit-identical rerun
+    torch.cuda.synchronize()
+    named = list(pol.named_parameters())
+    off, got = 0, {}
+    for name, p in named:
+        k = p.numel()
+        got[name] = g1[off:off + k].view_as(p).cpu().double()
+        if not name.startswith("base.human_node_final_linear"):       # (never written: still the NaN fill)
+            assert torch.equal(g1[off:off + k], flat["g"][off:off + k]), name
+        off += (k + 3) // 4 * 4
+    v_c, lp_c, sums_c, g_c = _cpu_grads_in_chunks(pol_c.double(), ro_c, adv.cpu(), idx, T, H, 0.2, 0.5, chunk=128)
+    v_g, lp_g = vlp[0].cpu().double(), vlp[1].cpu().double()
+    assert float((v_c - v_g).abs().max()) <= 1e-4, float((v_c - v_g).abs().max())
+    assert float((lp_c - lp_g).abs().max()) <= 1e-4, float((lp_c - lp_g).abs().max())
+    np.testing.assert_allclose(losses[:2].cpu().double().numpy(), sums_c.numpy(), rtol=2e-4, atol=1e-6)
+    ent = 0.5 + 0.5 * math.log(2 * math.pi) + float(pol_c.dist.logstd._bias.mean())
+    assert abs(float(losses[2]) - ent) <= 1e-6
+    worst = ("", 0.0)
+    for k, want in g_c.items():
+        scale = max(float(want.abs().max()), 1e-6)
+        err = float((want - got[k]).abs().max())
+        if err / scale > worst[1]:
+            worst = (k, err / scale)
+        assert err <= 5e-4 * scale + 1e-7, (k, err, scale)
+    for k in got:
+        if k not in g_c:       # parameters the loss does not reach: exact zeros (spatial_edge_layer bias) or untouched (human_node_final_linear)
+            assert (k.startswith("base.human_node_final_linear") and bool(torch.isnan(got[k]).all())) or float(got[k].abs().max()) == 0.0, k
+    print("bench-size minibatch: %d rows, worst relative gradient error %.2e (%s)" % (rows, worst[1], worst[0]))
+
+
+def test_ppo_update_through_the_minibatch_step_matches_the_cpu_update():
+    """PPO.update on the GPU (2 epochs x 2 minibatches through cn_ppo_minibatch_step + cn_adam_clip_step) vs the CPU torch update from the same
+    rollout and the same permutations; and the autograd-joined GPU path gives the same result to within the folds' summation order."""
+    from crowdnav_prediction_attngraph_amd.ppo import PPO
+    T, E, H, D, nmb = 30, 256, 20, 2, 2
+    pol_c, ro_c, pol_g, ro_g, _ = _setup(T, E, H, D, nmb, seed=41)
+    pol_a = copy.deepcopy(pol_g)
+    out = {}
+    for name, pol, ro, fast in (("cpu", pol_c, ro_c, False), ("gpu", pol_g, ro_g, True), ("autograd", pol_a, ro_g, False)):
+        agent = PPO(pol, 0.2, 2, nmb, 0.5, 0.0, lr=4e-5, eps=1e-5, max_grad_norm=0.5)
+        agent.use_minibatch_step = fast
+        torch.manual_seed(123)
+        res = agent.update(ro)
+        if name == "gpu":
+            assert agent._fast_path(ro)
+        out[name] = (res, {k: v.detach().cpu().double() for k, v in pol.state_dict().items()})
+    np.testing.assert_allclose(out["gpu"][0], out["cpu"][0], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(out["gpu"][0], out["autograd"][0], rtol=1e-5, atol=1e-6)
+    for k, wc in out["cpu"][1].items():
+        d = (out["gpu"][1][k] - wc).abs()
+        assert float(d.max()) <= 1.6e-5, (k, float(d.max()))
+        assert float(d.mean()) <= 2e-7, (k, float(d.mean()))
+        da = (out["gpu"][1][k] - out["autograd"][1][k]).abs()
+        assert float(da.max()) <= 1.6e-5 and float(da.mean()) <= 1e-7, (k, float(da.max()), float(da.mean()))
