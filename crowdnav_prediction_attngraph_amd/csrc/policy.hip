@@ -1707,9 +1707,23 @@ extern "C" int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node, const
     return CN_OK;
 }
 
+// side != NULL: the eight weight-gradient products (leaves of the dependency graph) go to that stream, each behind an event recorded on the
+// main stream after the kernel that produces its dY; the dX chain, the GRU and the attention backward stay on `stream`.  The caller joins
+// (waits for the side stream) before anything reads the gradients or reuses the workspace.  ev: five events.
+int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
+                    const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
+                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev);
+
 extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
                              const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
                              float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream)
+{
+    return rn_seq_bwd_impl(T, N, H, robot_node, temporal, out_sp, row_off, masks, actions, w, sv, d_value, d_logp, ws, d_out_sp, d_h0, g, stream, nullptr, nullptr);
+}
+
+int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
+                    const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
+                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev)
 {
     if (int rc = cn_require_device()) return rc;
     if (int rc = rn_check(T, N, H, robot_node, temporal, out_sp, row_off, w, sv)) return rc;
@@ -1723,6 +1737,15 @@ extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const
     const RnWs L = rn_ws(T, N);
     float *d2 = ws + L.d2, *d1 = ws + L.d1, *dhs = ws + L.dhs, *dgi = ws + L.dgi, *dgh = ws + L.dgh, *dz = ws + L.dz, *dhr = ws + L.dhr, *drs = ws + L.drs;
     int rc;
+    hipStream_t wst = side ? side : st; // the stream of the weight-gradient products
+    int evi = 0;
+    auto fork = [&]() -> int { // what `st` has enqueued so far precedes what `wst` gets from here on
+        if (!side) return CN_OK;
+        CN_HIP(hipEventRecord(ev[evi], st));
+        CN_HIP(hipStreamWaitEvent(side, ev[evi], 0));
+        ++evi;
+        return CN_OK;
+    };
     // ---- heads + the tanh of the second trunk layers; the heads' own weight gradients ----
     {
         const int blocks = B < 4 * L.small_rows ? (B + 3) / 4 : L.small_rows;
@@ -1742,25 +1765,30 @@ extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const
         (rc = rn_split(w->ac0_w, 512, 128, 1, 0, ws + L.ac0T, st)) || (rc = rn_split(w->wih, 384, 128, 1, 0, ws + L.wihT, st)) ||
         (rc = rn_split(w->edge_w, 64, 256, 1, 0, ws + L.edgeT, st)) || (rc = rn_split(w->te_w, 320, 256, 1, 0, ws + L.teT, st))) return rc;
     // ---- second trunk layers: weight gradients, then d1 = (d2 W2) (1 - a1^2) ----
-    if ((rc = rn_wgrad(B, 256, 256, d2, 512, sv->a1, 512, ws, L, g->a2_w, g->a2_b, st))) return rc;
-    if ((rc = rn_wgrad(B, 256, 256, d2 + 256, 512, sv->a1 + 256, 512, ws, L, g->c2_w, g->c2_b, st))) return rc;
+    if ((rc = fork())) return rc; // (behind the head reduction and its copies: they read ws + L.dbp, which the first weight gradient overwrites)
+    if ((rc = rn_wgrad(B, 256, 256, d2, 512, sv->a1, 512, ws, L, g->a2_w, g->a2_b, wst))) return rc;
+    if ((rc = rn_wgrad(B, 256, 256, d2 + 256, 512, sv->a1 + 256, 512, ws, L, g->c2_w, g->c2_b, wst))) return rc;
     if ((rc = rn_gemm3(ACT_MUL_DTANH, B, 256, 256, d2, 512, ws + L.a2T, nullptr, d1, 512, st, sv->a1, 512))) return rc;
     if ((rc = rn_gemm3(ACT_MUL_DTANH, B, 256, 256, d2 + 256, 512, ws + L.c2T, nullptr, d1 + 256, 512, st, sv->a1 + 256, 512))) return rc;
     // ---- first trunk layers (output_linear folded in) ----
-    if ((rc = rn_wgrad(B, 512, 128, d1, 512, sv->hs, 128, ws, L, g->ac0_w, g->ac0_b, st))) return rc;
+    if ((rc = fork())) return rc;
+    if ((rc = rn_wgrad(B, 512, 128, d1, 512, sv->hs, 128, ws, L, g->ac0_w, g->ac0_b, wst))) return rc;
     if ((rc = rn_gemm3(ACT_NONE, B, 128, 512, d1, 512, ws + L.ac0T, nullptr, dhs, 128, st))) return rc;
     // ---- GRU over the sequence ----
     if ((rc = cn_gru_seq_bwd(T, N, sv->gates, sv->hms, masks, w->whh, dhs, dgi, dgh, d_h0, stream))) return rc;
-    if ((rc = rn_wgrad(B, 384, 128, dgh, 384, sv->hms, 128, ws, L, g->whh, g->bhh, st))) return rc;
-    if ((rc = rn_wgrad(B, 384, 128, dgi, 384, sv->z + 256, 384, ws, L, g->wih, g->bih, st))) return rc;
+    if ((rc = fork())) return rc;
+    if ((rc = rn_wgrad(B, 384, 128, dgh, 384, sv->hms, 128, ws, L, g->whh, g->bhh, wst))) return rc;
+    if ((rc = rn_wgrad(B, 384, 128, dgi, 384, sv->z + 256, 384, ws, L, g->wih, g->bih, wst))) return rc;
     // ---- d[enc | edge] = (dgi W_ih) relu'(.) -> dz[:, 256:384]; d hr = d edge W_e; attention backward; d u -> dz[:, 0:256] ----
     if ((rc = rn_gemm3(ACT_MUL_DRELU, B, 128, 384, dgi, 384, ws + L.wihT, nullptr, dz + 256, 384, st, sv->z + 256, 384))) return rc;
-    if ((rc = rn_wgrad(B, 64, 256, dz + 320, 384, sv->hr, 256, ws, L, g->edge_w, g->edge_b, st))) return rc;
+    if ((rc = fork())) return rc;
+    if ((rc = rn_wgrad(B, 64, 256, dz + 320, 384, sv->hr, 256, ws, L, g->edge_w, g->edge_b, wst))) return rc;
     if ((rc = rn_gemm3(ACT_NONE, B, 256, 64, dz + 320, 384, ws + L.edgeT, nullptr, dhr, 256, st))) return rc;
     hipLaunchKernelGGL(hr_attention_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, H, sv->z, out_sp, row_off, sv->attn, dhr, dz, d_out_sp, 384, 384);
     CN_CHECK_LAUNCH();
     // ---- [u | enc] layer and robot_linear ----
-    if ((rc = rn_wgrad(B, 320, 256, dz, 384, sv->rs, 256, ws, L, g->te_w, g->te_b, st))) return rc;
+    if ((rc = fork())) return rc;
+    if ((rc = rn_wgrad(B, 320, 256, dz, 384, sv->rs, 256, ws, L, g->te_w, g->te_b, wst))) return rc;
     if ((rc = rn_gemm3(ACT_MUL_DRELU, B, 256, 320, dz, 384, ws + L.teT, nullptr, drs, 256, st, sv->rs, 256))) return rc;
     {
         const int blocks = B < 512 ? B : 512;

@@ -15,7 +15,12 @@
 #include "common.h"
 #include "hh_fused.h"
 
+#include <cstdlib>
 #include <cstring>
+
+int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
+                    const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
+                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev); // policy.hip
 
 namespace {
 
@@ -60,34 +65,48 @@ __global__ __launch_bounds__(64) void tr_gather_kernel(cn_ppo_batch b, GatherOut
     }
 }
 
-// exclusive prefix of nd [n] -> row_off [n + 1]: one workgroup, every thread a run of consecutive samples
-__global__ __launch_bounds__(1024) void tr_scan_kernel(int n, const int *__restrict__ nd, int *__restrict__ row_off)
+// exclusive prefix of nd [n] -> row_off [n + 1], and the compacted input rows x_live [R, D] (the input layer's weight gradient reads them:
+// sample s owns rows row_off[s] .. row_off[s + 1] - 1).  Workgroup b owns samples 1024 b .. 1024 b + 1023: it sums everything in front of
+// them itself (coalesced, <= 240 KB from the L2 -- cheaper than a second launch or a look-back chain), scans its own 1024 counts, and
+// its 16 wavefronts copy the rows of 64 samples each.
+__global__ __launch_bounds__(1024) void tr_scan_kernel(int n, int H, int D, const int *__restrict__ nd, int *__restrict__ row_off, const float *__restrict__ se,
+                                                       float *__restrict__ x)
 {
     __shared__ int part[1024];
-    const int tid = threadIdx.x, per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += nd[i];
-    part[tid] = s;
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = blockIdx.x * 1024;
+    int pre = 0;
+    for (int i = tid; i < first; i += 1024) pre += nd[i];
+    const int s = first + tid;
+    const int mine = s < n ? nd[s] : 0;
+    // wave-level inclusive scans (own counts) and sums (prefix), combined through the LDS
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    if (lane == 63) wsum[wave] = inc;
+    if (lane == 0) part[wave] = pre;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele over the 1024 run sums
-        const int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int base = 0, wpre = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { base += part[w]; if (w < wave) wpre += wsum[w]; }
+    const int off = base + wpre + inc - mine; // exclusive prefix of sample s
+    if (s < n) row_off[s] = off;
+    if (s == n - 1) row_off[n] = off + mine;
+    __syncthreads(); // everybody has read the wave sums
+    part[tid] = off;
+    __syncthreads();
+    // rows of the wave's 64 samples: lanes walk the nd * D floats of one sample at a time
+    for (int q = 0; q < 64; ++q) {
+        const int sq = first + wave * 64 + q;
+        if (sq >= n) break;
+        const int cnt = nd[sq] * D;
+        const float *src = se + (size_t)sq * H * D;
+        float *dst = x + (size_t)part[wave * 64 + q] * D;
+        for (int i = lane; i < cnt; i += 64) dst[i] = src[i];
     }
-    int run = tid ? part[tid - 1] : 0;
-    for (int i = lo; i < hi; ++i) { row_off[i] = run; run += nd[i]; }
-    if (tid == 1023) row_off[n] = part[1023];
-}
-
-// compacted input rows x_live [R, D] (the input layer's weight gradient reads them): sample s owns rows row_off[s] .. row_off[s + 1] - 1
-__global__ __launch_bounds__(64) void tr_xlive_kernel(int H, int D, const float *__restrict__ se, const int *__restrict__ row_off, float *__restrict__ x)
-{
-    const int s = blockIdx.x, r0 = row_off[s], n = (row_off[s + 1] - r0) * D;
-    const float *src = se + (size_t)s * H * D;
-    float *dst = x + (size_t)r0 * D;
-    for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void tr_row_totals_kernel(int T, int E, int H, const float *__restrict__ det, int *__restrict__ totals)
@@ -287,19 +306,44 @@ Ws carve(int T, int N, int H, int D, int64_t rows)
     return w;
 }
 
-// Linear (+ ReLU when gate = the layer's output) backward on the bf16x3 kernels: dX = (dY * [gate > 0]) W, dW = (dY * [gate > 0])^T X,
-// db = its column sums.  wT: scratch for the transposed split planes; dW / db land at the given pointers.
-int layer_bwd(int M, int N, int K, const float *dy, const float *gate, const float *w, const float *inp, float *dx, float *dW, float *db, char *base,
-              const Ws &L, hipStream_t st)
+// Linear (+ ReLU when gate = the layer's output) backward on the bf16x3 kernels, in its two independent halves:
+// layer_dx: dX = (dY * [gate > 0]) W   (wT: scratch for the transposed split planes of W [N,K])
+// layer_dw: dW = (dY * [gate > 0])^T X, db = its column sums, written at the given pointers
+int layer_dx(int M, int N, int K, const float *dy, const float *gate, const float *w, float *dx, char *base, const Ws &L, hipStream_t st)
 {
     float *planes = reinterpret_cast<float *>(base + L.wT);
     uint16_t *hi = reinterpret_cast<uint16_t *>(planes), *lo = hi + (size_t)N * K;
     int rc;
     if ((rc = cn_split_bf16(w, N, K, 1, hi, lo, (void *)st))) return rc;                                  // [K,N]: dX = dY W as an NT product with W^T
-    if ((rc = cn_linear_fwd(M, K, N, dy, N, gate, hi, lo, nullptr, 0, dx, K, (void *)st))) return rc;
+    return cn_linear_fwd(M, K, N, dy, N, gate, hi, lo, nullptr, 0, dx, K, (void *)st);
+}
+int layer_dw(int M, int N, int K, const float *dy, const float *gate, const float *inp, float *dW, float *db, char *base, const Ws &L, hipStream_t st)
+{
     const int splits = cn_linear_wgrad_splits(M, N, K);
     CN_REQUIRE(splits >= 1, "cn_ppo_minibatch_step: no split-K plan for a %d x %d weight gradient over %d rows", N, K, M);
     return cn_linear_wgrad(M, N, K, dy, N, gate, inp, K, splits, reinterpret_cast<float *>(base + L.part), reinterpret_cast<float *>(base + L.dbp), dW, db, (void *)st);
+}
+
+// Library-owned side stream (one per device): carries weight-gradient products that nothing on the critical path waits for, beside the
+// dX chain on the caller's stream.  Events are record / wait pairs inside one call; the call joins before it returns its last launches.
+struct SideCtx {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[8] = {};
+    bool ok = false;
+};
+SideCtx *side_ctx()
+{
+    static SideCtx ctx[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideCtx &c = ctx[dev];
+    if (!c.ok) {
+        if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (auto &e : c.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c.ok = true;
+    }
+    return &c;
 }
 
 } // namespace
@@ -354,9 +398,7 @@ extern "C" int cn_ppo_minibatch_step(const cn_ppo_batch *bp, int64_t rows, const
         GatherOut o{F(L.rn), F(L.te), F(L.se), F(L.h0), F(L.masks), F(L.act), F(L.vp), F(L.ret), F(L.olp), F(L.adv), nd};
         hipLaunchKernelGGL(tr_gather_kernel, dim3(B), dim3(64), 0, st, b, o);
         CN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(tr_scan_kernel, dim3(1), dim3(1024), 0, st, B, nd, row_off);
-        CN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(tr_xlive_kernel, dim3(B), dim3(64), 0, st, H, D, F(L.se), row_off, F(L.xlive));
+        hipLaunchKernelGGL(tr_scan_kernel, dim3((B + 1023) / 1024), dim3(1024), 0, st, B, H, D, nd, row_off, F(L.se), F(L.xlive));
         CN_CHECK_LAUNCH();
     }
 
@@ -419,14 +461,32 @@ extern "C" int cn_ppo_minibatch_step(const cn_ppo_batch *bp, int64_t rows, const
     cn_rn_grads rg{g(G->robot_linear_w), g(G->robot_linear_b), F(L.d_te_w), F(L.d_te_b), g(G->edge_embed_w), g(G->edge_embed_b), g(G->gru_w_ih), g(G->gru_b_ih),
                    g(G->gru_w_hh), g(G->gru_b_hh), F(L.d_ac0_w), F(L.d_ac0_b), g(G->actor2_w), g(G->actor2_b), g(G->critic2_w), g(G->critic2_b),
                    g(G->critic_linear_w), g(G->critic_linear_b), g(G->fc_mean_w), g(G->fc_mean_b), g(G->logstd)};
-    if ((rc = cn_rn_seq_bwd(T, N, H, F(L.rn), F(L.te), F(L.out), row_off, F(L.masks), F(L.act), &rw, &sv, F(L.d_value), F(L.d_logp), F(L.rn_bwd), F(L.d_out),
-                            F(L.d_h0), &rg, stream))) return rc;
+    // The weight-gradient products of the sequence (eight small split-K launches + their reductions, ~0.6 ms at 61 k samples) and the one of
+    // out_proj o spatial_linear run on the side stream beside the dX chain, the GRU, the two attention backward kernels (HBM-bound: the
+    // matrix cores are idle under them); CN_TRAIN_SIDE_STREAM=0 keeps everything on the caller's stream (A/B timing).
+    static const int use_side = getenv("CN_TRAIN_SIDE_STREAM") ? atoi(getenv("CN_TRAIN_SIDE_STREAM")) : 0; // 1: the sequence's products, 2: + out_proj o spatial_linear
+    SideCtx *sc = use_side ? side_ctx() : nullptr;
+    hipStream_t side = sc ? sc->s : nullptr;
+    if (sc) { // nothing of an earlier call may still be running there (a caller that switched streams between calls)
+        CN_HIP(hipEventRecord(sc->ev[7], st));
+        CN_HIP(hipStreamWaitEvent(side, sc->ev[7], 0));
+    }
+    if ((rc = rn_seq_bwd_impl(T, N, H, F(L.rn), F(L.te), F(L.out), row_off, F(L.masks), F(L.act), &rw, &sv, F(L.d_value), F(L.d_logp), F(L.rn_bwd), F(L.d_out),
+                              F(L.d_h0), &rg, stream, side, sc ? sc->ev : nullptr))) return rc;
 
     // ---- backward of the human-human block: the per-layer kernels on the saved activations, in reverse order ----
-    if ((rc = layer_bwd(R, 256, 512, F(L.d_out), F(L.out), F(L.os_w), F(L.attn), F(L.d_attn), F(L.d_os_w), F(L.d_os_b), base, L, st))) return rc;   // out = relu(attn Wos^T + b)
+    // out = relu(attn Wos^T + b): d_out is complete since the sequence's attention backward, i.e. before the side stream's last wait
+    if ((rc = layer_dw(R, 256, 512, F(L.d_out), F(L.out), F(L.attn), F(L.d_os_w), F(L.d_os_b), base, L, side && use_side >= 2 ? side : st))) return rc;
+    if ((rc = layer_dx(R, 256, 512, F(L.d_out), F(L.out), F(L.os_w), F(L.d_attn), base, L, st))) return rc;
     if ((rc = cn_hh_attention_bwd(B, H, F(L.qkv), row_off, F(L.d_attn), 0.125f, F(L.d_qkv), reinterpret_cast<int *>(base + L.cls), 0, stream))) return rc;
-    if ((rc = layer_bwd(R, 1536, 512, F(L.d_qkv), nullptr, F(L.qkv_w), F(L.x), F(L.d_x), F(L.d_qkv_w), F(L.d_qkv_b), base, L, st))) return rc;     // qkv = x Wc^T + bc
-    if ((rc = layer_bwd(R, 512, 128, F(L.d_x), F(L.x), P->emb2_w, F(L.e0), F(L.d_e0), g(G->emb2_w), g(G->emb2_b), base, L, st))) return rc;         // x = relu(e0 W2^T + b2)
+    if ((rc = layer_dx(R, 1536, 512, F(L.d_qkv), nullptr, F(L.qkv_w), F(L.d_x), base, L, st))) return rc;                                           // qkv = x Wc^T + bc
+    if (sc) { // join: the next weight gradient reuses the partial-sum buffers, and from here on everything is on the caller's stream again
+        CN_HIP(hipEventRecord(sc->ev[6], side));
+        CN_HIP(hipStreamWaitEvent(st, sc->ev[6], 0));
+    }
+    if ((rc = layer_dw(R, 1536, 512, F(L.d_qkv), nullptr, F(L.x), F(L.d_qkv_w), F(L.d_qkv_b), base, L, st))) return rc;
+    if ((rc = layer_dx(R, 512, 128, F(L.d_x), F(L.x), P->emb2_w, F(L.d_e0), base, L, st))) return rc;                                               // x = relu(e0 W2^T + b2)
+    if ((rc = layer_dw(R, 512, 128, F(L.d_x), F(L.x), F(L.e0), g(G->emb2_w), g(G->emb2_b), base, L, st))) return rc;
     if ((rc = cn_embed0_bwd(R, D, F(L.xlive), F(L.e0), F(L.d_e0), L.e0_blocks, F(L.e0part), F(L.dwb), stream))) return rc;
 
     // ---- chain rule of the folds back to the factors + the strided pieces (one grouped launch) ----
