@@ -380,6 +380,41 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(size_t n, int
     if (lane == 0) out[i] = acc;
 }
 
+// dW and db of one weight gradient in ONE launch: blocks 0 .. nb1-1 reduce (n1, part1 -> out1), the rest (n2, part2 -> out2), each with the
+// per-output summation order of the kernel above that launch_reduce_partials would have picked for it (results are bit-identical)
+__global__ __launch_bounds__(256) void reduce_partials_pair_kernel(size_t n1, size_t n2, int splits, const float *__restrict__ part1, float *__restrict__ out1,
+                                                                   const float *__restrict__ part2, float *__restrict__ out2, int nb1, int wide1, int wide2)
+{
+    const bool second = (int)blockIdx.x >= nb1;
+    const size_t n = second ? n2 : n1;
+    const float *part = second ? part2 : part1;
+    float *out = second ? out2 : out1;
+    const unsigned b = second ? blockIdx.x - nb1 : blockIdx.x;
+    if (second ? wide2 : wide1) {
+        const size_t i = (size_t)b * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (i >= n) return;
+        float acc = 0.0f;
+        for (int s = lane; s < splits; s += 64) acc += part[(size_t)s * n + i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) out[i] = acc;
+    } else {
+        const size_t i = (size_t)b * 256 + threadIdx.x;
+        if (i < n) {
+            float acc = 0.0f;
+            for (int s = 0; s < splits; ++s) acc += part[(size_t)s * n + i];
+            out[i] = acc;
+        }
+    }
+}
+static void launch_reduce_partials_pair(size_t n1, size_t n2, int splits, const float *part1, float *out1, const float *part2, float *out2, hipStream_t st)
+{
+    const int w1 = splits >= 48 && n1 <= 16384, w2 = splits >= 48 && n2 <= 16384;
+    const int nb1 = (int)(w1 ? (n1 + 3) / 4 : (n1 + 255) / 256), nb2 = (int)(w2 ? (n2 + 3) / 4 : (n2 + 255) / 256);
+    hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3(nb1 + nb2), dim3(256), 0, st, n1, n2, splits, part1, out1, part2, out2, nb1, w1, w2);
+}
+
 static void launch_reduce_partials(size_t n, int splits, const float *part, float *out, hipStream_t st)
 {
     if (splits >= 48 && n <= 16384) hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, splits, part, out);

@@ -35,6 +35,38 @@ __global__ void split_bf16_frag_kernel(int Nw, int Kw, int transpose, const floa
     lo[idx] = (__bf16)(x - (float)h);
 }
 
+// several weights in one launch (the robot-node sequence splits eleven per optimiser step): block b serves the job whose block range holds it
+struct SplitGroupJob {
+    const float *w;
+    __bf16 *hi, *lo;
+    int Nw, Kw, transpose, Nreal, block0;
+};
+struct SplitGroupTable {
+    int njobs;
+    SplitGroupJob job[20];
+};
+__global__ void split_bf16_group_kernel(const SplitGroupTable tab)
+{
+    int ji = 0;
+    while (ji + 1 < tab.njobs && (int)blockIdx.x >= tab.job[ji + 1].block0) ++ji;
+    const SplitGroupJob &J = tab.job[ji];
+    const size_t idx = (size_t)((int)blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
+    if (J.Kw == 0) { // a bias vector, zero-padded to Nw floats
+        if (idx < (size_t)J.Nw) reinterpret_cast<float *>(J.hi)[idx] = idx < (size_t)J.Nreal ? J.w[idx] : 0.0f;
+        return;
+    }
+    const int Nw = J.Nw, Kw = J.Kw, Nreal = J.Nreal;
+    if (idx >= (size_t)Nw * Kw) return;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const size_t blk = idx >> 9;
+    const int kk = (int)(blk % (Kw / 16)), cb = (int)(blk / (Kw / 16));
+    const int n = cb * 32 + (lane & 31), k = kk * 16 + (lane >> 5) * 8 + e;
+    const float x = n >= Nreal ? 0.0f : (J.transpose ? J.w[(size_t)k * Nreal + n] : J.w[(size_t)n * Kw + k]);
+    const __bf16 h = (__bf16)x;
+    J.hi[idx] = h;
+    J.lo[idx] = (__bf16)(x - (float)h);
+}
+
 // KO (experiments only): bit 0 = no C stores, bit 2 = no MFMA, bit 3 = no global loads in the loop
 template <int NB, int ACT, bool GATE, int KO = 0>
 __global__ __launch_bounds__(256, 1) void gemm3p_nt_kernel(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ Agate,

@@ -1526,9 +1526,8 @@ __global__ __launch_bounds__(512, 2) void hh_fused_kernel(int E, int H, int D, c
 // fragment entry (feature block fb, k-step ks, lane, u) = W[fb*16 + (lane & 15)][32*ks + koff(lane >> 4, u)]
 __device__ __forceinline__ int koff(int g, int u, bool perm) { return perm ? 16 * (u >> 2) + 4 * g + (u & 3) : 8 * g + u; }
 
-__global__ void bake_emb2_kernel(const float *__restrict__ w, __bf16 *__restrict__ out)
+__device__ __forceinline__ void bake_emb2(int idx, const float *__restrict__ w, __bf16 *__restrict__ out) // idx: one fragment entry element
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x; // one fragment entry element
     if (idx >= 512 * 128) return;
     const int u = idx & 7, lane = (idx >> 3) & 63, j = (idx >> 9) & 7, ks = (idx >> 12) & 3, wv = idx >> 14;
     const int fb = 8 * wv + j;
@@ -1538,9 +1537,8 @@ __global__ void bake_emb2_kernel(const float *__restrict__ w, __bf16 *__restrict
     out[base] = hi;
     out[base + 512] = (__bf16)(x - (float)hi);
 }
-__global__ void bake_qkv_kernel(const float *__restrict__ w, __bf16 *__restrict__ out)
+__device__ __forceinline__ void bake_qkv(int idx, const float *__restrict__ w, __bf16 *__restrict__ out)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 1536 * 512) return;
     const int u = idx & 7, lane = (idx >> 3) & 63;
     int rest = idx >> 9;                 // ((h*4 + wv)*16 + ks)*3 + j
@@ -1555,9 +1553,8 @@ __global__ void bake_qkv_kernel(const float *__restrict__ w, __bf16 *__restrict_
     out[base] = hi;
     out[base + 512] = (__bf16)(x - (float)hi);
 }
-__global__ void bake_os_kernel(const float *__restrict__ w, __bf16 *__restrict__ out)
+__device__ __forceinline__ void bake_os(int idx, const float *__restrict__ w, __bf16 *__restrict__ out)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 256 * 512) return;
     const int u = idx & 7, lane = (idx >> 3) & 63, j = (idx >> 9) & 3, ks = (idx >> 11) & 1, wv = (idx >> 12) & 3, h = idx >> 14;
     const float x = w[(size_t)((4 * wv + j) * 16 + (lane & 15)) * 512 + h * 64 + 32 * ks + koff(lane >> 4, u, true)];
@@ -1567,15 +1564,23 @@ __global__ void bake_os_kernel(const float *__restrict__ w, __bf16 *__restrict__
     out[base + 512] = (__bf16)(x - (float)hi);
 }
 
+__global__ void bake_all_kernel(const float *__restrict__ emb2_w, const float *__restrict__ qkv_w, const float *__restrict__ os_w, __bf16 *__restrict__ emb2_frag,
+                                __bf16 *__restrict__ qkv_frag, __bf16 *__restrict__ os_frag)
+{
+    constexpr int B1 = 512 * 128 / 256, B2 = B1 + 1536 * 512 / 256;
+    const int b = blockIdx.x;
+    if (b < B1) bake_emb2(b * 256 + (int)threadIdx.x, emb2_w, emb2_frag);
+    else if (b < B2) bake_qkv((b - B1) * 256 + (int)threadIdx.x, qkv_w, qkv_frag);
+    else bake_os((b - B2) * 256 + (int)threadIdx.x, os_w, os_frag);
+}
+
 } // namespace
 
 int hh_fused_bake(const float *emb2_w, const float *qkv_w, const float *os_w, void *emb2_frag, void *qkv_frag, void *os_frag, hipStream_t st)
 {
-    hipLaunchKernelGGL(bake_emb2_kernel, dim3(512 * 128 / 256), dim3(256), 0, st, emb2_w, (__bf16 *)emb2_frag);
-    CN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bake_qkv_kernel, dim3(1536 * 512 / 256), dim3(256), 0, st, qkv_w, (__bf16 *)qkv_frag);
-    CN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bake_os_kernel, dim3(256 * 512 / 256), dim3(256), 0, st, os_w, (__bf16 *)os_frag);
+    // one launch for the three images (the training forward bakes them every optimiser step): blocks 0..255 emb2, 256..3327 q.k.v, the rest os
+    hipLaunchKernelGGL(bake_all_kernel, dim3((512 * 128 + 1536 * 512 + 256 * 512) / 256), dim3(256), 0, st, emb2_w, qkv_w, os_w, (__bf16 *)emb2_frag, (__bf16 *)qkv_frag,
+                       (__bf16 *)os_frag);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -5,6 +5,7 @@
 // evaluate_actions -> loss.backward()).
 #include "common.h"
 #include "gemm3p.h"
+#include "train_internal.h"
 
 namespace {
 
@@ -418,6 +419,33 @@ extern "C" int cn_split_bf16_padded(const float *w, int rows, int cols, int tran
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
+CnSplitJob cn_split_job(const float *w, int rows, int cols, int transpose, int n_padded, float *planes)
+{
+    const int Nreal = transpose ? cols : rows, Kw = transpose ? rows : cols, Nw = n_padded > 0 ? n_padded : Nreal;
+    uint16_t *hi = reinterpret_cast<uint16_t *>(planes);
+    return CnSplitJob{w, hi, hi + (size_t)Nw * Kw, Nw, Kw, transpose, Nreal, 0};
+}
+
+int cn_split_group_launch(CnSplitJob *jobs, int n, hipStream_t st)
+{
+    CN_REQUIRE(n >= 0 && n <= CN_SPLIT_MAX_JOBS, "cn_split_group_launch: %d jobs (at most %d)", n, CN_SPLIT_MAX_JOBS);
+    if (n == 0) return CN_OK;
+    SplitGroupTable tab{};
+    tab.njobs = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const CnSplitJob &j = jobs[i];
+        CN_REQUIRE(j.w && j.hi && j.Nw >= j.Nreal && (j.Kw == 0 || (j.lo && j.Nw % 32 == 0 && j.Kw % 16 == 0)),
+                   "cn_split_group_launch: job %d: the weight seen by the product must be [32 a, 16 b], got [%d (padded %d), %d]", i, j.Nreal, j.Nw, j.Kw);
+        tab.job[i] = SplitGroupJob{j.w, (__bf16 *)j.hi, (__bf16 *)j.lo, j.Nw, j.Kw, j.transpose, j.Nreal, blocks};
+        const size_t elems = j.Kw == 0 ? (size_t)j.Nw : (size_t)j.Nw * j.Kw;
+        blocks += (int)((elems + 255) / 256);
+    }
+    hipLaunchKernelGGL(split_bf16_group_kernel, dim3(blocks), dim3(256), 0, st, tab);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 extern "C" int cn_split_bf16(const float *w, int rows, int cols, int transpose, void *hi, void *lo, void *stream)
 {
     return cn_split_bf16_padded(w, rows, cols, transpose, 0, hi, lo, stream);
@@ -560,12 +588,9 @@ extern "C" int cn_linear_wgrad(int M, int N, int K, const float *dY, int ldy, co
         CN_CHECK_LAUNCH();
     }
     const size_t nk = (size_t)N * K;
-    launch_reduce_partials(nk, used, partials, dW, st);
+    if (db) launch_reduce_partials_pair(nk, (size_t)N, used, partials, dW, db_partials, db, st); // one launch for both sums (same summation orders)
+    else launch_reduce_partials(nk, used, partials, dW, st);
     CN_CHECK_LAUNCH();
-    if (db) {
-        launch_reduce_partials((size_t)N, used, db_partials, db, st);
-        CN_CHECK_LAUNCH();
-    }
     return CN_OK;
 }
 

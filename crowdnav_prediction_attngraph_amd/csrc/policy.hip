@@ -24,6 +24,7 @@
 #include "hh_fused.h"
 #include "rn_fused.h"
 #include "row_plan.h"
+#include "train_internal.h"
 
 #include <cmath>
 #include <cstddef>
@@ -1672,9 +1673,42 @@ static int rn_check(int T, int N, int H, const void *a, const void *b, const voi
     return CN_OK;
 }
 
+// The weight preparation of one optimiser step's sequence as jobs of ONE grouped launch (cn_split_group_launch): forward planes (te: 320 rows
+// padded to 384 = three 128-column tiles; its bias padded with zeros) and the transposed planes of the backward's dX products.
+int rn_seq_prep_jobs(const cn_rn_weights *w, float *fwd_ws, float *bwd_ws, int T, int N, CnSplitJob *out)
+{
+    int n = 0;
+    if (fwd_ws) {
+        const RnFwdWs F = rn_fwd_ws();
+        out[n++] = cn_split_job(w->te_w, 320, 256, 0, 384, fwd_ws + F.te);
+        out[n++] = cn_split_job(w->wih, 384, 128, 0, 0, fwd_ws + F.wih);
+        out[n++] = cn_split_job(w->ac0_w, 512, 128, 0, 0, fwd_ws + F.ac0);
+        out[n++] = cn_split_job(w->a2_w, 256, 256, 0, 0, fwd_ws + F.a2);
+        out[n++] = cn_split_job(w->c2_w, 256, 256, 0, 0, fwd_ws + F.c2);
+        out[n++] = CnSplitJob{w->te_b, fwd_ws + F.teb, nullptr, 384, 0, 0, 320, 0};
+    }
+    if (bwd_ws) {
+        const RnWs L = rn_ws(T, N);
+        out[n++] = cn_split_job(w->a2_w, 256, 256, 1, 0, bwd_ws + L.a2T);
+        out[n++] = cn_split_job(w->c2_w, 256, 256, 1, 0, bwd_ws + L.c2T);
+        out[n++] = cn_split_job(w->ac0_w, 512, 128, 1, 0, bwd_ws + L.ac0T);
+        out[n++] = cn_split_job(w->wih, 384, 128, 1, 0, bwd_ws + L.wihT);
+        out[n++] = cn_split_job(w->edge_w, 64, 256, 1, 0, bwd_ws + L.edgeT);
+        out[n++] = cn_split_job(w->te_w, 320, 256, 1, 0, bwd_ws + L.teT);
+    }
+    return n;
+}
+
 extern "C" int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *h0,
                              const float *masks, const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, float *ws, float *value, float *logp,
                              void *stream)
+{
+    return rn_seq_fwd_impl(T, N, H, robot_node, temporal, out_sp, row_off, h0, masks, actions, w, sv, ws, value, logp, stream, false);
+}
+
+int rn_seq_fwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *h0,
+                    const float *masks, const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, float *ws, float *value, float *logp,
+                    void *stream, bool prepared)
 {
     if (int rc = cn_require_device()) return rc;
     if (int rc = rn_check(T, N, H, robot_node, temporal, out_sp, row_off, w, sv)) return rc;
@@ -1683,12 +1717,11 @@ extern "C" int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node, const
     const int B = T * N;
     const RnFwdWs F = rn_fwd_ws();
     int rc;
-    // split planes of this optimiser step's weights (te: 320 rows padded to 384 = three 128-column tiles; its bias padded with zeros)
-    if ((rc = rn_split(w->te_w, 320, 256, 0, 384, ws + F.te, st)) || (rc = rn_split(w->wih, 384, 128, 0, 0, ws + F.wih, st)) ||
-        (rc = rn_split(w->ac0_w, 512, 128, 0, 0, ws + F.ac0, st)) || (rc = rn_split(w->a2_w, 256, 256, 0, 0, ws + F.a2, st)) ||
-        (rc = rn_split(w->c2_w, 256, 256, 0, 0, ws + F.c2, st))) return rc;
-    CN_HIP(hipMemsetAsync(ws + F.teb, 0, 384 * sizeof(float), st));
-    CN_HIP(hipMemcpyAsync(ws + F.teb, w->te_b, 320 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (!prepared) { // split planes of this optimiser step's weights, one grouped launch
+        CnSplitJob jobs[8];
+        const int nj = rn_seq_prep_jobs(w, ws, nullptr, T, N, jobs);
+        if ((rc = cn_split_group_launch(jobs, nj, st))) return rc;
+    }
     hipLaunchKernelGGL(robot_embed_kernel, dim3(B < 2048 ? B : 2048), dim3(256), 0, st, B, temporal, robot_node, w->rl_w, w->rl_b, sv->rs);
     CN_CHECK_LAUNCH();
     // z = [u (256) | relu(enc) (64) | .] in one product (both read robot_states), then the attention over the compacted rows, then edge -> z[320:384]
@@ -1710,20 +1743,17 @@ extern "C" int cn_rn_seq_fwd(int T, int N, int H, const float *robot_node, const
 // side != NULL: the eight weight-gradient products (leaves of the dependency graph) go to that stream, each behind an event recorded on the
 // main stream after the kernel that produces its dY; the dX chain, the GRU and the attention backward stay on `stream`.  The caller joins
 // (waits for the side stream) before anything reads the gradients or reuses the workspace.  ev: five events.
-int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
-                    const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
-                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev);
-
 extern "C" int cn_rn_seq_bwd(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
                              const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
                              float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream)
 {
-    return rn_seq_bwd_impl(T, N, H, robot_node, temporal, out_sp, row_off, masks, actions, w, sv, d_value, d_logp, ws, d_out_sp, d_h0, g, stream, nullptr, nullptr);
+    return rn_seq_bwd_impl(T, N, H, robot_node, temporal, out_sp, row_off, masks, actions, w, sv, d_value, d_logp, ws, d_out_sp, d_h0, g, stream, nullptr, nullptr,
+                           false, nullptr);
 }
 
 int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
                     const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
-                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev)
+                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev, bool prepared, float **packed_heads)
 {
     if (int rc = cn_require_device()) return rc;
     if (int rc = rn_check(T, N, H, robot_node, temporal, out_sp, row_off, w, sv)) return rc;
@@ -1751,19 +1781,27 @@ int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *t
         const int blocks = B < 4 * L.small_rows ? (B + 3) / 4 : L.small_rows;
         hipLaunchKernelGGL(rn_head_bwd_kernel, dim3(blocks), dim3(256), 0, st, B, sv->a2, w->cl_w, w->fm_w, w->fm_b, w->logstd, actions, d_value, d_logp, d2, ws + L.small);
         CN_CHECK_LAUNCH();
-        float *red = ws + L.dbp; // RN_HEAD_COLS floats, free until the first weight gradient below
+        // the reduced head gradients: RN_HEAD_COLS floats in the bias-partial region (free until the first weight gradient below) -- or, for a
+        // caller that scatters them itself (packed_heads), at the end of the head partials' region, which nothing writes before robot_linear's
+        // partials at the very end of this call
+        float *red = packed_heads ? ws + L.small + (size_t)(L.small_rows - 1) * (RN_HEAD_COLS > 2560 ? RN_HEAD_COLS : 2560) + 1024 : ws + L.dbp;
         hipLaunchKernelGGL(rn_reduce_rows_kernel, dim3((RN_HEAD_COLS + 15) / 16), dim3(256), 0, st, blocks, RN_HEAD_COLS, ws + L.small, red, nullptr, 0);
         CN_CHECK_LAUNCH();
-        CN_HIP(hipMemcpyAsync(g->fm_w, red, 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        CN_HIP(hipMemcpyAsync(g->cl_w, red + 512, 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        CN_HIP(hipMemcpyAsync(g->fm_b, red + 768, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        CN_HIP(hipMemcpyAsync(g->cl_b, red + 770, 1 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        CN_HIP(hipMemcpyAsync(g->logstd, red + 771, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (packed_heads) *packed_heads = red;
+        else {
+            CN_HIP(hipMemcpyAsync(g->fm_w, red, 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CN_HIP(hipMemcpyAsync(g->cl_w, red + 512, 256 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CN_HIP(hipMemcpyAsync(g->fm_b, red + 768, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CN_HIP(hipMemcpyAsync(g->cl_b, red + 770, 1 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            CN_HIP(hipMemcpyAsync(g->logstd, red + 771, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
     }
-    // ---- split planes of the transposed weights for the dX products (dX = dY W as an NT product with W^T) ----
-    if ((rc = rn_split(w->a2_w, 256, 256, 1, 0, ws + L.a2T, st)) || (rc = rn_split(w->c2_w, 256, 256, 1, 0, ws + L.c2T, st)) ||
-        (rc = rn_split(w->ac0_w, 512, 128, 1, 0, ws + L.ac0T, st)) || (rc = rn_split(w->wih, 384, 128, 1, 0, ws + L.wihT, st)) ||
-        (rc = rn_split(w->edge_w, 64, 256, 1, 0, ws + L.edgeT, st)) || (rc = rn_split(w->te_w, 320, 256, 1, 0, ws + L.teT, st))) return rc;
+    // ---- split planes of the transposed weights for the dX products (dX = dY W as an NT product with W^T), one grouped launch ----
+    if (!prepared) {
+        CnSplitJob jobs[8];
+        const int nj = rn_seq_prep_jobs(w, nullptr, ws, T, N, jobs);
+        if ((rc = cn_split_group_launch(jobs, nj, st))) return rc;
+    }
     // ---- second trunk layers: weight gradients, then d1 = (d2 W2) (1 - a1^2) ----
     if ((rc = fork())) return rc; // (behind the head reduction and its copies: they read ws + L.dbp, which the first weight gradient overwrites)
     if ((rc = rn_wgrad(B, 256, 256, d2, 512, sv->a1, 512, ws, L, g->a2_w, g->a2_b, wst))) return rc;

@@ -69,9 +69,12 @@ __global__ __launch_bounds__(256) void ppo_loss_partial_kernel(int64_t n, const 
 }
 __global__ void ppo_loss_final_kernel(int64_t n, int blocks, const double *__restrict__ partials, float *__restrict__ losses)
 {
+    // one wavefront: lane l adds partials l, l + 64, ... (ascending), then a fixed butterfly -- deterministic, and four dependent loads deep
+    // instead of 256 (the serial loop of one lane took 22 us per optimiser step)
+    double sv = 0.0, sa = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 64) { sv += partials[2 * b]; sa += partials[2 * b + 1]; }
+    sv = wv_sum(sv); sa = wv_sum(sa);
     if (threadIdx.x == 0) {
-        double sv = 0.0, sa = 0.0;
-        for (int b = 0; b < blocks; ++b) { sv += partials[2 * b]; sa += partials[2 * b + 1]; }
         losses[0] = (float)(sv / (double)n); // value_loss = 0.5 * mean(max(...))
         losses[1] = (float)(sa / (double)n); // action_loss = -mean(min(surr1, surr2))
     }

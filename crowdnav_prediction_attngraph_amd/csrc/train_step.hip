@@ -15,12 +15,10 @@
 #include "common.h"
 #include "hh_fused.h"
 
+#include "train_internal.h"
+
 #include <cstdlib>
 #include <cstring>
-
-int rn_seq_bwd_impl(int T, int N, int H, const float *robot_node, const float *temporal, const float *out_sp, const int *row_off, const float *masks,
-                    const float *actions, const cn_rn_weights *w, const cn_rn_saved *sv, const float *d_value, const float *d_logp, float *ws,
-                    float *d_out_sp, float *d_h0, const cn_rn_grads *g, void *stream, hipStream_t side, hipEvent_t *ev); // policy.hip
 
 namespace {
 
@@ -129,16 +127,18 @@ __global__ __launch_bounds__(256) void tr_row_totals_kernel(int T, int E, int H,
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct FoldSeg {
     const float *A, *B;
-    int K, sam, sak, sbk, sbn;
+    short K, sam, sak, sbk, sbn; // (every dimension and stride of these weight-sized operands is <= 1536)
 };
 struct FoldJob {
     FoldSeg seg[2];
     const float *addend; // [M,N] with row stride ld_add, or NULL
     float *C;
-    int M, N, nseg, ldc, ld_add, tile0; // tile0: index of this job's first tile in the launch
+    int tile0;           // index of this job's first tile in the launch
     float add_const;
+    short M, N, nseg, ldc, ld_add;
 };
-constexpr int FOLD_MAX_JOBS = 30; // 30 x 128 B + 8 B: inside the 4 KB of kernel arguments
+constexpr int FOLD_MAX_JOBS = 36; // 36 x 104 B + 8 B: inside the 4 KB of kernel arguments
+static_assert(sizeof(FoldJob) <= 104, "FoldJob grew: the table must stay inside the kernel-argument segment");
 struct FoldTable {
     int njobs, ntiles;
     FoldJob job[FOLD_MAX_JOBS];
@@ -216,7 +216,7 @@ struct FoldBuilder {
         if (t.njobs >= FOLD_MAX_JOBS) { overflow = true; return &t.job[FOLD_MAX_JOBS - 1]; }
         FoldJob &j = t.job[t.njobs++];
         std::memset(&j, 0, sizeof(j));
-        j.M = M; j.N = N; j.C = C; j.ldc = ldc; j.tile0 = t.ntiles;
+        j.M = (short)M; j.N = (short)N; j.C = C; j.ldc = (short)ldc; j.tile0 = t.ntiles;
         t.ntiles += ((M + 63) / 64) * ((N + 63) / 64);
         return &j;
     }
@@ -224,9 +224,9 @@ struct FoldBuilder {
     static void seg(FoldJob *j, int K, const float *A, int sam, int sak, const float *B, int sbk, int sbn)
     {
         FoldSeg &s = j->seg[j->nseg++];
-        s.A = A; s.B = B; s.K = K; s.sam = sam; s.sak = sak; s.sbk = sbk; s.sbn = sbn;
+        s.A = A; s.B = B; s.K = (short)K; s.sam = (short)sam; s.sak = (short)sak; s.sbk = (short)sbk; s.sbn = (short)sbn;
     }
-    static void plus(FoldJob *j, const float *addend, int ld_add) { j->addend = addend; j->ld_add = ld_add; }
+    static void plus(FoldJob *j, const float *addend, int ld_add) { j->addend = addend; j->ld_add = (short)ld_add; }
     void copy(int M, int N, float *C, int ldc, const float *src, int ld_src) { plus(add(M, N, C, ldc), src, ld_src); }
     int launch(hipStream_t st)
     {
@@ -261,7 +261,7 @@ struct Ws {
     // folded weights and their gradients
     size_t qkv_w, qkv_b, os_w, os_b, te_w, te_b, ac0_w, ac0_b, d_qkv_w, d_qkv_b, d_os_w, d_os_b, d_te_w, d_te_b, d_ac0_w, d_ac0_b;
     // human-human block: fragment images, saved activations, backward
-    size_t frag, e0, x, qkv, attn, out, d_out, d_attn, d_qkv, d_x, d_e0, cls, wT, part, dbp, e0part, dwb;
+    size_t frag, e0, x, qkv, attn, out, d_out, d_attn, d_qkv, d_x, d_e0, cls, wT_os, wT_qkv, wT_emb2, part, dbp, e0part, dwb;
     // robot-node sequence
     size_t sv[10], value, logp, d_value, d_logp, rn_fwd, rn_bwd, d_h0;
     // losses
@@ -287,7 +287,7 @@ Ws carve(int T, int N, int H, int D, int64_t rows)
     w.e0 = f(R * 128); w.x = f(R * 512); w.qkv = f(R * 1536); w.attn = f(R * 512); w.out = f(R * 256);
     w.d_out = f(R * 256); w.d_attn = f(R * 512); w.d_qkv = f(R * 1536); w.d_x = f(R * 512); w.d_e0 = f(R * 128);
     w.cls = f((size_t)cn_hh_attention_workspace_ints((int)B));
-    w.wT = f(1536 * 512); // hi + lo planes of the largest transposed weight (N * K bf16 each = N * K floats together)
+    w.wT_os = f(256 * 512); w.wT_qkv = f(1536 * 512); w.wT_emb2 = f(512 * 128); // hi + lo planes of the transposed weights (N * K bf16 each = N * K floats)
     size_t pmax = 0, bmax = 0;
     const int shp[3][2] = {{256, 512}, {1536, 512}, {512, 128}};
     for (auto &q : shp) {
@@ -307,15 +307,12 @@ Ws carve(int T, int N, int H, int D, int64_t rows)
 }
 
 // Linear (+ ReLU when gate = the layer's output) backward on the bf16x3 kernels, in its two independent halves:
-// layer_dx: dX = (dY * [gate > 0]) W   (wT: scratch for the transposed split planes of W [N,K])
+// layer_dx: dX = (dY * [gate > 0]) W   (planes: the transposed split planes of W [N,K], prepared by the step's grouped split launch)
 // layer_dw: dW = (dY * [gate > 0])^T X, db = its column sums, written at the given pointers
-int layer_dx(int M, int N, int K, const float *dy, const float *gate, const float *w, float *dx, char *base, const Ws &L, hipStream_t st)
+int layer_dx(int M, int N, int K, const float *dy, const float *gate, const float *planes, float *dx, hipStream_t st)
 {
-    float *planes = reinterpret_cast<float *>(base + L.wT);
-    uint16_t *hi = reinterpret_cast<uint16_t *>(planes), *lo = hi + (size_t)N * K;
-    int rc;
-    if ((rc = cn_split_bf16(w, N, K, 1, hi, lo, (void *)st))) return rc;                                  // [K,N]: dX = dY W as an NT product with W^T
-    return cn_linear_fwd(M, K, N, dy, N, gate, hi, lo, nullptr, 0, dx, K, (void *)st);
+    const uint16_t *hi = reinterpret_cast<const uint16_t *>(planes), *lo = hi + (size_t)N * K;
+    return cn_linear_fwd(M, K, N, dy, N, gate, hi, lo, nullptr, 0, dx, K, (void *)st); // dX = dY W as an NT product with W^T [K,N]
 }
 int layer_dw(int M, int N, int K, const float *dy, const float *gate, const float *inp, float *dW, float *db, char *base, const Ws &L, hipStream_t st)
 {
@@ -442,7 +439,15 @@ extern "C" int cn_ppo_minibatch_step(const cn_ppo_batch *bp, int64_t rows, const
                      F(L.ac0_w), F(L.ac0_b), P->actor2_w, P->actor2_b, P->critic2_w, P->critic2_b, P->critic_linear_w, P->critic_linear_b, P->fc_mean_w, P->fc_mean_b,
                      P->logstd};
     cn_rn_saved sv{F(L.sv[0]), F(L.sv[1]), F(L.sv[2]), F(L.sv[3]), F(L.sv[4]), F(L.sv[5]), F(L.sv[6]), F(L.sv[7]), F(L.sv[8]), F(L.sv[9])};
-    if ((rc = cn_rn_seq_fwd(T, N, H, F(L.rn), F(L.te), F(L.out), row_off, F(L.h0), F(L.masks), F(L.act), &rw, &sv, F(L.rn_fwd), F(L.value), F(L.logp), stream))) return rc;
+    { // every split-plane image the step needs (the sequence's forward and backward weights, the transposed weights of the block's dX products): one launch
+        CnSplitJob jobs[CN_SPLIT_MAX_JOBS];
+        int nj = rn_seq_prep_jobs(&rw, F(L.rn_fwd), F(L.rn_bwd), T, N, jobs);
+        jobs[nj++] = cn_split_job(F(L.os_w), 256, 512, 1, 0, F(L.wT_os));
+        jobs[nj++] = cn_split_job(F(L.qkv_w), 1536, 512, 1, 0, F(L.wT_qkv));
+        jobs[nj++] = cn_split_job(P->emb2_w, 512, 128, 1, 0, F(L.wT_emb2));
+        if ((rc = cn_split_group_launch(jobs, nj, st))) return rc;
+    }
+    if ((rc = rn_seq_fwd_impl(T, N, H, F(L.rn), F(L.te), F(L.out), row_off, F(L.h0), F(L.masks), F(L.act), &rw, &sv, F(L.rn_fwd), F(L.value), F(L.logp), stream, true))) return rc;
 
     if (value_logp_out) {
         CN_HIP(hipMemcpyAsync(value_logp_out, F(L.value), (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -471,21 +476,22 @@ extern "C" int cn_ppo_minibatch_step(const cn_ppo_batch *bp, int64_t rows, const
         CN_HIP(hipEventRecord(sc->ev[7], st));
         CN_HIP(hipStreamWaitEvent(side, sc->ev[7], 0));
     }
+    float *heads = nullptr; // packed head gradients: fc_mean.w [2,256] | critic_linear.w [256] | fc_mean.b [2] | critic_linear.b [1] | logstd [2]
     if ((rc = rn_seq_bwd_impl(T, N, H, F(L.rn), F(L.te), F(L.out), row_off, F(L.masks), F(L.act), &rw, &sv, F(L.d_value), F(L.d_logp), F(L.rn_bwd), F(L.d_out),
-                              F(L.d_h0), &rg, stream, side, sc ? sc->ev : nullptr))) return rc;
+                              F(L.d_h0), &rg, stream, side, sc ? sc->ev : nullptr, true, &heads))) return rc;
 
     // ---- backward of the human-human block: the per-layer kernels on the saved activations, in reverse order ----
     // out = relu(attn Wos^T + b): d_out is complete since the sequence's attention backward, i.e. before the side stream's last wait
     if ((rc = layer_dw(R, 256, 512, F(L.d_out), F(L.out), F(L.attn), F(L.d_os_w), F(L.d_os_b), base, L, side && use_side >= 2 ? side : st))) return rc;
-    if ((rc = layer_dx(R, 256, 512, F(L.d_out), F(L.out), F(L.os_w), F(L.d_attn), base, L, st))) return rc;
+    if ((rc = layer_dx(R, 256, 512, F(L.d_out), F(L.out), F(L.wT_os), F(L.d_attn), st))) return rc;
     if ((rc = cn_hh_attention_bwd(B, H, F(L.qkv), row_off, F(L.d_attn), 0.125f, F(L.d_qkv), reinterpret_cast<int *>(base + L.cls), 0, stream))) return rc;
-    if ((rc = layer_dx(R, 1536, 512, F(L.d_qkv), nullptr, F(L.qkv_w), F(L.d_x), base, L, st))) return rc;                                           // qkv = x Wc^T + bc
+    if ((rc = layer_dx(R, 1536, 512, F(L.d_qkv), nullptr, F(L.wT_qkv), F(L.d_x), st))) return rc;                                                   // qkv = x Wc^T + bc
     if (sc) { // join: the next weight gradient reuses the partial-sum buffers, and from here on everything is on the caller's stream again
         CN_HIP(hipEventRecord(sc->ev[6], side));
         CN_HIP(hipStreamWaitEvent(st, sc->ev[6], 0));
     }
     if ((rc = layer_dw(R, 1536, 512, F(L.d_qkv), nullptr, F(L.x), F(L.d_qkv_w), F(L.d_qkv_b), base, L, st))) return rc;
-    if ((rc = layer_dx(R, 512, 128, F(L.d_x), F(L.x), P->emb2_w, F(L.d_e0), base, L, st))) return rc;                                               // x = relu(e0 W2^T + b2)
+    if ((rc = layer_dx(R, 512, 128, F(L.d_x), F(L.x), F(L.wT_emb2), F(L.d_e0), st))) return rc;                                                     // x = relu(e0 W2^T + b2)
     if ((rc = layer_dw(R, 512, 128, F(L.d_x), F(L.x), F(L.e0), g(G->emb2_w), g(G->emb2_b), base, L, st))) return rc;
     if ((rc = cn_embed0_bwd(R, D, F(L.xlive), F(L.e0), F(L.d_e0), L.e0_blocks, F(L.e0part), F(L.dwb), stream))) return rc;
 
@@ -542,11 +548,14 @@ extern "C" int cn_ppo_minibatch_step(const cn_ppo_batch *bp, int64_t rows, const
         // input layer: dwb [128, D + 1] = per output column the D weight gradients, then the bias gradient
         fb.copy(128, D, g(G->emb0_w), D, F(L.dwb), D + 1);
         fb.copy(128, 1, g(G->emb0_b), 1, F(L.dwb) + D, D + 1);
-        if (hy->entropy_coef != 0.0f) { // d(-coef * entropy) / d logstd_k = -coef / 2, on top of the log-prob path's gradient
-            FoldJob *j = fb.add(2, 1, g(G->logstd), 1);
-            FoldBuilder::plus(j, G->logstd, 1);
-            j->add_const = -0.5f * hy->entropy_coef;
-        }
+        // heads: scattered from the packed reduction; d(-coef * entropy) / d logstd_k = -coef / 2 on top of the log-prob path's gradient
+        fb.copy(2, 256, g(G->fc_mean_w), 256, heads, 256);
+        fb.copy(1, 256, g(G->critic_linear_w), 256, heads + 512, 256);
+        fb.copy(2, 1, g(G->fc_mean_b), 1, heads + 768, 1);
+        fb.copy(1, 1, g(G->critic_linear_b), 1, heads + 770, 1);
+        fb.add(2, 1, g(G->logstd), 1);
+        FoldBuilder::plus(&fb.t.job[fb.t.njobs - 1], heads + 771, 1);
+        fb.t.job[fb.t.njobs - 1].add_const = -0.5f * hy->entropy_coef;
         if ((rc = fb.launch(st))) return rc;
     }
     return CN_OK;
