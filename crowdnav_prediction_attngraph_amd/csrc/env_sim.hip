@@ -62,6 +62,7 @@ struct EnvDev {
     double *nx_shared_nd; // [E]
     uint32_t *nx_mt;    // [E][624]
     int32_t *nx_mt_pos; // [E]
+    int32_t *plan_arrive; // [1] row-plan builders' arrival counter (library-owned: the caller's plan buffer may hold anything)
     uint8_t *nx_ready;  // [E]
     int32_t *nx_prog;   // [E] pre-generation in progress: 0 = not started, k + 1 = seed, robot and the first k humans are staged
     uint64_t *nx_case;  // [E] the case counter that staging was started for (a reset in between makes it stale)
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(64) void orca_lane_kernel(EnvDev s, const float *pl
     // (dispatched first; a builder is the longest chain of the launch, so it also takes the issue priority)
     if (plan && (int)blockIdx.x < plan_groups) {
         __builtin_amdgcn_s_setprio(3);
-        rowplan::build((int)blockIdx.x, plan_groups, s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, *reinterpret_cast<rowplan::Lds *>(s_raw));
+        rowplan::build((int)blockIdx.x, plan_groups, s.E, s.H, rp_workgroups(s.E, s.H), plan_det, plan, *reinterpret_cast<rowplan::Lds *>(s_raw), nullptr, s.plan_arrive);
         return;
     }
     const int blk = (int)blockIdx.x - (plan ? plan_groups : 0);
@@ -2421,6 +2422,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const bool collect = cfg->env_kind == CN_ENV_COLLECT;
     const size_t o_pid = collect ? carve(E * H * 4) : 0, o_mpid = collect ? carve(E * 4) : 0, o_lobs = collect ? carve(E * H) : 0;
     const size_t state_bytes = off; // everything below is per-step scratch of the ORCA pass: not part of a snapshot
+    const size_t o_pa = carve(4); // arrival counter of the row-plan builders (row_plan.h): zero here, reset by the last builder of every build
     const size_t o_l3c = carve(4), o_l3h = lane_orca ? carve(E * H * sizeof(Lp3Hdr)) : 0, o_l3l = lane_orca ? carve(E * H * 32 * sizeof(float4)) : 0;
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
@@ -2439,6 +2441,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.mt = (uint32_t *)(base + o_mt); d.mt_pos = (int32_t *)(base + o_mp); d.hact = (float *)(base + o_ha);
     d.nx_hum = (double *)(base + o_nxh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
+    d.plan_arrive = (int32_t *)(base + o_pa);
     d.nx_prog = (int32_t *)(base + o_npg); d.nx_case = (uint64_t *)(base + o_ncs);
     d.tr = (test_phase || truth_obs) ? (double *)(base + o_tr) : nullptr; d.vis = (test_phase || truth_obs) ? (uint8_t *)(base + o_vis) : nullptr;
     d.pend = (uint8_t *)(base + o_pend);

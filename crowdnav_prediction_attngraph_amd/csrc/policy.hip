@@ -1339,8 +1339,10 @@ static int policy_forward(cn_policy *p, int E, const cn_obs *obs, const float *h
     CN_HIP(hipEventRecord(p->ev_join, p->side));
     // ---- human-human block on the compacted live rows (row_off[E] rows, known only on the device) ----
     const int *m_dev = p->row_off + E;
+    // (without the human-human block no launch of this path is bracketed by a profiling event pair: the live rows are not counted either,
+    // so that cn_policy_get_profile never reports rows without a matching device time)
     hipLaunchKernelGGL(row_offsets_kernel, dim3(1), dim3(1024), 0, st, E, H, obs->detected_human_num, p->row_off,
-                           p->profiling ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
+                           p->profiling && p->self_attn ? p->live_total : (unsigned long long *)nullptr, p->cls_cnt, p->cls_list);
     CN_CHECK_LAUNCH();
     if (!p->self_attn) {
         if ((rc = spatial_mlp_forward(p, E, obs, st))) return rc;

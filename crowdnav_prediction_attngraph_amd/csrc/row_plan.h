@@ -191,9 +191,13 @@ __device__ __forceinline__ bool fill(int H, int T, int TB, int rows, int hist, i
 
 // Wavefront g of G (all 64 lanes active; G = rp_groups(E), every wavefront its own workgroup / Lds).  det: detected_human_num of the
 // observation the plan is for.
-// The wavefronts meet once, at the end: each adds itself to the counter in header word 7 (a failed group adds a flag), the last one
+// The wavefronts meet once, at the end: each adds itself to the arrival counter (a failed group adds a flag), the last one
 // publishes the header (magic last) and clears the counter for the next build.
-__device__ __forceinline__ void build(int g, int G, int E, int H, int NW, const float *__restrict__ det, int32_t *__restrict__ plan, Lds &lds, long long *tim = nullptr)
+// arrive: the groups' arrival counter -- ONE int32 that is zero before the first build and that only this function touches (the last group
+// through resets it).  The simulator passes library-owned memory (cn_env_batch), so that a plan buffer of arbitrary content (a caller's
+// hipMalloc, 0xFF-filled) works: header word 7 is no longer read.  NULL (tools/row_plan_probe): header word 7 of a zeroed buffer, as before.
+__device__ __forceinline__ void build(int g, int G, int E, int H, int NW, const float *__restrict__ det, int32_t *__restrict__ plan, Lds &lds, long long *tim = nullptr,
+                                      int32_t *arrive = nullptr)
 {
     const int ln = threadIdx.x & 63;
     int32_t *hdr = plan, *row_off = plan + rp_off_rowoff(), *tcnt = plan + rp_off_tcnt(E), *items = plan + rp_off_items(E);
@@ -310,10 +314,11 @@ __device__ __forceinline__ void build(int g, int G, int E, int H, int NW, const 
     __threadfence();
     if (ln == 0) {
         // the groups meet here: count in the low half of word 7, a failure flag in the high half; the last one through decides
-        const int old = G > 1 ? atomicAdd(&hdr[7], ok ? 1 : 0x10001) : (ok ? 0 : 0x10000);
+        int32_t *ctr = arrive ? arrive : &hdr[7];
+        const int old = G > 1 ? atomicAdd(ctr, ok ? 1 : 0x10001) : (ok ? 0 : 0x10000);
         if ((old & 0xffff) == G - 1) {
             const bool all_ok = ok && (old >> 16) == 0;
-            hdr[7] = 0;
+            if (G > 1) *ctr = 0;
             if (all_ok) {
                 hdr[1] = NW; hdr[2] = n; hdr[3] = total; hdr[4] = E; hdr[5] = H; hdr[6] = Tall;
                 __threadfence();

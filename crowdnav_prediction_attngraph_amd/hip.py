@@ -298,6 +298,9 @@ class HipPolicy:
         if env is None:
             if getattr(self, "_h", None) is not None and self._h:
                 A.check(A.lib().cn_policy_set_post_hh_hook(self._h, None, None), "cn_policy_set_post_hh_hook")
+            old = getattr(self, "_tail_env", None)
+            if old is not None:      # forget this policy in the batch's list (repeated attach / detach must not grow it)
+                old._tail_policies[:] = [r for r in old._tail_policies if r() is not None and r() is not self]
             self._tail_env = None
             return
         if getattr(env, "_h", None) is None or not env._h:
@@ -306,6 +309,7 @@ class HipPolicy:
         A.check(A.lib().cn_policy_set_post_hh_hook(self._h, fn, env._h), "cn_policy_set_post_hh_hook")
         self._tail_env = env          # keeps the batch alive as long as the hook points at it
         import weakref
+        env._tail_policies[:] = [r for r in env._tail_policies if r() is not None and r() is not self]
         env._tail_policies.append(weakref.ref(self))   # ... and env.close() detaches the hook before the handle is freed
 
     def get_profile(self):

@@ -172,6 +172,14 @@ def train(env_name="CrowdSimVarNum-v0", num_processes=4096, num_steps=30, num_up
     # arguments.py:189, :206: use_self_attn, and sort_humans -- by default whatever the config's args say (it also decides the simulator's row order)
     if sort_humans is None:
         sort_humans = bool(getattr(getattr(config, "args", None), "sort_humans", True))
+    # the simulator's row order follows config.args.sort_humans (config.to_env_config): the policy must read the observation the same way, and the
+    # unsorted mode masks by `visible_masks`, which CrowdSimPred-v0's observation does not have (crowd_sim_pred.py:36-48) -- refuse both here,
+    # before anything is allocated, rather than with a KeyError in the middle of the first rollout
+    cfg_sort = bool(getattr(getattr(config, "args", None), "sort_humans", True))
+    if bool(sort_humans) != cfg_sort:
+        raise ValueError("train(sort_humans=%s) disagrees with config.args.sort_humans=%s, which decides the simulator's row order" % (sort_humans, cfg_sort))
+    if not sort_humans and "visible_masks" not in envs.observation_space.spaces:
+        raise ValueError("sort_humans=False needs the `visible_masks` observation, which %s does not provide" % env_name)
     base_kwargs = dict(env_name=env_name, num_processes=num_processes, num_mini_batch=num_mini_batch, seq_length=num_steps, use_self_attn=use_self_attn,
                        sort_humans=sort_humans)
     actor_critic = Policy(envs.observation_space.spaces, envs.action_space, base_kwargs=base_kwargs, base="selfAttn_merge_srnn").to(device)

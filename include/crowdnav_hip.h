@@ -137,7 +137,9 @@ typedef struct {
                         * write beside the observation and cn_policy_act reads with it -- the row offsets of the compacted (env, human) rows
                         * and a packing of the envs into equally filled tiles for the fused human-human kernel (csrc/row_plan.h).  Valid only
                         * together with the observation it was written with.  Not part of the reference's observation: without it (NULL, or
-                        * a config whose step does not build one) the policy derives the same row offsets itself and walks the envs in order. */
+                        * a config whose step does not build one) the policy derives the same row offsets itself and walks the envs in order.
+                        * The buffer needs NO initialisation (any content, e.g. a fresh hipMalloc): every reset / step either writes a complete
+                        * plan or clears word 0, and the builders' cross-workgroup counter lives in the batch's own memory. */
 } cn_obs;
 
 typedef struct cn_env_batch cn_env_batch;

@@ -117,3 +117,24 @@ def test_no_plan_is_said_in_the_header():
     env.load_state_dict(env.state_dict())
     assert int(env.row_plan[0]) == 0
     env.close()
+
+
+@pytest.mark.parametrize("E", [512, 1024, 2048, 4096])
+def test_plan_buffer_of_arbitrary_content_is_filled_correctly(E):
+    """The C ABI does not ask for a zeroed cn_obs.row_plan: a caller's hipMalloc'd buffer holds anything.  The grouped builder (several
+    wavefronts at >= 1024 envs) keeps its arrival counter in the library's own memory, so a 0xFF-filled buffer -- header word 7 included --
+    gets a complete, valid plan on every step (round 5 counted arrivals in header word 7 and relied on the binding's torch.zeros)."""
+    from crowdnav_prediction_attngraph_amd import _abi as A
+    from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch
+    H = 20
+    env = HipEnvBatch(A.default_env_config(human_num=H, nenv=E), E, 425)
+    env.row_plan.fill_(-1)                      # 0xFFFFFFFF everywhere
+    obs = env.reset()
+    _check_plan(env.row_plan, obs["detected_human_num"].view(E).cpu().numpy(), E, H)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for t in range(12):
+        if t % 4 == 0:
+            env.row_plan.fill_(-1)
+        obs = env.step(torch.randn(E, 2, device="cuda", generator=g))[0]
+        _check_plan(env.row_plan, obs["detected_human_num"].view(E).cpu().numpy(), E, H)
+    env.close()
