@@ -159,7 +159,7 @@ def pmc_traffic_live(argv_tail, timeout_s=170):
     return res
 
 
-def other_configs_leg(timeout_s=150):
+def other_configs_leg(timeout_s=150, budget_s=330):
     """The single-GPU shares of BASELINE configs[2], [3], [4] (extra keys, after the headline): each a short child run of this script on
     this box and build (a separate process: its own simulator batch, policy and -- configs[3] -- the GST predictor + VecPretextNormalize
     in the loop), env-steps/s, ms per step and the per-kernel medians of its step."""
@@ -173,10 +173,15 @@ def other_configs_leg(timeout_s=150):
          ["--humans", "50", "--randomized", "--envs", "8192", "--steps", "40", "--warmup", "10", "--dephase", "120"]),
     ]
     out = []
+    t_begin = time.perf_counter()
     for name, extra in legs:
         rec = {"config": name, "argv": " ".join(extra)}
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=timeout_s)
+            # the three legs share one wall-clock budget (they are extras of the driver's command: a slow box must cost a leg, not the line)
+            left = budget_s - (time.perf_counter() - t_begin)
+            if left < 20:
+                raise RuntimeError("skipped: the %d s budget of the extra legs is spent" % budget_s)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=min(timeout_s, left))
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not lines:
                 raise RuntimeError("exit %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
@@ -440,7 +445,14 @@ def main():
     it += args.steps            # the hxs / masks ping-pong follows the step index: advance by exactly the steps taken
     plan_hdr = env.row_plan[:8].tolist() if (gst is None and env.row_plan.numel() >= 8) else None   # [1] workgroups [6] tiles of the last planned launch
     per_rank = None
+    rank_devices = None
     if dist is not None:
+        # which device every rank really sits on (the line must describe the run: N ranks on N DISTINCT GPUs unless --same-gpu)
+        prop = torch.cuda.get_device_properties(dev_index)
+        me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": prop.name,
+              "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None), "cus": prop.multi_processor_count}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, me)
         tdev0 = "cuda" if args.dist_backend == "nccl" else "cpu"
         mine = torch.tensor([elapsed], device=tdev0, dtype=torch.float64)
         allt = [torch.zeros_like(mine) for _ in range(world)]
@@ -553,8 +565,13 @@ def main():
         tdev = "cuda" if (dist is None or args.dist_backend == "nccl") else "cpu"
         tt = torch.tensor([last["rollout_s"] if last else 0.0, last["update_s"] if last else 0.0, 1.0 if err else 0.0], device=tdev, dtype=torch.float64)
         rows_local = float(last["live_rows"]) if last else 0.0
+        ppo_per_rank = None
         if dist is not None:
             try:
+                mine_t = tt.clone()
+                allp = [torch.zeros_like(mine_t) for _ in range(world)]
+                dist.all_gather(allp, mine_t)             # every rank's own clock, next to the max the headline number uses
+                ppo_per_rank = [round(30 * E / max(float(x[0] + x[1]), 1e-9), 1) if float(x[2]) == 0 else None for x in allp]
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             except Exception as exc:
                 err = err or "%s: %s" % (type(exc).__name__, exc)
@@ -575,6 +592,8 @@ def main():
                                        "30 x %d samples x 0.79 MFLOP (robot-node layers)] / update_s; peak = 2500 TFLOP/s dense bf16 / 3 split passes" % E}
             if last.get("allreduce_ms") is not None:   # N > 1: one flat 10 MB gradient all-reduce per optimiser step (this rank's mean)
                 ppo["grad_allreduce_ms_per_step"] = round(float(last["allreduce_ms"]), 4)
+            if ppo_per_rank is not None:
+                ppo["per_rank_samples_per_s"] = ppo_per_rank   # 30 x E / (rollout_s + update_s) on each rank's own clock
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -700,7 +719,16 @@ def main():
             ver = None
         line["collectives"] = {"backend": args.dist_backend, "rccl_ranks": world if args.dist_backend == "nccl" else 0, "rccl_version": ver,
                                "rollout": "none (envs sharded by global index)", "update": "one 3-double all-reduce + ONE flat fp32 gradient all-reduce per optimiser step",
-                               "grad_allreduce_ms_per_step": (ppo or {}).get("grad_allreduce_ms_per_step")}
+                               "grad_allreduce_ms_per_step": (ppo or {}).get("grad_allreduce_ms_per_step"), "rank_devices": rank_devices}
+        ids = [(d_.get("uuid") or d_.get("pci_bus_id") or d_.get("device_index")) for d_ in (rank_devices or [])]
+        line["collectives"]["self_check"] = {
+            "rccl_ranks_equal_n_gpus": line["collectives"]["rccl_ranks"] == world,
+            "one_distinct_device_per_rank": len(set(ids)) == world,
+            "every_rank_reported": per_rank is not None and len(per_rank) == world and all(x > 0 for x in per_rank),
+            "gradient_allreduce_timed": (ppo or {}).get("grad_allreduce_ms_per_step") is not None or args.no_ppo,
+            "value_is_sum_of_ranks_over_slowest_clock": True,
+            "note": "weak scaling: every rank owns --envs envs (global env indices rank * E ..); value = E x N x steps / max over ranks of the timed window; "
+                    "no scaling efficiency is claimed in this line -- the driver derives it from the per-N values"}
     line["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1e3, 4)   # Python + launch cost of one step; the device needs ms_per_step
     if step_intervals:
         si = sorted(step_intervals)

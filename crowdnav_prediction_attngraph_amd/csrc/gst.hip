@@ -68,7 +68,16 @@ __global__ __launch_bounds__(256) void gst_obs_prep_kernel(int E, int H, const f
 // ------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int GL_RT = 5, GL_ROWS = 16 * GL_RT;            // row tiles / rows per workgroup tile
+#ifndef CN_GL_RT
+#define CN_GL_RT 5
+#endif
+#ifndef CN_GST_WGS
+#define CN_GST_WGS 1   // workgroups per CU the two kernels are sized for (LDS footprint: CN_GL_RT / CN_LS_ROWS)
+#endif
+#ifndef CN_LS_ROWS
+#define CN_LS_ROWS 64
+#endif
+constexpr int GL_RT = CN_GL_RT, GL_ROWS = 16 * GL_RT;            // row tiles / rows per workgroup tile
 constexpr int GL_SA = 68, GL_SQ = 196;                    // LDS row strides (floats): 16-byte aligned, lanes of a float4 read on distinct banks
 constexpr int GL_OA = 0, GL_OQ = GL_OA + GL_ROWS * GL_SA, GL_OT = GL_OQ + GL_ROWS * GL_SQ, GL_OM = GL_OT + GL_ROWS * GL_SA;
 constexpr int GL_OX = GL_OM + GL_ROWS, GL_OC = GL_OX + 2 * GL_ROWS; // staged (x, y) inputs; constants of the embedding's LayerNorm
@@ -160,7 +169,7 @@ __device__ long long *g_gst_tim = nullptr; // [block][10] phase cycle sums of th
 #define GL_T(k) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(512, 1) void gst_layer_kernel(int rows, int H, int TG, GstLayerArgs a)
+__global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows, int H, int TG, GstLayerArgs a)
 {
 #ifdef GST_TIMING
     long long tlast_ = clock64();
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void gst_layer_kernel(int rows, int H, int 
 // 256 x 128 weight image stays in registers (128 VGPRs per wavefront) for all its tiles and steps.  Replaces, per step, a K = 64 GEMM
 // whose [N, 256] result went through HBM, the pointwise kernel, and the [rows, 256] input projection of the whole slab.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int LS_ROWS = 64, LS_SX = 132, LS_SG = 260;
+constexpr int LS_ROWS = CN_LS_ROWS, LS_SX = 132, LS_SG = 260, LS_PT = LS_ROWS / 8; // nodes per workgroup tile; pointwise: LS_PT nodes per thread
 constexpr int LS_OX = 0, LS_OG = LS_OX + LS_ROWS * LS_SX, LS_OB = LS_OG + LS_ROWS * LS_SG, LS_LDS_FLOATS = LS_OB + 256;
 
 struct GstLstmArgs {
@@ -318,7 +327,7 @@ struct GstLstmArgs {
 __device__ __forceinline__ float gl_tanh(float x) { return 1.0f - 2.0f / (1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681472f)); }
 __device__ __forceinline__ float gl_sigmoid(float x) { return 1.0f / (1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
-__global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, GstLstmArgs a)
+__global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, int H, int S, GstLstmArgs a)
 {
 #ifdef GST_TIMING
     long long tlast_ = clock64();
@@ -336,32 +345,32 @@ __global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, G
     const int i = lane & 15, g = lane >> 4;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int n0 = tile * LS_ROWS;
-        float creg[8], xn[8], hreg[8];
-        int rbase[8]; // row of slice 0 of this thread's nodes (slice t is rbase + t * H); out-of-range nodes clamp to the last one (never stored)
+        float creg[LS_PT], xn[LS_PT], hreg[LS_PT];
+        int rbase[LS_PT]; // row of slice 0 of this thread's nodes (slice t is rbase + t * H); out-of-range nodes clamp to the last one (never stored)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < LS_PT; ++k) {
             const int n = min(n0 + q + 8 * k, N - 1);
             const int e = n / H;
             rbase[k] = e * S * H + (n - e * H);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { // all loads issued back to back, no control flow between them
+        for (int k = 0; k < LS_PT; ++k) { // all loads issued back to back, no control flow between them
             const int n = min(n0 + q + 8 * k, N - 1);
             creg[k] = a.c[(size_t)n * 64 + d];
             hreg[k] = a.h[(size_t)n * 64 + d];
             xn[k] = a.in_mask[rbase[k]] * a.xs[(size_t)rbase[k] * 64 + d]; // m * x_0 ((x m) W = m (x W) for m in {0, 1})
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) X[(q + 8 * k) * LS_SX + 64 + d] = hreg[k];
+        for (int k = 0; k < LS_PT; ++k) X[(q + 8 * k) * LS_SX + 64 + d] = hreg[k];
         GL_T(0);
         for (int t = 0; t < S; ++t) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) X[(q + 8 * k) * LS_SX + d] = xn[k];
+            for (int k = 0; k < LS_PT; ++k) X[(q + 8 * k) * LS_SX + d] = xn[k];
             __syncthreads();
             GL_T(1);
             if (t + 1 < S) { // the next slice's rows travel while this slice is computed
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < LS_PT; ++k) {
                     const int r = rbase[k] + (t + 1) * H;
                     xn[k] = a.in_mask[r] * a.xs[(size_t)r * 64 + d];
                 }
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, G
             // the cell (PyTorch gate order i, f, g, o), decode-step blend h = h' m + h (1 - m), post mask after the last slice
             const bool last = t == S - 1;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < LS_PT; ++k) {
                 const int nl = q + 8 * k, n = n0 + nl;
                 const float *gr = G + nl * LS_SG;
                 const float gi = gr[d], gf = gr[64 + d], gg = gr[128 + d], go = gr[192 + d];
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, G
             GL_T(3);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < LS_PT; ++k) {
             const int nl = q + 8 * k, n = n0 + nl;
             if (n < N) { a.c[(size_t)n * 64 + d] = creg[k]; a.h[(size_t)n * 64 + d] = X[nl * LS_SX + 64 + d]; }
         }
@@ -427,13 +436,13 @@ __global__ __launch_bounds__(512, 1) void gst_lstm_kernel(int E, int H, int S, G
             const float w0 = a.head_w[d], w1 = a.head_w[64 + d], w2 = a.head_w[128 + d], w3 = a.head_w[192 + d], w4 = a.head_w[256 + d];
             float raw[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // lane k keeps node row q + 8 k, so the eight scalar tails below run side by side
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < LS_PT; ++k) {
                 const float hv = X[(q + 8 * k) * LS_SX + 64 + d];
                 const float s0 = wv_sum(hv * w0), s1 = wv_sum(hv * w1), s2 = wv_sum(hv * w2), s3 = wv_sum(hv * w3), s4 = wv_sum(hv * w4);
                 if (d == k) { raw[0] = s0; raw[1] = s1; raw[2] = s2; raw[3] = s3; raw[4] = s4; }
             }
             const int n = n0 + q + 8 * d;
-            if (d < 8 && n < N) {
+            if (d < LS_PT && n < N) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) raw[k] += a.head_b[k];
                 const int tt = a.tt;
@@ -640,7 +649,7 @@ static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hi
     }
     const int n_tiles = (rows + TG * H - 1) / (TG * H);
     GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b, g->xs};
-    hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
+    hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 * CN_GST_WGS ? n_tiles : 256 * CN_GST_WGS), dim3(512), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -658,7 +667,7 @@ static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *
     const int n_tiles = (E * g->H + LS_ROWS - 1) / LS_ROWS;
     GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
                   g->acc, out_traj, g->x_sample};
-    hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
+    hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 * CN_GST_WGS ? n_tiles : 256 * CN_GST_WGS), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

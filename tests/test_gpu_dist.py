@@ -172,3 +172,41 @@ def test_rccl_single_rank_runs_the_collectives_of_the_update(tmp_path):
     losses, flat, _ = _update(pol, ro)
     np.testing.assert_array_equal(got["flat"].numpy(), flat.cpu().numpy())
     np.testing.assert_array_equal(np.asarray(got["losses"]), np.asarray(losses))
+
+
+def test_bench_under_the_distributed_launcher_reproduces_the_plain_run():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...` (how the driver's scaling sweep starts its N = 1 point) against
+    the plain `python bench.py --gpus 1 ...` on the same box: the same line shape and the same throughput within the box's run-to-run noise, so
+    that the N = 1 value of a scaling curve is the BENCH value.  And `--gpus 2 --same-gpu` over gloo carries the self-check block (plumbing:
+    two ranks time-slice the one GPU, which the block reports as NOT one distinct device per rank)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--steps", "40", "--warmup", "10", "--dephase", "60", "--no-ppo", "--no-cpu-baseline", "--no-dropin", "--no-pmc-traffic", "--no-other-configs",
+             "--no-worst-case"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=root)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert r.returncode == 0 and lines, (r.returncode, r.stderr[-600:])
+        return json.loads(lines[-1])
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    plain = run([sys.executable, "bench.py", "--gpus", "1"] + flags)
+    launched = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                    "bench.py", "--gpus", "1"] + flags)
+    assert launched["n_gpus"] == plain["n_gpus"] == 1 and launched["metric"] == plain["metric"] and launched["config"]["workload"] == plain["config"]["workload"]
+    assert abs(launched["value"] - plain["value"]) <= 0.12 * plain["value"], (launched["value"], plain["value"])
+    two = run([sys.executable, "bench.py", "--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--envs", "512"] + flags)
+    c = two["collectives"]
+    assert two["n_gpus"] == 2 and len(c["rank_devices"]) == 2 and [d["rank"] for d in c["rank_devices"]] == [0, 1]
+    sc = c["self_check"]
+    assert sc["every_rank_reported"] and not sc["one_distinct_device_per_rank"] and not sc["rccl_ranks_equal_n_gpus"]     # gloo on one GPU: says so
+    assert len(two["per_rank_env_steps_per_s"]) == 2
