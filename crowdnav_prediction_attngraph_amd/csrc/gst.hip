@@ -71,11 +71,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef CN_GL_RT
 #define CN_GL_RT 5
 #endif
+#ifndef CN_GL_WAVES
+#define CN_GL_WAVES 8   // wavefronts per workgroup of the encoder-layer kernel: 8 = two teams of four on alternate row tiles (one workgroup per CU);
+#endif                  // 4 = one team, and with CN_GL_RT = 3 (48 rows, 64 KB of LDS) TWO independent workgroups per CU whose phases drift apart
 #ifndef CN_GST_WGS
-#define CN_GST_WGS 1   // workgroups per CU the two kernels are sized for (LDS footprint: CN_GL_RT / CN_LS_ROWS)
+#define CN_GST_WGS 1   // workgroups per CU the LSTM kernel is sized for
 #endif
+constexpr int GL_NW = CN_GL_WAVES, GL_TEAMS = GL_NW / 4, GL_THREADS = 64 * GL_NW, GL_WGS = GL_NW == 4 ? 2 : 1;
 #ifndef CN_LS_ROWS
-#define CN_LS_ROWS 64
+#define CN_LS_ROWS 32  // nodes per LSTM tile: 1280 tiles at 2048 x 20 nodes spread better over 256 workgroups than 640 (round 6 A/B: 0.853 -> 0.825 ms per step)
 #endif
 constexpr int GL_RT = CN_GL_RT, GL_ROWS = 16 * GL_RT;            // row tiles / rows per workgroup tile
 constexpr int GL_SA = 68, GL_SQ = 196;                    // LDS row strides (floats): 16-byte aligned, lanes of a float4 read on distinct banks
@@ -126,8 +130,8 @@ __device__ __forceinline__ void gl_stage(const GlW<K, NFB> &w, int fb_first, int
     for (int j = 0; j < NFB; ++j) bv[j] = bias ? *reinterpret_cast<const f32x4 *>(bias + (fb_first + j * fb_step) * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     // the workgroup's two wavefront teams (4 wavefronts each, same feature blocks) take the even / the odd row tiles
 #pragma unroll
-    for (int rt2 = 0; rt2 < (GL_RT + 1) / 2; ++rt2) {
-        const int rt = 2 * rt2 + rt_first;
+    for (int rt2 = 0; rt2 < (GL_RT + GL_TEAMS - 1) / GL_TEAMS; ++rt2) {
+        const int rt = GL_TEAMS * rt2 + rt_first;
         if (16 * rt >= nrows) break; // wave-uniform
         f32x4 acc[NFB];
 #pragma unroll
@@ -169,7 +173,7 @@ __device__ long long *g_gst_tim = nullptr; // [block][10] phase cycle sums of th
 #define GL_T(k) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows, int H, int TG, GstLayerArgs a)
+__global__ __launch_bounds__(GL_THREADS, 2) void gst_layer_kernel(int rows, int H, int TG, GstLayerArgs a)
 {
 #ifdef GST_TIMING
     long long tlast_ = clock64();
@@ -191,10 +195,7 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows
         if (lane == 0) { EC[0] = m0; EC[1] = m1; EC[2] = mb; EC[3] = c00; EC[4] = c11; EC[5] = cbb; EC[6] = c01; EC[7] = c0b; EC[8] = c1b; }
     }
     float *BI = lds_f + GL_OB;
-    if (tid < 192) BI[tid] = a.in_b[tid];
-    else if (tid < 256) BI[tid] = a.out_b[tid - 192];
-    else if (tid < 384) BI[tid] = a.l1_b[tid - 256];
-    else if (tid < 448) BI[tid] = a.l2_b[tid - 384];
+    for (int t = tid; t < 448; t += GL_THREADS) BI[t] = t < 192 ? a.in_b[t] : (t < 256 ? a.out_b[t - 192] : (t < 384 ? a.l1_b[t - 256] : a.l2_b[t - 384]));
     const float ew0 = a.emb_w[2 * lane], ew1 = a.emb_w[2 * lane + 1], eb = a.emb_b[lane], ng = a.n_w[lane], nb = a.n_b[lane];
     const float n1g = a.n1_w[lane], n1b = a.n1_b[lane];
     GlW<64, 3> w_in;
@@ -204,14 +205,14 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows
         const int nrows = min(tile_rows, rows - r0);   // whole groups (rows is a multiple of H)
         const int nrows16 = (nrows + 15) & ~15;
         // ---- stage the tile's inputs (coalesced), then node_embedding (2 -> 64) + LayerNorm(norm_node) * mask -> A0 (padding rows = 0) ----
-        for (int r = tid; r < nrows16; r += 512) {
+        for (int r = tid; r < nrows16; r += GL_THREADS) {
             const bool live = r < nrows;
             XY[2 * r] = live ? a.x2[2 * (size_t)(r0 + r)] : 0.0f;
             XY[2 * r + 1] = live ? a.x2[2 * (size_t)(r0 + r) + 1] : 0.0f;
             MSK[r] = live ? a.mask[r0 + r] : 0.0f;
         }
         __syncthreads();
-        for (int r = wave8; r < nrows16; r += 8) {
+        for (int r = wave8; r < nrows16; r += GL_NW) {
             const float x = XY[2 * r], y = XY[2 * r + 1], m = MSK[r];
             const float mean = EC[0] * x + EC[1] * y + EC[2];
             const float var = EC[3] * x * x + EC[4] * y * y + EC[5] + 2.0f * (EC[6] * x * y + EC[7] * x + EC[8] * y);
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows
         // ---- attention core per group (mha.py:236-242): wavefront w takes groups w, w + 4, ...; lanes enumerate (node, head) ----
         {
             const float scale = 0.35355339059327373f; // 8^-0.5
-            for (int pq = tid; pq < nrows * 8; pq += 512) { // (row, head) pairs of the whole tile over all threads
+            for (int pq = tid; pq < nrows * 8; pq += GL_THREADS) { // (row, head) pairs of the whole tile over all threads
                 const int row = pq >> 3, hd = pq & 7;
                 const int gq = row / H;
                 const float *qb = QKV + gq * H * GL_SQ;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows
             }
         }
         // padding rows of ATT (read by the next product's fragments) must be finite
-        for (int r = nrows + wave8; r < nrows16; r += 8) ATT[r * GL_SA + lane] = 0.0f;
+        for (int r = nrows + wave8; r < nrows16; r += GL_NW) ATT[r * GL_SA + lane] = 0.0f;
         __syncthreads();
         GL_T(2);
         // ---- out_proj + residual: x1 = x0 + W_out att + b_out, in place over x0 ----
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_layer_kernel(int rows
         GlW<128, 1> w_l2;
         gl_load<128, 1>(w_l2, a.f_l2, wave, 4, lane);
         // ---- LayerNorm(norm1_node): x2 -> ATT (the attention output is dead) ----
-        for (int r = wave8; r < nrows16; r += 8) {
+        for (int r = wave8; r < nrows16; r += GL_NW) {
             const float v = A0[r * GL_SA + lane];
             const float mean = wv_sum(v) * (1.0f / 64.0f);
             const float d = v - mean;
@@ -319,6 +320,7 @@ struct GstLstmArgs {
     // decode head of the step that follows this LSTM pass (hidden2pos + raw2gaussian + the running sums of
     // crowd_nav_interface_parallel.py:99-113), tt = decode step index; head_w == null: no head
     int tt;
+    int zero_state;                 // 1: h = c = 0 on entry (the observation pass) instead of two memsets of the state in front of the launch
     const float *head_w, *head_b, *lm_fp, *last_pos;
     float *acc, *out_traj, *x_sample;
 };
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, in
 #pragma unroll
         for (int k = 0; k < LS_PT; ++k) { // all loads issued back to back, no control flow between them
             const int n = min(n0 + q + 8 * k, N - 1);
-            creg[k] = a.c[(size_t)n * 64 + d];
-            hreg[k] = a.h[(size_t)n * 64 + d];
+            creg[k] = a.zero_state ? 0.0f : a.c[(size_t)n * 64 + d];
+            hreg[k] = a.zero_state ? 0.0f : a.h[(size_t)n * 64 + d];
             xn[k] = a.in_mask[rbase[k]] * a.xs[(size_t)rbase[k] * 64 + d]; // m * x_0 ((x m) W = m (x W) for m in {0, 1})
         }
 #pragma unroll
@@ -649,13 +651,14 @@ static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hi
     }
     const int n_tiles = (rows + TG * H - 1) / (TG * H);
     GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b, g->xs};
-    hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 * CN_GST_WGS ? n_tiles : 256 * CN_GST_WGS), dim3(512), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
+    hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 * GL_WGS ? n_tiles : 256 * GL_WGS), dim3(GL_THREADS), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
 
 // the LSTM over S slices of the encoded rows g->xs (S = 5: the observation period from h = c = 0 set by the caller; S = 1: one decode step)
-static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *blend_mask, const float *post_mask, int tt, float *out_traj, hipStream_t st)
+static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *blend_mask, const float *post_mask, int tt, float *out_traj, hipStream_t st,
+                    int zero_state = 0)
 {
     static thread_local int attr_dev = -1;
     int dev = 0;
@@ -665,7 +668,7 @@ static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *
         attr_dev = dev;
     }
     const int n_tiles = (E * g->H + LS_ROWS - 1) / LS_ROWS;
-    GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
+    GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, zero_state, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
                   g->acc, out_traj, g->x_sample};
     hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 * CN_GST_WGS ? n_tiles : 256 * CN_GST_WGS), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
     CN_CHECK_LAUNCH();
@@ -683,9 +686,7 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
     CN_CHECK_LAUNCH();
     // observation period: spatial encoding of all 5 slices at once, then the LSTM over time
     if ((rc = gst_layer(g, R, g->rel, g->m_rel, st))) return rc;
-    CN_HIP(hipMemsetAsync(g->h, 0, (size_t)N * 64 * sizeof(float), st));
-    CN_HIP(hipMemsetAsync(g->c, 0, (size_t)N * 64 * sizeof(float), st));
-    if ((rc = gst_lstm(g, E, GT, g->m_rel, nullptr, g->lm_fp, 0, out_traj, st))) return rc; // + the head of decode step 0
+    if ((rc = gst_lstm(g, E, GT, g->m_rel, nullptr, g->lm_fp, 0, out_traj, st, 1))) return rc; // from h = c = 0; + the head of decode step 0
     // prediction period (recursive decoding on the mean)
     for (int tt = 1; tt < GP; ++tt) {
         if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st))) return rc;
