@@ -790,13 +790,20 @@ __device__ __forceinline__ RowBuf make_row_buf(float *base, int r0, int nrows, i
     rb.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(base + (size_t)r0 * width), 0, nrows * width * 4, 0x00020000);
     return rb;
 }
+// Stores of the TRAINING forward's saved activations (e0 / x / qkv / attn: 11.8 KB per row, 4.8 GB per launch at 405 k rows).  With the
+// default cache policy they allocate in the XCD's 4 MB L2 and evict the 3.9 MB weight image that every tile streams from there: round 6's
+// counters show 2.5 GB of fabric reads per training launch against 19 MB in the rollout (weights resident).  nt (aux bit 1) = streaming
+// stores that do not displace the weights.  HH_TRAIN_STORE_AUX=0 restores the default policy (A/B).
+#ifndef HH_TRAIN_STORE_AUX
+#define HH_TRAIN_STORE_AUX 2
+#endif
 __device__ __forceinline__ void st4(const RowBuf &b, int float_off, f32x4 v)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.rs, float_off * 4, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b.rs, float_off * 4, 0, HH_TRAIN_STORE_AUX);
 }
 __device__ __forceinline__ void st1(const RowBuf &b, int float_off, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.rs, float_off * 4, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b.rs, float_off * 4, 0, HH_TRAIN_STORE_AUX);
 }
 
 // Barrier among the four wavefronts of ONE team (gfx950 has a single s_barrier per workgroup, which would couple the teams): a
