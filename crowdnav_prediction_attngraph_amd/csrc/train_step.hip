@@ -96,14 +96,24 @@ __global__ __launch_bounds__(1024) void tr_scan_kernel(int n, int H, int D, cons
     __syncthreads(); // everybody has read the wave sums
     part[tid] = off;
     __syncthreads();
-    // rows of the wave's 64 samples: lanes walk the nd * D floats of one sample at a time
-    for (int q = 0; q < 64; ++q) {
-        const int sq = first + wave * 64 + q;
-        if (sq >= n) break;
-        const int cnt = nd[sq] * D;
-        const float *src = se + (size_t)sq * H * D;
-        float *dst = x + (size_t)part[wave * 64 + q] * D;
-        for (int i = lane; i < cnt; i += 64) dst[i] = src[i];
+    // rows of the wave's 64 samples = ONE contiguous range of x_live: lanes take its floats round robin and find each float's sample by
+    // bisection over the wave's 64 offsets in the LDS (independent iterations: a sample-by-sample loop was a chain of 64 load -> store
+    // round trips, 40 of the kernel's 52 us)
+    const int w0 = wave * 64;
+    const int out0 = part[w0];
+    const int last = min(first + w0 + 63, n - 1);
+    if (first + w0 >= n) return;
+    const int out1 = part[last - first] + nd[last];
+    for (int idx = out0 * D + lane; idx < out1 * D; idx += 64) {
+        const int row = idx / D; // global compacted row
+        int lo = 0, hi = last - first - w0; // sample index inside the wave's 64: the last q with part[w0 + q] <= row
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (part[w0 + mid] <= row) lo = mid; else hi = mid - 1;
+        }
+        const int sq = first + w0 + lo;
+        x[idx] = se[(size_t)sq * H * D + (idx - part[w0 + lo] * D)];
     }
 }
 
