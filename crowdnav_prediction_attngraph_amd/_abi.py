@@ -142,6 +142,7 @@ ABI_SYMBOLS = [
     "cn_gst_wrapper_reset", "cn_gst_wrapper_step", "cn_gst_wrapper_set_interval", "cn_gst_wrapper_history_len", "cn_gst_wrapper_save", "cn_gst_wrapper_load", "cn_gae", "cn_adv_stats", "cn_adv_normalize", "cn_episode_stats_update",
     "cn_ppo_loss_workspace_doubles", "cn_ppo_loss_fwd", "cn_ppo_loss_bwd", "cn_adam_workspace_doubles", "cn_adam_clip_step",
     "cn_ppo_minibatch_workspace_bytes", "cn_ppo_row_totals", "cn_ppo_minibatch_step",
+    "cn_gst_train_workspace_bytes", "cn_gst_train_step",
 ]
 
 _lib = None
@@ -255,6 +256,9 @@ def lib():
         L.cn_ppo_loss_fwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp]
         L.cn_ppo_loss_bwd.argtypes = [i64, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp]
         L.cn_adam_clip_step.argtypes = [i64, vp, vp, vp, vp, f64, f64, f64, f64, f64, f64, i64, vp, vp, vp]
+        L.cn_gst_train_workspace_bytes.restype = C.c_int64
+        L.cn_gst_train_workspace_bytes.argtypes = [i32, i32]
+        L.cn_gst_train_step.argtypes = [i32, i32, vp, vp, vp, C.POINTER(GstWeights), C.POINTER(GstWeights), f32, C.c_uint64, vp, i64, vp, vp, vp]
         L.cn_ppo_minibatch_workspace_bytes.restype = C.c_int64
         L.cn_ppo_minibatch_workspace_bytes.argtypes = [i32, i32, i32, i32, i64]
         L.cn_ppo_row_totals.argtypes = [i32, i32, i32, vp, vp, vp]

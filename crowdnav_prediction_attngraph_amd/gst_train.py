@@ -3,9 +3,13 @@ gst_updated/src/mgnn/trajectories.py (dataset), gst_updated/src/gumbel_social_tr
 loss, :62-112, :271-455) and gst_updated/scripts/experiments/train.py (loop), for the shipped hyper-parameters (SURVEY.md 8a-G3:
 embedding 64, 8 heads, 1 layer, spatial_num_heads_edges = 0, no ghost, faster_lstm, obs 5 / pred 5, recursive decoding).
 
-Dense torch ops on whatever device the model lives on (the MI355X through torch-ROCm, or the CPU in the tests): a sequence is a few
-dozen pedestrians x 10 steps, there is nothing here for a hand-written kernel.  What IS accelerated is the producer of the data
-(collect.py: thousands of simulated crowds per GPU).
+Two execution paths of the training step (train.py:121-146: forward, negative log-likelihood, backward, clip, Adam):
+  * on a GPU (backend 'hip', the default there): HipGstTrainer -- cn_gst_train_step (csrc/gst_train.hip: forward + loss + hand-derived
+    reverse pass, one workgroup per sequence, the reference's four dropout sites) and cn_adam_clip_step, through the C ABI;
+  * the torch-op graph below under autograd (backend 'torch'): what CPU tensors use (unit tests, pinned to the reference's numbers) and the
+    independent cross-check of the kernels (tests/test_gpu_gst_train.py holds the two against each other).
+The dataset, the rotation augmentation, the learning-rate schedule, evaluation and the checkpoint format are host code either way, and the
+producer of the data is the batched simulator (collect.py: thousands of simulated crowds per GPU).
 
 Scope note: the reference trains on `<dataset>_dset_<split>_batch_trajectories.pt` files produced by scripts/data/create_*datasets*.py,
 which are NOT part of the reference checkout (only the shell wrappers that call them are).  This module therefore feeds the loop with
@@ -252,6 +256,80 @@ def sequence_loss(model, item, device, p_drop=0.1):
     return prob_loss.sum() / elm.sum(), gp, xs, info, v_pred_gt
 
 
+class HipGstTrainer:
+    """The training step of the predictor on the MI355X through the C ABI: forward + negative log-likelihood + backward as ONE boundary call
+    (cn_gst_train_step, csrc/gst_train.hip: one workgroup per sequence, hand-derived reverse pass, the reference's four dropout sites with the
+    library's own counter-based masks) and gradient-norm clip + Adam as another (cn_adam_clip_step over one flat bucket).  Replaces, per
+    optimiser step, train.py:121-146: model(...) -> negative_log_likelihood_full_partial -> loss.backward() -> clip_grad_norm_ -> optimizer.step().
+    The model's parameters become views of the flat bucket, so state_dict() / checkpoints are those of the torch path."""
+
+    def __init__(self, model, lr=1e-3, clip_grad=10.0, betas=(0.9, 0.999), eps=1e-8, seed=1000, optimizer=None):
+        from . import _abi as A
+        self.A = A
+        self.model = model
+        params = [dict(model.named_parameters())[k] for _, k in A.GST_WEIGHT_KEYS]
+        if not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            raise A.CnError("HipGstTrainer: the predictor must live on the GPU in float32 (there is no CPU fallback of the HIP path)")
+        dev = params[0].device
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)         # every tensor 16-byte aligned inside the bucket
+        self.flat = {k: torch.zeros(n, dtype=torch.float32, device=dev) for k in ("p", "g", "m", "v")}
+        self.w, self.g = A.GstWeights(), A.GstWeights()
+        off = 0
+        for (field, _), p in zip(A.GST_WEIGHT_KEYS, params):
+            k = p.numel()
+            pv, gv = self.flat["p"][off:off + k].view_as(p), self.flat["g"][off:off + k].view_as(p)
+            pv.copy_(p.data)
+            p.data = pv
+            p.grad = gv
+            setattr(self.w, field, pv.data_ptr())
+            setattr(self.g, field, gv.data_ptr())
+            if optimizer is not None:      # the torch optimiser object stays the owner of the moments (its state_dict() goes into the checkpoints)
+                optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.flat["m"][off:off + k].view_as(p), "exp_avg_sq": self.flat["v"][off:off + k].view_as(p)}
+            off += (k + 3) // 4 * 4
+        self.optimizer = optimizer
+        self.lr, self.clip_grad, self.betas, self.eps = float(lr), clip_grad, betas, float(eps)
+        self.step_no, self.seed = 0, int(seed)
+        self.adam_ws = torch.empty(A.lib().cn_adam_workspace_doubles(), dtype=torch.float64, device=dev)
+        self.ws = None
+        self.dev = dev
+
+    def loss_and_grads(self, v_obs, v_pred, loss_mask_rel, p_drop=0.1, seed=None):
+        """v_obs [B,5,N,2], v_pred [B,5,N,2], loss_mask_rel [B,N,10] (any device) -> (loss_and_count [2] on the device, gauss [B,5,N,5]: mu_x, mu_y,
+        sigma_x, sigma_y, corr); the gradients land in the flat bucket (every parameter's .grad).  Crowds of fewer than 4 pedestrians are padded
+        with absent ones."""
+        A = self.A
+        C = A.C
+        B, T, N, _ = v_obs.shape
+        if T != 5 or v_pred.shape[1] != 5 or N > 64:
+            raise A.CnError("HipGstTrainer: 5 observed + 5 predicted steps and at most 64 pedestrians per sequence (got %d + %d steps, %d pedestrians)" % (T, v_pred.shape[1], N))
+        Np = max(N, 4)
+        f = lambda t: t.to(self.dev, torch.float32)   # noqa: E731
+        vo, vp, lm = f(v_obs), f(v_pred), f(loss_mask_rel)
+        if Np != N:
+            vo = torch.nn.functional.pad(vo, (0, 0, 0, Np - N)); vp = torch.nn.functional.pad(vp, (0, 0, 0, Np - N)); lm = torch.nn.functional.pad(lm, (0, 0, 0, Np - N))
+        vo, vp, lm = vo.contiguous(), vp.contiguous(), lm.contiguous()
+        need = int(A.lib().cn_gst_train_workspace_bytes(B, Np))
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        out = torch.empty(2, device=self.dev)
+        gauss = torch.empty(B, 5, Np, 5, device=self.dev)
+        sd = self.seed + 7919 * self.step_no if seed is None else int(seed)
+        with torch.cuda.device(self.dev):
+            A.check(A.lib().cn_gst_train_step(B, Np, A.ptr(vo), A.ptr(vp), A.ptr(lm), C.byref(self.w), C.byref(self.g), float(p_drop), C.c_uint64(sd & (2 ** 64 - 1)),
+                                              C.c_void_p(self.ws.data_ptr()), int(self.ws.numel()), A.ptr(out), A.ptr(gauss), A.stream_ptr()), "cn_gst_train_step")
+        return out, gauss[:, :, :N]
+
+    def optimizer_step(self):
+        """clip_grad_norm_(parameters, clip_grad) + Adam.step() (train.py:143-146) over the flat bucket."""
+        from . import hip
+        self.step_no += 1
+        if self.optimizer is not None:
+            for st in self.optimizer.state.values():
+                st["step"] = torch.tensor(float(self.step_no))
+        hip.adam_clip_step(self.flat["p"], self.flat["g"], self.flat["m"], self.flat["v"], self.step_no, self.lr, self.betas, self.eps, self.clip_grad,
+                           workspace=self.adam_ws)
+
+
 def temperature(epoch, total_epochs, base_temp, temp_min=0.03):
     """temperature_scheduler.py (kept for the checkpoint / log; without edge heads the Gumbel temperature is never read)."""
     return max((1 - epoch / total_epochs) * (base_temp - temp_min) + temp_min, temp_min)
@@ -275,7 +353,7 @@ def evaluate(model, loader, device):
 
 
 def train(data_dir, out_dir, num_epochs=100, temp_epochs=100, lr=1e-3, clip_grad=10.0, rotation_pattern="random", save_epochs=10, init_temp=0.5,
-          random_seed=1000, device=None, num_workers=0, log=print):
+          random_seed=1000, device=None, num_workers=0, log=print, backend=None):
     """gst_updated/scripts/experiments/train.py:49-195 for the shipped configuration.  data_dir holds the text files of collect.py /
     collect_data.py; the first 80 % of every file's windows train, the rest validate (TrajectoriesDataset modes).  Writes
     <out_dir>/checkpoint/{epoch_<n>.pt, args.pickle, train_hist.pickle} in the reference's format (+ args.json / train_hist.json): the
@@ -290,6 +368,13 @@ def train(data_dir, out_dir, num_epochs=100, temp_epochs=100, lr=1e-3, clip_grad
     model = GSTPredictor().to(device)
     optimizer = torch.optim.Adam(model.parameters(), lr=lr)
     scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=max(int(temp_epochs / 4), 1), gamma=0.3)
+    # backend: 'hip' = the training step as hand-written kernels through the C ABI (HipGstTrainer; the default on a GPU), 'torch' = the op graph
+    # above under autograd (CPU tests, and the cross-check of the kernels)
+    if backend is None:
+        backend = "hip" if device.type == "cuda" else "torch"
+    if backend == "hip" and clip_grad is None:
+        raise ValueError("backend='hip' clips the gradient norm in its fused Adam step: pass a clip_grad (the reference's default is 10)")
+    hip_tr = HipGstTrainer(model, lr=lr, clip_grad=clip_grad, seed=random_seed, optimizer=optimizer) if backend == "hip" else None
     ckpt_dir = os.path.join(out_dir, "checkpoint")
     os.makedirs(ckpt_dir, exist_ok=True)
     run_args = dict(spatial="gumbel_social_transformer", temporal="faster_lstm", output_dim=5, embedding_size=64, spatial_num_heads=8,
@@ -317,6 +402,20 @@ def train(data_dir, out_dir, num_epochs=100, temp_epochs=100, lr=1e-3, clip_grad
                 theta = (torch.randint(0, 4, ()).float() / 2. * np.pi).item() if rotation_pattern == "right_angle" else (torch.rand(()) * 2. * np.pi).item()
                 item = list(item)
                 item[6], item[8] = rotate_graph(item[6], theta), rotate_graph(item[8], theta)
+            if hip_tr is not None:
+                # one boundary call: forward, loss, backward (dropout 0.1 like model.train()); then the fused clip + Adam step
+                lm_rel = item[4].to(device)
+                hip_tr.lr = optimizer.param_groups[0]["lr"]                       # the StepLR schedule below drives the fused step too
+                out, gauss = hip_tr.loss_and_grads(item[6], item[8], lm_rel, p_drop=0.1)
+                hip_tr.optimizer_step()
+                losses.append(out[0].item())
+                lm_fp = lm_rel[:, :, model.obs_len - 1]
+                xs = gauss[..., :2] * lm_fp.unsqueeze(1).unsqueeze(-1)
+                lm = (lm_rel.sum(2) == lm_rel.shape[2]).float()
+                v_pred_gt = item[8].to(device)
+                aoes.append(average_offset_error(xs, v_pred_gt, lm).cpu().numpy()); foes.append(final_offset_error(xs, v_pred_gt, lm).cpu().numpy())
+                ms.append(lm[0].cpu().numpy())
+                continue
             loss, gp, xs, info, v_pred_gt = sequence_loss(model, item, device)
             losses.append(loss.item())
             loss.backward()

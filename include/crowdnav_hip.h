@@ -511,6 +511,20 @@ int cn_gst_wrapper_load(cn_gst *g, int E, const float *traj, const uint8_t *mask
 int cn_gst_wrapper_step(cn_gst *g, int E, const cn_obs *obs, float robot_plus_human_radius, float collision_penalty, float *rewards,
                         float *spatial_edges_out, void *stream);
 
+/* ---- GST predictor TRAINING step: forward + negative log-likelihood + backward of one batch of sequences ----
+ * gst_updated/scripts/experiments/train.py:107-146 (loop body) over st_model.py:271-455 (training-time forward: 'faster_lstm', recursive decoding on
+ * the mean, sampling = False) and :62-112 (negative_log_likelihood_full_partial), shipped hyper-parameters.  One workgroup per sequence:
+ *   v_obs [B,5,N,2], v_pred [B,5,N,2]: displacements of the N pedestrians (seq_to_graph's vertices; -999 where missing),
+ *   loss_mask_rel [B,N,10]: 1 where the displacement exists (the per-step attention masks are its outer products, trajectories.py:131-133).
+ * 4 <= N <= 64 (pad a smaller crowd with absent pedestrians: mask rows of zeros).  grads: same struct as the weights, every field WRITTEN with
+ * d(loss)/d(parameter), loss = sum of the masked NLL over the batch / number of valid (step, pedestrian) pairs (train.py:131-133; B = 1 is
+ * the shipped batch size).  p_drop: the reference's dropout (0.1 while training; four sites), masks from a counter-based hash of `seed` --
+ * this library's own stream, not torch's; p_drop = 0 reproduces the reference's gradients.  loss_out [2] = loss, valid-pair count;
+ * gauss_out (optional) [B,5,N,5] = mu_x, mu_y, sigma_x, sigma_y, corr of every predicted step.  The optimiser step is cn_adam_clip_step. */
+int64_t cn_gst_train_workspace_bytes(int B, int N);
+int cn_gst_train_step(int B, int N, const float *v_obs, const float *v_pred, const float *loss_mask_rel, const cn_gst_weights *w, const cn_gst_weights *grads,
+                      float p_drop, uint64_t seed, void *workspace, int64_t workspace_bytes, float *loss_out, float *gauss_out, void *stream);
+
 /* ---- rollout math ---- */
 /* rewards [T,N], values [T+1,N], masks [T+1,N] -> returns[t][n] for t < T (row T untouched).  fp32, torch op order. */
 int cn_gae(int T, int N, const float *rewards, const float *values, const float *masks, double gamma, double lam,
