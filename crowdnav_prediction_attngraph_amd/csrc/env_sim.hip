@@ -63,6 +63,7 @@ struct EnvDev {
     uint32_t *nx_mt;    // [E][624]
     int32_t *nx_mt_pos; // [E]
     int32_t *plan_arrive; // [1] row-plan builders' arrival counter (library-owned: the caller's plan buffer may hold anything)
+    int coop_after;       // candidates a placement loop evaluates on one wavefront before the env's helper wavefronts join (env_step_kernel<false, 4>)
     uint8_t *nx_ready;  // [E]
     int32_t *nx_prog;   // [E] pre-generation in progress: 0 = not started, k + 1 = seed, robot and the first k humans are staged
     uint64_t *nx_case;  // [E] the case counter that staging was started for (a reset in between makes it stale)
@@ -1065,9 +1066,8 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c)
 }
 // lane-parallel regeneration of the 624-word block; dependencies are at distance 227 (>= 64), so 64-wide chunks
 // processed in order reproduce the sequential recurrence exactly.
-__device__ __forceinline__ void rng_twist(Rng &R, int lane)
+__device__ __forceinline__ void mt_twist_buf(uint32_t *k, int lane)
 {
-    uint32_t *k = R.mt;
     rng_sync();
     for (int base = 0; base < 227; base += 64) {
         const int i = base + lane;
@@ -1089,6 +1089,10 @@ __device__ __forceinline__ void rng_twist(Rng &R, int lane)
     }
     if (lane == 0) k[623] = mt_mix(k[623], k[0], k[396]);
     rng_sync();
+}
+__device__ __forceinline__ void rng_twist(Rng &R, int lane)
+{
+    mt_twist_buf(R.mt, lane);
     R.pos = 0;
 }
 __device__ __forceinline__ uint32_t rng_u32(Rng &R, int lane)
@@ -1178,6 +1182,31 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
     return y;
 }
 
+// ---- a long rejection loop over FOUR wavefronts (env_step_kernel<false, 4>: dense crowds, BASELINE configs[4]) ----
+// In a crowd of ~50 randomised humans one placement in 10^4 runs to the bound of 65 536 candidates: ~1000 passes of one wavefront, 3 ms,
+// while the other 8191 envs of the step are long done.  The candidates are a pure function of the MT19937 stream: a 624-word block holds
+// 104 of them (two passes) and the next block is a cheap function of this one, so once a loop has run COOP_AFTER candidates on its own
+// the env's three helper wavefronts (parked at a barrier until then) join in: the master keeps the stream from the staged block on as a
+// linear window of four blocks in LDS (candidate j of a round = the six words at wpos + 6 j, whichever blocks they lie in), every
+// wavefront evaluates 64 candidates of a round of 256 behind the same fp32 screen, and the first accepted candidate IN STREAM ORDER wins
+// (or the first one past the bound) -- the same candidate, and the same staged block and position afterwards, as the serial loop, whose
+// own cutting of the stream into passes has no influence on either.  A helper that meets a square the screen cannot decide reports it
+// and the master re-evaluates those 64 candidates with the exact walk.
+constexpr int COOP_BLOCKS = 4;      // look-ahead window: the staged block and the three behind it (2496 words = 416 candidates)
+struct CoopLds {
+    int cmd;                        // 1 = a round of four passes is published, 2 = the kernel is over
+    int place_id;                   // changes with every placement that goes cooperative (the helpers reload its constants)
+    int kind, n_g, n_p, max_att;
+    int wpos, attempt0;             // word index (in the window) / candidate number of the round's first candidate
+    double circle_radius, vp;
+    float rgx, rpx, rgy, rpy, lor, hir;
+    float G[4][64], P[4][64];       // blocking points (x, y, lower / upper threshold): goals, positions -- the master's packed lists
+    uint32_t win[COOP_BLOCKS * MT_N]; // the stream from the staged block on, as one linear array of words
+    unsigned long long take[4], unsure[4];
+};
+constexpr int COOP_AFTER = 512;     // candidates a loop evaluates alone before the helpers join (99.9 % of the loops end earlier)
+__shared__ CoopLds g_coop;          // (only kernels instantiated with W > 1 reference it)
+
 // The reference's placement loops (crowd_sim_var_num.py:116-146 positions, crowd_sim.py:415-485 goals) are rejection sampling: candidate k
 // is made of the stream's next three doubles (angle, x noise, y noise), and the first candidate that keeps its distance from the robot
 // and from every human of the list is taken.  One candidate costs six words of the MT19937 stream whatever its fate, so candidate k of a
@@ -1187,6 +1216,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 // A candidate whose six words straddle the end of the block rides as lane 0 of the first pass over the regenerated block.  In crowds of ~50 randomised humans these loops run for 10^2 .. 10^5 candidates (BASELINE configs[4]).
 //   kind 0: position of a new human (noise = u * 2),  kind 1: new goal (noise = (u - 0.5) * vp)
 //   humans 0 .. n_list - 1 except `skip` are tested with md = radius + rad_j + discomfort_dist against their position and their goal
+template <int W = 1>
 __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int lane, int kind, double radius, double vp, double md_r, int n_list, int skip,
                                                    const Robot &rb, const Lane &h, double &out_x, double &out_y)
 {
@@ -1323,11 +1353,120 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
         }
         return hit;
     };
+    // one pass: candidates of lanes 0 .. nb-1 read from block `blk` -- whole candidates from word `first` on, or (first < 0) the candidate that
+    // straddles the block boundary as lane 0 (its nt words of the previous block in tl, the rest from the start of blk) and whole candidates
+    // behind it; returns the lanes whose candidate is taken (free, or past the bound)
+    auto eval_pass = [&](const uint32_t *blk, int first, int nt, const uint32_t *tl, int nb, int attempt0, double &x, double &y) -> uint64_t {
+        const bool live = lane < nb;
+        const int need = 6 - nt; // words of the new block that complete the straddling candidate
+        uint32_t wd[6];
+        if (first >= 0) {
+            const uint32_t *w = blk + first + 6 * (live ? lane : 0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wd[k] = w[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                // lane 0: tail words, then words 0 .. need - 1 of the new block; lane a >= 1: words need + 6 (a - 1) + k
+                const int idx = lane == 0 ? (k < nt ? 0 : k - nt) : need + 6 * (lane - 1) + k;
+                const uint32_t v = blk[idx];
+                wd[k] = (lane == 0 && k < nt) ? tl[k < 5 ? k : 4] : v;
+            }
+        }
+        const uint32_t a0 = mt_temper(wd[0]) >> 5, b0 = mt_temper(wd[1]) >> 6, a1 = mt_temper(wd[2]) >> 5, b1 = mt_temper(wd[3]) >> 6,
+                       a2 = mt_temper(wd[4]) >> 5, b2 = mt_temper(wd[5]) >> 6;
+        const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
+        const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
+        const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+        make(u0, u1, u2, x, y);
+        const bool coll = collides(x, y, live);
+        return __ballot(live && (!coll || attempt0 + lane >= max_att));
+    };
     int attempt = 0; // number of the next candidate
     for (;;) {
+        if constexpr (W > 1) {
+            if (attempt >= s.coop_after) {
+                CoopLds &Q = g_coop;
+                // candidates 64 p .. 64 p + 63 of the round that starts at window word wpos with candidate number att0
+                auto eval_win = [&](int wpos, int att0, int p, double &x, double &y) -> uint64_t {
+                    const uint32_t *w = Q.win + wpos + 6 * (64 * p + lane);
+                    uint32_t wd[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) wd[k] = w[k];
+                    const uint32_t a0 = mt_temper(wd[0]) >> 5, b0 = mt_temper(wd[1]) >> 6, a1 = mt_temper(wd[2]) >> 5, b1 = mt_temper(wd[3]) >> 6,
+                                   a2 = mt_temper(wd[4]) >> 5, b2 = mt_temper(wd[5]) >> 6;
+                    const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
+                    const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
+                    const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+                    make(u0, u1, u2, x, y);
+                    const bool coll = collides(x, y, true);
+                    return __ballot(!coll || att0 + 64 * p + lane >= max_att);
+                };
+                // the window: the staged block, then its successors (block b + 1 = twist of a copy of block b)
+                rng_sync();
+                for (int k = lane; k < MT_N; k += 64) Q.win[k] = R.mt[k];
+                for (int bq = 1; bq < COOP_BLOCKS; ++bq) {
+                    rng_sync();
+                    for (int k = lane; k < MT_N; k += 64) Q.win[bq * MT_N + k] = Q.win[(bq - 1) * MT_N + k];
+                    mt_twist_buf(Q.win + bq * MT_N, lane);
+                }
+                // the placement's constants: the helpers evaluate from their own registers what they load here once
+                Q.G[0][lane] = Gx; Q.G[1][lane] = Gy; Q.G[2][lane] = Gl; Q.G[3][lane] = Gh;
+                Q.P[0][lane] = Px; Q.P[1][lane] = Py; Q.P[2][lane] = Pl; Q.P[3][lane] = Ph;
+                if (lane == 0) {
+                    Q.kind = kind; Q.n_g = n_g; Q.n_p = n_p; Q.max_att = max_att; Q.circle_radius = c.circle_radius; Q.vp = vp;
+                    Q.rgx = rgx32; Q.rpx = rpx32; Q.rgy = rgy32; Q.rpy = rpy32; Q.lor = lor32; Q.hir = hir32;
+                    Q.place_id = Q.place_id + 1;
+                }
+                int wpos = R.pos;
+                for (;;) {
+                    // a round reads 1536 words from wpos on: drop the blocks that lie wholly in front of it, twist as many new ones behind
+                    const int cb = wpos / MT_N;
+                    if (cb > 0) {
+                        rng_sync();
+                        for (int bq = 0; bq + cb < COOP_BLOCKS; ++bq) {
+                            for (int k = lane; k < MT_N; k += 64) Q.win[bq * MT_N + k] = Q.win[(bq + cb) * MT_N + k];
+                            rng_sync();
+                        }
+                        for (int bq = COOP_BLOCKS - cb; bq < COOP_BLOCKS; ++bq) {
+                            for (int k = lane; k < MT_N; k += 64) Q.win[bq * MT_N + k] = Q.win[(bq - 1) * MT_N + k];
+                            mt_twist_buf(Q.win + bq * MT_N, lane);
+                        }
+                        wpos -= cb * MT_N;
+                    }
+                    if (lane == 0) { Q.wpos = wpos; Q.attempt0 = attempt; Q.cmd = 1; }
+                    __syncthreads(); // the helpers take candidates 64 .. 255
+                    double x, y;
+                    uint64_t take = eval_win(wpos, attempt, 0, x, y);
+                    __syncthreads(); // their verdicts are in
+                    int win = take ? 0 : -1;
+                    for (int p = 1; p < 4 && win < 0; ++p) {
+                        take = Q.unsure[p] ? eval_win(wpos, attempt, p, x, y) : Q.take[p]; // what the screen could not decide is evaluated again, exactly
+                        if (take) win = p;
+                    }
+                    if (win > 0 && !Q.unsure[win]) take = eval_win(wpos, attempt, win, x, y); // the winner's coordinates
+                    if (win >= 0) {
+                        const int f = __ffsll((unsigned long long)take) - 1;
+                        out_x = wv_readlane_d(x, f); out_y = wv_readlane_d(y, f);
+                        // the staged state afterwards: the block that holds the last word read, position behind it (624 = "twist before the next
+                        // draw", as the serial loop leaves it when a candidate ends a block)
+                        const int g = wpos + 6 * (64 * win + f + 1);
+                        int bi = g / MT_N, po = g - bi * MT_N;
+                        if (po == 0) { --bi; po = MT_N; }
+                        rng_sync();
+                        for (int k = lane; k < MT_N; k += 64) R.mt[k] = Q.win[bi * MT_N + k];
+                        rng_sync();
+                        R.pos = po;
+                        return;
+                    }
+                    wpos += 6 * 256;
+                    attempt += 256;
+                }
+            }
+        }
         const int left = MT_N - R.pos; // unread words of the current block
-        int nb, first;                 // candidates of this pass; word index (in the block R.mt holds at evaluation time) of lane 1's / lane 0's first word
-        uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0; // the straddling candidate's words of the OLD block (raw, wave-uniform)
+        int nb, first;                 // candidates of this pass; word index of lane 0's first word, or -1: lane 0 is the straddling candidate
+        uint32_t tl[5] = {0u, 0u, 0u, 0u, 0u}; // the straddling candidate's words of the OLD block (raw, wave-uniform)
         int nt = 0;                                        // ... and how many there are
         if (left >= 6) {
             nb = left / 6 < 64 ? left / 6 : 64;
@@ -1337,41 +1476,18 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
             // block are kept in registers, the block is regenerated, and the candidate is lane 0 of a pass whose other lanes take whole
             // candidates of the new block (as a pass of its own it cost a full walk for ONE candidate, every 104 candidates).
             nt = left;
-            if (nt > 0) t0 = R.mt[R.pos];
-            if (nt > 1) t1 = R.mt[R.pos + 1];
-            if (nt > 2) t2 = R.mt[R.pos + 2];
-            if (nt > 3) t3 = R.mt[R.pos + 3];
-            if (nt > 4) t4 = R.mt[R.pos + 4];
+            if (nt > 0) tl[0] = R.mt[R.pos];
+            if (nt > 1) tl[1] = R.mt[R.pos + 1];
+            if (nt > 2) tl[2] = R.mt[R.pos + 2];
+            if (nt > 3) tl[3] = R.mt[R.pos + 3];
+            if (nt > 4) tl[4] = R.mt[R.pos + 4];
             rng_twist(R, lane); // (R.pos = 0)
             nb = 64;            // 1 + (624 - 6) / 6 >= 64
             first = -1;
         }
-        const bool live = lane < nb;
-        const int need = 6 - nt; // words of the new block that complete the straddling candidate
-        uint32_t wd[6];
-        if (first >= 0) {
-            const uint32_t *w = R.mt + first + 6 * (live ? lane : 0);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wd[k] = w[k];
-        } else {
-            const uint32_t tl[5] = {t0, t1, t2, t3, t4};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                // lane 0: tail words, then words 0 .. need - 1 of the new block; lane a >= 1: words need + 6 (a - 1) + k
-                const int idx = lane == 0 ? (k < nt ? 0 : k - nt) : need + 6 * (lane - 1) + k;
-                const uint32_t v = R.mt[idx];
-                wd[k] = (lane == 0 && k < nt) ? tl[k < 5 ? k : 4] : v;
-            }
-        }
-        const uint32_t a0 = mt_temper(wd[0]) >> 5, b0 = mt_temper(wd[1]) >> 6, a1 = mt_temper(wd[2]) >> 5, b1 = mt_temper(wd[3]) >> 6,
-                       a2 = mt_temper(wd[4]) >> 5, b2 = mt_temper(wd[5]) >> 6;
-        const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
-        const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
-        const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+        const int need = 6 - nt;
         double x, y;
-        make(u0, u1, u2, x, y);
-        const bool coll = collides(x, y, live);
-        const uint64_t take = __ballot(live && (!coll || attempt + lane >= max_att));
+        const uint64_t take = eval_pass(R.mt, first, nt, tl, nb, attempt, x, y);
         // stream position behind candidate f of this pass
         if (take) {
             const int f = __ffsll((unsigned long long)take) - 1;
@@ -1384,9 +1500,78 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
     }
 }
 
+// helper wavefronts of an env (waves 1 .. 3 of env_step_kernel<false, 4>): parked at the barrier until the master publishes a round of passes
+// (place_by_rejection<4>), then pass `wave` behind the fp32 screen with the blocking points read from LDS; anything the screen cannot decide is
+// reported, not decided.  The arithmetic is the master's (same expressions, -ffp-contract=off): same verdicts.
+__device__ __forceinline__ void coop_helper_loop(int lane, int wave)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    CoopLds &Q = g_coop;
+    int have = -1; // the placement whose constants are in the registers below
+    float Gx = 0.f, Gy = 0.f, Gl = 0.f, Gh = 0.f, Px = 0.f, Py = 0.f, Pl = 0.f, Ph = 0.f;
+    for (;;) {
+        __syncthreads();
+        if (Q.cmd == 2) return;
+        if (Q.place_id != have) {
+            have = Q.place_id;
+            Gx = Q.G[0][lane]; Gy = Q.G[1][lane]; Gl = Q.G[2][lane]; Gh = Q.G[3][lane];
+            Px = Q.P[0][lane]; Py = Q.P[1][lane]; Pl = Q.P[2][lane]; Ph = Q.P[3][lane];
+        }
+        const int p = wave;
+        const uint32_t *w = Q.win + Q.wpos + 6 * (64 * p + lane);
+        uint32_t wd[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wd[k] = w[k];
+        const uint32_t a0 = mt_temper(wd[0]) >> 5, b0 = mt_temper(wd[1]) >> 6, a1 = mt_temper(wd[2]) >> 5, b1 = mt_temper(wd[3]) >> 6,
+                       a2 = mt_temper(wd[4]) >> 5, b2 = mt_temper(wd[5]) >> 6;
+        const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
+        const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
+        const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
+        const double angle = u0 * M_PI * 2.0;
+        const double nx = Q.kind == 0 ? (0.0 + (1.0 - 0.0) * u1) * 2.0 : (u1 - 0.5) * Q.vp;
+        const double ny = Q.kind == 0 ? (0.0 + (1.0 - 0.0) * u2) * 2.0 : (u2 - 0.5) * Q.vp;
+        double sn, cs;
+        det_sincos(angle, sn, cs);
+        const double x = Q.circle_radius * cs + nx, y = Q.circle_radius * sn + ny;
+        const float xf = (float)x, yf = (float)y;
+        const f2 xx = f2{xf, xf}, yy = f2{yf, yf};
+        f2 ax = xx - f2{Q.rgx, Q.rpx}, ay = yy - f2{Q.rgy, Q.rpy};
+        f2 q = ax * ax + ay * ay;
+        float m1 = fminf(q.x, q.y) - Q.lor;
+        float m2 = fminf(q.x, q.y) - Q.hir;
+        const int n_g = Q.n_g, n_p = Q.n_p;
+        for (int k = 0; k < n_g; k += 2) {
+            const int k1 = k + 1 < n_g ? k + 1 : k;
+            const f2 jx = f2{wv_readlane(Gx, k), wv_readlane(Gx, k1)}, jy = f2{wv_readlane(Gy, k), wv_readlane(Gy, k1)};
+            const f2 lo = f2{wv_readlane(Gl, k), wv_readlane(Gl, k1)}, hi = f2{wv_readlane(Gh, k), wv_readlane(Gh, k1)};
+            ax = xx - jx; ay = yy - jy;
+            q = ax * ax + ay * ay;
+            const f2 dl = q - lo, dh = q - hi;
+            m1 = fminf(m1, fminf(dl.x, dl.y));
+            m2 = fminf(m2, fminf(dh.x, dh.y));
+        }
+        for (int k = 0; k < n_p; k += 2) {
+            const int k1 = k + 1 < n_p ? k + 1 : k;
+            const f2 jx = f2{wv_readlane(Px, k), wv_readlane(Px, k1)}, jy = f2{wv_readlane(Py, k), wv_readlane(Py, k1)};
+            const f2 lo = f2{wv_readlane(Pl, k), wv_readlane(Pl, k1)}, hi = f2{wv_readlane(Ph, k), wv_readlane(Ph, k1)};
+            ax = xx - jx; ay = yy - jy;
+            q = ax * ax + ay * ay;
+            const f2 dl = q - lo, dh = q - hi;
+            m1 = fminf(m1, fminf(dl.x, dl.y));
+            m2 = fminf(m2, fminf(dh.x, dh.y));
+        }
+        const bool hit = m1 < 0.0f, open = m2 > 0.0f;
+        const uint64_t uns = __ballot(!hit && !open);
+        const uint64_t take = __ballot(!hit || Q.attempt0 + 64 * p + lane >= Q.max_att);
+        if (lane == 0) { Q.take[p] = take; Q.unsure[p] = uns; }
+        __syncthreads();
+    }
+}
+
 // crowd_sim_var_num.py:116-146 generate_circle_crossing_human (+ Agent.__init__/sample_random_attributes draws).
 // All lanes compute the candidate position identically; the min-distance test against the existing agents is
 // lane-parallel.  n_existing = number of humans currently in self.humans (slot itself included on respawn, :455).
+template <int W = 1>
 __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int slot, int n_existing, const Robot &rb, Lane &h, double &shared_nd)
 {
     const cn_env_config &c = s.cfg;
@@ -1400,7 +1585,7 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
     // (unbounded in the reference: see CN_MAX_PLACEMENT_ATTEMPTS)
     // :133-136: a unicycle robot keeps new humans half a circle radius away from its start and goal
     const double md_r = c.kinematics == CN_KIN_UNICYCLE ? c.circle_radius / 2.0 : radius + c.robot_radius + c.discomfort_dist;
-    place_by_rejection(s, R, lane, 0, radius, 0.0, md_r, n_existing, -1, rb, h, px, py);
+    place_by_rejection<W>(s, R, lane, 0, radius, 0.0, md_r, n_existing, -1, rb, h, px, py);
     if (lane == slot) {
         h.px = px; h.py = py; h.gx = -px; h.gy = -py; h.vx = 0.0; h.vy = 0.0; h.rad = radius; h.vpref = vpref;
         h.simv = 0; // new Human -> new ORCA object, sim rebuilt on next use
@@ -1409,6 +1594,7 @@ __device__ __forceinline__ void gen_human(const EnvDev &s, Rng &R, int lane, int
 
 // crowd_sim.py:415-450 update_human_goals_randomly (every human, goal_change_chance) and :453-485 update_human_goal (one human,
 // end_goal_change_chance: `only` >= 0 selects it)
+template <int W = 1>
 __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, int n, const Robot &rb, Lane &h, int only = -1)
 {
     const cn_env_config &c = s.cfg;
@@ -1420,7 +1606,7 @@ __device__ __forceinline__ void change_goals(const EnvDev &s, Rng &R, int lane, 
         if (vp_i == 0.0) vp_i = 1.0;
         if (rng_double(R, lane) <= (only >= 0 ? c.end_goal_change_chance : c.goal_change_chance)) {
             double gx, gy;
-            place_by_rejection(s, R, lane, 1, rad_i, vp_i, rad_i + c.robot_radius + c.discomfort_dist, H, i, rb, h, gx, gy);
+            place_by_rejection<W>(s, R, lane, 1, rad_i, vp_i, rad_i + c.robot_radius + c.discomfort_dist, H, i, rb, h, gx, gy);
             if (lane == i) { h.gx = gx; h.gy = gy; }
         }
     }
@@ -1769,6 +1955,7 @@ __global__ __launch_bounds__(256) void orca_lp3_kernel(EnvDev s)
 // crowd_sim_var_num.py:366-460 step (+ crowd_sim_pred.py:216-233 social reward) and the vec-env auto-reset
 // (rl/networks/shmem_vec_env.py:139-142).  ORCA velocities for this step were produced by orca_kernel.
 // goal changes every 5 s and respawns of the humans that reached their goal (crowd_sim_var_num.py:446-456): after the observation
+template <int W = 1>
 __device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e, int lane, int n, int step_counter, const Robot &rb, Lane &h, double &shared_nd)
 {
     const cn_env_config &c = s.cfg;
@@ -1777,7 +1964,7 @@ __device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e,
     const int period = (int)(5.0 / c.time_step + 0.5);
     if (c.random_goal_changing && (step_counter % period) == 0) {
         rng_load(R, s, e, lane);
-        change_goals(s, R, lane, n, rb, h);
+        change_goals<W>(s, R, lane, n, rb, h);
     }
     if (c.end_goal_changing) {
         uint64_t reached = __ballot(isH && norm2(h.gx - h.px, h.gy - h.py) < h.rad);
@@ -1787,8 +1974,8 @@ __device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e,
             reached &= reached - 1;
             // :451-456 respawned (holonomic robot) or given a new goal (unicycle robot)
             // (crowd_sim_pred.py:208-212 always respawns)
-            if (c.kinematics == CN_KIN_UNICYCLE && c.env_kind == CN_ENV_VARNUM) change_goals(s, R, lane, n, rb, h, i);
-            else gen_human(s, R, lane, i, H, rb, h, shared_nd);
+            if (c.kinematics == CN_KIN_UNICYCLE && c.env_kind == CN_ENV_VARNUM) change_goals<W>(s, R, lane, n, rb, h, i);
+            else gen_human<W>(s, R, lane, i, H, rb, h, shared_nd);
         }
     }
 }
@@ -1816,13 +2003,18 @@ __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
 
 // SPLIT = true: first half only (everything up to the kinematics and the reset bookkeeping); env_obs_kernel finishes the step after
 // the roll-out kernels.
-template <bool SPLIT>
-__global__ __launch_bounds__(64, 4) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
+// W = 4: three helper wavefronts per env for the long placement loops of dense crowds (see CoopLds); W = 1: one wavefront per env
+template <bool SPLIT, int W = 1>
+__global__ __launch_bounds__(64 * W, 4) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
                                                       uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
     const CnStampScope stamp_scope(s.stamp);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int e = blockIdx.x;
+    if constexpr (W > 1) {
+        if (threadIdx.x >= 64) { coop_helper_loop(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
+        if (lane == 0) g_coop.place_id = 0; // (the helpers read it behind the first barrier only)
+    }
     const cn_env_config &c = s.cfg;
     const int H = s.H;
     int n = crowd_size(s, e);  // humans present during this step's reward / kinematics
@@ -2131,7 +2323,7 @@ __global__ __launch_bounds__(64, 4) void env_step_kernel(EnvDev s, const float *
         }
         if (!SPLIT) {
             write_obs(s, e, lane, n, false, rb, h, ob, step_counter);
-            post_obs_updates(s, R, e, lane, n, step_counter, rb, h, shared_nd);
+            post_obs_updates<W>(s, R, e, lane, n, step_counter, rb, h, shared_nd);
         }
         if (lane == 0) { s.step_counter[e] = step_counter; s.ep_ret[e] = ep_ret; s.ep_cnt[e] = ep_cnt; }
     }
@@ -2139,6 +2331,10 @@ __global__ __launch_bounds__(64, 4) void env_step_kernel(EnvDev s, const float *
     if (lane == 0 && s.nh) s.nh[e] = n;
     if (lane == 0) s.shared_nd[e] = shared_nd;
     rng_store(R, s, e, lane);
+    if constexpr (W > 1) { // release the helpers
+        if (lane == 0) g_coop.cmd = 2;
+        __syncthreads();
+    }
 }
 
 __global__ void export_state_kernel(EnvDev s, double *humans, double *robot)
@@ -2536,7 +2732,15 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
         CN_CHECK_LAUNCH();
         if (int rc = truth_rollout_and_obs(env, obs, st)) return rc;
     } else {
-        hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        // dense crowds (the goals' exclusion zones cover the circle: BASELINE configs[4]) run their long placement loops on four wavefronts
+        const cn_env_config &cf = env->d.cfg;
+        const double zone = 2.0 * (2.0 * (cf.randomize_attributes ? 0.5 : cf.human_radius) + cf.discomfort_dist) * env->d.H;
+        static const int coop_env = getenv("CN_ENV_COOP") ? atoi(getenv("CN_ENV_COOP")) : -1; // 0 / 1 force (A/B), default: by density
+        const bool coop = coop_env >= 0 ? coop_env != 0 : zone > 0.9 * 2.0 * M_PI * cf.circle_radius;
+        static const int coop_after = getenv("CN_COOP_AFTER") ? atoi(getenv("CN_COOP_AFTER")) : COOP_AFTER;
+        env->d.coop_after = coop_after;
+        if (coop) hipLaunchKernelGGL((env_step_kernel<false, 4>), dim3(env->d.E), dim3(256), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        else hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         CN_CHECK_LAUNCH();
     }
     return prefetch_orca(env, st, obs); // next step's ORCA overlaps whatever the caller enqueues next (the policy forward)

@@ -187,6 +187,23 @@ def test_hip_env_matches_oracle_bit_exact(name):
     env.close()
 
 
+@pytest.mark.parametrize("after", [0, 5, 100])
+def test_cooperative_placement_is_bit_exact_wherever_the_helpers_join(after):
+    """BASELINE configs[4]'s dense crowds run their long placement loops on four wavefronts per env (env_sim.hip, place_by_rejection<4>):
+    the accepted candidate and the stream position behind it must not depend on WHEN the three helpers join.  The library reads the
+    switches once per process, so the oracle comparisons above are re-run in a child with the cooperative kernel forced on for every
+    crowd and the joining point at the first candidate (0), inside the first pass (5) and behind it (100)."""
+    import os, subprocess, sys
+    env = dict(os.environ, CN_ENV_COOP="1", CN_COOP_AFTER=str(after))
+    sel = "test_hip_env_matches_oracle_bit_exact and (varnum_h20_nonrand or varnum_h5_rand or varnum_h50_rand or varnum_h64_rand or varnum_h15_range5 " \
+          "or varnum_h50_rand_cap64 or pred_h10_rand or varnum_h10_rand_range4)"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    import re
+    assert int(re.search(r"(\d+) passed", r.stdout).group(1)) >= 8 and "failed" not in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("path", G.env_fixtures(device=True), ids=lambda p: p.split("env_")[-1][:-4])
 def test_hip_env_replays_reference_golden(path):
     """The reference's own traces (tests/golden) replayed on the GPU: flags exact, float32 obs <= 1e-6."""
