@@ -62,6 +62,7 @@ struct EnvDev {
     double *nx_shared_nd; // [E]
     uint32_t *nx_mt;    // [E][624]
     int32_t *nx_mt_pos; // [E]
+    int32_t *post_cnt, *post_list; // [1], [E] envs whose post-observation updates (goal changes, respawns) this step deferred to env_post_kernel
     int32_t *plan_arrive; // [1] row-plan builders' arrival counter (library-owned: the caller's plan buffer may hold anything)
     int coop_after;       // candidates a placement loop evaluates on one wavefront before the env's helper wavefronts join (env_step_kernel<false, 4>)
     uint8_t *nx_ready;  // [E]
@@ -1861,6 +1862,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev s, cn_obs ob, int 
 // next launch resumes there.  The episode is the same whichever way it is cut; an env that resets before its staging is complete
 // generates in place, as it always could, and the stale staging is restarted (nx_case).
 // (the body: one wavefront, one env; R.mt = that wavefront's 624-word LDS slice)
+template <int W = 1>
 __device__ __forceinline__ void pregen_env(const EnvDev &s, int e, int lane, long long budget, Rng &R)
 {
     if (s.nx_ready[e]) return;
@@ -1894,7 +1896,7 @@ __device__ __forceinline__ void pregen_env(const EnvDev &s, int e, int lane, lon
     }
     bool complete = true;
     for (int i = prog - 1; i < n; ++i) {
-        gen_human(s, R, lane, i, i, rb, h, shared_nd);
+        gen_human<W>(s, R, lane, i, i, rb, h, shared_nd);
         if (i + 1 < n && __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > budget))) { prog = i + 2; complete = false; break; }
     }
     if (complete) rb.pot = -fabs(norm2(rb.gx - rb.px, rb.gy - rb.py));
@@ -1917,11 +1919,23 @@ __device__ __forceinline__ void pregen_env(const EnvDev &s, int e, int lane, lon
     if (lane == 0 && complete) s.nx_ready[e] = 1;
 }
 
-__global__ __launch_bounds__(64) void env_pregen_kernel(EnvDev s, long long budget)
+// (W = 4: dense crowds, where ONE human of a new episode takes up to a millisecond of candidates on one wavefront -- the three helper
+// wavefronts of place_by_rejection<4>, as in env_step_kernel)
+template <int W = 1>
+__global__ __launch_bounds__(64 * W) void env_pregen_kernel(EnvDev s, long long budget)
 {
     const CnStampScope stamp_scope(s.stamp);
+    const int lane = threadIdx.x & 63;
+    if constexpr (W > 1) {
+        if (threadIdx.x >= 64) { coop_helper_loop(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
+        if (lane == 0) g_coop.place_id = 0;
+    }
     Rng R{MT_N, false};
-    pregen_env(s, blockIdx.x, threadIdx.x, budget, R);
+    pregen_env<W>(s, blockIdx.x, lane, budget, R);
+    if constexpr (W > 1) { // release the helpers
+        if (lane == 0) g_coop.cmd = 2;
+        __syncthreads();
+    }
 }
 
 // (Round 5 measured this generator INSIDE the ORCA tail's launch, i.e. behind the human-human kernel instead of beside the lane kernel, so
@@ -1980,6 +1994,36 @@ __device__ __forceinline__ void post_obs_updates(const EnvDev &s, Rng &R, int e,
     }
 }
 
+// The deferred post-observation updates of env_step_kernel<false, 1, true>: one workgroup of W wavefronts per listed env (the list is short:
+// an env changes goals every 5 s, so ~1/20 of a dephased batch, plus the envs where a human reached its goal), the placement loops on all
+// W of them (place_by_rejection<W>).  Same state in, same state out as the in-kernel call: load_env / store_env are exact.
+template <int W>
+__global__ __launch_bounds__(64 * W) void env_post_kernel(EnvDev s)
+{
+    if ((int)blockIdx.x >= *s.post_cnt) return;
+    const CnStampScope stamp_scope(s.stamp);
+    const int lane = threadIdx.x & 63;
+    if constexpr (W > 1) {
+        if (threadIdx.x >= 64) { coop_helper_loop(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
+        if (lane == 0) g_coop.place_id = 0;
+    }
+    const int e = s.post_list[blockIdx.x];
+    Rng R{MT_N, false};
+    Robot rb;
+    Lane h;
+    load_env(s, e, lane, rb, h);
+    double shared_nd = s.shared_nd[e];
+    const int n = crowd_size(s, e);
+    post_obs_updates<W>(s, R, e, lane, n, s.step_counter[e], rb, h, shared_nd);
+    store_env(s, e, lane, rb, h);
+    if (lane == 0) s.shared_nd[e] = shared_nd;
+    rng_store(R, s, e, lane);
+    if constexpr (W > 1) { // release the helpers
+        if (lane == 0) g_coop.cmd = 2;
+        __syncthreads();
+    }
+}
+
 // Second half of a step when the observation needs the 'truth' roll-outs of the state just reached (sim.predict_method = 'truth'):
 // observation (reset or step form), then the post-observation updates of the envs that were not reset.
 __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
@@ -2004,7 +2048,10 @@ __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
 // SPLIT = true: first half only (everything up to the kinematics and the reset bookkeeping); env_obs_kernel finishes the step after
 // the roll-out kernels.
 // W = 4: three helper wavefronts per env for the long placement loops of dense crowds (see CoopLds); W = 1: one wavefront per env
-template <bool SPLIT, int W = 1>
+// DEFER = true (dense crowds without a lane kernel): the observation is written, the post-observation updates -- which nothing in the
+// observation depends on -- are left to env_post_kernel on the side stream, in front of the ORCA pass that needs the new goals: the
+// long placement loops of the few envs that change goals then run beside the policy forward instead of in front of it.
+template <bool SPLIT, int W = 1, bool DEFER = false>
 __global__ __launch_bounds__(64 * W, 4) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
                                                       uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
@@ -2323,7 +2370,14 @@ __global__ __launch_bounds__(64 * W, 4) void env_step_kernel(EnvDev s, const flo
         }
         if (!SPLIT) {
             write_obs(s, e, lane, n, false, rb, h, ob, step_counter);
-            post_obs_updates<W>(s, R, e, lane, n, step_counter, rb, h, shared_nd);
+            if constexpr (DEFER) {
+                // (a superset of the envs post_obs_updates does anything for: it evaluates `reached` after the periodic goal changes)
+                bool need = c.random_goal_changing && (step_counter % (int)(5.0 / c.time_step + 0.5)) == 0;
+                if (c.end_goal_changing) need = need || __ballot(lane < n && norm2(h.gx - h.px, h.gy - h.py) < h.rad) != 0;
+                if (need && lane == 0) s.post_list[atomicAdd(s.post_cnt, 1)] = e;
+            } else {
+                post_obs_updates<W>(s, R, e, lane, n, step_counter, rb, h, shared_nd);
+            }
         }
         if (lane == 0) { s.step_counter[e] = step_counter; s.ep_ret[e] = ep_ret; s.ep_cnt[e] = ep_cnt; }
     }
@@ -2383,6 +2437,7 @@ struct cn_env_batch {
     hipStream_t side2;   // deferred mode: the pre-generation runs beside the ORCA tail, not in front of it
     hipEvent_t ev_pg;
     bool pg_pending;     // ev_pg was recorded for work the next reader of the staging arrays has to wait for
+    bool post_deferred;  // the step just enqueued left its post-observation updates to env_post_kernel (launch_tail runs it before ORCA)
 };
 
 // calc_human_future_traj(method='truth'): P rolls of every human with its own policy
@@ -2423,9 +2478,21 @@ static bool lane_path_of(const cn_env_batch *env)
 // refill the next-episode staging of the envs that just consumed theirs (rare: ~1.5 % of envs per step; a 60 us chain of serial fp64
 // work per such env).  It only depends on the step that just ran; nothing needs it before those envs finish their NEXT episode.
 // Budget (ticks of 10 ns; cn_env_set_pregen_budget): see cn_env_set_pregen_budget in the header.
+// dense crowds (the goals' exclusion zones cover the circle: BASELINE configs[4]) run their long placement loops on four wavefronts per env
+static bool dense_crowd(cn_env_batch *env)
+{
+    const cn_env_config &cf = env->d.cfg;
+    const double zone = 2.0 * (2.0 * (cf.randomize_attributes ? 0.5 : cf.human_radius) + cf.discomfort_dist) * env->d.H;
+    static const int coop_env = getenv("CN_ENV_COOP") ? atoi(getenv("CN_ENV_COOP")) : -1; // 0 / 1 force (A/B), default: by density
+    static const int coop_after = getenv("CN_COOP_AFTER") ? atoi(getenv("CN_COOP_AFTER")) : COOP_AFTER;
+    env->d.coop_after = coop_after;
+    return coop_env >= 0 ? coop_env != 0 : zone > 0.9 * 2.0 * M_PI * cf.circle_radius;
+}
+
 static int launch_pregen(cn_env_batch *env, hipStream_t on)
 {
-    hipLaunchKernelGGL(env_pregen_kernel, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
+    if (dense_crowd(env)) hipLaunchKernelGGL(env_pregen_kernel<4>, dim3(env->d.E), dim3(256), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
+    else hipLaunchKernelGGL(env_pregen_kernel<1>, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -2446,6 +2513,11 @@ static int launch_tail(cn_env_batch *env, hipStream_t main)
         if (int rc = launch_pregen(env, env->side2)) return rc;
         CN_HIP(hipEventRecord(env->ev_pg, env->side2));
         env->pg_pending = true;
+    }
+    if (env->post_deferred) { // the goal changes / respawns of the step just enqueued: the ORCA pass below reads the new goals
+        hipLaunchKernelGGL(env_post_kernel<4>, dim3(env->d.E), dim3(256), 0, env->side, stamped(env->d, CN_K_OTHER));
+        CN_CHECK_LAUNCH();
+        env->post_deferred = false;
     }
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
         if (lane_path) {
@@ -2499,8 +2571,17 @@ static int prefetch_orca(cn_env_batch *env, hipStream_t main, const cn_obs *obs)
         // ORCA tail kernel is queued behind this one, and when it starts before the policy's kernel has its workgroups on the CUs, that
         // kernel waits for them (the deferred mode removes exactly this coupling)
         CN_HIP(hipEventRecord(env->ev_pre, main));
-        CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
-        if (int rc = launch_pregen(env, env->side)) return rc;
+        if (env->post_deferred) {
+            // the side stream starts with the deferred goal changes, which the ORCA pass and with it the next step wait for: the
+            // pre-generation (whose workgroups mostly wait for the CUs the policy's kernel holds) goes beside them
+            CN_HIP(hipStreamWaitEvent(env->side2, env->ev_pre, 0));
+            if (int rc = launch_pregen(env, env->side2)) return rc;
+            CN_HIP(hipEventRecord(env->ev_pg, env->side2));
+            env->pg_pending = true;
+        } else {
+            CN_HIP(hipStreamWaitEvent(env->side, env->ev_pre, 0));
+            if (int rc = launch_pregen(env, env->side)) return rc;
+        }
     }
     if (lane_path) {
         // one lane per agent, on the CALLER's stream: the policy forward the caller enqueues next starts behind this kernel, not
@@ -2618,6 +2699,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     const bool collect = cfg->env_kind == CN_ENV_COLLECT;
     const size_t o_pid = collect ? carve(E * H * 4) : 0, o_mpid = collect ? carve(E * 4) : 0, o_lobs = collect ? carve(E * H) : 0;
     const size_t state_bytes = off; // everything below is per-step scratch of the ORCA pass: not part of a snapshot
+    const size_t o_pc = carve(4), o_pl = carve(E * 4); // envs with deferred post-observation updates (env_post_kernel)
     const size_t o_pa = carve(4); // arrival counter of the row-plan builders (row_plan.h): zero here, reset by the last builder of every build
     const size_t o_l3c = carve(4), o_l3h = lane_orca ? carve(E * H * sizeof(Lp3Hdr)) : 0, o_l3l = lane_orca ? carve(E * H * 32 * sizeof(float4)) : 0;
     char *base = nullptr;
@@ -2638,6 +2720,7 @@ extern "C" int cn_env_create(const cn_env_config *cfg, int num_envs, int64_t see
     d.nx_hum = (double *)(base + o_nxh); d.nx_rob = (double *)(base + o_nr); d.nx_shared_nd = (double *)(base + o_nn);
     d.nx_mt = (uint32_t *)(base + o_nm); d.nx_mt_pos = (int32_t *)(base + o_np); d.nx_ready = (uint8_t *)(base + o_ny);
     d.plan_arrive = (int32_t *)(base + o_pa);
+    d.post_cnt = (int32_t *)(base + o_pc); d.post_list = (int32_t *)(base + o_pl);
     d.nx_prog = (int32_t *)(base + o_npg); d.nx_case = (uint64_t *)(base + o_ncs);
     d.tr = (test_phase || truth_obs) ? (double *)(base + o_tr) : nullptr; d.vis = (test_phase || truth_obs) ? (uint8_t *)(base + o_vis) : nullptr;
     d.pend = (uint8_t *)(base + o_pend);
@@ -2732,14 +2815,17 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
         CN_CHECK_LAUNCH();
         if (int rc = truth_rollout_and_obs(env, obs, st)) return rc;
     } else {
-        // dense crowds (the goals' exclusion zones cover the circle: BASELINE configs[4]) run their long placement loops on four wavefronts
-        const cn_env_config &cf = env->d.cfg;
-        const double zone = 2.0 * (2.0 * (cf.randomize_attributes ? 0.5 : cf.human_radius) + cf.discomfort_dist) * env->d.H;
-        static const int coop_env = getenv("CN_ENV_COOP") ? atoi(getenv("CN_ENV_COOP")) : -1; // 0 / 1 force (A/B), default: by density
-        const bool coop = coop_env >= 0 ? coop_env != 0 : zone > 0.9 * 2.0 * M_PI * cf.circle_radius;
-        static const int coop_after = getenv("CN_COOP_AFTER") ? atoi(getenv("CN_COOP_AFTER")) : COOP_AFTER;
-        env->d.coop_after = coop_after;
-        if (coop) hipLaunchKernelGGL((env_step_kernel<false, 4>), dim3(env->d.E), dim3(256), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+        const bool coop = dense_crowd(env);
+        static const int defer_env = getenv("CN_ENV_DEFER") ? atoi(getenv("CN_ENV_DEFER")) : 1; // 0: placement loops inside the step kernel (A/B)
+        // without a lane kernel the next consumer of the goals is the ORCA pass on the side stream: the updates go there, in front of it
+        // (with one, that kernel follows on the caller's stream and the loops stay in the step kernel, on four wavefronts)
+        const bool defer = coop && defer_env && !lane_path_of(env) && env->d.cfg.humans_policy == CN_HUMANS_ORCA;
+        if (defer) {
+            CN_HIP(hipMemsetAsync(env->d.post_cnt, 0, 4, st));
+            hipLaunchKernelGGL((env_step_kernel<false, 1, true>), dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
+            env->post_deferred = true;
+        }
+        else if (coop) hipLaunchKernelGGL((env_step_kernel<false, 4>), dim3(env->d.E), dim3(256), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         else hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         CN_CHECK_LAUNCH();
     }
