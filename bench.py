@@ -473,10 +473,12 @@ def main():
         it += DEC
         med = lambda v: (sorted(v)[len(v) // 2] if v else None)   # noqa: E731
         decomp = {"window": "%d extra steps after the timed window, every kernel stamped (device clock, 10 ns)" % DEC, "median_us": {}}
-        for k in ("env_step", "orca_lane", "row_plan", "hh_fused", "rn_fused", "orca_lp3", "env_pregen"):
+        for k in ("env_step", "orca_lane", "row_plan", "hh_fused", "rn_fused", "orca_lp3", "env_pregen", "other"):
             d = dst.durations_us(k)
-            if d:
-                decomp["median_us"][k] = round(med(d), 2)
+            if d:   # slot "other" = env_post_kernel (dense crowds: the deferred goal changes, on the side stream in front of ORCA)
+                decomp["median_us"]["env_post" if k == "other" else k] = round(med(d), 2)
+                if k == "other":
+                    decomp["env_post_max_us"] = round(max(d), 2)
         tab = dst.table()
         # critical path of a step on the caller's stream: env_step -> orca_lane (+ row plan) -> hh_fused -> rn_fused -> next env_step
         by = {}

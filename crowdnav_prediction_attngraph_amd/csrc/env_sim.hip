@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -1183,30 +1184,148 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
     return y;
 }
 
-// ---- a long rejection loop over FOUR wavefronts (env_step_kernel<false, 4>: dense crowds, BASELINE configs[4]) ----
-// In a crowd of ~50 randomised humans one placement in 10^4 runs to the bound of 65 536 candidates: ~1000 passes of one wavefront, 3 ms,
-// while the other 8191 envs of the step are long done.  The candidates are a pure function of the MT19937 stream: a 624-word block holds
-// 104 of them (two passes) and the next block is a cheap function of this one, so once a loop has run COOP_AFTER candidates on its own
-// the env's three helper wavefronts (parked at a barrier until then) join in: the master keeps the stream from the staged block on as a
-// linear window of four blocks in LDS (candidate j of a round = the six words at wpos + 6 j, whichever blocks they lie in), every
-// wavefront evaluates 64 candidates of a round of 256 behind the same fp32 screen, and the first accepted candidate IN STREAM ORDER wins
-// (or the first one past the bound) -- the same candidate, and the same staged block and position afterwards, as the serial loop, whose
-// own cutting of the stream into passes has no influence on either.  A helper that meets a square the screen cannot decide reports it
-// and the master re-evaluates those 64 candidates with the exact walk.
-constexpr int COOP_BLOCKS = 4;      // look-ahead window: the staged block and the three behind it (2496 words = 416 candidates)
+// ---- a long rejection loop over the W wavefronts of a workgroup (dense crowds, BASELINE configs[4]) ----
+// In a crowd of ~50 randomised humans a placement takes 4 candidates in the median, one in 40 more than 64, and one in 10^4 runs to the bound
+// of 65 536: ~1000 passes of one wavefront, 3 ms, while the other 8191 envs of the step are long done -- and with ~400 envs of a batch changing
+// 25 goals each in a step, nearly every step has one.  The candidates are a pure function of the MT19937 stream (candidate j of a loop that
+// starts at stream word g reads the words g + 6 j .. g + 6 j + 5, whatever its fate), and the stream is a recurrence with a lag of 227 words:
+//     s[m] = s[m - 227] ^ f(s[m - 624], s[m - 623]),
+// so one wavefront can run it 192 words at a time without ever waiting for anybody else.  Once a loop has run COOP_AFTER candidates on its
+// own, the workgroup's other wavefronts (parked at a barrier until then) join in, in rounds of 64 (W - 1) candidates: the last wavefront is
+// the PRODUCER -- while the others evaluate round r it extends the stream, in a ring of LDS blocks, as far as round r + 1 reads -- the master
+// and the W - 2 helpers put 64 candidates each through a COARSE fp32 screen (coop_screen_pass: "collides for certain", with 1e-3 of slack on
+// the squared thresholds; a bound-hitting loop is 65 537 candidates x ~100 points, and one CU evaluates ~400 candidates per microsecond this
+// way whatever W is), and the master re-evaluates with the exact walk, in stream order, the passes that reported a candidate the screen
+// could not reject: the first accepted candidate IN STREAM ORDER wins (or the first one past the bound) -- the same candidate, and the
+// same staged block and position afterwards, as the serial loop, whose own cutting of the stream into passes has no influence on either.
+// One workgroup barrier per round; every thread tracks the round's stream position itself, and the master only speaks up (a second
+// barrier) in rounds where some wavefront reported something.
+// groups of 64 candidates one evaluating wavefront screens per round, C per lane: a pair of points is read from LDS once (a broadcast read of
+// 24 bytes per lane: 12 clocks of the CU's LDS pipe) and tested against C candidates (6 C packed instructions), so with C = 1 four busy SIMDs
+// ask for twice what the LDS delivers
+#ifndef CN_COOP_C4
+#define CN_COOP_C4 4
+#endif
+#ifndef CN_COOP_C8
+#define CN_COOP_C8 2
+#endif
+#ifndef CN_COOP_C16
+#define CN_COOP_C16 1
+#endif
+constexpr int coop_c(int W) { return W <= 4 ? CN_COOP_C4 : (W <= 8 ? CN_COOP_C8 : CN_COOP_C16); }
+template <int W>
 struct CoopLds {
-    int cmd;                        // 1 = a round of four passes is published, 2 = the kernel is over
-    int place_id;                   // changes with every placement that goes cooperative (the helpers reload its constants)
-    int kind, n_g, n_p, max_att;
-    int wpos, attempt0;             // word index (in the window) / candidate number of the round's first candidate
-    double circle_radius, vp;
-    float rgx, rpx, rgy, rpy, lor, hir;
-    float G[4][64], P[4][64];       // blocking points (x, y, lower / upper threshold): goals, positions -- the master's packed lists
-    uint32_t win[COOP_BLOCKS * MT_N]; // the stream from the staged block on, as one linear array of words
-    unsigned long long take[4], unsure[4];
+    static constexpr int NE = W - 1;                          // evaluating wavefronts (master + helpers)
+    static constexpr int C = coop_c(W);
+    static constexpr int NG = NE * C;                         // groups of 64 candidates per round
+    static constexpr int NB1 = (384 * NG + 623) / MT_N;       // new blocks a round can need
+    static constexpr int BW = MT_N * (NB1 + 1) + 227;         // one buffer: the last block of the round before, the new ones, the producer's overshoot
+    int cmd;                        // 1 = a placement is published, 2 = the kernel is over
+    int verdict;                    // the master's answer in a round with reports: 1 = the placement is over, 0 = next round
+    int kind, n_pairs, max_att;
+    int pos0, attempt0;             // position in the staged block / candidate number of the first cooperative candidate
+    float circle_radius, vp;
+    // the blocking points two by two, as the coarse screen reads them (one broadcast read per pair): {x0, x1, y0, y1} and the squared
+    // thresholds minus the slack; pair 0 = the robot's goal and position, then the master's packed lists (goals, positions), the last
+    // point twice when the count is odd
+    float4 pxy[66];
+    float2 plo[66];
+    // round r reads buf[r & 1]: the stream LINEARLY from block b1(r - 1) (the last block round r - 1 touched; block 0 = the staged one, for
+    // round 0) to block b1(r), whole blocks; the producer fills buf[(r + 1) & 1] meanwhile
+    uint32_t buf[2][BW];
+    unsigned long long take[2][NG]; // by round parity, per group
 };
-constexpr int COOP_AFTER = 512;     // candidates a loop evaluates alone before the helpers join (99.9 % of the loops end earlier)
-__shared__ CoopLds g_coop;          // (only kernels instantiated with W > 1 reference it)
+#ifdef CN_POST_DEBUG
+__device__ long long g_post_dbg[8192 * 8]; // per block: ticks total, ticks in coop, coop placements, coop rounds, placements, serial passes, start tick, -
+__shared__ long long g_dbg_blk[8];
+#define DBG_ADD(i, v) do { if (lane == 0) g_dbg_blk[i] += (v); } while (0)
+#else
+#define DBG_ADD(i, v) do { } while (0)
+#endif
+constexpr int COOP_AFTER = 128;     // candidates a loop evaluates alone before the helpers join (98.5 % of the loops end earlier)
+template <int W>
+__device__ __forceinline__ CoopLds<W> &coop_lds()
+{
+    __shared__ CoopLds<W> q; // (only kernels instantiated with W > 1 reference it)
+    return q;
+}
+// ONE wavefront: dst[0 .. 623] = hist[0 .. 623] (a complete block), then n_new more words of the stream behind it, 227 per iteration with a
+// fixed word -> (step, lane) mapping: the lag-227 operand of a word is then the word the same lane made in the same step of the iteration
+// before -- it never leaves its register -- and the other two operands (624 and 623 words back) were written at least one whole iteration
+// earlier by this same wavefront (the LDS executes a wavefront's accesses in order), so they are loaded one iteration ahead and nothing in
+// the loop waits for a store.  May overshoot n_new by up to 226 words (correct stream words; the buffer has the room).
+__device__ __forceinline__ void coop_produce(uint32_t *dst, const uint32_t *hist, int lane, int n_new)
+{
+    if (hist) {
+        uint32_t t[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) t[k] = hist[64 * k + (k < 9 || lane < MT_N - 576 ? lane : 0)];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[64 * k + lane] = t[k];
+        if (lane < MT_N - 576) dst[576 + lane] = t[9];
+        rng_sync();
+    }
+    // word m (relative to dst + 624) of an iteration that starts at m0: step u, lane l <-> m = m0 + 64 u + l, 64 u + l < 227
+    const bool last = lane < 227 - 192;
+    uint32_t *p = dst + lane; // &dst[m0 + lane], m0 = 0: operands at p[64 u], p[64 u + 1]; lag-227 operand at p[64 u + 397]; result to p[64 u + 624]
+    uint32_t far[4], a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { far[u] = p[64 * u + 397]; a[u] = p[64 * u]; b[u] = p[64 * u + 1]; } // (u = 3, lanes >= 35: read but never used)
+    for (int m = 0; m < n_new; m += 227, p += 227) {
+        uint32_t na[4], nb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { na[u] = p[227 + 64 * u]; nb[u] = p[227 + 64 * u + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t y = (a[u] & 0x80000000u) | (b[u] & 0x7fffffffu);
+            far[u] = far[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            if (u < 3 || last) p[64 * u + MT_N] = far[u];
+            a[u] = na[u]; b[u] = nb[u];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    rng_sync();
+}
+
+// groups p C .. p C + C - 1 (64 candidates each, C per lane) of the round whose first candidate starts at word `off` of `rb`: which candidates can
+// the coarse screen NOT reject (or lie past the bound)?  -> Q.take[round & 1][group]  Candidate and squares in fp32 from the 27 high bits of each double's first word (the angle's sine and cosine from
+// V_SIN_F32 / V_COS_F32, whose argument is in revolutions): the candidate is within ~1e-5 of the fp64 one, a square near md^2 ~ 1 within 3e-5
+// of the true one, and "square < md^2 (1 - 1e-3)" therefore means closer than md for certain.  The other direction is not needed: whatever
+// is not rejected here is evaluated by the master, exactly.
+template <int W>
+__device__ __forceinline__ void coop_screen_pass(CoopLds<W> &Q, const uint32_t *rb, int off, int att0, int p, int lane, int round,
+                                                 int kind, int n_pairs, int max_att, float radius, float vp)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int C = CoopLds<W>::C;
+    f2 xx[C], yy[C];
+    float m[C]; // min over the points of (square - lowered threshold)
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+        const uint32_t *w = rb + off + 6 * (64 * (p * C + cc) + lane);
+        const float u0 = (float)(mt_temper(w[0]) >> 5) * 0x1p-27f, u1 = (float)(mt_temper(w[2]) >> 5) * 0x1p-27f, u2 = (float)(mt_temper(w[4]) >> 5) * 0x1p-27f;
+        const float cs = __builtin_amdgcn_cosf(u0), sn = __builtin_amdgcn_sinf(u0);
+        const float nx = kind == 0 ? u1 * 2.0f : (u1 - 0.5f) * vp, ny = kind == 0 ? u2 * 2.0f : (u2 - 0.5f) * vp;
+        const float xf = radius * cs + nx, yf = radius * sn + ny;
+        xx[cc] = f2{xf, xf}; yy[cc] = f2{yf, yf};
+        m[cc] = 1.0f;
+    }
+    for (int k = 0; k < n_pairs; ++k) {
+        const float4 pq = Q.pxy[k];
+        const float2 lo = Q.plo[k];
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) {
+            const f2 ax = xx[cc] - f2{pq.x, pq.y}, ay = yy[cc] - f2{pq.z, pq.w};
+            const f2 d = (ax * ax + ay * ay) - f2{lo.x, lo.y};
+            m[cc] = fminf(m[cc], fminf(d.x, d.y));
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+        const uint64_t take = __ballot(!(m[cc] < 0.0f) || att0 + 64 * (p * C + cc) + lane >= max_att);
+        if (lane == 0) Q.take[round & 1][p * C + cc] = take;
+    }
+}
 
 // The reference's placement loops (crowd_sim_var_num.py:116-146 positions, crowd_sim.py:415-485 goals) are rejection sampling: candidate k
 // is made of the stream's next three doubles (angle, x noise, y noise), and the first candidate that keeps its distance from the robot
@@ -1384,13 +1503,18 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
         return __ballot(live && (!coll || attempt0 + lane >= max_att));
     };
     int attempt = 0; // number of the next candidate
+    DBG_ADD(4, 1);
     for (;;) {
         if constexpr (W > 1) {
             if (attempt >= s.coop_after) {
-                CoopLds &Q = g_coop;
-                // candidates 64 p .. 64 p + 63 of the round that starts at window word wpos with candidate number att0
-                auto eval_win = [&](int wpos, int att0, int p, double &x, double &y) -> uint64_t {
-                    const uint32_t *w = Q.win + wpos + 6 * (64 * p + lane);
+                CoopLds<W> &Q = coop_lds<W>();
+#ifdef CN_POST_DEBUG
+                const long long dbg_t0 = wall_clock64();
+                DBG_ADD(2, 1);
+#endif
+                // candidates 64 p .. 64 p + 63 of the round whose first candidate starts at word `off` of `rb`, the exact way
+                auto eval_ring = [&](const uint32_t *rb, int off, int att0, int p, double &x, double &y) -> uint64_t {
+                    const uint32_t *w = rb + off + 6 * (64 * p + lane);
                     uint32_t wd[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) wd[k] = w[k];
@@ -1403,65 +1527,73 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
                     const bool coll = collides(x, y, true);
                     return __ballot(!coll || att0 + 64 * p + lane >= max_att);
                 };
-                // the window: the staged block, then its successors (block b + 1 = twist of a copy of block b)
+                // the points for the coarse screen, two by two
+                {
+                    const float lo32c = (float)(dd_l * (1.0 - 1e-3));
+                    const float Gc = pack(goal_mask, n_g, lo32c), Pc = pack(pos_mask, n_p, lo32c);
+                    float *xy = reinterpret_cast<float *>(Q.pxy), *lo = reinterpret_cast<float *>(Q.plo);
+                    auto put = [&](int slot, float x, float y, float l) {
+                        xy[(slot >> 1) * 4 + (slot & 1)] = x; xy[(slot >> 1) * 4 + 2 + (slot & 1)] = y; lo[slot] = l;
+                    };
+                    const int n_s = 2 + n_g + n_p;
+                    const float lorc = (float)(ddr * (1.0 - 1e-3));
+                    if (lane == 0) { put(0, rgx32, rgy32, lorc); put(1, rpx32, rpy32, lorc); }
+                    if (lane < n_g) put(2 + lane, Gx, Gy, Gc);
+                    if (lane < n_p) put(2 + n_g + lane, Px, Py, Pc);
+                    if (n_s & 1) { // (n_g + n_p is odd: the last point twice)
+                        if (n_p > 0 ? lane == n_p - 1 : lane == n_g - 1) put(n_s, n_p > 0 ? Px : Gx, n_p > 0 ? Py : Gy, n_p > 0 ? Pc : Gc);
+                    }
+                    if (lane == 0) {
+                        Q.kind = kind; Q.n_pairs = (n_s + 1) >> 1; Q.max_att = max_att; Q.circle_radius = (float)c.circle_radius; Q.vp = (float)vp;
+                        Q.pos0 = R.pos; Q.attempt0 = attempt; Q.cmd = 1;
+                    }
+                }
                 rng_sync();
-                for (int k = lane; k < MT_N; k += 64) Q.win[k] = R.mt[k];
-                for (int bq = 1; bq < COOP_BLOCKS; ++bq) {
-                    rng_sync();
-                    for (int k = lane; k < MT_N; k += 64) Q.win[bq * MT_N + k] = Q.win[(bq - 1) * MT_N + k];
-                    mt_twist_buf(Q.win + bq * MT_N, lane);
-                }
-                // the placement's constants: the helpers evaluate from their own registers what they load here once
-                Q.G[0][lane] = Gx; Q.G[1][lane] = Gy; Q.G[2][lane] = Gl; Q.G[3][lane] = Gh;
-                Q.P[0][lane] = Px; Q.P[1][lane] = Py; Q.P[2][lane] = Pl; Q.P[3][lane] = Ph;
-                if (lane == 0) {
-                    Q.kind = kind; Q.n_g = n_g; Q.n_p = n_p; Q.max_att = max_att; Q.circle_radius = c.circle_radius; Q.vp = vp;
-                    Q.rgx = rgx32; Q.rpx = rpx32; Q.rgy = rgy32; Q.rpy = rpy32; Q.lor = lor32; Q.hir = hir32;
-                    Q.place_id = Q.place_id + 1;
-                }
-                int wpos = R.pos;
-                for (;;) {
-                    // a round reads 1536 words from wpos on: drop the blocks that lie wholly in front of it, twist as many new ones behind
-                    const int cb = wpos / MT_N;
-                    if (cb > 0) {
-                        rng_sync();
-                        for (int bq = 0; bq + cb < COOP_BLOCKS; ++bq) {
-                            for (int k = lane; k < MT_N; k += 64) Q.win[bq * MT_N + k] = Q.win[(bq + cb) * MT_N + k];
-                            rng_sync();
-                        }
-                        for (int bq = COOP_BLOCKS - cb; bq < COOP_BLOCKS; ++bq) {
-                            for (int k = lane; k < MT_N; k += 64) Q.win[bq * MT_N + k] = Q.win[(bq - 1) * MT_N + k];
-                            mt_twist_buf(Q.win + bq * MT_N, lane);
-                        }
-                        wpos -= cb * MT_N;
-                    }
-                    if (lane == 0) { Q.wpos = wpos; Q.attempt0 = attempt; Q.cmd = 1; }
-                    __syncthreads(); // the helpers take candidates 64 .. 255
+                __syncthreads(); // the helpers wake up
+                for (int k = threadIdx.x; k < MT_N; k += 64 * W) Q.buf[0][k] = R.mt[k]; // (all threads: block 0 = the staged block)
+                __syncthreads();
+                __syncthreads(); // the producer has made the first round's words
+                constexpr int NG = CoopLds<W>::NG;
+                int g0 = R.pos, bprev = 0;
+                for (int round = 0;; ++round) {
+                    const uint32_t *rb = Q.buf[round & 1];
+                    const int off = g0 - MT_N * bprev;
                     double x, y;
-                    uint64_t take = eval_win(wpos, attempt, 0, x, y);
-                    __syncthreads(); // their verdicts are in
-                    int win = take ? 0 : -1;
-                    for (int p = 1; p < 4 && win < 0; ++p) {
-                        take = Q.unsure[p] ? eval_win(wpos, attempt, p, x, y) : Q.take[p]; // what the screen could not decide is evaluated again, exactly
-                        if (take) win = p;
+                    uint64_t take = 0ull;
+                    coop_screen_pass<W>(Q, rb, off, attempt, 0, lane, round, kind, (2 + n_g + n_p + 1) >> 1, max_att, (float)c.circle_radius, (float)vp);
+                    __syncthreads(); // every wavefront's report is in (and the next round's words are made)
+                    unsigned long long any = 0ull;
+                    for (int p = 0; p < NG; ++p) any |= Q.take[round & 1][p];
+                    if (any) {
+                        int win = -1;
+                        for (int p = 0; p < NG && win < 0; ++p) {
+                            if (Q.take[round & 1][p] == 0ull) continue;
+                            take = eval_ring(rb, off, attempt, p, x, y); // what the screen could not reject: exactly
+                            if (take) win = p;
+                        }
+                        if (lane == 0) Q.verdict = win >= 0;
+                        __syncthreads(); // the others learn whether the placement goes on
+                        if (win >= 0) {
+                            const int f = __ffsll((unsigned long long)take) - 1;
+                            out_x = wv_readlane_d(x, f); out_y = wv_readlane_d(y, f);
+                            // the staged state afterwards: the block that holds the last word read and the position behind that word
+                            // (624 = "twist before the next draw", as the serial loop leaves it when a candidate ends a block)
+                            const int g = g0 + 6 * (64 * win + f + 1);
+                            const int bi = (g - 1) / MT_N;
+                            rng_sync();
+                            for (int k = lane; k < MT_N; k += 64) R.mt[k] = rb[(bi - bprev) * MT_N + k];
+                            rng_sync();
+                            R.pos = g - bi * MT_N;
+#ifdef CN_POST_DEBUG
+                            DBG_ADD(1, wall_clock64() - dbg_t0);
+                            DBG_ADD(3, round + 1);
+#endif
+                            return;
+                        }
                     }
-                    if (win > 0 && !Q.unsure[win]) take = eval_win(wpos, attempt, win, x, y); // the winner's coordinates
-                    if (win >= 0) {
-                        const int f = __ffsll((unsigned long long)take) - 1;
-                        out_x = wv_readlane_d(x, f); out_y = wv_readlane_d(y, f);
-                        // the staged state afterwards: the block that holds the last word read, position behind it (624 = "twist before the next
-                        // draw", as the serial loop leaves it when a candidate ends a block)
-                        const int g = wpos + 6 * (64 * win + f + 1);
-                        int bi = g / MT_N, po = g - bi * MT_N;
-                        if (po == 0) { --bi; po = MT_N; }
-                        rng_sync();
-                        for (int k = lane; k < MT_N; k += 64) R.mt[k] = Q.win[bi * MT_N + k];
-                        rng_sync();
-                        R.pos = po;
-                        return;
-                    }
-                    wpos += 6 * 256;
-                    attempt += 256;
+                    bprev = (g0 + 384 * NG - 1) / MT_N;
+                    g0 += 384 * NG;
+                    attempt += 64 * NG;
                 }
             }
         }
@@ -1488,6 +1620,7 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
         }
         const int need = 6 - nt;
         double x, y;
+        DBG_ADD(5, 1);
         const uint64_t take = eval_pass(R.mt, first, nt, tl, nb, attempt, x, y);
         // stream position behind candidate f of this pass
         if (take) {
@@ -1501,71 +1634,68 @@ __device__ __forceinline__ void place_by_rejection(const EnvDev &s, Rng &R, int 
     }
 }
 
-// helper wavefronts of an env (waves 1 .. 3 of env_step_kernel<false, 4>): parked at the barrier until the master publishes a round of passes
-// (place_by_rejection<4>), then pass `wave` behind the fp32 screen with the blocking points read from LDS; anything the screen cannot decide is
-// reported, not decided.  The arithmetic is the master's (same expressions, -ffp-contract=off): same verdicts.
+// the other wavefronts of an env: parked at the barrier until the master publishes a placement (place_by_rejection<W>), then round by
+// round.  Waves 1 .. W - 2 (helpers) put candidates 64 wave .. 64 wave + 63 through the coarse screen and report what it cannot reject (the
+// master decides those); wave W - 1 (producer) makes the next round's words meanwhile.
+template <int W>
 __device__ __forceinline__ void coop_helper_loop(int lane, int wave)
 {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    CoopLds &Q = g_coop;
-    int have = -1; // the placement whose constants are in the registers below
-    float Gx = 0.f, Gy = 0.f, Gl = 0.f, Gh = 0.f, Px = 0.f, Py = 0.f, Pl = 0.f, Ph = 0.f;
+    constexpr int NG = CoopLds<W>::NG;
+    CoopLds<W> &Q = coop_lds<W>();
     for (;;) {
-        __syncthreads();
+        __syncthreads(); // a placement, or the end
         if (Q.cmd == 2) return;
-        if (Q.place_id != have) {
-            have = Q.place_id;
-            Gx = Q.G[0][lane]; Gy = Q.G[1][lane]; Gl = Q.G[2][lane]; Gh = Q.G[3][lane];
-            Px = Q.P[0][lane]; Py = Q.P[1][lane]; Pl = Q.P[2][lane]; Ph = Q.P[3][lane];
-        }
-        const int p = wave;
-        const uint32_t *w = Q.win + Q.wpos + 6 * (64 * p + lane);
-        uint32_t wd[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) wd[k] = w[k];
-        const uint32_t a0 = mt_temper(wd[0]) >> 5, b0 = mt_temper(wd[1]) >> 6, a1 = mt_temper(wd[2]) >> 5, b1 = mt_temper(wd[3]) >> 6,
-                       a2 = mt_temper(wd[4]) >> 5, b2 = mt_temper(wd[5]) >> 6;
-        const double u0 = ((double)a0 * 67108864.0 + (double)b0) / 9007199254740992.0;
-        const double u1 = ((double)a1 * 67108864.0 + (double)b1) / 9007199254740992.0;
-        const double u2 = ((double)a2 * 67108864.0 + (double)b2) / 9007199254740992.0;
-        const double angle = u0 * M_PI * 2.0;
-        const double nx = Q.kind == 0 ? (0.0 + (1.0 - 0.0) * u1) * 2.0 : (u1 - 0.5) * Q.vp;
-        const double ny = Q.kind == 0 ? (0.0 + (1.0 - 0.0) * u2) * 2.0 : (u2 - 0.5) * Q.vp;
-        double sn, cs;
-        det_sincos(angle, sn, cs);
-        const double x = Q.circle_radius * cs + nx, y = Q.circle_radius * sn + ny;
-        const float xf = (float)x, yf = (float)y;
-        const f2 xx = f2{xf, xf}, yy = f2{yf, yf};
-        f2 ax = xx - f2{Q.rgx, Q.rpx}, ay = yy - f2{Q.rgy, Q.rpy};
-        f2 q = ax * ax + ay * ay;
-        float m1 = fminf(q.x, q.y) - Q.lor;
-        float m2 = fminf(q.x, q.y) - Q.hir;
-        const int n_g = Q.n_g, n_p = Q.n_p;
-        for (int k = 0; k < n_g; k += 2) {
-            const int k1 = k + 1 < n_g ? k + 1 : k;
-            const f2 jx = f2{wv_readlane(Gx, k), wv_readlane(Gx, k1)}, jy = f2{wv_readlane(Gy, k), wv_readlane(Gy, k1)};
-            const f2 lo = f2{wv_readlane(Gl, k), wv_readlane(Gl, k1)}, hi = f2{wv_readlane(Gh, k), wv_readlane(Gh, k1)};
-            ax = xx - jx; ay = yy - jy;
-            q = ax * ax + ay * ay;
-            const f2 dl = q - lo, dh = q - hi;
-            m1 = fminf(m1, fminf(dl.x, dl.y));
-            m2 = fminf(m2, fminf(dh.x, dh.y));
-        }
-        for (int k = 0; k < n_p; k += 2) {
-            const int k1 = k + 1 < n_p ? k + 1 : k;
-            const f2 jx = f2{wv_readlane(Px, k), wv_readlane(Px, k1)}, jy = f2{wv_readlane(Py, k), wv_readlane(Py, k1)};
-            const f2 lo = f2{wv_readlane(Pl, k), wv_readlane(Pl, k1)}, hi = f2{wv_readlane(Ph, k), wv_readlane(Ph, k1)};
-            ax = xx - jx; ay = yy - jy;
-            q = ax * ax + ay * ay;
-            const f2 dl = q - lo, dh = q - hi;
-            m1 = fminf(m1, fminf(dl.x, dl.y));
-            m2 = fminf(m2, fminf(dh.x, dh.y));
-        }
-        const bool hit = m1 < 0.0f, open = m2 > 0.0f;
-        const uint64_t uns = __ballot(!hit && !open);
-        const uint64_t take = __ballot(!hit || Q.attempt0 + 64 * p + lane >= Q.max_att);
-        if (lane == 0) { Q.take[p] = take; Q.unsure[p] = uns; }
+        const int kind = Q.kind, n_pairs = Q.n_pairs, max_att = Q.max_att;
+        const float circle_radius = Q.circle_radius, vp = Q.vp;
+        int g0 = Q.pos0, attempt = Q.attempt0;
+        for (int k = threadIdx.x; k < MT_N; k += 64 * W) Q.buf[0][k] = g_mt_lds[k];
         __syncthreads();
+        if (wave == W - 1) { // ---- producer
+            int bprev = 0, b1 = (g0 + 384 * NG - 1) / MT_N; // round 0 reads blocks 0 .. b1
+            coop_produce(Q.buf[0], nullptr, lane, MT_N * b1);
+            __syncthreads(); // the first round's words are made
+            for (int round = 0;; ++round) {
+                const int b2 = (g0 + 768 * NG - 1) / MT_N; // round + 1 reads blocks b1 .. b2
+#ifdef CN_POST_DEBUG
+                const long long dbg_p0 = wall_clock64();
+#endif
+                coop_produce(Q.buf[(round + 1) & 1], Q.buf[round & 1] + MT_N * (b1 - bprev), lane, MT_N * (b2 - b1));
+#ifdef CN_POST_DEBUG
+                DBG_ADD(7, wall_clock64() - dbg_p0);
+#endif
+                __syncthreads();
+                unsigned long long any = 0ull;
+                for (int p = 0; p < NG; ++p) any |= Q.take[round & 1][p];
+                if (any) {
+                    __syncthreads();
+                    if (Q.verdict) break;
+                }
+                g0 += 384 * NG;
+                bprev = b1; b1 = b2;
+            }
+            continue;
+        }
+        __syncthreads(); // the first round's words are made
+        int bprev = 0;
+        for (int round = 0;; ++round) {
+#ifdef CN_POST_DEBUG
+            const long long dbg_e0 = wall_clock64();
+#endif
+            coop_screen_pass<W>(Q, Q.buf[round & 1], g0 - MT_N * bprev, attempt, wave, lane, round, kind, n_pairs, max_att, circle_radius, vp);
+#ifdef CN_POST_DEBUG
+            if (wave == 1) DBG_ADD(6, wall_clock64() - dbg_e0);
+#endif
+            __syncthreads(); // every wavefront's report is in (and the next round's words are made)
+            unsigned long long any = 0ull;
+            for (int p = 0; p < NG; ++p) any |= Q.take[round & 1][p];
+            if (any) {
+                __syncthreads(); // the master has looked at the reports
+                if (Q.verdict) break;
+            }
+            bprev = (g0 + 384 * NG - 1) / MT_N;
+            g0 += 384 * NG;
+            attempt += 64 * NG;
+        }
     }
 }
 
@@ -1919,21 +2049,19 @@ __device__ __forceinline__ void pregen_env(const EnvDev &s, int e, int lane, lon
     if (lane == 0 && complete) s.nx_ready[e] = 1;
 }
 
-// (W = 4: dense crowds, where ONE human of a new episode takes up to a millisecond of candidates on one wavefront -- the three helper
-// wavefronts of place_by_rejection<4>, as in env_step_kernel)
+// (W > 1: with the helper wavefronts of place_by_rejection<W>, as in env_step_kernel; not launched -- see launch_pregen)
 template <int W = 1>
 __global__ __launch_bounds__(64 * W) void env_pregen_kernel(EnvDev s, long long budget)
 {
     const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x & 63;
     if constexpr (W > 1) {
-        if (threadIdx.x >= 64) { coop_helper_loop(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
-        if (lane == 0) g_coop.place_id = 0;
+        if (threadIdx.x >= 64) { coop_helper_loop<W>(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
     }
     Rng R{MT_N, false};
     pregen_env<W>(s, blockIdx.x, lane, budget, R);
     if constexpr (W > 1) { // release the helpers
-        if (lane == 0) g_coop.cmd = 2;
+        if (lane == 0) coop_lds<W>().cmd = 2;
         __syncthreads();
     }
 }
@@ -2004,10 +2132,13 @@ __global__ __launch_bounds__(64 * W) void env_post_kernel(EnvDev s)
     const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x & 63;
     if constexpr (W > 1) {
-        if (threadIdx.x >= 64) { coop_helper_loop(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
-        if (lane == 0) g_coop.place_id = 0;
+        if (threadIdx.x >= 64) { coop_helper_loop<W>(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
     }
     const int e = s.post_list[blockIdx.x];
+#ifdef CN_POST_DEBUG
+    const long long dbg_start = wall_clock64();
+    if (lane < 8) g_dbg_blk[lane] = 0;
+#endif
     Rng R{MT_N, false};
     Robot rb;
     Lane h;
@@ -2015,11 +2146,15 @@ __global__ __launch_bounds__(64 * W) void env_post_kernel(EnvDev s)
     double shared_nd = s.shared_nd[e];
     const int n = crowd_size(s, e);
     post_obs_updates<W>(s, R, e, lane, n, s.step_counter[e], rb, h, shared_nd);
+#ifdef CN_POST_DEBUG
+    if (lane == 0) g_dbg_blk[0] = wall_clock64() - dbg_start;
+    if (lane < 8) g_post_dbg[blockIdx.x * 8 + lane] = g_dbg_blk[lane];
+#endif
     store_env(s, e, lane, rb, h);
     if (lane == 0) s.shared_nd[e] = shared_nd;
     rng_store(R, s, e, lane);
     if constexpr (W > 1) { // release the helpers
-        if (lane == 0) g_coop.cmd = 2;
+        if (lane == 0) coop_lds<W>().cmd = 2;
         __syncthreads();
     }
 }
@@ -2052,15 +2187,14 @@ __global__ __launch_bounds__(64) void env_obs_kernel(EnvDev s, cn_obs ob)
 // observation depends on -- are left to env_post_kernel on the side stream, in front of the ORCA pass that needs the new goals: the
 // long placement loops of the few envs that change goals then run beside the policy forward instead of in front of it.
 template <bool SPLIT, int W = 1, bool DEFER = false>
-__global__ __launch_bounds__(64 * W, 4) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
+__global__ __launch_bounds__(64 * W, W > 1 ? 2 : 4) void env_step_kernel(EnvDev s, const float *actions, cn_obs ob, float *reward_out,
                                                       uint8_t *done_out, uint8_t *info_out, double *ep_ret_out, int32_t *ep_len_out, float *not_done_out)
 {
     const CnStampScope stamp_scope(s.stamp);
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x;
     if constexpr (W > 1) {
-        if (threadIdx.x >= 64) { coop_helper_loop(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
-        if (lane == 0) g_coop.place_id = 0; // (the helpers read it behind the first barrier only)
+        if (threadIdx.x >= 64) { coop_helper_loop<W>(lane, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))); return; }
     }
     const cn_env_config &c = s.cfg;
     const int H = s.H;
@@ -2386,7 +2520,7 @@ __global__ __launch_bounds__(64 * W, 4) void env_step_kernel(EnvDev s, const flo
     if (lane == 0) s.shared_nd[e] = shared_nd;
     rng_store(R, s, e, lane);
     if constexpr (W > 1) { // release the helpers
-        if (lane == 0) g_coop.cmd = 2;
+        if (lane == 0) coop_lds<W>().cmd = 2;
         __syncthreads();
     }
 }
@@ -2489,10 +2623,38 @@ static bool dense_crowd(cn_env_batch *env)
     return coop_env >= 0 ? coop_env != 0 : zone > 0.9 * 2.0 * M_PI * cf.circle_radius;
 }
 
+static int launch_post(cn_env_batch *env, hipStream_t on)
+{
+    static const int post_waves = getenv("CN_POST_WAVES") ? atoi(getenv("CN_POST_WAVES")) : 4; // (A/B: 4, 8, 16)
+    if (post_waves == 4) hipLaunchKernelGGL(env_post_kernel<4>, dim3(env->d.E), dim3(256), 0, on, stamped(env->d, CN_K_OTHER));
+    else if (post_waves == 8) hipLaunchKernelGGL(env_post_kernel<8>, dim3(env->d.E), dim3(512), 0, on, stamped(env->d, CN_K_OTHER));
+    else hipLaunchKernelGGL(env_post_kernel<16>, dim3(env->d.E), dim3(1024), 0, on, stamped(env->d, CN_K_OTHER));
+    CN_CHECK_LAUNCH();
+#ifdef CN_POST_DEBUG
+    {
+        static int calls = 0;
+        (void)hipStreamSynchronize(on);
+        int cnt = 0;
+        (void)hipMemcpy(&cnt, env->d.post_cnt, 4, hipMemcpyDeviceToHost);
+        static long long host[8192 * 8];
+        (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_post_dbg), sizeof(long long) * 8 * (size_t)cnt);
+        int worst = 0;
+        for (int i = 0; i < cnt; ++i) if (host[i * 8] > host[worst * 8]) worst = i;
+        if (++calls % 4 == 0 && cnt > 0) {
+            const long long *w = host + worst * 8;
+            fprintf(stderr, "[post] envs %d | worst block: %.1f us (coop %.1f us, %lld coop placements, %lld rounds: producer busy %.1f us, helper 1 screening %.1f us; %lld placements, %lld serial passes)\n",
+                    cnt, w[0] * 0.01, w[1] * 0.01, w[2], w[3], w[7] * 0.01, w[6] * 0.01, w[4], w[5]);
+        }
+    }
+#endif
+    return CN_OK;
+}
+
 static int launch_pregen(cn_env_batch *env, hipStream_t on)
 {
-    if (dense_crowd(env)) hipLaunchKernelGGL(env_pregen_kernel<4>, dim3(env->d.E), dim3(256), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
-    else hipLaunchKernelGGL(env_pregen_kernel<1>, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
+    // (one wavefront per env also for dense crowds: a NEW episode's humans are placed in 4 candidates on average -- positions, with noise of up to
+    // 2 m, against goals on the far side -- it is the goal changes mid-episode that run long)
+    hipLaunchKernelGGL(env_pregen_kernel<1>, dim3(env->d.E), dim3(64), 0, on, stamped(env->d, CN_K_PREGEN), env->pregen_ticks);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -2515,8 +2677,7 @@ static int launch_tail(cn_env_batch *env, hipStream_t main)
         env->pg_pending = true;
     }
     if (env->post_deferred) { // the goal changes / respawns of the step just enqueued: the ORCA pass below reads the new goals
-        hipLaunchKernelGGL(env_post_kernel<4>, dim3(env->d.E), dim3(256), 0, env->side, stamped(env->d, CN_K_OTHER));
-        CN_CHECK_LAUNCH();
+        if (int rc = launch_post(env, env->side)) return rc;
         env->post_deferred = false;
     }
     if (env->d.cfg.humans_policy == CN_HUMANS_ORCA) { // social-force humans act inside env_step_kernel (one lane per human, no solver)
@@ -2824,6 +2985,8 @@ extern "C" int cn_env_step(cn_env_batch *env, const float *actions, const cn_obs
             CN_HIP(hipMemsetAsync(env->d.post_cnt, 0, 4, st));
             hipLaunchKernelGGL((env_step_kernel<false, 1, true>), dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
             env->post_deferred = true;
+            static const int post_main = getenv("CN_POST_MAIN") ? atoi(getenv("CN_POST_MAIN")) : 0; // (measurement: the kernel on its own, behind the step)
+            if (post_main) { if (int rc = launch_post(env, st)) return rc; env->post_deferred = false; }
         }
         else if (coop) hipLaunchKernelGGL((env_step_kernel<false, 4>), dim3(env->d.E), dim3(256), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
         else hipLaunchKernelGGL(env_step_kernel<false>, dim3(env->d.E), dim3(64), 0, st, stamped(env->d, CN_K_ENV_STEP), actions, *obs, reward, done, info, ep_return, ep_len, not_done);
