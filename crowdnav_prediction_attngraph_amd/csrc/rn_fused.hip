@@ -44,11 +44,33 @@ __device__ __forceinline__ float fast_tanh(float x)
 }
 __device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
+// The first k-steps' weight fragments of a stage, fetched BEFORE the barrier that releases the stage's input activations (they depend on
+// nothing): the L2 round trip of every stage's first fragments (~1-2 us beside the ORCA tail, seven stages in a chain) then runs under the
+// previous stage's epilogue / the barrier instead of behind it.
+template <int K, int NFB, int D = 2> // D: k-steps fetched ahead (<= the stage's own prefetch depth - 1)
+struct WPre {
+    static constexpr int KS = K / 32, PF = KS < 3 ? KS : 3, N = (PF - 1 < D ? PF - 1 : D) > 0 ? (PF - 1 < D ? PF - 1 : D) : 1;
+    bf16x8 ah[N][NFB], al[N][NFB];
+};
+template <int K, int NFB, int D>
+__device__ __forceinline__ void wpre_load(WPre<K, NFB, D> &w, const float *__restrict__ Wfrag_, int fb_first, int fb_step, int lane)
+{
+    const bf16x8 *__restrict__ Wfrag = reinterpret_cast<const bf16x8 *>(Wfrag_);
+    constexpr int KS = K / 32, PF = KS < 3 ? KS : 3;
+#pragma unroll
+    for (int p = 0; p < PF - 1 && p < D; ++p)
+#pragma unroll
+        for (int j = 0; j < NFB; ++j) {
+            const size_t base = ((size_t)(fb_first + j * fb_step) * KS + (p < KS ? p : KS - 1)) * 128 + lane;
+            w.ah[p][j] = Wfrag[base]; w.al[p][j] = Wfrag[base + 64];
+        }
+}
+
 // out[env][out_off + 16*fb + ..] = act(W[fb] . in[env][in_off ..] + bias) for the feature blocks fb = fb0 + wave, fb0 + wave + 4, ...
 // Wfrag: baked fragments [fb][K/32][plane hi,lo][64 lanes][8 bf16]; NFB = feature blocks of this wavefront
-template <int K, int NFB, int ACT>
+template <int K, int NFB, int ACT, bool PRE = false, int D = 2>
 __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_first, int fb_step, const float *__restrict__ bias, const float *in, int in_stride,
-                                      float *out, int out_stride, int out_off, int relu_from, int lane)
+                                      float *out, int out_stride, int out_off, int relu_from, int lane, const WPre<K, NFB, D> &pre = WPre<K, NFB, D>{})
 {
     const bf16x8 *__restrict__ Wfrag = reinterpret_cast<const bf16x8 *>(Wfrag_);
     const int i = lane & 15, g = lane >> 4;
@@ -76,6 +98,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_f
     for (int p = 0; p < PF - 1; ++p)
 #pragma unroll
         for (int j = 0; j < NFB; ++j) {
+            if (PRE && p < D) { ah[p][j] = pre.ah[p < D ? p : 0][j]; al[p][j] = pre.al[p < D ? p : 0][j]; continue; }
             const size_t base = ((size_t)(fb_first + j * fb_step) * KS + (p < KS ? p : KS - 1)) * 128 + lane;
             ah[p][j] = Wfrag[base]; al[p][j] = Wfrag[base + 64];
         }
@@ -120,6 +143,14 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     float *R0 = smem + O_R0, *R1 = smem + O_R1, *R2 = smem + O_R2, *R3 = smem + O_R3, *R4 = smem + O_R4, *R5 = smem + O_R5;
     // ---- robot_linear.0: relu(W [256,9] . [temporal_edges(2) | robot_node(7)] + b); thread = feature; h_in -> LDS ----
     const int w4 = wave & 3, hi = wave >> 2; // two groups of four wavefronts run independent products side by side
+#ifndef RN_NO_PREFETCH
+    WPre<256, 5, 1> p_te; WPre<128, 6, 1> p_whh;
+    if (hi == 0) wpre_load(p_te, a.f_te, w4, 4, lane); else wpre_load(p_whh, a.f_whh, w4, 4, lane);
+#define RN_PRE true
+#else
+#define RN_PRE false
+    const WPre<256, 1> p_edge{}; const WPre<128, 3> p_wih{}; const WPre<128, 4> p_ac0{}; const WPre<256, 4> p_2{};
+#endif
     {
         const int n = tid & 255; // feature; the two thread halves split the envs
         float w[9];
@@ -145,8 +176,17 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
     __syncthreads();
     // ---- z = [u (256) | relu(enc) (64)] = te_w [320,256] . robot_states + te_b ;  gh = W_hh [384,128] . h_in (unmasked, no bias) ----
+#ifndef RN_NO_PREFETCH
+    if (hi == 0) stage<256, 5, A_RELU, true, 1>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane, p_te);
+    else stage<128, 6, A_NONE, true, 1>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane, p_whh);
+    // the next two products' first fragments travel while the attention runs
+    WPre<256, 1> p_edge; WPre<128, 3> p_wih;
+    if (hi == 0) wpre_load(p_edge, a.f_edge, w4, 4, lane);
+    wpre_load(p_wih, a.f_wih, wave, 8, lane);
+#else
     if (hi == 0) stage<256, 5, A_RELU>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane);
     else stage<128, 6, A_NONE>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane);
+#endif
     __syncthreads();
     // ---- robot-human attention (u-form, see hr_attention_kernel in policy.hip): wavefront w owns envs 2w, 2w+1 ----
     // out_sp was written a moment ago by the human-human kernel on (mostly) other XCDs: every row read is a trip to the fabric.  A
@@ -229,10 +269,18 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
     __syncthreads();
     // ---- edge = relu(edge_attention_embed [64,256] . hr + b) -> z[320:384] ----
-    if (hi == 0) stage<256, 1, A_RELU>(a.f_edge, w4, 4, a.edge_b, R0, S512, R1, S512, 320, 0, lane);
+    if (hi == 0) stage<256, 1, A_RELU, RN_PRE>(a.f_edge, w4, 4, a.edge_b, R0, S512, R1, S512, 320, 0, lane, p_edge);
+#ifndef RN_NO_PREFETCH
+    WPre<128, 4> p_ac0;
+    wpre_load(p_ac0, a.f_ac0, wave, 8, lane);
+#endif
     __syncthreads();
     // ---- gi = W_ih [384,128] . [enc | edge] + b_ih ----
-    stage<128, 3, A_NONE>(a.f_wih, wave, 8, a.bih, R1 + 256, S512, R3, S384, 0, 0, lane);
+    stage<128, 3, A_NONE, RN_PRE>(a.f_wih, wave, 8, a.bih, R1 + 256, S512, R3, S384, 0, 0, lane, p_wih);
+#ifndef RN_NO_PREFETCH
+    WPre<256, 4> p_2;
+    if (hi == 0) wpre_load(p_2, a.f_a2, w4, 4, lane); else wpre_load(p_2, a.f_c2, w4, 4, lane);
+#endif
     __syncthreads();
     // ---- GRU cell, pointwise part (gate order r,z,n; h and gh masked by the done mask: srnn_model.py:43-46) ----
     for (int idx = tid; idx < TE * 128; idx += 512) {
@@ -251,10 +299,10 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
     __syncthreads();
     // ---- actor / critic trunks: tanh((W0 Wo) h + ..) [512,128], then the two [256,256] second layers ----
-    stage<128, 4, A_TANH>(a.f_ac0, wave, 8, a.ac0_b, R5, S128, R0, S512, 0, 0, lane);
+    stage<128, 4, A_TANH, RN_PRE>(a.f_ac0, wave, 8, a.ac0_b, R5, S128, R0, S512, 0, 0, lane, p_ac0);
     __syncthreads();
-    if (hi == 0) stage<256, 4, A_TANH>(a.f_a2, w4, 4, a.a2_b, R0, S512, R1, S512, 0, 0, lane);
-    else stage<256, 4, A_TANH>(a.f_c2, w4, 4, a.c2_b, R0 + 256, S512, R1, S512, 256, 0, lane);
+    if (hi == 0) stage<256, 4, A_TANH, RN_PRE>(a.f_a2, w4, 4, a.a2_b, R0, S512, R1, S512, 0, 0, lane, p_2);
+    else stage<256, 4, A_TANH, RN_PRE>(a.f_c2, w4, 4, a.c2_b, R0 + 256, S512, R1, S512, 256, 0, lane, p_2);
     __syncthreads();
     // ---- critic_linear + DiagGaussian head (model.py:64-72): wavefront w owns envs 2w, 2w+1 ----
     for (int q = 0; q < 2; ++q) {
