@@ -14,8 +14,10 @@
 // the caller's stream.
 #include "common.h"
 #include "rn_fused.h" // rn_fused_bake: bf16 hi/lo MFMA-fragment image of a weight matrix
+#include <utility>
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 namespace {
@@ -86,13 +88,15 @@ constexpr int GL_SA = 68, GL_SQ = 196;                    // LDS row strides (fl
 constexpr int GL_OA = 0, GL_OQ = GL_OA + GL_ROWS * GL_SA, GL_OT = GL_OQ + GL_ROWS * GL_SQ, GL_OM = GL_OT + GL_ROWS * GL_SA;
 constexpr int GL_OX = GL_OM + GL_ROWS, GL_OC = GL_OX + 2 * GL_ROWS; // staged (x, y) inputs; constants of the embedding's LayerNorm
 constexpr int GL_OB = GL_OC + 16;            // biases: in_proj 192 | out_proj 64 | linear1 128 | linear2 64 (read by every tile: staged once)
-constexpr int GL_LDS_FLOATS = GL_OB + 448;
+constexpr int GL_ORM = GL_OB + 448;         // row map of a tile of listed groups (ints): row r of the tile -> row of x2 / mask / xs
+constexpr int GL_LDS_FLOATS = GL_ORM + GL_ROWS;
 
 struct GstLayerArgs {
     const float *x2, *mask;                                   // [rows,2], [rows]
     const float *emb_w, *emb_b, *n_w, *n_b, *n1_w, *n1_b;     // fp32 small tensors
     const float *f_in, *in_b, *f_out, *out_b, *f_l1, *l1_b, *f_l2, *l2_b; // baked fragments + biases
     float *xs;                                                // [rows,64] encoded rows (input of the LSTM)
+    const int *glist, *gcount; int gbase;                     // optional: only the groups glist[0 .. gbase + *gcount) (gst_reuse_kernel), any order
 };
 
 // The weight fragments of a stage for the feature blocks fb_first, fb_first + fb_step, ... of this wavefront.  Wfrag: [fb][K/32][hi,lo]
@@ -119,7 +123,7 @@ __device__ __forceinline__ void gl_load(GlW<K, NFB> &w, const float *__restrict_
 template <int K, int NFB, bool RELU>
 __device__ __forceinline__ void gl_stage(const GlW<K, NFB> &w, int fb_first, int fb_step, const float *__restrict__ bias, const float *in,
                                          int in_stride, float *out, size_t out_stride, int out_off, const float *res, int res_stride, int nrows, int lane,
-                                         int rt_first)
+                                         int rt_first, const int *rowmap = nullptr)
 {
     const int i = lane & 15, g = lane >> 4;
     constexpr int KS = K / 32;
@@ -161,7 +165,7 @@ __device__ __forceinline__ void gl_stage(const GlW<K, NFB> &w, int fb_first, int
             f32x4 v = acc[j] + bv[j];
             if (res) v += *reinterpret_cast<const f32x4 *>(res + row * res_stride + f0);
             if (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            if (row < nrows) *reinterpret_cast<f32x4 *>(out + (size_t)row * out_stride + out_off + f0) = v;
+            if (row < nrows) *reinterpret_cast<f32x4 *>(out + (size_t)(rowmap ? rowmap[row] : row) * out_stride + out_off + f0) = v;
         }
     }
 }
@@ -183,6 +187,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gst_layer_kernel(int rows, int 
     const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave8 & 3, team = wave8 >> 2; // feature-block owner; row-tile parity (8 wavefronts: two per SIMD hide each other's latencies)
     const int tile_rows = TG * H;
+    int *RM = reinterpret_cast<int *>(lds_f + GL_ORM);
+    if (a.glist) rows = (a.gbase + *a.gcount) * H; // the listed groups only (the others' rows were taken over from the previous call: gst_reuse_kernel)
     const int n_tiles = (rows + tile_rows - 1) / tile_rows;
     // LayerNorm of the embedding v_f = We[f][0] x + We[f][1] y + be[f] needs no reduction per row: its mean and variance over the 64
     // features are a linear / quadratic form of (x, y) with nine constants of the weight snapshot (computed here once per workgroup)
@@ -207,9 +213,15 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gst_layer_kernel(int rows, int 
         // ---- stage the tile's inputs (coalesced), then node_embedding (2 -> 64) + LayerNorm(norm_node) * mask -> A0 (padding rows = 0) ----
         for (int r = tid; r < nrows16; r += GL_THREADS) {
             const bool live = r < nrows;
-            XY[2 * r] = live ? a.x2[2 * (size_t)(r0 + r)] : 0.0f;
-            XY[2 * r + 1] = live ? a.x2[2 * (size_t)(r0 + r) + 1] : 0.0f;
-            MSK[r] = live ? a.mask[r0 + r] : 0.0f;
+            size_t src = (size_t)(r0 + r);
+            if (a.glist) { // row r of this tile = node r % H of listed group tile * TG + r / H
+                const int k = r / H;
+                src = live ? (size_t)a.glist[tile * TG + k] * H + (r - k * H) : 0;
+                RM[r] = (int)src;
+            }
+            XY[2 * r] = live ? a.x2[2 * src] : 0.0f;
+            XY[2 * r + 1] = live ? a.x2[2 * src + 1] : 0.0f;
+            MSK[r] = live ? a.mask[src] : 0.0f;
         }
         __syncthreads();
         for (int r = wave8; r < nrows16; r += GL_NW) {
@@ -296,7 +308,8 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gst_layer_kernel(int rows, int 
         __syncthreads();
         GL_T(5);
         // xs = x1 + W_2 ff + b_2 -> HBM (64 floats per row; the LSTM kernel applies W_ih itself: its [rows, 256] image would be 4x the bytes)
-        gl_stage<128, 1, false>(w_l2, wave, 4, BI + 384, QKV, GL_SQ, a.xs + (size_t)r0 * 64, 64, 0, A0, GL_SA, nrows, lane, team);
+        if (a.glist) gl_stage<128, 1, false>(w_l2, wave, 4, BI + 384, QKV, GL_SQ, a.xs, 64, 0, A0, GL_SA, nrows, lane, team, RM);
+        else gl_stage<128, 1, false>(w_l2, wave, 4, BI + 384, QKV, GL_SQ, a.xs + (size_t)r0 * 64, 64, 0, A0, GL_SA, nrows, lane, team);
         if (tile + (int)gridDim.x < n_tiles) gl_load<64, 3>(w_in, a.f_in, wave, 4, lane); // (w_in's registers were free since the in_proj stage)
         __syncthreads(); // the next tile overwrites A0 / MSK
         GL_T(7);
@@ -525,6 +538,62 @@ __global__ __launch_bounds__(64) void pretext_post_kernel(int E, int H, int D, c
     }
 }
 
+// The observation window of one call is the previous call's window moved on by one frame (the wrapper's history ring), and the spatial encoding
+// of a frame -- NodeEncoderLayer over the H nodes of one (env, frame) group -- is a function of that group's inputs only: displacements
+// (x_t - x_{t-1}) m and masks m = mask[t-1] mask[T-1].  Frame t of this call (t = 1 .. T-2) therefore has the encoding frame t + 1 had in the
+// previous call whenever its H inputs and masks are the same 3 H numbers -- which they are unless a human's visibility in the NEWEST frame
+// changed (that mask multiplies every frame's) or the env was reset.  One wavefront per group compares them bit for bit: equal -> the 64 H
+// encoded values are copied over from the previous call's buffer, anything else (and always frame 0, whose displacement is defined as 0, and the
+// newest frame) -> the group goes on the list gst_layer_kernel works through.  Same numbers either way: a row's encoding does not depend on
+// which other groups share its tile.
+// The list: frames 0 and T - 1 of every env at fixed places (entries [0, 2 E)), the other groups that could not be taken over behind them -- one
+// device-scope atomic per workgroup of 16 groups (same-address atomics serialise in the L2 at ~12 ns each: one per group took 60 us).
+__global__ __launch_bounds__(1024) void gst_reuse_kernel(int E, int H, int have_prev, const float *__restrict__ rel, const float *__restrict__ m_rel,
+                                                         const float *__restrict__ rel_prev, const float *__restrict__ m_prev, const float *__restrict__ xs_prev,
+                                                         float *__restrict__ xs, int *__restrict__ glist, int *__restrict__ gcount)
+{
+    __shared__ int s_cnt, s_base;
+    const int lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * 16 + (threadIdx.x >> 6); // group = (env e, frame t): rows gidx * H .. + H; one wavefront each
+    const bool live = gidx < E * GT;
+    const int e = gidx / GT, t = gidx - e * GT;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    bool same = live && have_prev && t >= 1 && t <= GT - 2;
+    if (same) {
+        const size_t r = (size_t)gidx * H + lane, rp = r + H; // the same env's frame t + 1 of the previous call
+        bool eq = true;
+        if (lane < H) {
+            eq = __float_as_uint(rel[2 * r]) == __float_as_uint(rel_prev[2 * rp]) && __float_as_uint(rel[2 * r + 1]) == __float_as_uint(rel_prev[2 * rp + 1]) &&
+                 __float_as_uint(m_rel[r]) == __float_as_uint(m_prev[rp]);
+        }
+        same = __ballot(!eq) == 0ull;
+    }
+    const bool listed = live && !same && t >= 1 && t <= GT - 2;
+    int slot = 0;
+    if (listed && lane == 0) slot = atomicAdd(&s_cnt, 1);
+    if (same) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(xs_prev + ((size_t)gidx + 1) * H * 64);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(xs + (size_t)gidx * H * 64);
+        const int n = H * 16;
+        for (int k0 = lane; k0 < n; k0 += 64 * 5) { // (H = 20: the group's 320 float4 in one go, all loads in flight before the first store)
+            f32x4 v[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) if (k0 + 64 * u < n) v[u] = __builtin_nontemporal_load(src + k0 + 64 * u);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) if (k0 + 64 * u < n) dst[k0 + 64 * u] = v[u];
+        }
+    }
+    if (live && lane == 0) {
+        if (t == 0) glist[e] = gidx;
+        if (t == GT - 1) glist[E + e] = gidx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(gcount, s_cnt);
+    __syncthreads();
+    if (listed && lane == 0) glist[2 * E + s_base + slot] = gidx;
+}
+
 constexpr size_t g_align(size_t x) { return (x + 255) & ~size_t(255); }
 
 } // namespace
@@ -540,6 +609,12 @@ struct cn_gst {
     // workspace (rows = maxE * 5 * H)
     float *m_rel, *lm_fp, *rel, *last_pos, *xs, *h, *c, *acc, *x_sample;
     float *out_traj, *out_mask; // internal buffers for the wrapper path
+    // the previous call's observation-period inputs and encodings (gst_reuse_kernel); xs_dec: the decode steps' encoded rows (they must not
+    // overwrite the window's)
+    float *m_rel_prev, *rel_prev, *xs_prev, *xs_dec;
+    int *glist, *gcount;
+    int prev_E;        // envs of the call whose window the *_prev buffers hold (0 = none: first call, new weights)
+    bool reuse;        // CN_GST_REUSE=0 switches the reuse off (A/B, tests)
     // VecPretextNormalize history
     // (its own allocation: the length depends on the prediction stride, cn_gst_wrapper_set_interval)
     float *ring_traj;   // [ring_len][maxE][H][2]
@@ -577,6 +652,7 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     const size_t o_mrel = carve(R), o_lm = carve(N), o_rel = carve(2 * R), o_lp = carve(2 * N), o_xs = carve(R * 64);
     const size_t o_h = carve(N * 64), o_c = carve(N * 64), o_acc = carve(N * 5), o_xsamp = carve(N * 2), o_ot = carve(N * GP * 5), o_om = carve(N);
     const size_t o_wcat = carve(256 * 128), o_flstm = carve(256 * 128);
+    const size_t o_mrelp = carve(R), o_relp = carve(2 * R), o_xsp = carve(R * 64), o_xsd = carve(N * 64), o_gl = carve(R / human_num + 64);
     const size_t o_fin = carve(192 * 64), o_fout = carve(64 * 64), o_fl1 = carve(128 * 64), o_fl2 = carve(64 * 128);
     char *base = nullptr;
     hipError_t herr = hipMalloc((void **)&base, off);
@@ -590,6 +666,10 @@ extern "C" int cn_gst_create(int human_num, int max_envs, cn_gst **out)
     g->acc = F(o_acc); g->x_sample = F(o_xsamp); g->out_traj = F(o_ot); g->out_mask = F(o_om);
     g->w_cat = F(o_wcat); g->f_lstm = F(o_flstm);
     g->f_in = F(o_fin); g->f_out = F(o_fout); g->f_l1 = F(o_fl1); g->f_l2 = F(o_fl2);
+    g->m_rel_prev = F(o_mrelp); g->rel_prev = F(o_relp); g->xs_prev = F(o_xsp); g->xs_dec = F(o_xsd);
+    g->glist = reinterpret_cast<int *>(F(o_gl)) + 64; g->gcount = reinterpret_cast<int *>(F(o_gl));
+    g->prev_E = 0;
+    g->reuse = !(getenv("CN_GST_REUSE") && atoi(getenv("CN_GST_REUSE")) == 0);
     g->weights_set = false;
     if (int rc = gst_alloc_ring(g, 1)) { (void)hipFree(base); delete g; return rc; }
     *out = g;
@@ -625,6 +705,7 @@ extern "C" int cn_gst_set_weights(cn_gst *g, const cn_gst_weights *w, void *stre
     CN_HIP(hipMemcpy2DAsync(g->w_cat + 64, 128 * sizeof(float), g->whh, 64 * sizeof(float), 64 * sizeof(float), 256, hipMemcpyDeviceToDevice, st));
     if ((rc = rn_fused_bake(256, 128, g->w_cat, g->f_lstm, st))) return rc;
     g->weights_set = true;
+    g->prev_E = 0; // encodings of the old weights are not this model's
     return CN_OK;
 }
 
@@ -637,7 +718,7 @@ extern "C" int cn_gst_set_timing(long long *buf)
 #endif
 
 // NodeEncoderLayer over `rows` rows in groups of H nodes: x2 [rows,2], mask [rows] -> g->xs [rows,64] (one launch)
-static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hipStream_t st)
+static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hipStream_t st, float *xs_out = nullptr, bool listed = false)
 {
     const int H = g->H;
     int TG = GL_ROWS / H; TG = TG < 1 ? 1 : TG;
@@ -650,7 +731,8 @@ static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hi
         attr_dev = dev;
     }
     const int n_tiles = (rows + TG * H - 1) / (TG * H);
-    GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b, g->xs};
+    GstLayerArgs a{x2, mask, g->emb_w, g->emb_b, g->n_w, g->n_b, g->n1_w, g->n1_b, g->f_in, g->in_b, g->f_out, g->out_b, g->f_l1, g->l1_b, g->f_l2, g->l2_b,
+                   xs_out ? xs_out : g->xs, listed ? g->glist : nullptr, listed ? g->gcount : nullptr, listed ? 2 * (rows / (GT * H)) : 0};
     hipLaunchKernelGGL(gst_layer_kernel, dim3(n_tiles < 256 * GL_WGS ? n_tiles : 256 * GL_WGS), dim3(GL_THREADS), GL_LDS_FLOATS * sizeof(float), st, rows, H, TG, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -658,7 +740,7 @@ static int gst_layer(cn_gst *g, int rows, const float *x2, const float *mask, hi
 
 // the LSTM over S slices of the encoded rows g->xs (S = 5: the observation period from h = c = 0 set by the caller; S = 1: one decode step)
 static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *blend_mask, const float *post_mask, int tt, float *out_traj, hipStream_t st,
-                    int zero_state = 0)
+                    int zero_state = 0, const float *xs_in = nullptr)
 {
     static thread_local int attr_dev = -1;
     int dev = 0;
@@ -668,7 +750,7 @@ static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *
         attr_dev = dev;
     }
     const int n_tiles = (E * g->H + LS_ROWS - 1) / LS_ROWS;
-    GstLstmArgs a{g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, zero_state, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
+    GstLstmArgs a{xs_in ? xs_in : g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, zero_state, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
                   g->acc, out_traj, g->x_sample};
     hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 * CN_GST_WGS ? n_tiles : 256 * CN_GST_WGS), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
     CN_CHECK_LAUNCH();
@@ -681,16 +763,25 @@ static int gst_forward(cn_gst *g, int E, const float *traj, long long se, long l
     if (!g->weights_set) { cn_set_error("cn_gst: call cn_gst_set_weights first"); return CN_ERR_STATE; }
     const int H = g->H, N = E * H, R = N * GT;
     int rc;
+    // the previous call's window becomes `prev`, this call's is written over the one before it
+    if (g->reuse) { std::swap(g->rel, g->rel_prev); std::swap(g->m_rel, g->m_rel_prev); std::swap(g->xs, g->xs_prev); }
     hipLaunchKernelGGL(gst_obs_prep_kernel, dim3((N + 255) / 256), dim3(256), 0, st, E, H, traj, se, sh, stt, mask_u8, mask_f, me, mh, mt, rot, step, ring,
                        g->m_rel, g->lm_fp, g->rel, g->last_pos);
     CN_CHECK_LAUNCH();
     // observation period: spatial encoding of all 5 slices at once, then the LSTM over time
-    if ((rc = gst_layer(g, R, g->rel, g->m_rel, st))) return rc;
+    if (g->reuse) {
+        CN_HIP(hipMemsetAsync(g->gcount, 0, sizeof(int), st));
+        hipLaunchKernelGGL(gst_reuse_kernel, dim3((E * GT + 15) / 16), dim3(1024), 0, st, E, H, g->prev_E == E ? 1 : 0, g->rel, g->m_rel, g->rel_prev, g->m_rel_prev, g->xs_prev,
+                           g->xs, g->glist, g->gcount);
+        CN_CHECK_LAUNCH();
+        if ((rc = gst_layer(g, R, g->rel, g->m_rel, st, g->xs, true))) return rc;
+        g->prev_E = E;
+    } else if ((rc = gst_layer(g, R, g->rel, g->m_rel, st))) return rc;
     if ((rc = gst_lstm(g, E, GT, g->m_rel, nullptr, g->lm_fp, 0, out_traj, st, 1))) return rc; // from h = c = 0; + the head of decode step 0
     // prediction period (recursive decoding on the mean)
     for (int tt = 1; tt < GP; ++tt) {
-        if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st))) return rc;
-        if ((rc = gst_lstm(g, E, 1, g->lm_fp, g->lm_fp, nullptr, tt, out_traj, st))) return rc; // + the head of decode step tt
+        if ((rc = gst_layer(g, N, g->x_sample, g->lm_fp, st, g->xs_dec))) return rc;
+        if ((rc = gst_lstm(g, E, 1, g->lm_fp, g->lm_fp, nullptr, tt, out_traj, st, 0, g->xs_dec))) return rc; // + the head of decode step tt
     }
     if (out_mask != g->lm_fp) CN_HIP(hipMemcpyAsync(out_mask, g->lm_fp, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st));
     return CN_OK;

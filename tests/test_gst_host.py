@@ -260,6 +260,46 @@ def test_hip_gst_wrapper_with_a_prediction_stride_matches_torch_expression(inter
             w_hip.load_state_dict(sd_h)             # un-rotated reload: the following steps must not notice
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("interval", [1, 2])
+def test_hip_gst_wrapper_taking_over_the_last_steps_encodings_is_bit_identical(interval):
+    """Round 6: frames 1..3 of a step's observation window take their spatial encodings over from the previous step wherever the group's
+    inputs and masks are the same bits (gst.hip, gst_reuse_kernel) -- the usual case with a stable visibility pattern -- and are encoded again
+    wherever they are not (a human's visibility in the newest frame flipped, a history rewritten by load_state_dict).  The same stream of
+    observations through a wrapper with the reuse switched off (CN_GST_REUSE=0, read when the handle is created) must give the same bits."""
+    z = np.load(os.path.join(GOLDEN, "gst_e4_h20.npz"))
+    pred = _model(json.loads(str(z["meta"])), "cuda")
+    E, H = 97, 20
+    w_on = PretextProcessor(pred, E, H, 5, 0.3, 0.3, -20.0, torch.device("cuda"), use_hip=True, pred_interval=interval)
+    os.environ["CN_GST_REUSE"] = "0"
+    try:
+        w_off = PretextProcessor(pred, E, H, 5, 0.3, 0.3, -20.0, torch.device("cuda"), use_hip=True, pred_interval=interval)
+    finally:
+        del os.environ["CN_GST_REUSE"]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    pos = torch.randn(E, H, 2, device="cuda", generator=g) * 3
+    vel = torch.randn(E, H, 2, device="cuda", generator=g) * 0.2
+    vel[::3] = 0.0                                          # every third env stands still: equal displacements also across a stride
+    rob = torch.zeros(E, 1, 7, device="cuda")
+    vis = torch.rand(E, H, device="cuda", generator=g) > 0.2
+    for t in range(16):
+        pos = pos + vel
+        rob[:, 0, :2] = 0.05 * t
+        se = torch.zeros(E, H, 12, device="cuda")
+        se[:, :, :2] = pos - rob[:, :, :2]
+        se[:, :, 2:] = 15.0
+        flip = torch.rand(E, H, device="cuda", generator=g) < 0.01   # ~1 human in 100 enters / leaves the view per step: ~18 % of the envs change
+        vis = vis ^ flip
+        obs = {"robot_node": rob.clone(), "spatial_edges": se, "visible_masks": vis.clone()}
+        a_se, a_r = w_on.process(obs, torch.zeros(E, device="cuda"))
+        b_se, b_r = w_off.process(obs, torch.zeros(E, device="cuda"))
+        assert torch.equal(a_se, b_se) and torch.equal(a_r, b_r), t
+        if t == 9:                                          # a rewritten history: nothing of the previous window may be taken over blindly
+            sd = w_on.state_dict()
+            sd["traj"] = sd["traj"] + 0.125
+            w_on.load_state_dict(sd); w_off.load_state_dict(sd)
+
+
 def _check_wide(device, use_hip, interval):
     """PretextProcessor against the reference's VecPretextNormalize.process_obs_rew at 64 envs (tests/golden/gst_wrapper_e64_h20.npz, made by
     make_golden_gst.py --wide from the reference's own class): predictions / rewards <= 1e-4 absolute, identical row order wherever the
