@@ -32,13 +32,13 @@
 //     half-fragment stores of O are 2-way (its 16-byte entries are shared by two wavefronts: a wavefront has ONE v block).
 //
 // Two kernels share this file:
-//   hh_fused_kernel       (crowds of <= 48 humans, the default): 8 wavefronts = TWO TEAMS of four, two wavefronts per SIMD, 256
+//   hh_fused_kernel       (crowds of <= 63 humans, the default): 8 wavefronts = TWO TEAMS of four, two wavefronts per SIMD, 256
 //       registers each.  After the embedding phases the teams walk ALTERNATE HEADS on their own (team barriers on LDS counters,
 //       s_barrier only between tile phases), so that on every SIMD the barrier / LDS / softmax chain of one head sits beside the
 //       q.k.v MFMA loop of another head.  Tiles of <= 48 rows give each team its own scratch region; tiles of 49..63 rows fill the
 //       LDS with X and share one scratch region in turns (namespace team, struct Layout).  The teams' partial out_sp accumulators
 //       are exchanged through the (dead) X region at the end of the tile.  DESIGN.md section 4 has the measurements behind each choice.
-//   hh_fused_wide_kernel  (crowds of 49..64 humans: an env must fit one tile): the round-2 schedule, 4 wavefronts (one per SIMD),
+//   hh_fused_wide_kernel  (crowds of 64 humans -- an env must fit one tile -- and CN_HH_WIDE=1): the round-2 schedule, 4 wavefronts (one per SIMD),
 //       64-row tiles.
 #include "hh_fused.h"
 #include "row_plan.h"
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 1) void hh_fused_wide_kernel(int E, int H, int
     }
 }
 
-// ===================================================== two-team kernel: 8 wavefronts, 63-row tiles (<= 48 humans) =====================
+// ===================================================== two-team kernel: 8 wavefronts, 63-row tiles (<= 63 humans) =====================
 namespace team {
 
 #ifndef HH_TEAM_PFC
@@ -1622,15 +1622,19 @@ int hh_fused_forward(int E, int H, int D, const float *spatial_edges, const floa
     }
     // one workgroup per CU (the LDS footprint admits exactly one); small batches get fewer so that a chunk is >= one row block
     const int grid = rp_workgroups(E, H);
-    // an env must fit one tile: the two-team kernel holds 48 rows, the wide one 64 (CN_HH_WIDE=1 forces the latter: A/B measurements)
+    // an env must fit one tile: the two-team kernel holds 63 rows, the wide one 64 (CN_HH_WIDE=1 forces the latter: A/B measurements)
     static int force_wide = -1;
     if (force_wide < 0) { const char *v = getenv("CN_HH_WIDE"); force_wide = v ? atoi(v) : 0; }
+    // (round 6: crowds of 49..63 humans also go through the two-team kernel -- an env of <= 63 rows fits its 4-row-block layout; measured at 50
+    // randomised humans x 8192 envs: 1.39 -> 1.14 ms beside the simulator's side-stream kernels.  CN_HH_TEAM_MAX=48 restores the round-5 split.)
+    static int team_max = -1;
+    if (team_max < 0) { const char *v = getenv("CN_HH_TEAM_MAX"); team_max = v ? atoi(v) : team::FR; }
     const bool train = w.e0_out != nullptr;
     if (train) {
         CN_REQUIRE(H <= 48 && w.x_out && w.qkv_out && w.attn_out, "hh_fused_forward: the training outputs need H <= 48 and all four buffers");
         hipLaunchKernelGGL(hh_fused_kernel<true>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp,
                            (const int32_t *)nullptr, stamp);
-    } else if (H > 48 || force_wide)
+    } else if (H > team_max || force_wide > 0)
         hipLaunchKernelGGL(hh_fused_wide_kernel, dim3(grid), dim3(256), wide::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp, stamp);
     else
         hipLaunchKernelGGL(hh_fused_kernel<false>, dim3(grid), dim3(512), team::LDS_BYTES, st, E, H, D, spatial_edges, det, row_off, live_total, w, out_sp,

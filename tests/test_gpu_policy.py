@@ -65,7 +65,7 @@ def test_policy_act_matches_reference_golden(path, mode):
 
 
 @pytest.mark.parametrize("mode", ["fused", "bf16x3", "fp32"])
-@pytest.mark.parametrize("E,H,D", [(257, 20, 2), (130, 20, 12), (64, 5, 2), (40, 50, 2), (3, 64, 2), (1, 1, 2)])
+@pytest.mark.parametrize("E,H,D", [(257, 20, 2), (130, 20, 12), (64, 5, 2), (40, 50, 2), (21, 57, 2), (9, 63, 12), (3, 64, 2), (1, 1, 2)])
 def test_policy_act_matches_numpy_oracle(E, H, D, mode):
     """Sizes with ragged tiles (E*H not a multiple of 128), random-looking weights, random detected counts."""
     from crowdnav_prediction_attngraph_amd.hip import HipPolicy
