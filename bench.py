@@ -624,7 +624,8 @@ def main():
     split = args.gemm in ("bf16x3", "fused")
     # the split runs 3 bf16 MFMA passes per algorithmic product, so its attainable algorithmic rate is the bf16 peak / 3
     peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
-    kname = (("hh_fused_wide_kernel" if H > 48 else "hh_fused_kernel") + " (v_mfma_f32_16x16x32_bf16, 3 passes hi*hi+hi*lo+lo*hi): embedding -> q|k|v -> attention -> out_proj∘spatial_linear in one launch" if fused else
+    team_max = int(os.environ.get("CN_HH_TEAM_MAX", "63"))   # hh_fused.hip: the two-team kernel takes crowds of <= 63 humans (round 6), the wide one 64
+    kname = (("hh_fused_wide_kernel" if (H > team_max or os.environ.get("CN_HH_WIDE", "0") not in ("", "0")) else "hh_fused_kernel") + " (v_mfma_f32_16x16x32_bf16, 3 passes hi*hi+hi*lo+lo*hi): embedding -> q|k|v -> attention -> out_proj∘spatial_linear in one launch" if fused else
              "gemm3_nt_kernel<128,NONE> (v_mfma_f32_32x32x16_bf16, 3 passes hi*hi+hi*lo+lo*hi): folded q|k|v projection" if split
              else "gemm_nt_kernel<128,NONE> (v_mfma_f32_32x32x2_f32): folded q|k|v projection")
     # HBM traffic of the dominant kernel: bench.py cannot run rocprofv3 on itself, so the number comes from the committed PMC passes of
