@@ -131,6 +131,14 @@ CASES = {
     "pred_h8_sfhumans_truthobs_stride2_test": dict(human_num=8, env_kind=1, predict_truth=1, humans_policy=1, pred_interval=2, phase=2),
     "predgst_h8_rand_robotvisible_stride2_test": dict(human_num=8, env_kind=2, robot_visible=1, pred_interval=2, phase=2, randomize_attributes=1, random_goal_changing=1),
     "pred_h10_constvel_stride4_val": dict(human_num=10, env_kind=1, phase=1, pred_interval=4),
+    # round 6, dense crowds without a lane kernel (> 32 agents per env): the post-observation updates run as env_post_kernel on the side stream,
+    # placement loops over a workgroup -- with a varying crowd size, in the test phase (truth roll-outs behind the ORCA pass), with the robot
+    # visible to the humans' ORCA, with the predicted-trajectory observation; social-force humans keep the loops inside the step kernel
+    "varnum_h36_rand_range8": dict(human_num=36, human_num_range=8, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h40_rand_test": dict(human_num=40, phase=2, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h40_rand_robotvisible": dict(human_num=40, robot_visible=1, randomize_attributes=1, random_goal_changing=1),
+    "pred_h40_rand": dict(human_num=40, env_kind=1, randomize_attributes=1, random_goal_changing=1),
+    "varnum_h40_rand_sfhumans": dict(human_num=40, humans_policy=1, randomize_attributes=1, random_goal_changing=1),
 }
 
 
@@ -139,7 +147,7 @@ def test_hip_env_matches_oracle_bit_exact(name):
     from crowdnav_prediction_attngraph_amd.hip import HipEnvBatch
     from oracle import oracle as O
     kw = dict(CASES[name])
-    E, T, seed = 48, 260 if kw["human_num"] + kw.get("human_num_range", 0) < 50 else 110, 425
+    E, T, seed = 48, 260 if kw["human_num"] + kw.get("human_num_range", 0) < 36 else 110, 425
     kw["nenv"] = E
     ccfg, ocfg = _cfgs(**kw)
     env = HipEnvBatch(ccfg, E, seed)
