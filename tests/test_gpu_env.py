@@ -139,6 +139,11 @@ CASES = {
     "varnum_h40_rand_robotvisible": dict(human_num=40, robot_visible=1, randomize_attributes=1, random_goal_changing=1),
     "pred_h40_rand": dict(human_num=40, env_kind=1, randomize_attributes=1, random_goal_changing=1),
     "varnum_h40_rand_sfhumans": dict(human_num=40, humans_policy=1, randomize_attributes=1, random_goal_changing=1),
+    # a jammed circle (50 humans on a circle of radius 4.5: no room for a new goal anywhere): most goal changes run to the bound, through the
+    # one-wavefront passes AND several cooperative rounds -- the bound inside the first round, at 3.1 rounds, and far behind
+    "varnum_h50_rand_jam_cap700": dict(human_num=50, randomize_attributes=1, random_goal_changing=1, circle_radius=4.5, max_placement_attempts=700),
+    "varnum_h50_rand_jam_cap2500": dict(human_num=50, randomize_attributes=1, random_goal_changing=1, circle_radius=4.5, max_placement_attempts=2500),
+    "varnum_h50_rand_jam_cap9000": dict(human_num=50, randomize_attributes=1, random_goal_changing=1, circle_radius=4.5, max_placement_attempts=9000),
 }
 
 
