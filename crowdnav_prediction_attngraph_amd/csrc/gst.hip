@@ -81,7 +81,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 constexpr int GL_NW = CN_GL_WAVES, GL_TEAMS = GL_NW / 4, GL_THREADS = 64 * GL_NW, GL_WGS = GL_NW == 4 ? 2 : 1;
 #ifndef CN_LS_ROWS
-#define CN_LS_ROWS 32  // nodes per LSTM tile: 1280 tiles at 2048 x 20 nodes spread better over 256 workgroups than 640 (round 6 A/B: 0.853 -> 0.825 ms per step)
+#define CN_LS_ROWS 0   // nodes per LSTM tile: 0 = chosen per launch between 32 and 80 (gst_lstm); 32 / 80 force one
 #endif
 constexpr int GL_RT = CN_GL_RT, GL_ROWS = 16 * GL_RT;            // row tiles / rows per workgroup tile
 constexpr int GL_SA = 68, GL_SQ = 196;                    // LDS row strides (floats): 16-byte aligned, lanes of a float4 read on distinct banks
@@ -350,8 +350,10 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gst_layer_kernel(int rows, int 
 // 256 x 128 weight image stays in registers (128 VGPRs per wavefront) for all its tiles and steps.  Replaces, per step, a K = 64 GEMM
 // whose [N, 256] result went through HBM, the pointwise kernel, and the [rows, 256] input projection of the whole slab.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int LS_ROWS = CN_LS_ROWS, LS_SX = 132, LS_SG = 260, LS_PT = LS_ROWS / 8; // nodes per workgroup tile; pointwise: LS_PT nodes per thread
-constexpr int LS_OX = 0, LS_OG = LS_OX + LS_ROWS * LS_SX, LS_OB = LS_OG + LS_ROWS * LS_SG, LS_LDS_FLOATS = LS_OB + 256;
+// nodes per workgroup tile LS_ROWS (template parameter: 32 or 80, picked per launch by which spreads the batch's tiles better over the
+// workgroups -- see gst_lstm); pointwise part: LS_PT nodes per thread
+constexpr int LS_SX = 132, LS_SG = 260;
+constexpr int ls_lds_floats(int rows) { return rows * LS_SX + rows * LS_SG + 256; }
 
 struct GstLstmArgs {
     const float *xs, *in_mask;      // [E*S*H, 64] encoded rows, [E*S*H] input mask
@@ -370,8 +372,10 @@ struct GstLstmArgs {
 __device__ __forceinline__ float gl_tanh(float x) { return 1.0f - 2.0f / (1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681472f)); }
 __device__ __forceinline__ float gl_sigmoid(float x) { return 1.0f / (1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
+template <int LS_ROWS>
 __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, int H, int S, GstLstmArgs a)
 {
+    constexpr int LS_PT = LS_ROWS / 8, LS_OX = 0, LS_OG = LS_OX + LS_ROWS * LS_SX, LS_OB = LS_OG + LS_ROWS * LS_SG;
 #ifdef GST_TIMING
     long long tlast_ = clock64();
 #endif
@@ -774,13 +778,22 @@ static int gst_lstm(cn_gst *g, int E, int S, const float *in_mask, const float *
     int dev = 0;
     CN_HIP(hipGetDevice(&dev));
     if (dev != attr_dev) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gst_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LS_LDS_FLOATS * sizeof(float))));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gst_lstm_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ls_lds_floats(32) * sizeof(float))));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gst_lstm_kernel<80>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ls_lds_floats(80) * sizeof(float))));
         attr_dev = dev;
     }
-    const int n_tiles = (E * g->H + LS_ROWS - 1) / LS_ROWS;
     GstLstmArgs a{xs_in ? xs_in : g->xs, in_mask, g->f_lstm, g->bih, g->bhh, g->h, g->c, blend_mask, post_mask, tt, zero_state, g->h2p_w, g->h2p_b, g->lm_fp, g->last_pos,
                   g->acc, out_traj, g->x_sample};
-    hipLaunchKernelGGL(gst_lstm_kernel, dim3(n_tiles < 256 * CN_GST_WGS ? n_tiles : 256 * CN_GST_WGS), dim3(512), LS_LDS_FLOATS * sizeof(float), st, E, g->H, S, a);
+    // Tile size: a pass over an 80-node tile costs ~2.25x a pass over a 32-node one (measured at 2048 envs x 20 nodes: 2 tiles of 80 per workgroup
+    // 0.716 ms per step against 5 tiles of 32 0.745, 64-node tiles 0.767: 640 tiles on 256 workgroups leave a third of them idle in the last
+    // turn), so the larger tile wins where it does not cost a whole extra turn of the workgroups.  CN_LS_ROWS=32 / 80 forces one (A/B).
+    static const int forced = getenv("CN_LS_ROWS") ? atoi(getenv("CN_LS_ROWS")) : CN_LS_ROWS;
+    const int N = E * g->H, wgs = 256 * CN_GST_WGS;
+    const int t32 = (N + 31) / 32, t80 = (N + 79) / 80;
+    const double c32 = (double)((t32 + wgs - 1) / wgs), c80 = 2.25 * (double)((t80 + wgs - 1) / wgs);
+    const bool big = forced == 80 || (forced != 32 && c80 < c32);
+    if (big) hipLaunchKernelGGL(gst_lstm_kernel<80>, dim3(t80 < wgs ? t80 : wgs), dim3(512), ls_lds_floats(80) * sizeof(float), st, E, g->H, S, a);
+    else hipLaunchKernelGGL(gst_lstm_kernel<32>, dim3(t32 < wgs ? t32 : wgs), dim3(512), ls_lds_floats(32) * sizeof(float), st, E, g->H, S, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
