@@ -171,8 +171,8 @@ __device__ __forceinline__ void gl_stage(const GlW<K, NFB> &w, int fb_first, int
 }
 
 #ifdef GST_TIMING
-__device__ long long *g_gst_tim = nullptr; // [block][10] phase cycle sums of thread 0 (measurement build only)
-#define GL_T(k) do { if (g_gst_tim && threadIdx.x == 0) { const long long now_ = clock64(); g_gst_tim[(size_t)blockIdx.x * 10 + (k)] += now_ - tlast_; tlast_ = now_; } } while (0)
+__device__ long long *g_gst_tim = nullptr; // [block][16] phase cycle sums of thread 0 (measurement build only): slots 0..7 the layer kernel's phases, 8..12 the LSTM kernel's
+#define GL_T(k) do { if (g_gst_tim && threadIdx.x == 0) { const long long now_ = clock64(); g_gst_tim[(size_t)blockIdx.x * 16 + (k)] += now_ - tlast_; tlast_ = now_; } } while (0)
 #else
 #define GL_T(k) do {} while (0)
 #endif
@@ -390,9 +390,28 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, in
     GlW<128, 2> w;
     gl_load<128, 2>(w, a.f_w, wave8, 8, lane);
     const int i = lane & 15, g = lane >> 4;
+    // the head's weights (this thread's hidden unit d) and biases: constants of the launch, fetched once -- and what the head's scalar tail reads
+    // per node (running sums, last position, mask) is requested at the START of a tile: fetched behind the reductions, those loads were a chain
+    // of two global round trips at the end of every tile and launch (27 % of the kernel's time on its own clock)
+    float hw_[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, hb_[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.head_w) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { hw_[k] = a.head_w[64 * k + d]; hb_[k] = a.head_b[k]; }
+    }
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int n0 = tile * LS_ROWS;
         float creg[LS_PT], xn[LS_PT], hreg[LS_PT];
+        float t_lm = 0.f, t_lp0 = 0.f, t_lp1 = 0.f, t_acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const int nh = n0 + q + 8 * d; // the node whose scalar tail this thread runs (lanes d < LS_PT)
+            if (a.head_w && d < LS_PT && nh < N) {
+                t_lm = a.lm_fp[nh]; t_lp0 = a.last_pos[2 * nh]; t_lp1 = a.last_pos[2 * nh + 1];
+                if (a.tt) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) t_acc[k] = a.acc[(size_t)nh * 5 + k];
+                }
+            }
+        }
         int rbase[LS_PT]; // row of slice 0 of this thread's nodes (slice t is rbase + t * H); out-of-range nodes clamp to the last one (never stored)
 #pragma unroll
         for (int k = 0; k < LS_PT; ++k) {
@@ -409,12 +428,12 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, in
         }
 #pragma unroll
         for (int k = 0; k < LS_PT; ++k) X[(q + 8 * k) * LS_SX + 64 + d] = hreg[k];
-        GL_T(0);
+        GL_T(8);
         for (int t = 0; t < S; ++t) {
 #pragma unroll
             for (int k = 0; k < LS_PT; ++k) X[(q + 8 * k) * LS_SX + d] = xn[k];
             __syncthreads();
-            GL_T(1);
+            GL_T(9);
             if (t + 1 < S) { // the next slice's rows travel while this slice is computed
 #pragma unroll
                 for (int k = 0; k < LS_PT; ++k) {
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, in
                     *reinterpret_cast<f32x4 *>(G + (16 * rt + i) * LS_SG + (wave8 + 8 * j) * 16 + 4 * g) = acc[j] + bv[j];
             }
             __syncthreads();
-            GL_T(2);
+            GL_T(10);
             // the cell (PyTorch gate order i, f, g, o), decode-step blend h = h' m + h (1 - m), post mask after the last slice
             const bool last = t == S - 1;
 #pragma unroll
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, in
                 X[nl * LS_SX + 64 + d] = hn;
             }
             // (the next slice's staging only writes the x half of X, which nobody reads before the barrier that follows it)
-            GL_T(3);
+            GL_T(11);
         }
 #pragma unroll
         for (int k = 0; k < LS_PT; ++k) {
@@ -480,35 +499,34 @@ __global__ __launch_bounds__(512, 2 * CN_GST_WGS) void gst_lstm_kernel(int E, in
         }
         if (a.head_w) {
             // the head on the hidden state this thread's wavefront just wrote (node rows q, q + 8, ...: lane = hidden unit)
-            const float w0 = a.head_w[d], w1 = a.head_w[64 + d], w2 = a.head_w[128 + d], w3 = a.head_w[192 + d], w4 = a.head_w[256 + d];
             float raw[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // lane k keeps node row q + 8 k, so the eight scalar tails below run side by side
 #pragma unroll
             for (int k = 0; k < LS_PT; ++k) {
                 const float hv = X[(q + 8 * k) * LS_SX + 64 + d];
-                const float s0 = wv_sum(hv * w0), s1 = wv_sum(hv * w1), s2 = wv_sum(hv * w2), s3 = wv_sum(hv * w3), s4 = wv_sum(hv * w4);
+                const float s0 = wv_sum(hv * hw_[0]), s1 = wv_sum(hv * hw_[1]), s2 = wv_sum(hv * hw_[2]), s3 = wv_sum(hv * hw_[3]), s4 = wv_sum(hv * hw_[4]);
                 if (d == k) { raw[0] = s0; raw[1] = s1; raw[2] = s2; raw[3] = s3; raw[4] = s4; }
             }
             const int n = n0 + q + 8 * d;
             if (d < LS_PT && n < N) {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) raw[k] += a.head_b[k];
+                for (int k = 0; k < 5; ++k) raw[k] += hb_[k];
                 const int tt = a.tt;
-                const float lm = a.lm_fp[n];
+                const float lm = t_lm;
                 const float sx = expf(raw[2]), sy = expf(raw[3]), corr = tanhf(raw[4]);
                 float *ac = a.acc + (size_t)n * 5;
-                const float a0 = (tt ? ac[0] : 0.f) + raw[0], a1 = (tt ? ac[1] : 0.f) + raw[1];
-                const float a2 = (tt ? ac[2] : 0.f) + sx * sx, a3 = (tt ? ac[3] : 0.f) + sy * sy, a4 = (tt ? ac[4] : 0.f) + corr * sx * sy;
+                const float a0 = (tt ? t_acc[0] : 0.f) + raw[0], a1 = (tt ? t_acc[1] : 0.f) + raw[1];
+                const float a2 = (tt ? t_acc[2] : 0.f) + sx * sx, a3 = (tt ? t_acc[3] : 0.f) + sy * sy, a4 = (tt ? t_acc[4] : 0.f) + corr * sx * sy;
                 ac[0] = a0; ac[1] = a1; ac[2] = a2; ac[3] = a3; ac[4] = a4;
                 const float sxc = sqrtf(a2), syc = sqrtf(a3);
                 float *o = a.out_traj + ((size_t)n * GP + tt) * 5;
-                o[0] = (a0 + a.last_pos[2 * n]) * lm + GST_INVALID * (1.0f - lm);
-                o[1] = (a1 + a.last_pos[2 * n + 1]) * lm + GST_INVALID * (1.0f - lm);
+                o[0] = (a0 + t_lp0) * lm + GST_INVALID * (1.0f - lm);
+                o[1] = (a1 + t_lp1) * lm + GST_INVALID * (1.0f - lm);
                 o[2] = sxc; o[3] = syc; o[4] = a4 / (sxc * syc);
                 a.x_sample[2 * n] = raw[0] * lm; a.x_sample[2 * n + 1] = raw[1] * lm; // sampling = False: the mean, masked for the next step
             }
         }
         __syncthreads(); // the next tile refills X
-        GL_T(4);
+        GL_T(12);
     }
 }
 
