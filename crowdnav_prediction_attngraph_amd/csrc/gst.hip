@@ -272,7 +272,7 @@ __global__ __launch_bounds__(GL_THREADS, 2) void gst_layer_kernel(int rows, int 
 #pragma unroll
                     for (int j = 0; j < 20; ++j) {
                         if (j < H) {
-                            const float ex = expf(scv[j] - mx);
+                            const float ex = __builtin_amdgcn_exp2f((scv[j] - mx) * 1.44269504088896340736f); // (v_exp_f32: the argument is <= 0)
                             Z += ex;
                             const float em = ex * ms[j];
                             Zm += em;
