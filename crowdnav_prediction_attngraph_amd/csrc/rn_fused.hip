@@ -16,6 +16,8 @@
 #include "rn_fused.h"
 #include "row_plan.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -68,17 +70,28 @@ __device__ __forceinline__ void wpre_load(WPre<K, NFB, D> &w, const float *__res
 
 // out[env][out_off + 16*fb + ..] = act(W[fb] . in[env][in_off ..] + bias) for the feature blocks fb = fb0 + wave, fb0 + wave + 4, ...
 // Wfrag: baked fragments [fb][K/32][plane hi,lo][64 lanes][8 bf16]; NFB = feature blocks of this wavefront
-template <int K, int NFB, int ACT, bool PRE = false, int D = 2>
+template <int K, int NFB, int ACT, bool PRE = false, int D = 2, bool LEAN = false>
 __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_first, int fb_step, const float *__restrict__ bias, const float *in, int in_stride,
                                       float *out, int out_stride, int out_off, int relu_from, int lane, const WPre<K, NFB, D> &pre = WPre<K, NFB, D>{})
 {
     const bf16x8 *__restrict__ Wfrag = reinterpret_cast<const bf16x8 *>(Wfrag_);
     const int i = lane & 15, g = lane >> 4;
     constexpr int KS = K / 32;
-    // activations of env i, k = 32 ks + 8 g .. + 7, as bf16 hi / lo (the B operand of every feature block of this stage)
-    bf16x8 bh[KS], bl[KS];
+    // activations of env i, k = 32 ks + 8 g .. + 7, as bf16 hi / lo (the B operand of every feature block of this stage); LEAN: split per
+    // k-step inside the loop instead of up front (64 registers less at K = 256)
+    bf16x8 bh[LEAN ? 1 : KS], bl[LEAN ? 1 : KS];
+    auto split = [&](int ks, bf16x8 &h, bf16x8 &l) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 32 * ks + 8 * g);
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 32 * ks + 8 * g + 4);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+        for (int u = 0; u < 4; ++u) {
+            const __bf16 h0 = (__bf16)x0[u], h1 = (__bf16)x1[u];
+            h[u] = h0; h[4 + u] = h1;
+            l[u] = (__bf16)(x0[u] - (float)h0); l[4 + u] = (__bf16)(x1[u] - (float)h1);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < (LEAN ? 0 : KS); ++ks) {
         const f32x4 x0 = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 32 * ks + 8 * g);
         const f32x4 x1 = *reinterpret_cast<const f32x4 *>(in + i * in_stride + 32 * ks + 8 * g + 4);
 #pragma unroll
@@ -92,7 +105,7 @@ __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_f
 #pragma unroll
     for (int j = 0; j < NFB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // weight fragments: PF k-steps in flight (the scheduling barriers pin the issue points, see hh_fused.hip)
-    constexpr int PF = KS < 3 ? KS : 3;
+    constexpr int PF = KS < (LEAN ? 2 : 3) ? KS : (LEAN ? 2 : 3);
     bf16x8 ah[PF][NFB], al[PF][NFB];
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p)
@@ -110,12 +123,13 @@ __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_f
             const size_t base = ((size_t)(fb_first + j * fb_step) * KS + kp) * 128 + lane;
             ah[(ks + PF - 1) % PF][j] = Wfrag[base]; al[(ks + PF - 1) % PF][j] = Wfrag[base + 64];
         }
+        if (LEAN) split(ks, bh[0], bl[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NFB; ++j) {
-            acc[j] = mfma32(al[ks % PF][j], bh[ks], acc[j]);
-            acc[j] = mfma32(ah[ks % PF][j], bl[ks], acc[j]);
-            acc[j] = mfma32(ah[ks % PF][j], bh[ks], acc[j]);
+            acc[j] = mfma32(al[ks % PF][j], bh[LEAN ? 0 : ks], acc[j]);
+            acc[j] = mfma32(ah[ks % PF][j], bl[LEAN ? 0 : ks], acc[j]);
+            acc[j] = mfma32(ah[ks % PF][j], bh[LEAN ? 0 : ks], acc[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -133,7 +147,14 @@ __device__ __forceinline__ void stage(const float *__restrict__ Wfrag_, int fb_f
     }
 }
 
-__global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedArgs a)
+// LEAN (the default since round 6; CN_RN_LEAN=0: the 255-register variant): the same chain -- same products, same order, same bits -- in 128
+// registers per lane (activations split per k-step, two k-steps of weight fragments in flight, the wide stages in chunks of <= 3 feature blocks,
+// nothing held across the barriers).  On its own it is a few us slower; but a workgroup then takes HALF of its CU's registers, and the ORCA tail's
+// wavefronts (orca_lp3_kernel on the simulator's side stream: 32 registers, no LDS, 37 us of VALU work for the whole chip) run on the same CUs
+// beside this latency chain instead of making it wait for CUs of its own: hh_fused -> rn_fused gap 17.7 -> 9.9 us, step 0.2806 -> 0.2705 ms at
+// 4096 envs x 20 humans (same box), configs[4] 2.07 -> 2.05 ms beside the cooperative ORCA kernel.
+template <bool LEAN>
+__global__ __launch_bounds__(512, LEAN ? 4 : 2) void rn_fused_kernel(int E, int H, RnFusedArgs a)
 {
     const CnStampScope stamp_scope(a.stamp);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -143,14 +164,10 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     float *R0 = smem + O_R0, *R1 = smem + O_R1, *R2 = smem + O_R2, *R3 = smem + O_R3, *R4 = smem + O_R4, *R5 = smem + O_R5;
     // ---- robot_linear.0: relu(W [256,9] . [temporal_edges(2) | robot_node(7)] + b); thread = feature; h_in -> LDS ----
     const int w4 = wave & 3, hi = wave >> 2; // two groups of four wavefronts run independent products side by side
-#ifndef RN_NO_PREFETCH
+    constexpr bool PRE = !LEAN;
     WPre<256, 5, 1> p_te; WPre<128, 6, 1> p_whh;
-    if (hi == 0) wpre_load(p_te, a.f_te, w4, 4, lane); else wpre_load(p_whh, a.f_whh, w4, 4, lane);
-#define RN_PRE true
-#else
-#define RN_PRE false
-    const WPre<256, 1> p_edge{}; const WPre<128, 3> p_wih{}; const WPre<128, 4> p_ac0{}; const WPre<256, 4> p_2{};
-#endif
+    WPre<256, 1> p_edge; WPre<128, 3> p_wih; WPre<128, 4> p_ac0; WPre<256, 4> p_2;
+    if (PRE) { if (hi == 0) wpre_load(p_te, a.f_te, w4, 4, lane); else wpre_load(p_whh, a.f_whh, w4, 4, lane); }
     {
         const int n = tid & 255; // feature; the two thread halves split the envs
         float w[9];
@@ -176,17 +193,20 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
     __syncthreads();
     // ---- z = [u (256) | relu(enc) (64)] = te_w [320,256] . robot_states + te_b ;  gh = W_hh [384,128] . h_in (unmasked, no bias) ----
-#ifndef RN_NO_PREFETCH
-    if (hi == 0) stage<256, 5, A_RELU, true, 1>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane, p_te);
-    else stage<128, 6, A_NONE, true, 1>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane, p_whh);
+    if (hi == 0 && LEAN) { // (five feature blocks do not fit 128 registers: three and two)
+        stage<256, 3, A_RELU, false, 2, true>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane);
+        stage<256, 2, A_RELU, false, 2, true>(a.f_te, w4 + 12, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane);
+    } else if (hi == 0) stage<256, 5, A_RELU, PRE, 1, LEAN>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane, p_te);
+    else if (!LEAN) stage<128, 6, A_NONE, PRE, 1, LEAN>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane, p_whh);
+    else { // (six feature blocks of weight fragments, two k-steps deep, do not fit 128 registers: three and three)
+        stage<128, 3, A_NONE, false, 2, true>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane);
+        stage<128, 3, A_NONE, false, 2, true>(a.f_whh, w4 + 12, 4, nullptr, R4, S128, R2, S384, 0, 0, lane);
+    }
     // the next two products' first fragments travel while the attention runs
-    WPre<256, 1> p_edge; WPre<128, 3> p_wih;
-    if (hi == 0) wpre_load(p_edge, a.f_edge, w4, 4, lane);
-    wpre_load(p_wih, a.f_wih, wave, 8, lane);
-#else
-    if (hi == 0) stage<256, 5, A_RELU>(a.f_te, w4, 4, a.te_b, R0, S512, R1, S512, 0, 256, lane);
-    else stage<128, 6, A_NONE>(a.f_whh, w4, 4, nullptr, R4, S128, R2, S384, 0, 0, lane);
-#endif
+    if (PRE) {
+        if (hi == 0) wpre_load(p_edge, a.f_edge, w4, 4, lane);
+        wpre_load(p_wih, a.f_wih, wave, 8, lane);
+    }
     __syncthreads();
     // ---- robot-human attention (u-form, see hr_attention_kernel in policy.hip): wavefront w owns envs 2w, 2w+1 ----
     // out_sp was written a moment ago by the human-human kernel on (mostly) other XCDs: every row read is a trip to the fabric.  A
@@ -269,18 +289,12 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
     __syncthreads();
     // ---- edge = relu(edge_attention_embed [64,256] . hr + b) -> z[320:384] ----
-    if (hi == 0) stage<256, 1, A_RELU, RN_PRE>(a.f_edge, w4, 4, a.edge_b, R0, S512, R1, S512, 320, 0, lane, p_edge);
-#ifndef RN_NO_PREFETCH
-    WPre<128, 4> p_ac0;
-    wpre_load(p_ac0, a.f_ac0, wave, 8, lane);
-#endif
+    if (hi == 0) stage<256, 1, A_RELU, PRE, 2, LEAN>(a.f_edge, w4, 4, a.edge_b, R0, S512, R1, S512, 320, 0, lane, p_edge);
+    if (PRE) wpre_load(p_ac0, a.f_ac0, wave, 8, lane);
     __syncthreads();
     // ---- gi = W_ih [384,128] . [enc | edge] + b_ih ----
-    stage<128, 3, A_NONE, RN_PRE>(a.f_wih, wave, 8, a.bih, R1 + 256, S512, R3, S384, 0, 0, lane, p_wih);
-#ifndef RN_NO_PREFETCH
-    WPre<256, 4> p_2;
-    if (hi == 0) wpre_load(p_2, a.f_a2, w4, 4, lane); else wpre_load(p_2, a.f_c2, w4, 4, lane);
-#endif
+    stage<128, 3, A_NONE, PRE, 2, LEAN>(a.f_wih, wave, 8, a.bih, R1 + 256, S512, R3, S384, 0, 0, lane, p_wih);
+    if (PRE) { if (hi == 0) wpre_load(p_2, a.f_a2, w4, 4, lane); else wpre_load(p_2, a.f_c2, w4, 4, lane); }
     __syncthreads();
     // ---- GRU cell, pointwise part (gate order r,z,n; h and gh masked by the done mask: srnn_model.py:43-46) ----
     for (int idx = tid; idx < TE * 128; idx += 512) {
@@ -299,10 +313,15 @@ __global__ __launch_bounds__(512, 2) void rn_fused_kernel(int E, int H, RnFusedA
     }
     __syncthreads();
     // ---- actor / critic trunks: tanh((W0 Wo) h + ..) [512,128], then the two [256,256] second layers ----
-    stage<128, 4, A_TANH, RN_PRE>(a.f_ac0, wave, 8, a.ac0_b, R5, S128, R0, S512, 0, 0, lane, p_ac0);
+    stage<128, 4, A_TANH, PRE, 2, LEAN>(a.f_ac0, wave, 8, a.ac0_b, R5, S128, R0, S512, 0, 0, lane, p_ac0);
     __syncthreads();
-    if (hi == 0) stage<256, 4, A_TANH, RN_PRE>(a.f_a2, w4, 4, a.a2_b, R0, S512, R1, S512, 0, 0, lane, p_2);
-    else stage<256, 4, A_TANH, RN_PRE>(a.f_c2, w4, 4, a.c2_b, R0 + 256, S512, R1, S512, 256, 0, lane, p_2);
+    if (LEAN) {
+        const float *fw = hi == 0 ? a.f_a2 : a.f_c2, *fb = hi == 0 ? a.a2_b : a.c2_b;
+        const float *src = hi == 0 ? R0 : R0 + 256;
+        stage<256, 2, A_TANH, false, 2, true>(fw, w4, 4, fb, src, S512, R1, S512, hi * 256, 0, lane);
+        stage<256, 2, A_TANH, false, 2, true>(fw, w4 + 8, 4, fb, src, S512, R1, S512, hi * 256, 0, lane);
+    } else if (hi == 0) stage<256, 4, A_TANH, PRE, 2, LEAN>(a.f_a2, w4, 4, a.a2_b, R0, S512, R1, S512, 0, 0, lane, p_2);
+    else stage<256, 4, A_TANH, PRE, 2, LEAN>(a.f_c2, w4, 4, a.c2_b, R0 + 256, S512, R1, S512, 256, 0, lane, p_2);
     __syncthreads();
     // ---- critic_linear + DiagGaussian head (model.py:64-72): wavefront w owns envs 2w, 2w+1 ----
     for (int q = 0; q < 2; ++q) {
@@ -371,12 +390,15 @@ int rn_fused_forward(int E, int H, const RnFusedArgs &args, hipStream_t st)
     int dev = 0;
     CN_HIP(hipGetDevice(&dev));
     if (dev != attr_dev) {
-        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rn_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rn_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_dev = dev;
     }
     RnFusedArgs a = args;
     a.stamp = cn_stamp_slot(CN_K_RN_FUSED);
-    hipLaunchKernelGGL(rn_fused_kernel, dim3((E + TE - 1) / TE), dim3(512), lds, st, E, H, a);
+    static const int lean = getenv("CN_RN_LEAN") ? atoi(getenv("CN_RN_LEAN")) : 1;
+    if (lean) hipLaunchKernelGGL(rn_fused_kernel<true>, dim3((E + TE - 1) / TE), dim3(512), lds, st, E, H, a);
+    else hipLaunchKernelGGL(rn_fused_kernel<false>, dim3((E + TE - 1) / TE), dim3(512), lds, st, E, H, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
